@@ -1,0 +1,440 @@
+"""Generate golden fixtures by running the REFERENCE's own pure-torch path (container only).
+
+    python tests/golden/make_golden.py
+
+Imports /root/reference/nerfstudio-0.3.3 (with stub modules for packages that are missing from
+this image, see _ref_import.py), pushes deterministic parameters into the reference's modules,
+runs them on seeded inputs and stores inputs + outputs (+ autograd gradients) as small .npz files
+in this directory.  The fixtures are data only; no reference source travels.
+
+Inputs/parameters come from oracle.nerf_oracle.make_params / make_scene / make_batch (our own
+deterministic generators), the *expected outputs* come from the reference.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _ref_import as R  # noqa: E402
+from oracle import nerf_oracle as O  # noqa: E402
+
+ns = R.ref_modules()
+torch.manual_seed(0)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+class PatchedRand:
+    """Replace torch.rand by a queue of pre-drawn tensors (ray_samplers.py:105,322)."""
+
+    def __init__(self, draws):
+        self.draws = list(draws)
+        self.orig = torch.rand
+
+    def __enter__(self):
+        def fake(*size, **kw):
+            d = self.draws.pop(0)
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            assert tuple(d.shape) == shape, (d.shape, shape)
+            return d.clone()
+
+        torch.rand = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self.orig
+
+
+# ---------------------------------------------------------------------------- hash grid
+def gold_hashgrid():
+    g = torch.Generator().manual_seed(11)
+    cases = {}
+    # (tag, L, base, max, log2T, F, N)
+    for tag, L, base, mx, l2t, F, N in [
+        ("kat", 2, 16, 64, 5, 2, 0),
+        ("cfg2small", 16, 16, 2048, 10, 2, 300),
+        ("prodsmall", 10, 16, 16384, 10, 4, 300),
+        ("prop0small", 8, 16, 1024, 11, 1, 300),
+        ("prop1small", 8, 16, 4096, 11, 1, 300),
+    ]:
+        enc = ns.encodings.HashEncoding(num_levels=L, min_res=base, max_res=mx, log2_hashmap_size=l2t,
+                                        features_per_level=F, implementation="torch")
+        T = 1 << l2t
+        if tag == "kat":
+            table = (torch.arange(T * L * F, dtype=torch.float32).view(T * L, F)) * 1e-3
+            x = torch.tensor([[0.5, 0.25, 0.75], [0.3, 0.7, 0.1], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]])
+        else:
+            table = (torch.rand(T * L, F, generator=g) * 2 - 1) * 1e-1
+            x = torch.rand(N, 3, generator=g)
+            # exact lattice hits, zeros (what masked-out samples become) and ones
+            x[:8] = torch.tensor([0.0, 0.0, 0.0])
+            x[8:12] = torch.tensor([1.0, 1.0, 1.0])
+            x[12:20] = torch.round(x[12:20] * 16) / 16
+        enc.hash_table.data = table.clone()
+        out = enc(x)
+        cot = torch.rand(out.shape, generator=g) - 0.5
+        (gt,) = torch.autograd.grad((out * cot).sum(), enc.hash_table)
+        # indices via the reference's own hash_fn
+        scaled = x[:, None, :] * enc.scalings.view(-1, 1)
+        c = torch.ceil(scaled).type(torch.int32)
+        f = torch.floor(scaled).type(torch.int32)
+        pick = {"c": c, "f": f}
+        idx = torch.stack([enc.hash_fn(torch.stack([pick[k[0]][..., 0], pick[k[1]][..., 1], pick[k[2]][..., 2]], -1))
+                           for k in O._CORNERS], -1)
+        cases.update({f"{tag}_x": x, f"{tag}_table": table, f"{tag}_scalings": enc.scalings, f"{tag}_out": out,
+                      f"{tag}_idx": idx, f"{tag}_cot": cot, f"{tag}_grad_table": gt,
+                      f"{tag}_meta": np.array([L, base, mx, l2t, F])})
+    # full-size index-only checks (table contents irrelevant): cfg2 + production + prop nets
+    for tag, L, base, mx, l2t in [("cfg2", 16, 16, 2048, 19), ("prod", 10, 16, 16384, 20), ("prop0", 8, 16, 1024, 20),
+                                   ("prop1", 8, 16, 4096, 20)]:
+        enc = ns.encodings.HashEncoding(num_levels=L, min_res=base, max_res=mx, log2_hashmap_size=4,
+                                        features_per_level=1, implementation="torch")
+        enc.hash_table_size = 1 << l2t
+        enc.hash_offset = torch.arange(L) * enc.hash_table_size
+        x = torch.rand(128, 3, generator=g)
+        scaled = x[:, None, :] * enc.scalings.view(-1, 1)
+        c = torch.ceil(scaled).type(torch.int32)
+        f = torch.floor(scaled).type(torch.int32)
+        pick = {"c": c, "f": f}
+        idx = torch.stack([enc.hash_fn(torch.stack([pick[k[0]][..., 0], pick[k[1]][..., 1], pick[k[2]][..., 2]], -1))
+                           for k in O._CORNERS], -1)
+        cases.update({f"{tag}_full_x": x, f"{tag}_full_scalings": enc.scalings, f"{tag}_full_idx": idx,
+                      f"{tag}_full_meta": np.array([L, base, mx, l2t, 1])})
+    save("hashgrid", **cases)
+
+
+# ---------------------------------------------------------------------------- small ops
+def gold_ops():
+    g = torch.Generator().manual_seed(12)
+    # contraction + normalisation (a6)
+    aabb = torch.tensor([[-1.0, -2.0, -0.5], [3.0, 1.0, 0.7]])
+    p = (torch.rand(400, 3, generator=g) - 0.5) * 30
+    p[:50] = aabb[0] + (aabb[1] - aabb[0]) * torch.rand(50, 3, generator=g)  # inside
+    p[50] = aabb[0]
+    p[51] = aabb[1]
+    q = ns.ingp.get_normalized_position(p, aabb)
+    q = ns.spatial.SceneContraction(order=float("inf"))(q)
+    q = (q + 2.0) / 4.0
+    sel = ((q > 0.0) & (q < 1.0)).all(dim=-1)
+    u = q * sel[..., None]
+    kat = ns.spatial.SceneContraction(order=float("inf"))(torch.tensor([[2.0, -4.0, 1.0]]))
+    # SH (a10)
+    d = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1)
+    d[0] = torch.tensor([0.0, 0.0, 1.0])
+    sh = ns.encodings.SHEncoding(levels=4, implementation="torch")(ns.ingp.get_normalized_directions(d))
+    # trunc_exp (a9)
+    xr = (torch.rand(200, generator=g) - 0.5) * 60
+    xr.requires_grad_(True)
+    y = ns.activations.trunc_exp(xr)
+    cot = torch.rand(200, generator=g)
+    (gx,) = torch.autograd.grad((y * cot).sum(), xr)
+    # MLPs (a8) - every shape of SURVEY 8a row a8
+    mlps = {}
+    for tag, dims, act in [("base", [32, 64, 80], None), ("sem", [64, 64, 64, 64], None), ("rgb", [47, 64, 64, 3], "sig"),
+                           ("prop", [8, 64, 1], None), ("skyrgb", [32, 32, 32, 3], "sig"), ("skysem", [16, 32, 32, 64], None),
+                           ("base_prod", [40, 64, 80], None), ("tiny", [4, 32, 80], None)]:
+        m = ns.mlp.MLP(in_dim=dims[0], num_layers=len(dims) - 1, layer_width=dims[1], out_dim=dims[-1],
+                       activation=torch.nn.ReLU(), out_activation=torch.nn.Sigmoid() if act else None,
+                       implementation="torch")
+        x = torch.randn(200, dims[0], generator=g, requires_grad=True)
+        yy = m(x)
+        ct = torch.randn(yy.shape, generator=g)
+        grads = torch.autograd.grad((yy * ct).sum(), [x] + list(m.parameters()))
+        mlps[f"mlp_{tag}_x"] = x
+        mlps[f"mlp_{tag}_y"] = yy
+        mlps[f"mlp_{tag}_cot"] = ct
+        mlps[f"mlp_{tag}_gx"] = grads[0]
+        for i, layer in enumerate(m.layers):
+            mlps[f"mlp_{tag}_W{i}"] = layer.weight
+            mlps[f"mlp_{tag}_b{i}"] = layer.bias
+            mlps[f"mlp_{tag}_gW{i}"] = grads[1 + 2 * i]
+            mlps[f"mlp_{tag}_gb{i}"] = grads[2 + 2 * i]
+        mlps[f"mlp_{tag}_sigmoid"] = np.array(1 if act else 0)
+    # router (a5)
+    cent = torch.randn(16, 3, generator=g)
+    pts = torch.randn(500, 3, generator=g) * 2
+    assign = torch.cdist(pts, cent).argmin(dim=1)
+    save("ops", aabb=aabb, p=p, u=u, sel=sel, contract_kat=kat, d=d, sh=sh, te_x=xr, te_y=y, te_cot=cot, te_gx=gx,
+         route_pts=pts, route_centroids=cent, route_assign=assign, **mlps)
+
+
+# ---------------------------------------------------------------------------- rays / samplers / renderers / losses
+def _cameras(scene):
+    C = scene["c2w"].shape[0]
+    return ns.cameras.Cameras(camera_to_worlds=scene["c2w"], fx=scene["fx"], fy=scene["fy"], cx=scene["cx"], cy=scene["cy"],
+                              width=scene["W"], height=scene["H"])
+
+
+def _ray_bundle(scene, ray_indices):
+    cams = _cameras(scene)
+    coords = cams.get_image_coords()[ray_indices[:, 1], ray_indices[:, 2]]
+    return cams.generate_rays(camera_indices=ray_indices[:, 0:1], coords=coords)
+
+
+def gold_sampling():
+    cfg = O.tiny_config()
+    scene = O.make_scene(cfg)
+    batch = O.make_batch(cfg, scene, 32, step=3)
+    rb = _ray_bundle(scene, batch["ray_indices"])
+    arrs = dict(ray_indices=batch["ray_indices"], c2w=scene["c2w"], fx=scene["fx"], fy=scene["fy"], cx=scene["cx"],
+                cy=scene["cy"], origins=rb.origins, directions=rb.directions, pixel_area=rb.pixel_area,
+                directions_norm=rb.metadata["directions_norm"])
+    thr = 5.0
+    sampler = ns.samplers.SpacedSampler(
+        spacing_fn=lambda x: torch.where(x < thr, x / (2 * thr), 1 - 1 / (2 * x / thr)),
+        spacing_fn_inv=lambda x: torch.where(x < 0.5, x * (2 * thr), thr / (2 - 2 * x)),
+        single_jitter=True)
+    g = torch.Generator().manual_seed(13)
+    for mode in ("train", "eval"):
+        sampler.train(mode == "train")
+        col = ns.colliders.NearFarCollider(near_plane=0.005, far_plane=50.0)
+        col.train(mode == "train")
+        rbc = col(_ray_bundle(scene, batch["ray_indices"]))
+        jit = torch.rand(32, 1, generator=g)
+        with PatchedRand([jit]):
+            rs = sampler(rbc, num_samples=128)
+        arrs[f"sp_{mode}_jitter"] = jit
+        arrs[f"sp_{mode}_starts"] = rs.frustums.starts[..., 0]
+        arrs[f"sp_{mode}_ends"] = rs.frustums.ends[..., 0]
+        arrs[f"sp_{mode}_sstarts"] = rs.spacing_starts[..., 0]
+        arrs[f"sp_{mode}_sends"] = rs.spacing_ends[..., 0]
+        arrs[f"sp_{mode}_positions"] = rs.frustums.get_positions()
+        # weights from a random density, then pdf resample
+        sigma = torch.rand(32, 128, 1, generator=g) * 3
+        sigma[:4] = 0.0  # zero-density rays exercise the eps padding path
+        sigma[4, 10] = 1e4  # saturating sample
+        sigma.requires_grad_(True)
+        w = rs.get_weights(sigma)
+        cot = torch.rand(w.shape, generator=g)
+        (gs,) = torch.autograd.grad((w * cot).sum(), sigma)
+        arrs[f"w_{mode}_sigma"] = sigma[..., 0]
+        arrs[f"w_{mode}_weights"] = w[..., 0]
+        arrs[f"w_{mode}_cot"] = cot[..., 0]
+        arrs[f"w_{mode}_gsigma"] = gs[..., 0]
+        pdf = ns.samplers.PDFSampler(include_original=False, single_jitter=True)
+        pdf.train(mode == "train")
+        jit2 = torch.rand(32, 1, generator=g)
+        anneal = 0.37
+        with PatchedRand([jit2]):
+            rs2 = pdf(rbc, rs, torch.pow(w.detach(), anneal), num_samples=64, eps=torch.finfo(torch.float32).eps)
+        arrs[f"pdf_{mode}_jitter"] = jit2
+        arrs[f"pdf_{mode}_anneal"] = np.array(anneal)
+        arrs[f"pdf_{mode}_sstarts"] = rs2.spacing_starts[..., 0]
+        arrs[f"pdf_{mode}_sends"] = rs2.spacing_ends[..., 0]
+        arrs[f"pdf_{mode}_starts"] = rs2.frustums.starts[..., 0]
+        arrs[f"pdf_{mode}_ends"] = rs2.frustums.ends[..., 0]
+        # renderers on level-2 samples
+        sigma2 = torch.rand(32, 64, 1, generator=g) * 40
+        sigma2[:3] = 0.0
+        w2 = rs2.get_weights(sigma2)
+        rgb = torch.rand(32, 64, 3, generator=g)
+        sem = torch.rand(32, 64, 64, generator=g)
+        rr = ns.renderers.RGBRenderer(background_color="black")
+        rr.train(mode == "train")
+        arrs[f"r_{mode}_sigma"] = sigma2[..., 0]
+        arrs[f"r_{mode}_w"] = w2[..., 0]
+        arrs[f"r_{mode}_rgb_in"] = rgb
+        arrs[f"r_{mode}_sem_in"] = sem
+        arrs[f"r_{mode}_rgb"] = rr(rgb=rgb, weights=w2)
+        arrs[f"r_{mode}_acc"] = ns.renderers.AccumulationRenderer()(weights=w2)
+        arrs[f"r_{mode}_depth"] = ns.renderers.DepthRenderer(method="threshold")(weights=w2, ray_samples=rs2)
+        arrs[f"r_{mode}_expdepth"] = ns.renderers.DepthRenderer(method="expected")(weights=w2, ray_samples=rs2)
+        arrs[f"r_{mode}_sem"] = torch.sum(sem * w2, dim=-2)
+    # appendix A known answers (eval, near 0, far 50, 8 samples)
+    sampler.eval()
+    rb1 = rb[:1]
+    rb1.nears = torch.zeros(1, 1)
+    rb1.fars = torch.full((1, 1), 50.0)
+    rs = sampler(rb1, num_samples=8)
+    arrs["kat_sp_starts"] = rs.frustums.starts[..., 0]
+    arrs["kat_sp_ends"] = rs.frustums.ends[..., 0]
+    w1 = torch.zeros(1, 8, 1)
+    w1[0, 2, 0] = 1.0
+    pdf = ns.samplers.PDFSampler(include_original=False, single_jitter=True)
+    pdf.eval()
+    rs2 = pdf(rb1, rs, w1, num_samples=4, eps=torch.finfo(torch.float32).eps)
+    arrs["kat_pdf_starts"] = rs2.frustums.starts[..., 0]
+    arrs["kat_pdf_ends"] = rs2.frustums.ends[..., 0]
+    save("sampling", **arrs)
+
+
+def gold_losses():
+    g = torch.Generator().manual_seed(14)
+    R_ = 40
+
+    def rand_bins(S):
+        b = torch.sort(torch.rand(R_, S + 1, generator=g), dim=-1).values
+        b[:, 0], b[:, -1] = 0.0, 1.0
+        return b
+
+    def fake_samples(b):
+        return ns.rays.RaySamples(frustums=None, spacing_starts=b[:, :-1, None], spacing_ends=b[:, 1:, None])
+
+    bl = [rand_bins(128), rand_bins(64), rand_bins(64)]
+    wl = [torch.rand(R_, S, generator=g).requires_grad_(True) for S in (128, 64, 64)]
+    wl_n = [w / w.sum(-1, keepdim=True) * 0.9 for w in wl]
+    il = ns.ps_losses.z_anti_anliasing_interlevel_loss([w[..., None] for w in wl_n], [fake_samples(b) for b in bl],
+                                                       pulse_width=(0.03, 0.003))
+    g_il = torch.autograd.grad(il, wl[:2], retain_graph=True)
+    dl = ns.losses.distortion_loss([w[..., None] for w in wl_n], [fake_samples(b) for b in bl])
+    (g_dl,) = torch.autograd.grad(dl, wl[2])
+    acc = torch.rand(R_, 1, generator=g).requires_grad_(True)
+    acc.data[0] = 0.0
+    acc.data[1] = 1.0
+    skym = (torch.rand(R_, 1, generator=g) < 0.3).float()
+    sl = ns.ps_losses.sky_loss(acc, skym)
+    (g_sl,) = torch.autograd.grad(sl, acc)
+    pred = torch.rand(R_, 64, generator=g).requires_grad_(True)
+    tgt = torch.rand(R_, 64, generator=g) * 1.4 - 0.2
+    sm = ns.ps_losses.semantic_loss(pred, tgt, clip=True)
+    (g_sm,) = torch.autograd.grad(sm, pred)
+    save("losses", bins0=bl[0], bins1=bl[1], bins2=bl[2], w0=wl_n[0], w1=wl_n[1], w2=wl_n[2], w0_raw=wl[0], w1_raw=wl[1],
+         w2_raw=wl[2], interlevel=il, g_interlevel_w0=g_il[0], g_interlevel_w1=g_il[1], distortion=dl, g_distortion_w2=g_dl,
+         acc=acc, sky_mask=skym, sky_loss=sl, g_sky=g_sl, sem_pred=pred, sem_tgt=tgt, sem_loss=sm, g_sem=g_sm)
+
+
+# ---------------------------------------------------------------------------- fields + whole model
+def _build_ref_model(cfg, scene, P):
+    mod = __import__("importlib").import_module("nerfstudio.models.PreSight.nerfacto_nusc_ms")
+    m = cfg["main"]
+    conf = mod.NerfactoNuscMSModelConfig(
+        near_plane=cfg["near"], far_plane=cfg["far"], piecewise_sampler_threshold=cfg["thr"],
+        hidden_dim=m["hidden_dim"], hidden_dim_color=m["hidden_dim_color"], num_levels=m["num_levels"],
+        base_res=m["base_res"], max_res=m["max_res"], log2_hashmap_size=m["log2_hashmap_size"],
+        features_per_level=m["features_per_level"],
+        proposal_net_args_list=[dict(features_per_level=p["features_per_level"], log2_hashmap_size=p["log2_hashmap_size"],
+                                     num_levels=p["num_levels"], base_res=p["base_res"], max_res=p["max_res"],
+                                     hidden_dim=p["hidden_dim"], use_linear=False) for p in cfg["props"]],
+        implementation="torch", use_lidar_loss=False, distortion_loss_mult=cfg["distortion_loss_mult"],
+        sky_mlp_dims=cfg["sky"]["width"], num_sky_mlp_layers=cfg["sky"]["num_layers"],
+    )
+    conf.enable_collider = False
+    conf.collider_params = None
+    model = mod.NerfactoNuscMSModel(conf, scene_box=None, num_train_data=-1, num_train_cameras=cfg["num_cameras"],
+                                    num_train_videos=cfg["num_videos"], dino_to_rgb=scene["dino_to_rgb"], centroids=scene["centroids"],
+                                    aabbs=scene["aabbs"])
+    sd = model.state_dict()
+    missing = [k for k in P if k not in sd]
+    assert not missing, missing
+    for k, v in P.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+    model.load_state_dict({**sd, **P})
+    return model, mod
+
+
+def gold_model():
+    cfg = O.tiny_config()
+    cfg["num_fields"] = 3
+    for p in [cfg["main"]] + cfg["props"]:
+        p["log2_hashmap_size"] = 9
+    scene = O.make_scene(cfg)
+    P = O.make_params(cfg, seed=5, table_scale=0.3)
+    # make density non-trivial: bias the density heads
+    for k in range(cfg["num_fields"]):
+        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = 2.0
+        for i in range(2):
+            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = 1.5
+    model, mod = _build_ref_model(cfg, scene, P)
+    R_ = 64
+    batch = O.make_batch(cfg, scene, R_, step=1)
+    rb = _ray_bundle(scene, batch["ray_indices"])
+    rb.metadata["video_id"] = batch["video_ids"][:, None]
+    arrs = {"P_" + k: v for k, v in P.items()}
+    arrs.update({"B_" + k: v for k, v in batch.items()})
+    arrs.update(centroids=scene["centroids"], aabbs=scene["aabbs"])
+    # --- per-field fixtures (sub-field 1)
+    f1 = model.field.fields[1]
+    g = torch.Generator().manual_seed(15)
+    lo, hi = scene["aabbs"][1][0], scene["aabbs"][1][1]
+    pos = lo + (hi - lo) * (torch.rand(200, 3, generator=g) * 1.6 - 0.3)
+    dirs = torch.nn.functional.normalize(torch.randn(200, 3, generator=g), dim=-1)
+    app = torch.randn(200, 16, generator=g)
+    dens, emb = f1.density_fn(pos)
+    fo = f1.get_outputs(dirs, density_embedding=emb, appearance_embedding=app)
+    cots = [torch.rand(dens.shape, generator=g), torch.rand(200, 3, generator=g) - 0.5, torch.rand(200, 64, generator=g) - 0.5]
+    scalar = (dens * cots[0]).sum() + (fo[ns.field_heads.FieldHeadNames.RGB] * cots[1]).sum() + \
+        (fo[ns.field_heads.FieldHeadNames.SEMANTICS] * cots[2]).sum()
+    names = [n for n, _ in f1.named_parameters()]
+    gr = torch.autograd.grad(scalar, list(f1.parameters()))
+    arrs.update(F_pos=pos, F_dirs=dirs, F_app=app, F_density=dens, F_embedding=emb,
+                F_rgb=fo[ns.field_heads.FieldHeadNames.RGB], F_sem=fo[ns.field_heads.FieldHeadNames.SEMANTICS],
+                F_cot_density=cots[0], F_cot_rgb=cots[1], F_cot_sem=cots[2], F_semantic_fn=f1.semantic_fn(pos))
+    for n, gg in zip(names, gr):
+        arrs["Fg_" + n] = gg
+    p1 = model.proposal_networks[0].fields[1]
+    pd = p1.density_fn(pos)
+    cot = torch.rand(pd.shape, generator=g)
+    gr = torch.autograd.grad((pd * cot).sum(), list(p1.parameters()))
+    arrs.update(Pp_density=pd, Pp_cot=cot)
+    for (n, _), gg in zip(p1.named_parameters(), gr):
+        arrs["Ppg_" + n] = gg
+    sk = model.sky_model.fields[1]
+    so = sk.get_outputs(dirs, app)
+    arrs.update(S_rgb=so[ns.field_heads.FieldHeadNames.RGB], S_sem=so[ns.field_heads.FieldHeadNames.SEMANTICS])
+    # --- whole model, training mode
+    model.train()
+    model.proposal_sampler._anneal = 0.6
+    with PatchedRand([batch["jitter"][0], batch["jitter"][1], batch["jitter"][2]]):
+        out = model(rb)
+    gt = {"rgb": batch["rgb"], "features": batch["features"], "sky": batch["sky"]}
+    ld = model.get_loss_dict(out, gt)
+    total = sum(ld.values())
+    model.zero_grad()
+    total.backward()
+    for k in ["rgb", "accumulation", "depth", "expected_depth", "semantics", "prop_depth_0", "prop_depth_1"]:
+        arrs["T_" + k] = out[k]
+    for i in range(3):
+        arrs[f"T_weights_{i}"] = out["weights_list"][i][..., 0]
+        arrs[f"T_sbins_{i}"] = torch.cat([out["ray_samples_list"][i].spacing_starts[..., 0],
+                                          out["ray_samples_list"][i].spacing_ends[..., -1:, 0]], -1)
+    for k, v in ld.items():
+        arrs["TL_" + k] = v
+    for n, p in model.named_parameters():
+        if n in P:
+            arrs["TG_" + n] = p.grad if p.grad is not None else torch.zeros_like(p)
+    arrs["T_anneal"] = np.array(0.6)
+    # --- whole model, eval mode
+    model.eval()
+    with torch.no_grad():
+        oute = model(_with_meta(_ray_bundle(scene, batch["ray_indices"]), batch))
+        for k in ["rgb", "accumulation", "depth", "expected_depth", "semantics", "dino_rgb"]:
+            arrs["E_" + k] = oute[k]
+        dd = model.get_depth(_with_meta(_ray_bundle(scene, batch["ray_indices"]), batch))
+        arrs["E_get_depth"] = dd["depth"]
+        arrs["E_get_expected_depth"] = dd["expected_depth"]
+        # extraction queries (extract_priors.py:133-138)
+        pts = scene["c2w"][:, :, 3][torch.randint(0, scene["c2w"].shape[0], (150,), generator=g)] + \
+            torch.randn(150, 3, generator=g) * 0.3
+        dl = [p.density_fn(pts).squeeze(-1) for p in model.proposal_networks]
+        dl.append(model.field.density_fn(pts)[0].squeeze(-1))
+        arrs["X_pts"] = pts
+        arrs["X_density_mean"] = torch.stack(dl, 0).mean(0)
+        arrs["X_feats"] = model.field.semantic_fn(pts).clip(0.0, 1.0).to(torch.float16)
+        cm = __import__("importlib").import_module("nerfstudio.utils.colormaps")
+        arrs["X_colors"] = cm.apply_feature_colormap(arrs["X_feats"], scene["dino_to_rgb"])
+    save("model", **arrs)
+
+
+def _with_meta(rb, batch):
+    rb.metadata["video_id"] = batch["video_ids"][:, None]
+    return rb
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "model"]
+    for w in which:
+        globals()["gold_" + w]()

@@ -1,0 +1,312 @@
+"""Pin the CPU oracle (oracle/nerf_oracle.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py) and against SURVEY.md Appendix A known answers.  CPU only."""
+import numpy as np
+import torch
+
+from conftest import model_fixture_setup, t
+from oracle import nerf_oracle as O
+
+F32 = dict(rtol=1e-5, atol=1e-6)
+
+
+def close(a, b, **kw):
+    kw = {**F32, **kw}
+    a = a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    b = t(b) if isinstance(b, np.ndarray) else b
+    torch.testing.assert_close(a.to(b.dtype).reshape(b.shape), b, **kw)
+
+
+# ------------------------------------------------------------------------------ hash grid
+def test_hash_scalings_match_reference(gold_hashgrid):
+    G = gold_hashgrid
+    for tag in ["kat", "cfg2small", "prodsmall", "prop0small", "prop1small", "cfg2_full", "prod_full", "prop0_full", "prop1_full"]:
+        L, base, mx, _, _ = G[tag + "_meta"]
+        sc = O.hash_scalings(int(L), int(base), int(mx))
+        assert torch.equal(sc, t(G[tag + "_scalings"])), tag
+    # values quoted in SURVEY.md 8a row a7
+    assert O.hash_scalings(16, 16, 2048).tolist() == [16, 22, 30, 42, 58, 80, 111, 153, 212, 294, 406, 561, 776, 1072, 1482, 2047]
+    assert O.hash_scalings(10, 16, 16384).tolist() == [16, 34, 74, 161, 348, 752, 1625, 3511, 7584, 16384]
+
+
+def test_hash_encode_known_answers(gold_hashgrid):
+    G = gold_hashgrid
+    out, idx = O.hash_encode(t(G["kat_x"]), t(G["kat_table"]), t(G["kat_scalings"]), 5, return_indices=True)
+    close(out[0], np.array([0.032, 0.033, 0.064, 0.065], np.float32))
+    close(out[1], np.array([0.031488001, 0.032488003, 0.101247981, 0.102247983], np.float32))
+    assert idx[0].tolist() == [[16] * 8, [32] * 8]
+    assert idx[1, 0, 0] == 3 and idx[1, 1, 0] == 58 and idx[1, 0, 6] == 10 and idx[1, 1, 6] == 33
+    assert idx[1, 0, 1] == 20 and idx[1, 1, 1] == 43
+
+
+def test_hash_encode_matches_reference(gold_hashgrid):
+    G = gold_hashgrid
+    for tag in ["kat", "cfg2small", "prodsmall", "prop0small", "prop1small"]:
+        l2t = int(G[tag + "_meta"][3])
+        table = t(G[tag + "_table"]).clone().requires_grad_(True)
+        out, idx = O.hash_encode(t(G[tag + "_x"]), table, t(G[tag + "_scalings"]), l2t, return_indices=True)
+        assert torch.equal(idx, t(G[tag + "_idx"])), tag  # integer work: bit exact
+        assert torch.equal(out.detach(), t(G[tag + "_out"])), tag  # same ATen ops in the same order -> bit exact on CPU
+        (g,) = torch.autograd.grad((out * t(G[tag + "_cot"])).sum(), table)
+        close(g, G[tag + "_grad_table"])
+
+
+def test_hash_index_full_size(gold_hashgrid):
+    G = gold_hashgrid
+    for tag in ["cfg2_full", "prod_full", "prop0_full", "prop1_full"]:
+        l2t = int(G[tag + "_meta"][3])
+        sc = t(G[tag + "_scalings"])
+        dummy = torch.zeros((1 << l2t) * sc.numel(), 1)
+        _, idx = O.hash_encode(t(G[tag + "_x"]), dummy, sc, l2t, return_indices=True)
+        assert torch.equal(idx, t(G[tag + "_idx"])), tag
+
+
+# ------------------------------------------------------------------------------ small ops
+def test_contraction(gold_ops):
+    G = gold_ops
+    u, sel = O.normalize_contract(t(G["p"]), t(G["aabb"]))
+    assert torch.equal(sel, t(G["sel"]))
+    assert torch.equal(u, t(G["u"]))
+    # Appendix A.2 KAT
+    q = torch.tensor([[2.0, -4.0, 1.0]])
+    mag = q.abs().amax(-1, keepdim=True)
+    close((2 - 1 / mag) * (q / mag), np.array([[0.875, -1.75, 0.4375]], np.float32))
+    close(t(G["contract_kat"]), np.array([[0.875, -1.75, 0.4375]], np.float32))
+
+
+def test_sh4(gold_ops):
+    G = gold_ops
+    sh = O.sh4_of_direction(t(G["d"]))
+    assert torch.equal(sh, t(G["sh"]))
+    kat = [0.28209481, 0.24430126, 0.48860252, 0.24430126, 0.27313712, 0.54627424, 0.63078308, 0.54627424, 0, 0.14751090,
+           0.72265285, 0.91409159, 0.74635267, 0.91409159, 0, -0.14751090]
+    close(sh[0], np.array(kat, np.float32), atol=1e-7)
+
+
+def test_trunc_exp(gold_ops):
+    G = gold_ops
+    x = t(G["te_x"]).clone().requires_grad_(True)
+    y = O.trunc_exp(x)
+    assert torch.equal(y.detach(), t(G["te_y"]))
+    (g,) = torch.autograd.grad((y * t(G["te_cot"])).sum(), x)
+    assert torch.equal(g, t(G["te_gx"]))
+
+
+def test_mlp_all_shapes(gold_ops):
+    G = gold_ops
+    for tag in ["base", "sem", "rgb", "prop", "skyrgb", "skysem", "base_prod", "tiny"]:
+        n = len([k for k in G if k.startswith(f"mlp_{tag}_W")])
+        layers = [(t(G[f"mlp_{tag}_W{i}"]).clone().requires_grad_(True), t(G[f"mlp_{tag}_b{i}"]).clone().requires_grad_(True))
+                  for i in range(n)]
+        x = t(G[f"mlp_{tag}_x"]).clone().requires_grad_(True)
+        y = O.mlp_forward(x, layers, out_act="sigmoid" if int(G[f"mlp_{tag}_sigmoid"]) else None)
+        close(y, G[f"mlp_{tag}_y"])
+        gr = torch.autograd.grad((y * t(G[f"mlp_{tag}_cot"])).sum(), [x] + [p for wb in layers for p in wb])
+        close(gr[0], G[f"mlp_{tag}_gx"])
+        for i in range(n):
+            close(gr[1 + 2 * i], G[f"mlp_{tag}_gW{i}"], rtol=1e-4, atol=1e-5)
+            close(gr[2 + 2 * i], G[f"mlp_{tag}_gb{i}"], rtol=1e-4, atol=1e-5)
+
+
+def test_router(gold_ops):
+    G = gold_ops
+    assert torch.equal(O.route(t(G["route_pts"]), t(G["route_centroids"])), t(G["route_assign"]))
+
+
+# ------------------------------------------------------------------------------ rays, samplers, renderers
+def test_ray_generation(gold_sampling):
+    G = gold_sampling
+    o, d, pa, dn = O.generate_rays(t(G["ray_indices"]), t(G["c2w"]), t(G["fx"]), t(G["fy"]), t(G["cx"]), t(G["cy"]))
+    close(o, G["origins"])
+    close(d, G["directions"], atol=1e-7)
+    close(pa, G["pixel_area"], rtol=1e-4, atol=1e-12)
+    close(dn, G["directions_norm"])
+
+
+def _euclid(G, mode, bins):
+    R = bins.shape[0]
+    nears = torch.full((R, 1), 0.005 if mode == "train" else 0.0)
+    fars = torch.full((R, 1), 50.0)
+    return O.s_to_euclid(bins, nears, fars, 5.0)
+
+
+def test_spaced_sampler(gold_sampling):
+    G = gold_sampling
+    for mode in ("train", "eval"):
+        jit = t(G[f"sp_{mode}_jitter"]) if mode == "train" else None
+        bins = O.spaced_bins(G["ray_indices"].shape[0], 128, jit)
+        close(bins[:, :-1], G[f"sp_{mode}_sstarts"], atol=1e-7)
+        close(bins[:, 1:], G[f"sp_{mode}_sends"], atol=1e-7)
+        eu = _euclid(G, mode, bins)
+        close(eu[:, :-1], G[f"sp_{mode}_starts"])
+        close(eu[:, 1:], G[f"sp_{mode}_ends"])
+        mid = (eu[:, :-1] + eu[:, 1:]) / 2
+        pos = t(G["origins"])[:, None] + t(G["directions"])[:, None] * mid[..., None]
+        close(pos, G[f"sp_{mode}_positions"])
+    # Appendix A.5
+    bins = O.spaced_bins(1, 8, None)
+    eu = O.s_to_euclid(bins, torch.zeros(1, 1), torch.full((1, 1), 50.0), 5.0)
+    close(eu[:, :-1], G["kat_sp_starts"])
+    close(eu[0, :-1], np.array([0, 1.1875, 2.375, 3.5625, 4.75, 6.15384626, 8.69565105, 14.81481552], np.float32))
+    close(eu[0, -1], np.array(49.99999237, np.float32))
+    # Appendix A.6
+    w = torch.zeros(1, 8)
+    w[0, 2] = 1.0
+    nb = O.pdf_resample(w, bins, 4, None)
+    eu2 = O.s_to_euclid(nb, torch.zeros(1, 1), torch.full((1, 1), 50.0), 5.0)
+    close(eu2[:, :-1], G["kat_pdf_starts"])
+    close(eu2[:, 1:], G["kat_pdf_ends"])
+    close(eu2[0, :-1], np.array([2.47846532, 2.73242569, 2.98638606, 3.24034643], np.float32))
+
+
+def test_weights_scan(gold_sampling):
+    G = gold_sampling
+    for mode in ("train", "eval"):
+        deltas = t(G[f"sp_{mode}_ends"]) - t(G[f"sp_{mode}_starts"])
+        sigma = t(G[f"w_{mode}_sigma"]).clone().requires_grad_(True)
+        w = O.weights_from_density(deltas, sigma)
+        close(w, G[f"w_{mode}_weights"])
+        (g,) = torch.autograd.grad((w * t(G[f"w_{mode}_cot"])).sum(), sigma)
+        close(g, G[f"w_{mode}_gsigma"])
+    # Appendix A.4
+    w = O.weights_from_density(torch.tensor([[0.1, 0.2, 0.3, 0.4]]), torch.tensor([[1.0, 2.0, 0.0, 5.0]]))
+    close(w[0], np.array([0.09516257, 0.29830676, 0, 0.52444565], np.float32))
+    steps = torch.tensor([[0.05, 0.2, 0.45, 0.8]])
+    close(O.expected_depth(w, steps), np.array([[0.52725583]], np.float32))
+    close(O.threshold_depth(w, steps), np.array([[0.8]], np.float32))
+
+
+def test_pdf_sampler(gold_sampling):
+    G = gold_sampling
+    for mode in ("train", "eval"):
+        bins = torch.cat([t(G[f"sp_{mode}_sstarts"]), t(G[f"sp_{mode}_sends"])[:, -1:]], -1)
+        w = torch.pow(t(G[f"w_{mode}_weights"]), float(G[f"pdf_{mode}_anneal"]))
+        jit = t(G[f"pdf_{mode}_jitter"]) if mode == "train" else None
+        nb = O.pdf_resample(w, bins, 64, jit)
+        close(nb[:, :-1], G[f"pdf_{mode}_sstarts"], atol=1e-7)
+        close(nb[:, 1:], G[f"pdf_{mode}_sends"], atol=1e-7)
+        eu = _euclid(G, mode, nb)
+        close(eu[:, :-1], G[f"pdf_{mode}_starts"])
+        close(eu[:, 1:], G[f"pdf_{mode}_ends"])
+
+
+def test_renderers(gold_sampling):
+    G = gold_sampling
+    for mode in ("train", "eval"):
+        st, en = t(G[f"pdf_{mode}_starts"]), t(G[f"pdf_{mode}_ends"])
+        w = O.weights_from_density(en - st, t(G[f"r_{mode}_sigma"]))
+        close(w, G[f"r_{mode}_w"])
+        steps = (st + en) / 2
+        close((w[..., None] * t(G[f"r_{mode}_rgb_in"])).sum(1), G[f"r_{mode}_rgb"])
+        close(w.sum(-1, keepdim=True), G[f"r_{mode}_acc"])
+        assert torch.equal(O.threshold_depth(w, steps), t(G[f"r_{mode}_depth"]))
+        close(O.expected_depth(w, steps), G[f"r_{mode}_expdepth"])
+        close((w[..., None] * t(G[f"r_{mode}_sem_in"])).sum(1), G[f"r_{mode}_sem"])
+
+
+# ------------------------------------------------------------------------------ losses
+def test_losses(gold_losses):
+    G = gold_losses
+    raw = [t(G[f"w{i}_raw"]).clone().requires_grad_(True) for i in range(3)]
+    wl = [w / w.sum(-1, keepdim=True) * 0.9 for w in raw]
+    bl = [t(G[f"bins{i}"]) for i in range(3)]
+    il = O.interlevel_loss_zaa(wl, bl, (0.03, 0.003))
+    close(il, G["interlevel"])
+    g = torch.autograd.grad(il, raw[:2], retain_graph=True)
+    close(g[0], G["g_interlevel_w0"], rtol=1e-4)
+    close(g[1], G["g_interlevel_w1"], rtol=1e-4)
+    dl = O.distortion_loss(bl[2], wl[2])
+    close(dl, G["distortion"])
+    (g2,) = torch.autograd.grad(dl, raw[2])
+    close(g2, G["g_distortion_w2"], rtol=1e-4)
+    acc = t(G["acc"]).clone().requires_grad_(True)
+    sl = O.sky_loss(acc, t(G["sky_mask"]))
+    close(sl, G["sky_loss"])
+    close(torch.autograd.grad(sl, acc)[0], G["g_sky"])
+    pred = t(G["sem_pred"]).clone().requires_grad_(True)
+    sm = O.semantic_loss(pred, t(G["sem_tgt"]))
+    close(sm, G["sem_loss"])
+    close(torch.autograd.grad(sm, pred)[0], G["g_sem"])
+
+
+# ------------------------------------------------------------------------------ fields + whole model
+def test_fields(gold_model):
+    G = gold_model
+    cfg, scene, P, _ = model_fixture_setup(G)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    pos, dirs, app = t(G["F_pos"]), t(G["F_dirs"]), t(G["F_app"])
+    dens, emb = O.main_density(Pg, cfg, 1, pos, scene["aabbs"][1])
+    rgb, sem = O.main_heads(Pg, cfg, 1, dirs, emb, app)
+    close(dens, G["F_density"], rtol=1e-4)
+    close(emb, G["F_embedding"], rtol=1e-4, atol=1e-5)
+    close(rgb, G["F_rgb"], rtol=1e-4)
+    close(sem, G["F_sem"], rtol=1e-4, atol=1e-5)
+    close(sem, G["F_semantic_fn"], rtol=1e-4, atol=1e-5)
+    s = (dens * t(G["F_cot_density"])[:, 0]).sum() + (rgb * t(G["F_cot_rgb"])).sum() + (sem * t(G["F_cot_sem"])).sum()
+    s.backward()
+    for k in G:
+        if k.startswith("Fg_"):
+            name = "field.fields.1." + k[3:]
+            close(Pg[name].grad, G[k], rtol=2e-4, atol=2e-5)
+    pd = O.prop_density(Pg, cfg, 0, 1, pos, scene["aabbs"][1])
+    close(pd, G["Pp_density"], rtol=1e-4)
+    for p in Pg.values():
+        p.grad = None
+    (pd * t(G["Pp_cot"])[:, 0]).sum().backward()
+    for k in G:
+        if k.startswith("Ppg_"):
+            name = "proposal_networks.0.fields.1." + k[4:]
+            close(Pg[name].grad, G[k], rtol=2e-4, atol=2e-5)
+    srgb, ssem = O.sky_outputs(P, 1, dirs, app)
+    close(srgb, G["S_rgb"])
+    close(ssem, G["S_sem"], atol=1e-5)
+
+
+def test_whole_model_training_step(gold_model):
+    G = gold_model
+    cfg, scene, P, batch = model_fixture_setup(G)
+    L, out, grads = O.train_step(P, cfg, scene, batch, anneal=float(G["T_anneal"]))
+    for i in range(3):
+        close(out["bins_list"][i], G[f"T_sbins_{i}"], atol=2e-6)
+        close(out["weights_list"][i], G[f"T_weights_{i}"], rtol=1e-4, atol=1e-6)
+    for k in ["rgb", "accumulation", "expected_depth", "semantics"]:
+        close(out[k], G["T_" + k], rtol=1e-4, atol=1e-5)
+    for k in ["depth", "prop_depth_0", "prop_depth_1"]:
+        close(out[k], G["T_" + k], rtol=1e-5, atol=1e-6)
+    for k, v in L.items():
+        close(v, G["TL_" + k], rtol=1e-4, atol=1e-7)
+    n_checked = 0
+    for k in G:
+        if k.startswith("TG_"):
+            ref = t(G[k])
+            tol = 2e-4 * float(ref.abs().max()) + 1e-7
+            close(grads[k[3:]], ref, rtol=2e-3, atol=tol)
+            n_checked += 1
+    assert n_checked == len(P)
+
+
+def test_whole_model_eval_and_extraction(gold_model):
+    G = gold_model
+    cfg, scene, P, batch = model_fixture_setup(G)
+    with torch.no_grad():
+        out = O.model_forward(P, cfg, scene, batch, training=False, anneal=float(G["T_anneal"]))  # sampler keeps its anneal in eval
+    for k in ["rgb", "accumulation", "expected_depth", "semantics"]:
+        close(out[k], G["E_" + k], rtol=1e-4, atol=1e-5)
+    close(out["depth"], G["E_depth"])
+    close(out["depth"], G["E_get_depth"])
+    close(out["expected_depth"], G["E_get_expected_depth"], rtol=1e-4)
+    close(O.feature_colormap(out["semantics"], scene["dino_to_rgb"]), G["E_dino_rgb"], rtol=1e-4, atol=1e-5)
+    dens, feats = O.prior_query(P, cfg, scene, t(G["X_pts"]))
+    close(dens, G["X_density_mean"], rtol=1e-4)
+    assert feats.dtype == torch.float16
+    d = (feats.float() - t(G["X_feats"]).float()).abs().max()
+    assert d <= 2 ** -10, d  # at most one fp16 ulp in [0,1]
+    close(O.feature_colormap(t(G["X_feats"]), scene["dino_to_rgb"]).float(), G["X_colors"].astype(np.float32), rtol=2e-3, atol=2e-3)
+
+
+def test_voxel_index_rule():
+    pts = torch.tensor([[0.0, 0.0, 0.0], [0.39, 0.0, -0.01], [0.41, 0.8, 1.2], [-0.2, -0.2, -0.2]])
+    mn = pts.min(0).values - 1.0
+    idx = O.voxel_index(pts, 0.4, mn)
+    ref = np.floor((pts.double().numpy() - (mn.double().numpy() - 0.2)) / 0.4).astype(np.int64)
+    assert np.array_equal(idx.numpy(), ref)
+    assert (idx >= 0).all()
