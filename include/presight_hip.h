@@ -1,0 +1,101 @@
+/* presight_hip.h — C ABI of libpresight_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the NeRF prior-builder hot path of PreSight (ray sampling -> multires hash
+ * grid -> tiny MLP -> volumetric rendering, forward and backward, plus the dense field query used
+ * for prior extraction).  The reference reaches this functionality through nerfstudio's operator
+ * seam: the `tcnn_encoding` backend object of HashEncoding / SHEncoding / MLP selected by the
+ * `implementation` string (ns/field_components/encodings.py:288-310,694-706, mlp.py:100-136), and
+ * through plain torch ops for samplers/renderers.  A maintainer binds these symbols with ctypes
+ * (see INTEGRATION.md); no torch types cross the boundary.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; buffers are caller-allocated
+ *     (torch caching allocator), contiguous, fp32 unless stated otherwise; no ownership transfer
+ *   - `stream` is a hipStream_t; all work is asynchronous on it, no host synchronisation inside
+ *   - return value 0 = ok, non-zero = error (ps_last_error() gives the text); callers raise
+ *   - "ns/" = /root/reference/nerfstudio-0.3.3/nerfstudio
+ */
+#ifndef PRESIGHT_HIP_H
+#define PRESIGHT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int ps_abi_version(void);
+const char* ps_last_error(void);
+int ps_device_info(int* cu_count, int* wave_size, char* arch /*host*/, int arch_len);
+
+/* ---- a7 HashEncoding (torch-fallback semantics), ns/field_components/encodings.py:324-384 ------
+ * x [N,3]; table [L*2^log2T, F] level-major; scalings [L] (floor(min_res*g^l), fp32); out [N, L*F]. */
+int ps_hashgrid_fwd(const float* x, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
+                    float* out, void* stream);
+/* dtable += d(out)/d(table)^T dout   (fp32 atomics; dtable must be pre-zeroed or hold the running grad) */
+int ps_hashgrid_bwd(const float* x, const float* dout, const float* scalings, int L, int F, int log2T, int64_t N,
+                    float* dtable, void* stream);
+/* idx [N, L, 8] int64: the 8 corner rows per level in the reference's corner order (encodings.py:354-361) */
+int ps_hashgrid_indices(const float* x, const float* scalings, int L, int log2T, int64_t N, int64_t* idx, void* stream);
+
+/* ---- a8 MLP, ns/field_components/mlp.py:138-174 ------------------------------------------------
+ * Supported shapes: see ps_mlp_shape_supported.  Weights are used in a packed "fragment order":
+ *   packed = [forward block of each layer][transposed block of each layer]   (ps_mlp_sizes)
+ * built from the torch-layout tensors by one ps_mlp_pack_layer call per layer. */
+int ps_mlp_shape_supported(int in_dim, int hidden, int out_dim, int num_layers);
+int ps_mlp_sizes(int in_dim, int hidden, int out_dim, int num_layers, int64_t N, int64_t* packed_floats /*host*/,
+                 int64_t* grad_floats /*host*/, int* n_parts /*host*/);
+/* W [out,in], b [out]; colmap int32 [KS*4] (input column per (k-step, lane group), -1 = pad) */
+int ps_mlp_pack_layer(const float* W, const float* b, int out_dim, int in_dim, const int* colmap, int KS, int NB,
+                      float* fw_block, float* wt_block, void* stream);
+/* gW [out,in] += sum_parts dW ; gb [out] += sum_parts db */
+int ps_mlp_unpack_grad_layer(const float* gpart, int n_parts, int64_t part_stride, int out_dim, int in_dim,
+                             const int* colmap, int KS, int NB, float* gW, float* gb, void* stream);
+/* y [N,out] = MLP(x [N,in]); out_act: 0 none, 1 sigmoid */
+int ps_mlp_fwd(const float* x, const float* packed, float* y, int64_t N, int in_dim, int hidden, int out_dim,
+               int num_layers, int out_act, void* stream);
+/* recomputes the hidden activations from x; dx may be NULL; gpart [n_parts, grad_floats] is overwritten */
+int ps_mlp_bwd(const float* x, const float* dy, const float* packed, float* dx, float* gpart, int64_t N, int in_dim,
+               int hidden, int out_dim, int num_layers, int out_act, void* stream);
+
+/* ---- a6 / a10 / a5 / a4 point-wise operators --------------------------------------------------- */
+/* ns/fields/PreSight/ingp_field.py:169-177: aabb [2,3]; u [M,3]; sel uint8 [M] (may be NULL) */
+int ps_contract(const float* p, const float* aabb, int64_t M, int contract, float* u, uint8_t* sel, void* stream);
+/* SH degree 4 of (d+1)/2, ns/utils/math.py:27-79 via ns/fields/base_field.py:136-142; out [M,16] */
+int ps_sh4(const float* dirs, int64_t M, float* out, void* stream);
+/* argmin_k ||p - c_k||, ns/fields/PreSight/ingp_field_ms.py:97; assign int32 [M] */
+int ps_route(const float* p, int64_t M, const float* centroids, int K, int32_t* assign, void* stream);
+/* o + d*(start+end)/2, ns/cameras/rays.py:49-58; ebins [R,S+1]; pos [R*S,3] */
+int ps_sample_positions(const float* origins, const float* dirs, const float* ebins, int64_t R, int S, float* pos,
+                        void* stream);
+
+/* ---- a1 / a3 / a12 / a13 / a15 per-ray operators ----------------------------------------------- */
+/* ns/cameras/cameras.py:497-880 (pinhole): ray_indices int64 [R,3] = (cam,row,col); c2w [C,3,4] */
+int ps_generate_rays(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy, const float* cx,
+                     const float* cy, int64_t R, float* origins, float* dirs, float* pixel_area, float* dir_norm,
+                     void* stream);
+/* ns/model_components/ray_samplers.py:78-128 with the piecewise spacing of nerfacto_nusc_ms.py:312-317.
+ * jitter [R] (training, single jitter) or NULL (eval); sbins/ebins [R,S+1] */
+int ps_spaced_bins(const float* jitter, int64_t R, int S, float near, float far, float thr, float* sbins, float* ebins,
+                   void* stream);
+/* ns/cameras/rays.py:128-150; sigma/weights [R,S] */
+int ps_weights_fwd(const float* ebins, const float* sigma, int64_t R, int S, float* weights, void* stream);
+int ps_weights_bwd(const float* ebins, const float* sigma, const float* dweights, int64_t R, int S, float* dsigma,
+                   void* stream);
+/* ns/model_components/ray_samplers.py:305-372 (include_original=False, single jitter); weights are raised
+ * to `anneal` first (ray_samplers.py:597).  new_* [R, n_new+1] */
+int ps_pdf_resample(const float* weights, const float* sbins, const float* jitter, int64_t R, int S, int n_new,
+                    float anneal, float pad, float eps, float near, float far, float thr, float* new_sbins,
+                    float* new_ebins, void* stream);
+/* ns/model_components/renderers.py:70-117,286-383 + nerfacto_nusc_ms.py:530.  rgb_s [R,S,3], sem_s [R,S,C];
+ * outputs may be NULL; minmax[2] (pre-set to {+inf, 0}) receives the batch-global min/max sample midpoint */
+int ps_composite_fwd(const float* weights, const float* ebins, const float* rgb_s, const float* sem_s, int64_t R, int S,
+                     int C, float threshold, float* rgb, float* acc, float* depth, float* exp_depth, float* sem,
+                     float* minmax, void* stream);
+int ps_clip(float* v, int64_t n, const float* minmax, void* stream);
+int ps_composite_bwd(const float* weights, const float* ebins, const float* rgb_s, const float* sem_s, const float* d_rgb,
+                     const float* d_acc, const float* d_sem, const float* d_exp, int64_t R, int S, int C,
+                     float* d_weights, float* d_rgb_s, float* d_sem_s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

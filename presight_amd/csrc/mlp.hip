@@ -1,0 +1,299 @@
+// Operator-level fused MLP (MLP.forward / backward of ns/field_components/mlp.py:155-174) on the
+// exact-fp32 matrix cores, plus the weight pack / gradient unpack kernels shared with the fused
+// field kernels.  See mlp_core.hpp for the register/fragment layout.
+#include "common.hpp"
+#include "mlp_core.hpp"
+
+namespace {
+
+using namespace ps;
+
+// ------------------------------------------------------------------------------------------
+// pack: torch layout W[out][in], b[out]  ->  forward fragments + transposed fragments
+// colmap[t*4+g] = torch input column supplied by lane group g at k-step t (-1 = zero pad)
+// ------------------------------------------------------------------------------------------
+__global__ void mlp_pack_layer_kernel(const float* __restrict__ W, const float* __restrict__ b, int out_dim, int in_dim,
+                                      const int* __restrict__ colmap, int KS, int NB, float* __restrict__ fw_block,
+                                      float* __restrict__ wt_block) {
+  const int IB = (KS + 3) / 4, KSO = NB * 4;
+  const int n_bias = NB * 16, n_wf = NB * KS * 64, n_wt = IB * KSO * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_bias + n_wf + n_wt; i += gridDim.x * blockDim.x) {
+    if (i < n_bias) {
+      fw_block[i] = (i < out_dim) ? b[i] : 0.0f;
+    } else if (i < n_bias + n_wf) {
+      const int e = i - n_bias;
+      const int lane = e & 63, t = (e >> 6) % KS, nb = (e >> 6) / KS;
+      const int o = 16 * nb + (lane & 15);
+      const int col = colmap[t * 4 + (lane >> 4)];
+      fw_block[i] = (o < out_dim && col >= 0 && col < in_dim) ? W[(size_t)o * in_dim + col] : 0.0f;
+    } else {
+      const int e = i - n_bias - n_wf;
+      const int lane = e & 63, t = (e >> 6) % KSO, ib = (e >> 6) / KSO;
+      const int o = 16 * (t >> 2) + 4 * (lane >> 4) + (t & 3);
+      const int row = lane & 15;
+      const int tin = 4 * ib + (row & 3);
+      const int col = (tin < KS) ? colmap[tin * 4 + (row >> 2)] : -1;
+      wt_block[e] = (o < out_dim && col >= 0 && col < in_dim) ? W[(size_t)o * in_dim + col] : 0.0f;
+    }
+  }
+}
+
+// unpack: sum the per-workgroup partial gradient blocks and add into torch-layout grads
+__global__ void mlp_unpack_grad_layer_kernel(const float* __restrict__ gpart, int n_parts, int64_t part_stride, int out_dim,
+                                             int in_dim, const int* __restrict__ colmap, int KS, int NB,
+                                             float* __restrict__ gW, float* __restrict__ gb) {
+  const int IB = (KS + 3) / 4;
+  const int n_w = NB * IB * 256, n_b = NB * 16;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_w + n_b; i += gridDim.x * blockDim.x) {
+    float* dst = nullptr;
+    if (i < n_w) {
+      const int lane = i & 63, r = (i >> 6) & 3, ib = (i >> 8) % IB, ob = (i >> 8) / IB;
+      const int o = 16 * ob + 4 * (lane >> 4) + r;
+      const int row = lane & 15;
+      const int tin = 4 * ib + (row & 3);
+      const int col = (tin < KS) ? colmap[tin * 4 + (row >> 2)] : -1;
+      if (o < out_dim && col >= 0 && col < in_dim) dst = gW + (size_t)o * in_dim + col;
+    } else {
+      const int o = i - n_w;
+      if (o < out_dim) dst = gb + o;
+    }
+    if (dst == nullptr) continue;
+    float s = 0.f;
+    for (int p = 0; p < n_parts; ++p) s += gpart[(size_t)p * part_stride + i];
+    *dst += s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// operator-level forward / backward
+// ------------------------------------------------------------------------------------------
+constexpr int ACT_NONE = 0, ACT_SIGMOID = 1;
+
+template <class M, int PB>
+__device__ __forceinline__ void load_rows_linear(const float* __restrict__ x, int64_t first, int64_t N, int dim,
+                                                 float (&v)[PB][M::KS0]) {
+  const int lane = ps_lane(), j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int64_t p = first + pb * 16 + j;
+#pragma unroll
+    for (int t = 0; t < M::KS0; ++t) {
+      const int col = 4 * t + g;
+      v[pb][t] = (p < N && col < dim) ? x[p * dim + col] : 0.0f;
+    }
+  }
+}
+
+template <class M, int PB, int ACT>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ packed,
+                                                      float* __restrict__ y, int64_t N, int in_dim, int out_dim) {
+  __shared__ __attribute__((aligned(16))) float lds[M::FW];
+  for (int i = threadIdx.x * 4; i < M::FW; i += 256 * 4)
+    *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(packed + i);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t first = tile * 16 * PB;
+    float xin[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
+    load_rows_linear<M, PB>(x, first, N, in_dim, xin);
+    mlp_forward<M, PB>(lds, xin, h1, h2, z);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t p = first + pb * 16 + j;
+#pragma unroll
+      for (int t = 0; t < M::NBO * 4; ++t) {
+        const int col = 16 * (t >> 2) + 4 * g + (t & 3);
+        float v = z[pb][t];
+        if (ACT == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        if (p < N && col < out_dim) y[p * out_dim + col] = v;
+      }
+    }
+  }
+}
+
+template <class M, int PB, int ACT, bool WANT_DX>
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ packed, float* __restrict__ dx,
+                                                      float* __restrict__ gpart, int64_t N, int in_dim, int out_dim) {
+  constexpr int SCR = M::SCRATCH_ROWS * kScratchLd;
+  __shared__ __attribute__((aligned(16))) float lds[M::GPACKED + 4 * SCR];
+  float* gacc = lds;
+  for (int i = threadIdx.x; i < M::GPACKED; i += 256) gacc[i] = 0.0f;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  float* scratch = lds + M::GPACKED + wave * SCR;
+  const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t first = tile * 16 * PB;
+    float xin[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
+    load_rows_linear<M, PB>(x, first, N, in_dim, xin);
+    mlp_forward<M, PB>(packed, xin, h1, h2, z);
+    // dz = dy (* sigmoid') in D layout
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t p = first + pb * 16 + j;
+#pragma unroll
+      for (int t = 0; t < M::NBO * 4; ++t) {
+        const int col = 16 * (t >> 2) + 4 * g + (t & 3);
+        float d = (p < N && col < out_dim) ? dy[p * out_dim + col] : 0.0f;
+        if (ACT == ACT_SIGMOID) {
+          const float s = 1.0f / (1.0f + expf(-z[pb][t]));
+          d *= s * (1.0f - s);
+        }
+        z[pb][t] = d;
+      }
+    }
+    float dxin[PB][M::L0::IB * 4];
+    mlp_backward<M, PB, WANT_DX>(packed, scratch, gacc, xin, h1, h2, z, dxin);
+    if constexpr (WANT_DX) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j;
+#pragma unroll
+        for (int t = 0; t < M::KS0; ++t) {
+          const int col = 4 * t + g;
+          if (p < N && col < in_dim) dx[p * in_dim + col] = dxin[pb][t];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* out = gpart + (size_t)blockIdx.x * M::GPACKED;
+  for (int i = threadIdx.x; i < M::GPACKED; i += 256) out[i] = gacc[i];
+}
+
+struct MlpShape {
+  int ks0, hb, nbo, nl;
+};
+
+template <class M>
+int launch_fwd(const float* x, const float* packed, float* y, int64_t N, int in_dim, int out_dim, int act, hipStream_t s) {
+  constexpr int PB = 4;
+  const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
+  int grid = (int)((tiles + 3) / 4);
+  if (grid > 256 * 2) grid = 256 * 2;
+  if (grid < 1) grid = 1;
+  if (act == ACT_SIGMOID)
+    mlp_fwd_kernel<M, PB, ACT_SIGMOID><<<grid, 256, 0, s>>>(x, packed, y, N, in_dim, out_dim);
+  else
+    mlp_fwd_kernel<M, PB, ACT_NONE><<<grid, 256, 0, s>>>(x, packed, y, N, in_dim, out_dim);
+  PS_CHECK_LAUNCH();
+}
+
+template <class M>
+int bwd_grid(int64_t N) {
+  constexpr int PB = 2;
+  const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
+  int grid = (int)((tiles + 3) / 4);
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  return grid;
+}
+
+template <class M>
+int launch_bwd(const float* x, const float* dy, const float* packed, float* dx, float* gpart, int64_t N, int in_dim,
+               int out_dim, int act, hipStream_t s) {
+  constexpr int PB = 2;
+  const int grid = bwd_grid<M>(N);
+  if (dx != nullptr) {
+    if (act == ACT_SIGMOID)
+      mlp_bwd_kernel<M, PB, ACT_SIGMOID, true><<<grid, 256, 0, s>>>(x, dy, packed, dx, gpart, N, in_dim, out_dim);
+    else
+      mlp_bwd_kernel<M, PB, ACT_NONE, true><<<grid, 256, 0, s>>>(x, dy, packed, dx, gpart, N, in_dim, out_dim);
+  } else {
+    if (act == ACT_SIGMOID)
+      mlp_bwd_kernel<M, PB, ACT_SIGMOID, false><<<grid, 256, 0, s>>>(x, dy, packed, dx, gpart, N, in_dim, out_dim);
+    else
+      mlp_bwd_kernel<M, PB, ACT_NONE, false><<<grid, 256, 0, s>>>(x, dy, packed, dx, gpart, N, in_dim, out_dim);
+  }
+  PS_CHECK_LAUNCH();
+}
+
+// shapes used by the PreSight fields + the cfg-1 tiny variants
+#define PS_MLP_SHAPES(X) \
+  X(8, 4, 5, 2)          \
+  X(10, 4, 5, 2)         \
+  X(1, 2, 5, 2)          \
+  X(16, 4, 4, 3)         \
+  X(12, 4, 1, 3)         \
+  X(12, 2, 1, 3)         \
+  X(2, 4, 1, 2)          \
+  X(1, 2, 1, 2)          \
+  X(8, 2, 1, 3)          \
+  X(4, 2, 4, 3)
+
+}  // namespace
+
+extern "C" int ps_mlp_shape_supported(int in_dim, int hidden, int out_dim, int num_layers) {
+  const int ks0 = (in_dim + 3) / 4, hb = hidden / 16, nbo = (out_dim + 15) / 16;
+  if (hidden % 16 != 0) return 0;
+#define X(a, b, c, d) \
+  if (ks0 == a && hb == b && nbo == c && num_layers == d) return 1;
+  PS_MLP_SHAPES(X)
+#undef X
+  return 0;
+}
+
+// sizes (in floats) of the packed parameter block, of one partial gradient block, and the number of
+// partial blocks ps_mlp_bwd writes for N rows
+extern "C" int ps_mlp_sizes(int in_dim, int hidden, int out_dim, int num_layers, int64_t N, int64_t* packed_floats,
+                            int64_t* grad_floats, int* n_parts) {
+  const int ks0 = (in_dim + 3) / 4, hb = hidden / 16, nbo = (out_dim + 15) / 16;
+#define X(a, b, c, d)                                               \
+  if (ks0 == a && hb == b && nbo == c && num_layers == d) {         \
+    using M = ps::MlpT<a, b, c, d>;                                 \
+    *packed_floats = M::PACKED;                                     \
+    *grad_floats = M::GPACKED;                                      \
+    *n_parts = bwd_grid<M>(N);                                      \
+    return 0;                                                       \
+  }
+  PS_MLP_SHAPES(X)
+#undef X
+  ps_set_error("ps_mlp_sizes: unsupported MLP shape");
+  return -2;
+}
+
+extern "C" int ps_mlp_pack_layer(const float* W, const float* b, int out_dim, int in_dim, const int* colmap, int KS, int NB,
+                                 float* fw_block, float* wt_block, void* stream) {
+  const int IB = (KS + 3) / 4;
+  const int total = NB * 16 + NB * KS * 64 + IB * NB * 4 * 64;
+  mlp_pack_layer_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(W, b, out_dim, in_dim, colmap, KS, NB, fw_block,
+                                                                              wt_block);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_mlp_unpack_grad_layer(const float* gpart, int n_parts, int64_t part_stride, int out_dim, int in_dim,
+                                        const int* colmap, int KS, int NB, float* gW, float* gb, void* stream) {
+  const int IB = (KS + 3) / 4;
+  const int total = NB * IB * 256 + NB * 16;
+  mlp_unpack_grad_layer_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(gpart, n_parts, part_stride, out_dim,
+                                                                                    in_dim, colmap, KS, NB, gW, gb);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_mlp_fwd(const float* x, const float* packed, float* y, int64_t N, int in_dim, int hidden, int out_dim,
+                          int num_layers, int out_act, void* stream) {
+  if (N == 0) return 0;
+  const int ks0 = (in_dim + 3) / 4, hb = hidden / 16, nbo = (out_dim + 15) / 16;
+#define X(a, b, c, d)                                       \
+  if (ks0 == a && hb == b && nbo == c && num_layers == d)   \
+    return launch_fwd<ps::MlpT<a, b, c, d>>(x, packed, y, N, in_dim, out_dim, out_act, (hipStream_t)stream);
+  PS_MLP_SHAPES(X)
+#undef X
+  ps_set_error("ps_mlp_fwd: unsupported MLP shape");
+  return -2;
+}
+
+extern "C" int ps_mlp_bwd(const float* x, const float* dy, const float* packed, float* dx, float* gpart, int64_t N,
+                          int in_dim, int hidden, int out_dim, int num_layers, int out_act, void* stream) {
+  if (N == 0) return 0;
+  const int ks0 = (in_dim + 3) / 4, hb = hidden / 16, nbo = (out_dim + 15) / 16;
+#define X(a, b, c, d)                                       \
+  if (ks0 == a && hb == b && nbo == c && num_layers == d)   \
+    return launch_bwd<ps::MlpT<a, b, c, d>>(x, dy, packed, dx, gpart, N, in_dim, out_dim, out_act, (hipStream_t)stream);
+  PS_MLP_SHAPES(X)
+#undef X
+  ps_set_error("ps_mlp_bwd: unsupported MLP shape");
+  return -2;
+}

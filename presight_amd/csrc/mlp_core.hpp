@@ -1,0 +1,257 @@
+// Exact-fp32 MFMA building blocks for the tiny MLPs of the NeRF fields (nn.Linear chains,
+// ns/field_components/mlp.py:138-174), written for 64-wide wavefronts.
+//
+// Formulation.  A layer y = W x + b is evaluated "transposed": D = W * X^T with the weights as
+// the MFMA A operand and 16 points as the B operand of v_mfma_f32_16x16x4_f32:
+//     A[i][k]  lane l holds i = l&15 (output neuron in a block of 16), k = l>>4
+//     B[k][j]  lane l holds k = l>>4, j = l&15 (point in a block of 16)
+//     D[r][j]  lane l, reg r holds row 4*(l>>4)+r, column j = l&15
+// With lane = (j, g) = (l&15, l>>4), a lane owns 4 consecutive neurons 4g..4g+3 of every 16-neuron
+// block for "its" point j.  Because a contraction may enumerate k in any order, the D registers of
+// one layer are *directly* the B operands of the next one: k-step t = 4*nb + r pairs the neurons
+// {16*nb + 4*g + r : g = 0..3}.  Activations therefore never leave registers between layers; only
+// the (tiny) weights are re-arranged, once per step, by the pack kernel into "fragment order"
+//     wf[nb][t][lane] = W[16*nb + (lane&15)][colmap(t, lane>>4)]
+// so that every MFMA A operand is one coalesced 256-byte wave load.  `colmap(t, g)` is the torch
+// input column that group g supplies at k-step t; for chained layers it is 16*(t/4)+4*g+t%4.
+//
+// Backward.  dX^T = W^T dY^T uses the same trick with transposed fragments
+//     wtf[ib][t][lane] = W[16*(t/4) + 4*(lane>>4) + t%4][colmap(4*ib + (lane&3), (lane&15)>>2)]
+// and yields dX in exactly the register layout the forward input had.  dW = dY^T H contracts over
+// points, which needs "lane = neuron" operands; both tiles take one trip through a small per-wave
+// LDS scratch (written 4 bytes/lane, read back 16 bytes/lane), and the 16x16 dW tiles are
+// accumulated in registers over the wave's points, then added into workgroup-level LDS
+// accumulators (ds_add_f32) and finally written as one partial per workgroup.
+#pragma once
+#include "common.hpp"
+
+namespace ps {
+
+// ---- compile-time description of one layer -------------------------------------------------
+template <int KS_, int NB_>
+struct LayerT {
+  static constexpr int KS = KS_;             // k-steps over the inputs (4 inputs each)
+  static constexpr int NB = NB_;             // 16-neuron output blocks
+  static constexpr int IB = (KS_ + 3) / 4;   // 16-row blocks of dX / columns of dW
+  static constexpr int KSO = NB_ * 4;        // k-steps over the outputs (backward data)
+  // forward block: bias[NB*16] | wf[NB][KS][64];  transposed block: wtf[IB][KSO][64]  (floats)
+  static constexpr int BIAS_OFF = 0;
+  static constexpr int WF_OFF = NB_ * 16;
+  static constexpr int FW = WF_OFF + NB_ * KS_ * 64;
+  static constexpr int WT = IB * KSO * 64;
+  // packed gradient block: dW tiles in MFMA D layout, then the bias gradient
+  static constexpr int GW_OFF = 0;
+  static constexpr int GB_OFF = NB_ * IB * 256;
+  static constexpr int GPACKED = GB_OFF + NB_ * 16;
+  static constexpr int SCRATCH_ROWS = (NB_ + IB) * 16;  // per-wave LDS rows for the dW transposes
+};
+
+constexpr int kScratchLd = 20;  // floats per scratch row: 16 points + 4 pad (keeps 16-B alignment)
+
+// ---- forward -------------------------------------------------------------------------------
+// v[pb][t] is the B-operand array of a 16-point block: for D-chained data t = 4*nb + r.
+template <class LT, int PB>
+__device__ __forceinline__ void layer_fwd(const float* __restrict__ params, const float (&vin)[PB][LT::KS],
+                                          float (&vout)[PB][LT::NB * 4]) {
+  const int lane = ps_lane();
+  const int g = lane >> 4;
+  f32x4 acc[LT::NB][PB];
+#pragma unroll
+  for (int nb = 0; nb < LT::NB; ++nb) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(params + LT::BIAS_OFF + 16 * nb + 4 * g);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = b4;
+  }
+  const float* wf = params + LT::WF_OFF + lane;
+#pragma unroll
+  for (int nb = 0; nb < LT::NB; ++nb) {
+    __builtin_amdgcn_sched_barrier(0);  // keep the weight-fragment loads of later blocks from being hoisted
+#pragma unroll
+    for (int t = 0; t < LT::KS; ++t) {
+      const float a = wf[(nb * LT::KS + t) * 64];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = ps_mfma16(a, vin[pb][t], acc[nb][pb]);
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < LT::NB; ++nb)
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vout[pb][4 * nb + r] = acc[nb][pb][r];
+}
+
+template <int PB, int N>
+__device__ __forceinline__ void relu_inplace(float (&v)[PB][N]) {
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[pb][i] = fmaxf(v[pb][i], 0.0f);
+}
+
+// dv *= (h > 0)
+template <int PB, int N>
+__device__ __forceinline__ void relu_mask(float (&dv)[PB][N], const float (&h)[PB][N]) {
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+    for (int i = 0; i < N; ++i) dv[pb][i] = h[pb][i] > 0.0f ? dv[pb][i] : 0.0f;
+}
+
+// ---- backward (data) -----------------------------------------------------------------------
+// dvin[pb][t], t = 4*ib + r, comes out in the layout the forward input of this layer had.
+template <class LT, int PB>
+__device__ __forceinline__ void layer_bwd_data(const float* __restrict__ wt_block, const float (&dvout)[PB][LT::NB * 4],
+                                               float (&dvin)[PB][LT::IB * 4]) {
+  const int lane = ps_lane();
+  const float* wtf = wt_block + lane;
+#pragma unroll
+  for (int ib = 0; ib < LT::IB; ++ib) {
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) acc[pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < LT::KSO; ++t) {
+      const float a = wtf[(ib * LT::KSO + t) * 64];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) acc[pb] = ps_mfma16(a, dvout[pb][t], acc[pb]);
+    }
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dvin[pb][4 * ib + r] = acc[pb][r];
+  }
+}
+
+// ---- backward (weights) --------------------------------------------------------------------
+// Accumulates dW += dY^T H and db += sum_p dY over the PB*16 points held by this wave.
+//   scratch : per-wave LDS, LT::SCRATCH_ROWS * kScratchLd floats
+//   gacc    : workgroup LDS accumulator block of this layer, LT::GPACKED floats
+template <class LT, int PB>
+__device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, float* __restrict__ gacc,
+                                                  const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS]) {
+  const int lane = ps_lane();
+  const int j = lane & 15, g = lane >> 4;
+  f32x4 dw[LT::NB][LT::IB];
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float* sy = scratch;                               // dY tile rows [NB*16]
+  float* sh = scratch + LT::NB * 16 * kScratchLd;    // H tile rows  [IB*16]
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    __builtin_amdgcn_sched_barrier(0);
+    // stage: row = neuron (D-row numbering), column = point j
+#pragma unroll
+    for (int t = 0; t < LT::NB * 4; ++t) sy[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = dvout[pb][t];
+#pragma unroll
+    for (int t = 0; t < LT::IB * 4; ++t)
+      sh[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = (t < LT::KS) ? vin[pb][t < LT::KS ? t : 0] : 0.0f;
+    __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; only stop compiler reordering
+    // k-step r of this 16-point block contracts over points {4*g + r}
+    f32x4 bfrag[LT::IB];
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(sh + (16 * ib + j) * kScratchLd + 4 * g);
+#pragma unroll
+    for (int ob = 0; ob < LT::NB; ++ob) {
+      const f32x4 afrag = *reinterpret_cast<const f32x4*>(sy + (16 * ob + j) * kScratchLd + 4 * g);
+#pragma unroll
+      for (int ib = 0; ib < LT::IB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dw[ob][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ob][ib]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // flush the register tiles into the workgroup accumulators
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 4 + r) * 64 + lane, dw[ob][ib][r]);
+  // bias gradient: sum over the wave's points
+#pragma unroll
+  for (int t = 0; t < LT::NB * 4; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) s += dvout[pb][t];
+    s = ps_row16_sum(s);
+    if (j == 0) atomicAdd(gacc + LT::GB_OFF + 16 * (t >> 2) + 4 * g + (t & 3), s);
+  }
+}
+
+// ---- whole-MLP description -----------------------------------------------------------------
+// NL linear layers: KS0*4 inputs -> HB*16 hidden (NL-1 times) -> NBO*16 outputs.
+template <int KS0_, int HB_, int NBO_, int NL_>
+struct MlpT {
+  static constexpr int KS0 = KS0_, HB = HB_, NBO = NBO_, NL = NL_;
+  static_assert(NL_ == 2 || NL_ == 3, "2 or 3 linear layers");
+  using L0 = LayerT<KS0_, HB_>;
+  using L1 = LayerT<HB_ * 4, HB_>;                 // only when NL == 3
+  using LZ = LayerT<HB_ * 4, NBO_>;                // last layer
+  // packed parameters: [forward blocks of all layers][transposed blocks of all layers]
+  static constexpr int OFF0 = 0;
+  static constexpr int OFF1 = L0::FW;
+  static constexpr int OFFZ = OFF1 + (NL_ == 3 ? L1::FW : 0);
+  static constexpr int FW = OFFZ + LZ::FW;
+  static constexpr int TOFF0 = FW;
+  static constexpr int TOFF1 = TOFF0 + L0::WT;
+  static constexpr int TOFFZ = TOFF1 + (NL_ == 3 ? L1::WT : 0);
+  static constexpr int PACKED = TOFFZ + LZ::WT;
+  static constexpr int GOFF0 = 0;
+  static constexpr int GOFF1 = L0::GPACKED;
+  static constexpr int GOFFZ = GOFF1 + (NL_ == 3 ? L1::GPACKED : 0);
+  static constexpr int GPACKED = GOFFZ + LZ::GPACKED;
+  static constexpr int SCRATCH_ROWS =
+      (L0::SCRATCH_ROWS > LZ::SCRATCH_ROWS ? L0::SCRATCH_ROWS : LZ::SCRATCH_ROWS) > L1::SCRATCH_ROWS
+          ? (L0::SCRATCH_ROWS > LZ::SCRATCH_ROWS ? L0::SCRATCH_ROWS : LZ::SCRATCH_ROWS)
+          : L1::SCRATCH_ROWS;
+};
+
+// forward through all layers, keeping the post-ReLU hidden activations (needed by backward)
+template <class M, int PB>
+__device__ __forceinline__ void mlp_forward(const float* __restrict__ params, const float (&x)[PB][M::KS0],
+                                            float (&h1)[PB][M::HB * 4], float (&h2)[PB][M::HB * 4],
+                                            float (&z)[PB][M::NBO * 4]) {
+  layer_fwd<typename M::L0, PB>(params + M::OFF0, x, h1);
+  relu_inplace<PB, M::HB * 4>(h1);
+  if constexpr (M::NL == 3) {
+    layer_fwd<typename M::L1, PB>(params + M::OFF1, h1, h2);
+    relu_inplace<PB, M::HB * 4>(h2);
+    layer_fwd<typename M::LZ, PB>(params + M::OFFZ, h2, z);
+  } else {
+    layer_fwd<typename M::LZ, PB>(params + M::OFFZ, h1, z);
+  }
+}
+
+// backward through all layers given dz (gradient w.r.t. the last layer's pre-activation output).
+// WANT_DX selects whether dX (layout of x) is produced.
+// `params` is the global packed block (transposed fragments are read from it through L2).
+template <class M, int PB, bool WANT_DX>
+__device__ __forceinline__ void mlp_backward(const float* __restrict__ params, float* __restrict__ scratch,
+                                             float* __restrict__ gacc, const float (&x)[PB][M::KS0],
+                                             const float (&h1)[PB][M::HB * 4], const float (&h2)[PB][M::HB * 4],
+                                             const float (&dz)[PB][M::NBO * 4], float (&dx)[PB][M::L0::IB * 4]) {
+  float dh[PB][M::HB * 4];
+  if constexpr (M::NL == 3) {
+    layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, dz, h2);
+    layer_bwd_data<typename M::LZ, PB>(params + M::TOFFZ, dz, dh);
+    relu_mask<PB, M::HB * 4>(dh, h2);
+    float dh1[PB][M::HB * 4];
+    layer_bwd_weights<typename M::L1, PB>(scratch, gacc + M::GOFF1, dh, h1);
+    layer_bwd_data<typename M::L1, PB>(params + M::TOFF1, dh, dh1);
+    relu_mask<PB, M::HB * 4>(dh1, h1);
+    layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, dh1, x);
+    if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params + M::TOFF0, dh1, dx);
+  } else {
+    layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, dz, h1);
+    layer_bwd_data<typename M::LZ, PB>(params + M::TOFFZ, dz, dh);
+    relu_mask<PB, M::HB * 4>(dh, h1);
+    layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, dh, x);
+    if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params + M::TOFF0, dh, dx);
+  }
+}
+
+}  // namespace ps

@@ -1,0 +1,447 @@
+// Per-ray kernels: pinhole ray generation, piecewise spaced sampler, density->weights scan,
+// PDF resampling and the alpha-composite renderers.  One 64-lane wavefront owns one ray; prefix
+// sums along the ray are wavefront shuffles (no LDS round trip), a lane holds CH = ceil(S/64)
+// consecutive samples.
+//
+// Reference semantics (file:line in nerfstudio-0.3.3/nerfstudio):
+//   rays      cameras/cameras.py:614-616,773-778,841-870 ; model_components/ray_generators.py:43-61
+//   sampler   model_components/ray_samplers.py:78-128 ; models/PreSight/nerfacto_nusc_ms.py:312-317
+//   weights   cameras/rays.py:128-150
+//   pdf       model_components/ray_samplers.py:305-372
+//   renderers model_components/renderers.py:70-117,286-383 ; nerfacto_nusc_ms.py:503-533
+#include <type_traits>
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxCh = 4;  // up to 256 samples per ray
+
+__device__ __forceinline__ float spacing_fn(float x, float thr) { return x < thr ? x / (2.0f * thr) : 1.0f - 1.0f / (2.0f * x / thr); }
+__device__ __forceinline__ float spacing_inv(float x, float thr) { return x < 0.5f ? x * (2.0f * thr) : thr / (2.0f - 2.0f * x); }
+__device__ __forceinline__ float s_to_euclid(float s, float s_near, float s_far, float thr) {
+  return spacing_inv(s * s_far + (1.0f - s) * s_near, thr);
+}
+__device__ __forceinline__ float nan_to_num(float v) {
+  if (isnan(v)) return 0.0f;
+  if (isinf(v)) return v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ rays
+__global__ void generate_rays_kernel(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w,
+                                     const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ cx,
+                                     const float* __restrict__ cy, int64_t R, float* __restrict__ origins,
+                                     float* __restrict__ dirs, float* __restrict__ pixel_area, float* __restrict__ dir_norm) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const int64_t cam = ray_indices[i * 3 + 0];
+  const float y = (float)ray_indices[i * 3 + 1] + 0.5f;
+  const float x = (float)ray_indices[i * 3 + 2] + 0.5f;
+  const float fx_ = fx[cam], fy_ = fy[cam], cx_ = cx[cam], cy_ = cy[cam];
+  const float* M = c2w + cam * 12;
+  const float px[3] = {(x - cx_) / fx_, (x - cx_ + 1.0f) / fx_, (x - cx_) / fx_};
+  const float py[3] = {-(y - cy_) / fy_, -(y - cy_) / fy_, -(y - cy_ + 1.0f) / fy_};
+  float d[3][3];
+  float n0 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) v[r] = px[k] * M[r * 4 + 0] + py[k] * M[r * 4 + 1] + (-1.0f) * M[r * 4 + 2];
+    float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    nrm = fmaxf(nrm, 1e-8f);
+    if (k == 0) n0 = nrm;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[k][r] = v[r] / nrm;
+  }
+  float dx = 0.f, dy = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    dx += (d[0][r] - d[1][r]) * (d[0][r] - d[1][r]);
+    dy += (d[0][r] - d[2][r]) * (d[0][r] - d[2][r]);
+    origins[i * 3 + r] = M[r * 4 + 3];
+    dirs[i * 3 + r] = d[0][r];
+  }
+  pixel_area[i] = sqrtf(dx) * sqrtf(dy);
+  if (dir_norm) dir_norm[i] = n0;
+}
+
+// ------------------------------------------------------------------------------------------ spaced sampler
+__global__ void spaced_bins_kernel(const float* __restrict__ jitter, int64_t R, int S, float near, float far, float thr,
+                                   float* __restrict__ sbins, float* __restrict__ ebins) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int nb = S + 1;
+  if (i >= R * nb) return;
+  const int64_t r = i / nb;
+  const int k = (int)(i % nb);
+  // torch.linspace(0,1,S+1): symmetric evaluation around the midpoint
+  const float step = 1.0f / (float)S;
+  auto lin = [&](int idx) { return idx < nb / 2 ? step * (float)idx : 1.0f - step * (float)(nb - idx - 1); };
+  float b = lin(k);
+  if (jitter != nullptr) {
+    const float lo = (k == 0) ? lin(0) : (lin(k) + lin(k - 1)) / 2.0f;
+    const float hi = (k == S) ? lin(S) : (lin(k + 1) + lin(k)) / 2.0f;
+    b = lo + (hi - lo) * jitter[r];
+  }
+  sbins[i] = b;
+  ebins[i] = s_to_euclid(b, spacing_fn(near, thr), spacing_fn(far, thr), thr);
+}
+
+// ------------------------------------------------------------------------------------------ weights scan
+// lane owns samples [lane*CH, lane*CH+CH)
+template <int CH>
+__global__ __launch_bounds__(256) void weights_fwd_kernel(const float* __restrict__ ebins, const float* __restrict__ sigma,
+                                                          int64_t R, int S, float* __restrict__ weights) {
+  const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  const float* e = ebins + ray * (S + 1);
+  float dd[CH], local = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int s = lane * CH + c;
+    dd[c] = (s < S) ? (e[s + 1] - e[s]) * sigma[ray * S + s] : 0.0f;
+    local += dd[c];
+  }
+  float excl = ps_wave_incl_scan(local) - local;  // sum of dd over all earlier lanes
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int s = lane * CH + c;
+    const float w = (1.0f - expf(-dd[c])) * expf(-excl);
+    if (s < S) weights[ray * S + s] = nan_to_num(w);
+    excl += dd[c];
+  }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restrict__ ebins, const float* __restrict__ sigma,
+                                                          const float* __restrict__ dweights, int64_t R, int S,
+                                                          float* __restrict__ dsigma) {
+  const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  const float* e = ebins + ray * (S + 1);
+  float dd[CH], delta[CH], gw[CH], local = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int s = lane * CH + c;
+    delta[c] = (s < S) ? (e[s + 1] - e[s]) : 0.0f;
+    dd[c] = (s < S) ? delta[c] * sigma[ray * S + s] : 0.0f;
+    gw[c] = (s < S) ? dweights[ray * S + s] : 0.0f;
+    local += dd[c];
+  }
+  float excl = ps_wave_incl_scan(local) - local;
+  // a_k = gw_k * w_k (zero where the raw weight is not finite, as torch.nan_to_num's backward does)
+  float a[CH], tr_after[CH], asum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const float T = expf(-excl), ed = expf(-dd[c]);
+    const float w = (1.0f - ed) * T;
+    const bool fin = isfinite(w);
+    a[c] = fin ? gw[c] * w : 0.0f;
+    tr_after[c] = fin ? gw[c] * ed * T : 0.0f;  // d w_k / d dd_k
+    asum += a[c];
+    excl += dd[c];
+  }
+  // suffix sum over later samples: total - inclusive prefix
+  const float incl = ps_wave_incl_scan(asum);
+  const float total = __shfl(incl, 63, 64);
+  float later = total - incl;  // sum of a over all later lanes
+#pragma unroll
+  for (int c = CH - 1; c >= 0; --c) {
+    const int s = lane * CH + c;
+    if (s < S) dsigma[ray * S + s] = (tr_after[c] - later) * delta[c];
+    later += a[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ pdf resampling
+// one wave per ray; cdf staged in LDS, each lane binary-searches its new bin edges
+__global__ __launch_bounds__(256) void pdf_resample_kernel(const float* __restrict__ weights, const float* __restrict__ sbins,
+                                                           const float* __restrict__ jitter, int64_t R, int S, int n_new,
+                                                           float anneal, float pad, float eps, float near, float far,
+                                                           float thr, float* __restrict__ new_sbins,
+                                                           float* __restrict__ new_ebins) {
+  __shared__ float lds[4][2][kMaxCh * 64 + 1];
+  const int wv = threadIdx.x >> 6;
+  const int64_t ray = blockIdx.x * 4 + wv;
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  float* cdf = lds[wv][0];
+  float* eb = lds[wv][1];
+  const int CH = (S + 63) / 64;
+  // w = pow(weights, anneal) + pad, summed over the ray
+  float wloc[kMaxCh], local = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxCh; ++c) {
+    const int s = lane * CH + c;
+    float w = 0.f;
+    if (c < CH && s < S) {
+      w = weights[ray * S + s];
+      if (anneal != 1.0f) w = powf(w, anneal);
+      w += pad;
+    }
+    wloc[c] = w;
+    local += w;
+  }
+  float wsum = ps_wave_sum(local);
+  const float padding = fmaxf(eps - wsum, 0.0f);
+  const float padw = padding / (float)S;
+  wsum += padding;
+  local = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxCh; ++c) {
+    const int s = lane * CH + c;
+    wloc[c] = (c < CH && s < S) ? (wloc[c] + padw) / wsum : 0.0f;
+    local += wloc[c];
+  }
+  float run = ps_wave_incl_scan(local) - local;
+  if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < kMaxCh; ++c) {
+    const int s = lane * CH + c;
+    run += wloc[c];
+    if (c < CH && s < S) cdf[s + 1] = fminf(1.0f, run);
+  }
+  for (int s = lane; s <= S; s += 64) eb[s] = sbins[ray * (S + 1) + s];
+  __builtin_amdgcn_wave_barrier();
+  const int nb = n_new + 1;
+  const float end = (float)(1.0 - 1.0 / (double)nb);
+  const float step = end / (float)(nb - 1);
+  const float s_near = spacing_fn(near, thr), s_far = spacing_fn(far, thr);
+  for (int i = lane; i < nb; i += 64) {
+    float u = (i < nb / 2) ? step * (float)i : end - step * (float)(nb - i - 1);
+    if (jitter != nullptr)
+      u = u + jitter[ray] / (float)nb;
+    else
+      u = u + (float)(1.0 / (2.0 * (double)nb));
+    // searchsorted(cdf, u, right): number of entries <= u
+    int lo = 0, hi = S + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int below = min(max(lo - 1, 0), S), above = min(max(lo, 0), S);
+    const float c0 = cdf[below], c1 = cdf[above], b0 = eb[below], b1 = eb[above];
+    float t = (u - c0) / (c1 - c0);
+    if (isnan(t)) t = 0.0f;
+    t = fminf(fmaxf(nan_to_num(t), 0.0f), 1.0f);
+    const float b = b0 + t * (b1 - b0);
+    new_sbins[ray * nb + i] = b;
+    new_ebins[ray * nb + i] = s_to_euclid(b, s_near, s_far, thr);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ composite
+// One wave per ray.  Lane c accumulates channel c of the C-dim features (C <= 64); lanes 0..2 also
+// the rgb channels; sample-indexed scalars (acc, depths) are done with CH samples per lane + shuffles.
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ weights, const float* __restrict__ ebins,
+                                                            const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
+                                                            int64_t R, int S, int C, float threshold, float* __restrict__ rgb,
+                                                            float* __restrict__ acc, float* __restrict__ depth,
+                                                            float* __restrict__ exp_depth, float* __restrict__ sem,
+                                                            float* __restrict__ minmax) {
+  const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  const float* w = weights + ray * S;
+  const float* e = ebins + ray * (S + 1);
+  // channel-parallel accumulations
+  float a_sem = 0.f, a_rgb = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float ws = w[s];
+    if (sem_s != nullptr && lane < C) a_sem += ws * sem_s[(ray * S + s) * C + lane];
+    if (rgb_s != nullptr && lane < 3) a_rgb += ws * rgb_s[(ray * S + s) * 3 + lane];
+  }
+  if (sem != nullptr && lane < C) sem[ray * C + lane] = a_sem;
+  if (rgb != nullptr && lane < 3) rgb[ray * 3 + lane] = a_rgb;
+  // sample-parallel part
+  const int CH = (S + 63) / 64;
+  float wl[kMaxCh], st[kMaxCh], local = 0.f, wt = 0.f, smin = 3.4e38f, smax = -3.4e38f;
+#pragma unroll
+  for (int c = 0; c < kMaxCh; ++c) {
+    const int s = lane * CH + c;
+    const bool ok = (c < CH && s < S);
+    wl[c] = ok ? w[s] : 0.0f;
+    st[c] = ok ? (e[s] + e[s + 1]) / 2.0f : 0.0f;
+    local += wl[c];
+    wt += wl[c] * st[c];
+    if (ok) {
+      smin = fminf(smin, st[c]);
+      smax = fmaxf(smax, st[c]);
+    }
+  }
+  const float incl = ps_wave_incl_scan(local);
+  const float total = __shfl(incl, 63, 64);
+  const float wtsum = ps_wave_sum(wt);
+  // threshold depth: first sample whose inclusive cumsum >= threshold (searchsorted left), clamped to S-1
+  float run = incl - local;
+  int first = S;  // sentinel
+#pragma unroll
+  for (int c = 0; c < kMaxCh; ++c) {
+    const int s = lane * CH + c;
+    run += wl[c];
+    if (c < CH && s < S && run >= threshold && first == S) first = s;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) first = min(first, __shfl_xor(first, m, 64));
+  const int idx = min(first, S - 1);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    smin = fminf(smin, __shfl_xor(smin, m, 64));
+    smax = fmaxf(smax, __shfl_xor(smax, m, 64));
+  }
+  if (lane == 0) {
+    if (acc) acc[ray] = total;
+    if (depth) depth[ray] = (e[idx] + e[idx + 1]) / 2.0f;
+    if (exp_depth) exp_depth[ray] = wtsum / (total + 1e-10f);
+    if (minmax) {  // steps are positive: the int ordering of the bit patterns equals the float ordering
+      atomicMin(reinterpret_cast<int*>(minmax), __float_as_int(smin));
+      atomicMax(reinterpret_cast<int*>(minmax) + 1, __float_as_int(smax));
+    }
+  }
+}
+
+__global__ void clip_kernel(float* __restrict__ v, int64_t n, const float* __restrict__ minmax) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) v[i] = fminf(fmaxf(v[i], minmax[0]), minmax[1]);
+}
+
+// d_w[s] = sum_c rgb_s*d_rgb + sum_c sem_s*d_sem + d_acc + d_expdepth-terms ; d_rgb_s = w*d_rgb ; d_sem_s = w*d_sem
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ weights, const float* __restrict__ ebins,
+                                                            const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
+                                                            const float* __restrict__ d_rgb, const float* __restrict__ d_acc,
+                                                            const float* __restrict__ d_sem, const float* __restrict__ d_exp,
+                                                            int64_t R, int S, int C, float* __restrict__ d_weights,
+                                                            float* __restrict__ d_rgb_s, float* __restrict__ d_sem_s) {
+  const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  const float* w = weights + ray * S;
+  const float* e = ebins + ray * (S + 1);
+  const float gsem = (d_sem != nullptr && lane < C) ? d_sem[ray * C + lane] : 0.0f;
+  const float grgb = (d_rgb != nullptr && lane < 3) ? d_rgb[ray * 3 + lane] : 0.0f;
+  const float gacc = d_acc ? d_acc[ray] : 0.0f;
+  // expected depth D = A/(B+eps), A = sum w t, B = sum w  ->  dD/dw_s = t_s/(B+eps) - A/(B+eps)^2
+  float ge = 0.f, A = 0.f, B = 0.f;
+  if (d_exp != nullptr) {
+    ge = d_exp[ray];
+    float la = 0.f, lb = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      la += w[s] * (e[s] + e[s + 1]) / 2.0f;
+      lb += w[s];
+    }
+    A = ps_wave_sum(la);
+    B = ps_wave_sum(lb) + 1e-10f;
+  }
+  for (int s = 0; s < S; ++s) {
+    const float ws = w[s];
+    float part = 0.f;
+    if (sem_s != nullptr && lane < C) {
+      part += sem_s[(ray * S + s) * C + lane] * gsem;
+      if (d_sem_s) d_sem_s[(ray * S + s) * C + lane] = ws * gsem;
+    }
+    if (rgb_s != nullptr && lane < 3) {
+      part += rgb_s[(ray * S + s) * 3 + lane] * grgb;
+      if (d_rgb_s) d_rgb_s[(ray * S + s) * 3 + lane] = ws * grgb;
+    }
+    part = ps_wave_sum(part);
+    if (lane == 0) {
+      float g = part + gacc;
+      if (d_exp != nullptr) g += ge * (((e[s] + e[s + 1]) / 2.0f) / B - A / (B * B));
+      d_weights[ray * S + s] = g;
+    }
+  }
+}
+
+template <class F>
+int by_chunk(int S, F f) {
+  const int ch = (S + 63) / 64;
+  if (ch <= 1) return f(std::integral_constant<int, 1>());
+  if (ch == 2) return f(std::integral_constant<int, 2>());
+  if (ch <= 4) return f(std::integral_constant<int, 4>());
+  ps_set_error("samples per ray must be <= 256");
+  return -1;
+}
+
+}  // namespace
+
+extern "C" int ps_generate_rays(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
+                                const float* cx, const float* cy, int64_t R, float* origins, float* dirs, float* pixel_area,
+                                float* dir_norm, void* stream) {
+  if (R == 0) return 0;
+  generate_rays_kernel<<<(unsigned)((R + 255) / 256), 256, 0, (hipStream_t)stream>>>(ray_indices, c2w, fx, fy, cx, cy, R,
+                                                                                    origins, dirs, pixel_area, dir_norm);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_spaced_bins(const float* jitter, int64_t R, int S, float near, float far, float thr, float* sbins,
+                              float* ebins, void* stream) {
+  if (R == 0) return 0;
+  const int64_t n = R * (S + 1);
+  spaced_bins_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(jitter, R, S, near, far, thr, sbins, ebins);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_weights_fwd(const float* ebins, const float* sigma, int64_t R, int S, float* weights, void* stream) {
+  if (R == 0) return 0;
+  const unsigned grid = (unsigned)((R + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = by_chunk(S, [&](auto ch) {
+    weights_fwd_kernel<decltype(ch)::value><<<grid, 256, 0, s>>>(ebins, sigma, R, S, weights);
+    return 0;
+  });
+  if (rc) return rc;
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_weights_bwd(const float* ebins, const float* sigma, const float* dweights, int64_t R, int S,
+                              float* dsigma, void* stream) {
+  if (R == 0) return 0;
+  const unsigned grid = (unsigned)((R + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = by_chunk(S, [&](auto ch) {
+    weights_bwd_kernel<decltype(ch)::value><<<grid, 256, 0, s>>>(ebins, sigma, dweights, R, S, dsigma);
+    return 0;
+  });
+  if (rc) return rc;
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_pdf_resample(const float* weights, const float* sbins, const float* jitter, int64_t R, int S, int n_new,
+                               float anneal, float pad, float eps, float near, float far, float thr, float* new_sbins,
+                               float* new_ebins, void* stream) {
+  PS_REQUIRE(S <= kMaxCh * 64, "ps_pdf_resample: samples per ray must be <= 256");
+  if (R == 0) return 0;
+  pdf_resample_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, sbins, jitter, R, S, n_new, anneal,
+                                                                               pad, eps, near, far, thr, new_sbins, new_ebins);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_composite_fwd(const float* weights, const float* ebins, const float* rgb_s, const float* sem_s, int64_t R,
+                                int S, int C, float threshold, float* rgb, float* acc, float* depth, float* exp_depth,
+                                float* sem, float* minmax, void* stream) {
+  PS_REQUIRE(S <= kMaxCh * 64 && C <= 64, "ps_composite_fwd: S must be <= 256 and C <= 64");
+  if (R == 0) return 0;
+  composite_fwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, R, S, C,
+                                                                                threshold, rgb, acc, depth, exp_depth, sem,
+                                                                                minmax);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_clip(float* v, int64_t n, const float* minmax, void* stream) {
+  if (n == 0) return 0;
+  clip_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(v, n, minmax);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_composite_bwd(const float* weights, const float* ebins, const float* rgb_s, const float* sem_s,
+                                const float* d_rgb, const float* d_acc, const float* d_sem, const float* d_exp, int64_t R,
+                                int S, int C, float* d_weights, float* d_rgb_s, float* d_sem_s, void* stream) {
+  PS_REQUIRE(S <= kMaxCh * 64 && C <= 64, "ps_composite_bwd: S must be <= 256 and C <= 64");
+  if (R == 0) return 0;
+  composite_bwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
+                                                                                d_sem, d_exp, R, S, C, d_weights, d_rgb_s,
+                                                                                d_sem_s);
+  PS_CHECK_LAUNCH();
+}

@@ -1,0 +1,359 @@
+"""Python host side of the C ABI: thin wrappers (raw device pointers + sizes + current HIP stream)
+and torch.autograd.Function glue for the operator-level kernels.  torch is used for device memory,
+streams and autograd bookkeeping only; all arithmetic of the hot path runs in libpresight_hip.so."""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from ._lib import check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: Tensor, name: str = "tensor") -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"presight_amd: {name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# hash grid (operator level)
+# ------------------------------------------------------------------------------------------------
+class _HashGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table, scalings, L, F, log2T):
+        x = _f32(x, "positions")
+        N = x.shape[0]
+        out = torch.empty(N, L * F, device=x.device, dtype=torch.float32)
+        check(lib().ps_hashgrid_fwd(_p(x), _p(table), _p(scalings), L, F, log2T, N, _p(out), _stream()), "ps_hashgrid_fwd")
+        ctx.save_for_backward(x, scalings)
+        ctx.meta = (L, F, log2T, table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, scalings = ctx.saved_tensors
+        L, F, log2T, tshape = ctx.meta
+        dout = _f32(dout)
+        dtable = torch.zeros(tshape, device=x.device, dtype=torch.float32)
+        check(lib().ps_hashgrid_bwd(_p(x), _p(dout), _p(scalings), L, F, log2T, x.shape[0], _p(dtable), _stream()),
+              "ps_hashgrid_bwd")
+        return None, dtable, None, None, None, None
+
+
+def hashgrid_encode(x: Tensor, table: Tensor, scalings: Tensor, L: int, F: int, log2T: int) -> Tensor:
+    """x [N,3] -> [N, L*F]; differentiable w.r.t. table (positions carry no gradient: bins are detached in
+    the reference, ns/model_components/ray_samplers.py:360)."""
+    return _HashGrid.apply(x, table, scalings, L, F, log2T)
+
+
+def hashgrid_indices(x: Tensor, scalings: Tensor, L: int, log2T: int) -> Tensor:
+    x = _f32(x)
+    idx = torch.empty(x.shape[0], L, 8, device=x.device, dtype=torch.int64)
+    check(lib().ps_hashgrid_indices(_p(x), _p(scalings), L, log2T, x.shape[0], _p(idx), _stream()), "ps_hashgrid_indices")
+    return idx
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP (operator level)
+# ------------------------------------------------------------------------------------------------
+def linear_colmap(ks: int, in_dim: int) -> List[int]:
+    """k-step t, lane group g supplies input column 4t+g."""
+    return [(4 * t + g if 4 * t + g < in_dim else -1) for t in range(ks) for g in range(4)]
+
+
+def chain_colmap(ks: int, in_dim: int) -> List[int]:
+    """input comes straight from the previous layer's MFMA D registers: column 16*(t//4)+4g+t%4."""
+    out = []
+    for t in range(ks):
+        for g in range(4):
+            c = 16 * (t // 4) + 4 * g + (t % 4)
+            out.append(c if c < in_dim else -1)
+    return out
+
+
+class MlpSpec:
+    """Mirror of ps::MlpT (csrc/mlp_core.hpp): packed-parameter and packed-gradient layouts."""
+
+    def __init__(self, dims: Sequence[int], first_colmap: Optional[List[int]] = None, ks0: Optional[int] = None):
+        self.dims = list(dims)
+        self.nl = len(dims) - 1
+        hidden = dims[1]
+        if self.nl not in (2, 3) or any(d != hidden for d in dims[1:-1]) or hidden % 16:
+            raise NotImplementedError(f"presight_amd MLP: unsupported layer dims {dims} (2-3 linear layers, equal hidden "
+                                      f"width that is a multiple of 16)")
+        self.ks = [ks0 if ks0 is not None else (dims[0] + 3) // 4] + [hidden // 4] * (self.nl - 1)
+        self.nb = [hidden // 16] * (self.nl - 1) + [(dims[-1] + 15) // 16]
+        self.ib = [(k + 3) // 4 for k in self.ks]
+        self.colmaps = [first_colmap if first_colmap is not None else linear_colmap(self.ks[0], dims[0])]
+        self.colmaps += [chain_colmap(self.ks[i], dims[i]) for i in range(1, self.nl)]
+        self.fw = [nb * 16 + nb * ks * 64 for nb, ks in zip(self.nb, self.ks)]
+        self.wt = [ib * nb * 4 * 64 for ib, nb in zip(self.ib, self.nb)]
+        self.g = [nb * ib * 256 + nb * 16 for nb, ib in zip(self.nb, self.ib)]
+        self.fw_off = [sum(self.fw[:i]) for i in range(self.nl)]
+        self.fw_total = sum(self.fw)
+        self.wt_off = [self.fw_total + sum(self.wt[:i]) for i in range(self.nl)]
+        self.packed = self.fw_total + sum(self.wt)
+        self.g_off = [sum(self.g[:i]) for i in range(self.nl)]
+        self.g_total = sum(self.g)
+        self._dev_colmaps = {}
+
+    def dev_colmaps(self, device) -> List[Tensor]:
+        key = str(device)
+        if key not in self._dev_colmaps:
+            self._dev_colmaps[key] = [torch.tensor(c, dtype=torch.int32, device=device) for c in self.colmaps]
+        return self._dev_colmaps[key]
+
+    def pack_into(self, layers: Sequence[Tuple[Tensor, Tensor]], packed: Tensor):
+        """layers: [(W [out,in], b [out])] in torch layout -> packed fragment buffer (device)."""
+        cms = self.dev_colmaps(packed.device)
+        base = packed.data_ptr()
+        for i, (W, b) in enumerate(layers):
+            W, b = _f32(W), _f32(b)
+            check(lib().ps_mlp_pack_layer(_p(W), _p(b), W.shape[0], W.shape[1], _p(cms[i]), self.ks[i], self.nb[i],
+                                          base + 4 * self.fw_off[i], base + 4 * self.wt_off[i], _stream()), "ps_mlp_pack_layer")
+
+    def pack(self, layers, device) -> Tensor:
+        packed = torch.empty(self.packed, device=device, dtype=torch.float32)
+        self.pack_into(layers, packed)
+        return packed
+
+    def unpack_grads(self, gpart: Tensor, n_parts: int, part_stride: int, part_offset: int,
+                     shapes: Sequence[Tuple[int, int]]) -> List[Tuple[Tensor, Tensor]]:
+        """Sum per-workgroup partial blocks into torch-layout (dW, db) per layer."""
+        cms = self.dev_colmaps(gpart.device)
+        grads = []
+        for i, (o, n_in) in enumerate(shapes):
+            gW = torch.zeros(o, n_in, device=gpart.device, dtype=torch.float32)
+            gb = torch.zeros(o, device=gpart.device, dtype=torch.float32)
+            check(lib().ps_mlp_unpack_grad_layer(gpart.data_ptr() + 4 * (part_offset + self.g_off[i]), n_parts, part_stride, o,
+                                                 n_in, _p(cms[i]), self.ks[i], self.nb[i], _p(gW), _p(gb), _stream()),
+                  "ps_mlp_unpack_grad_layer")
+            grads.append((gW, gb))
+        return grads
+
+
+_SPEC_CACHE = {}
+
+
+def mlp_spec(dims: Sequence[int]) -> MlpSpec:
+    key = tuple(dims)
+    if key not in _SPEC_CACHE:
+        spec = MlpSpec(dims)
+        if not lib().ps_mlp_shape_supported(dims[0], dims[1], dims[-1], len(dims) - 1):
+            raise NotImplementedError(f"presight_amd MLP: no HIP kernel instantiated for layer dims {list(dims)}")
+        _SPEC_CACHE[key] = spec
+    return _SPEC_CACHE[key]
+
+
+class _Mlp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_act, *wb):
+        x = _f32(x, "MLP input")
+        layers = [(wb[2 * i], wb[2 * i + 1]) for i in range(len(wb) // 2)]
+        dims = [layers[0][0].shape[1]] + [W.shape[0] for W, _ in layers]
+        spec = mlp_spec(dims)
+        packed = spec.pack(layers, x.device)
+        N = x.shape[0]
+        y = torch.empty(N, dims[-1], device=x.device, dtype=torch.float32)
+        check(lib().ps_mlp_fwd(_p(x), _p(packed), _p(y), N, dims[0], dims[1], dims[-1], spec.nl, out_act, _stream()), "ps_mlp_fwd")
+        ctx.save_for_backward(x, packed)
+        ctx.meta = (dims, out_act, [tuple(W.shape) for W, _ in layers])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+
+        x, packed = ctx.saved_tensors
+        dims, out_act, shapes = ctx.meta
+        spec = mlp_spec(dims)
+        dy = _f32(dy)
+        N = x.shape[0]
+        pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        check(lib().ps_mlp_sizes(dims[0], dims[1], dims[-1], spec.nl, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart)),
+              "ps_mlp_sizes")
+        assert pf.value == spec.packed and gf.value == spec.g_total, (pf.value, spec.packed, gf.value, spec.g_total)
+        gpart = torch.empty(npart.value, spec.g_total, device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(lib().ps_mlp_bwd(_p(x), _p(dy), _p(packed), _p(dx), _p(gpart), N, dims[0], dims[1], dims[-1], spec.nl, out_act,
+                               _stream()), "ps_mlp_bwd")
+        grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes)
+        flat = []
+        for gW, gb in grads:
+            flat += [gW, gb]
+        return (dx, None, *flat)
+
+
+def mlp(x: Tensor, layers: Sequence[Tuple[Tensor, Tensor]], out_act: Optional[str] = None) -> Tensor:
+    """y = MLP(x) with ReLU between layers and an optional sigmoid on the output."""
+    flat = []
+    for W, b in layers:
+        flat += [W, b]
+    act = {None: 0, "none": 0, "sigmoid": 1}[out_act]
+    return _Mlp.apply(x, act, *flat)
+
+
+# ------------------------------------------------------------------------------------------------
+# point-wise operators
+# ------------------------------------------------------------------------------------------------
+def contract(p: Tensor, aabb: Tensor, contract_: bool = True) -> Tuple[Tensor, Tensor]:
+    p = _f32(p)
+    M = p.shape[0]
+    u = torch.empty_like(p)
+    sel = torch.empty(M, device=p.device, dtype=torch.uint8)
+    check(lib().ps_contract(_p(p), _p(_f32(aabb)), M, int(contract_), _p(u), _p(sel), _stream()), "ps_contract")
+    return u, sel.bool()
+
+
+def sh4(dirs: Tensor) -> Tensor:
+    d = _f32(dirs)
+    out = torch.empty(d.shape[0], 16, device=d.device, dtype=torch.float32)
+    check(lib().ps_sh4(_p(d), d.shape[0], _p(out), _stream()), "ps_sh4")
+    return out
+
+
+def route(p: Tensor, centroids: Tensor) -> Tensor:
+    p = _f32(p)
+    c = _f32(centroids)
+    a = torch.empty(p.shape[0], device=p.device, dtype=torch.int32)
+    check(lib().ps_route(_p(p), p.shape[0], _p(c), c.shape[0], _p(a), _stream()), "ps_route")
+    return a
+
+
+def sample_positions(origins: Tensor, dirs: Tensor, ebins: Tensor) -> Tensor:
+    R, S = ebins.shape[0], ebins.shape[1] - 1
+    pos = torch.empty(R * S, 3, device=ebins.device, dtype=torch.float32)
+    check(lib().ps_sample_positions(_p(_f32(origins)), _p(_f32(dirs)), _p(_f32(ebins)), R, S, _p(pos), _stream()),
+          "ps_sample_positions")
+    return pos
+
+
+# ------------------------------------------------------------------------------------------------
+# per-ray operators
+# ------------------------------------------------------------------------------------------------
+def generate_rays(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor):
+    if not ray_indices.is_cuda:
+        raise RuntimeError("presight_amd: ray_indices must live on the GPU")
+    ri = ray_indices.to(torch.int64).contiguous()
+    R = ri.shape[0]
+    dev = ri.device
+    o = torch.empty(R, 3, device=dev)
+    d = torch.empty(R, 3, device=dev)
+    pa = torch.empty(R, 1, device=dev)
+    dn = torch.empty(R, 1, device=dev)
+    check(lib().ps_generate_rays(_p(ri), _p(_f32(c2w)), _p(_f32(fx)), _p(_f32(fy)), _p(_f32(cx)), _p(_f32(cy)), R, _p(o), _p(d),
+                                 _p(pa), _p(dn), _stream()), "ps_generate_rays")
+    return o, d, pa, dn
+
+
+def spaced_bins(num_rays: int, S: int, near: float, far: float, thr: float, jitter: Optional[Tensor], device):
+    sb = torch.empty(num_rays, S + 1, device=device)
+    eb = torch.empty(num_rays, S + 1, device=device)
+    j = None if jitter is None else _f32(jitter).view(-1)
+    check(lib().ps_spaced_bins(_p(j), num_rays, S, near, far, thr, _p(sb), _p(eb), _stream()), "ps_spaced_bins")
+    return sb, eb
+
+
+class _Weights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ebins, sigma):
+        ebins, sigma = _f32(ebins), _f32(sigma)
+        R, S = sigma.shape
+        w = torch.empty_like(sigma)
+        check(lib().ps_weights_fwd(_p(ebins), _p(sigma), R, S, _p(w), _stream()), "ps_weights_fwd")
+        ctx.save_for_backward(ebins, sigma)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        ebins, sigma = ctx.saved_tensors
+        R, S = sigma.shape
+        ds = torch.empty_like(sigma)
+        check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(_f32(dw)), R, S, _p(ds), _stream()), "ps_weights_bwd")
+        return None, ds
+
+
+def weights_from_density(ebins: Tensor, sigma: Tensor) -> Tensor:
+    """ebins [R,S+1] euclidean bin edges, sigma [R,S] -> weights [R,S] (differentiable w.r.t. sigma)."""
+    return _Weights.apply(ebins, sigma)
+
+
+def pdf_resample(weights: Tensor, sbins: Tensor, n_new: int, jitter: Optional[Tensor], anneal: float, near: float,
+                 far: float, thr: float, pad: float = 0.01, eps: float = float(torch.finfo(torch.float32).eps)):
+    w = _f32(weights.detach())
+    sb = _f32(sbins)
+    R, S = w.shape
+    nsb = torch.empty(R, n_new + 1, device=w.device)
+    neb = torch.empty(R, n_new + 1, device=w.device)
+    j = None if jitter is None else _f32(jitter).view(-1)
+    check(lib().ps_pdf_resample(_p(w), _p(sb), _p(j), R, S, n_new, float(anneal), pad, eps, near, far, thr, _p(nsb), _p(neb),
+                                _stream()), "ps_pdf_resample")
+    return nsb, neb
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, ebins, rgb_s, sem_s, threshold):
+        weights, ebins = _f32(weights), _f32(ebins)
+        R, S = weights.shape
+        dev = weights.device
+        rgb_s = None if rgb_s is None else _f32(rgb_s)
+        sem_s = None if sem_s is None else _f32(sem_s)
+        C = 0 if sem_s is None else sem_s.shape[-1]
+        rgb = torch.empty(R, 3, device=dev) if rgb_s is not None else None
+        sem = torch.empty(R, C, device=dev) if sem_s is not None else None
+        acc = torch.empty(R, 1, device=dev)
+        depth = torch.empty(R, 1, device=dev)
+        expd = torch.empty(R, 1, device=dev)
+        minmax = torch.tensor([float("inf"), 0.0], device=dev)
+        check(lib().ps_composite_fwd(_p(weights), _p(ebins), _p(rgb_s), _p(sem_s), R, S, C, threshold, _p(rgb), _p(acc), _p(depth),
+                                     _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
+        raw = expd.clone()
+        check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
+        ctx.save_for_backward(weights, ebins, rgb_s, sem_s, raw, expd)
+        ctx.C = C
+        ctx.mark_non_differentiable(depth)
+        outs = (rgb if rgb is not None else torch.empty(0, device=dev), acc, depth, expd,
+                sem if sem is not None else torch.empty(0, device=dev))
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, _d_depth, d_exp, d_sem):
+        weights, ebins, rgb_s, sem_s, raw, expd = ctx.saved_tensors
+        R, S = weights.shape
+        dev = weights.device
+        d_rgb = _f32(d_rgb) if rgb_s is not None and d_rgb is not None else None
+        d_sem = _f32(d_sem) if sem_s is not None and d_sem is not None else None
+        d_acc = _f32(d_acc) if d_acc is not None else None
+        if d_exp is not None:
+            d_exp = _f32(d_exp * (raw == expd).float())  # gradient of clip
+        dw = torch.empty_like(weights)
+        d_rgb_s = torch.empty_like(rgb_s) if (rgb_s is not None and ctx.needs_input_grad[2]) else None
+        d_sem_s = torch.empty_like(sem_s) if (sem_s is not None and ctx.needs_input_grad[3]) else None
+        check(lib().ps_composite_bwd(_p(weights), _p(ebins), _p(rgb_s) if d_rgb is not None else None,
+                                     _p(sem_s) if d_sem is not None else None, _p(d_rgb), _p(d_acc), _p(d_sem), _p(d_exp), R, S,
+                                     ctx.C, _p(dw), _p(d_rgb_s) if d_rgb is not None else None,
+                                     _p(d_sem_s) if d_sem is not None else None, _stream()), "ps_composite_bwd")
+        if d_rgb is None and d_rgb_s is not None:
+            d_rgb_s.zero_()
+        if d_sem is None and d_sem_s is not None:
+            d_sem_s.zero_()
+        return dw, None, d_rgb_s, d_sem_s, None
+
+
+def composite(weights: Tensor, ebins: Tensor, rgb_s: Optional[Tensor], sem_s: Optional[Tensor], threshold: float = 0.5):
+    """-> (rgb [R,3], acc [R,1] (unclamped), threshold depth [R,1], expected depth [R,1] (batch-clipped), sem [R,C])."""
+    return _Composite.apply(weights, ebins, rgb_s, sem_s, threshold)
