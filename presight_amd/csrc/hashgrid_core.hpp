@@ -13,7 +13,10 @@ struct Cell {
 };
 
 __device__ __forceinline__ Cell make_cell(float x, float y, float z, float scale) {
+#pragma clang fp contract(off)
   Cell c;
+  // rounded products (no fma contraction): the fractional offset must see the same fp32 `scaled` as the
+  // reference, whose ulp at resolution ~2^11..2^14 is what dominates the interpolation error
   const float sx = x * scale, sy = y * scale, sz = z * scale;
   const float flx = floorf(sx), fly = floorf(sy), flz = floorf(sz);
   c.cx = (int)ceilf(sx);
