@@ -95,6 +95,40 @@ int ps_composite_bwd(const float* weights, const float* ebins, const float* rgb_
                      const float* d_acc, const float* d_sem, const float* d_exp, int64_t R, int S, int C,
                      float* d_weights, float* d_rgb_s, float* d_sem_s, void* stream);
 
+/* ---- field level (fused) -------------------------------------------------------------------------
+ * A field evaluation is:  ps_field_points -> ps_grid_encode -> ps_{prop,main}_field_fwd, and backward
+ * ps_{prop,main}_field_bwd -> ps_grid_scatter.  Features travel as level planes feat[l][n][f]
+ * (plane_stride floats between levels).  Semantics: ns/fields/PreSight/ingp_field.py:168-237,
+ * prop_density_field.py:129-153, ns/cameras/rays.py:49-58, ns/field_components/encodings.py:343-384. */
+/* positions (pos [N,3]) or rays (origins/dirs [R,3], ebins [R,S+1], point n = ray n/S sample n%S);
+ * u [N,3] normalised+contracted+masked, sel [N] (1.0 / 0.0) */
+int ps_field_points(const float* pos, const float* origins, const float* dirs, const float* ebins, int S,
+                    const float* aabb, int contract, int64_t N, float* u, float* sel, void* stream);
+int ps_grid_encode(const float* u, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
+                   int64_t plane_stride, float* feat, void* stream);
+/* table gradient without HBM atomics (LDS slice owners); accumulate=0 overwrites dtable, 1 adds to it */
+int ps_grid_scatter(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
+                    int64_t plane_stride, float* dtable, int accumulate, void* stream);
+/* proposal field: MLP (L*F -> hidden -> 1), packed with ps_mlp_pack_layer (LINEAR first-layer colmap) */
+int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
+                        int* n_parts /*host*/);
+int ps_prop_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
+                      const float* packed, int64_t N, float* sigma, void* stream);
+int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
+                      const float* packed, const float* dsigma, int64_t N, float* dfeat, float* gpart, void* stream);
+/* main field: packed = [base | semantic head | colour head]; offsets[6] = packed offsets of the three MLPs then
+ * their gradient-block offsets.  dirs [R,3], app [R,A] (A <= 16, may be NULL), point n belongs to ray n/S.
+ * Outputs sigma [N], rgb [N,3], sem [N,64]; any of them may be NULL to skip that head. */
+int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t* packed_floats /*host*/,
+                        int64_t* grad_floats /*host*/, int* n_parts /*host*/, int64_t* offsets /*host [6]*/);
+int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                      const float* sel, const float* dirs, const float* app, int S, int A, const float* packed, int64_t N,
+                      float* sigma, float* rgb, float* sem, void* stream);
+int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                      const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                      const float* dsigma, const float* drgb, const float* dsem, int64_t N, float* dfeat, float* dapp,
+                      float* gpart, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,480 @@
+// Fused field kernels: everything between the hash-grid features and the per-sample outputs of a
+// PreSight field runs in ONE kernel per direction, activations never leave registers.
+//
+//   proposal field  (ns/fields/PreSight/prop_density_field.py:129-153)
+//       feat[L*F] -> Linear(64) ReLU Linear(1) -> trunc_exp * selector
+//   main field      (ns/fields/PreSight/ingp_field.py:168-237)
+//       feat[L*F] -> Linear(64) ReLU Linear(80) = [sigma_raw | geo15 | sem_embed64]
+//       sigma      = trunc_exp(sigma_raw) * selector
+//       semantics  = Linear(64) ReLU Linear(64) ReLU Linear(64) (sem_embed)
+//       rgb        = sigmoid(Linear(64) ReLU Linear(64) ReLU Linear(3) ([SH16(d) | geo15 | app]))
+//
+// The 80 outputs of the base MLP sit in MFMA D registers; blocks 1..4 are consumed as the B operand of
+// the semantic head, block 0 (sigma_raw + geo15) is spliced between the SH and appearance k-steps of
+// the colour head by giving that head's first layer a custom column map (host side, fields.py).
+// Backward recomputes the forward from the features (no activation is stored), back-propagates through
+// the three MLPs with the LDS-transposed dW scheme of mlp_core.hpp and emits d(features) as level planes
+// for ps_grid_scatter.
+#include "common.hpp"
+#include "mlp_core.hpp"
+#include "pointwise_core.hpp"
+
+namespace {
+
+using namespace ps;
+
+// features are stored as level planes feat[l][n][f]; the first layer uses the LINEAR column map
+// (k-step t, lane group g -> column 4t+g)
+template <int KS0, int PB>
+__device__ __forceinline__ void load_feat(const float* __restrict__ feat, int64_t plane_stride, int LF, int F, int64_t first,
+                                          int64_t N, float (&x)[PB][KS0]) {
+  const int lane = ps_lane(), j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int64_t p = first + pb * 16 + j;
+#pragma unroll
+    for (int t = 0; t < KS0; ++t) {
+      const int col = 4 * t + g;
+      const int level = col / F, f = col - level * F;
+      x[pb][t] = (p < N && col < LF) ? feat[level * plane_stride + p * F + f] : 0.0f;
+    }
+  }
+}
+
+template <int KS0, int PB>
+__device__ __forceinline__ void store_dfeat(float* __restrict__ dfeat, int64_t plane_stride, int LF, int F, int64_t first,
+                                            int64_t N, const float (&dx)[PB][((KS0 + 3) / 4) * 4]) {
+  const int lane = ps_lane(), j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int64_t p = first + pb * 16 + j;
+#pragma unroll
+    for (int t = 0; t < KS0; ++t) {
+      const int col = 4 * t + g;
+      const int level = col / F, f = col - level * F;
+      if (p < N && col < LF) dfeat[level * plane_stride + p * F + f] = dx[pb][t];
+    }
+  }
+}
+
+__device__ __forceinline__ float trunc_exp_grad(float raw) { return expf(fminf(fmaxf(raw, -15.0f), 15.0f)); }
+
+// ------------------------------------------------------------------------------------------ proposal field
+template <class M, int PB>
+__global__ __launch_bounds__(256) void prop_fwd_kernel(const float* __restrict__ feat, int64_t plane_stride, int LF, int F,
+                                                       const float* __restrict__ sel, const float* __restrict__ packed,
+                                                       int64_t N, float* __restrict__ sigma) {
+  __shared__ __attribute__((aligned(16))) float lds[M::FW];
+  for (int i = threadIdx.x * 4; i < M::FW; i += 256 * 4)
+    *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(packed + i);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t first = tile * 16 * PB;
+    float x[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
+    load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
+    mlp_forward<M, PB>(LdsW{lds}, x, h1, h2, z);
+    if (g == 0) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j;
+        if (p < N) sigma[p] = expf(z[pb][0]) * sel[p];
+      }
+    }
+  }
+}
+
+template <class M, int PB>
+__global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__ feat, int64_t plane_stride, int LF, int F,
+                                                       const float* __restrict__ sel, const float* __restrict__ packed,
+                                                       const float* __restrict__ dsigma, int64_t N, float* __restrict__ dfeat,
+                                                       float* __restrict__ gpart) {
+  constexpr int SCR = M::SCRATCH_ROWS * kScratchLd;
+  __shared__ __attribute__((aligned(16))) float lds[M::GPACKED + 4 * SCR];
+  float* gacc = lds;
+  for (int i = threadIdx.x; i < M::GPACKED; i += 256) gacc[i] = 0.0f;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  float* scratch = lds + M::GPACKED + wave * SCR;
+  const GlobalW gw = make_global_w(packed, M::PACKED);
+  const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t first = tile * 16 * PB;
+    float x[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
+    load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
+    mlp_forward<M, PB>(gw, x, h1, h2, z);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t p = first + pb * 16 + j;
+      const float d = (g == 0 && p < N) ? dsigma[p] * sel[p] * trunc_exp_grad(z[pb][0]) : 0.0f;
+#pragma unroll
+      for (int t = 0; t < M::NBO * 4; ++t) z[pb][t] = 0.0f;
+      z[pb][0] = d;
+    }
+    float dx[PB][M::L0::IB * 4];
+    mlp_backward<M, PB, true>(gw, scratch, gacc, x, h1, h2, z, dx);
+    store_dfeat<M::KS0, PB>(dfeat, plane_stride, LF, F, first, N, dx);
+  }
+  __syncthreads();
+  float* out = gpart + (size_t)blockIdx.x * M::GPACKED;
+  for (int i = threadIdx.x; i < M::GPACKED; i += 256) out[i] = gacc[i];
+}
+
+// ------------------------------------------------------------------------------------------ main field
+struct MainArgs {
+  const float* feat;
+  int64_t plane_stride;
+  int LF, F;
+  const float* sel;
+  const float* dirs;  // [R,3]
+  const float* app;   // [R,A] or null
+  int S, A;
+  const float* packed;  // [base | sem | rgb] packed blocks
+  int64_t N;
+  // forward outputs (any may be null)
+  float* sigma;
+  float* rgb;
+  float* sem;
+  // backward inputs / outputs
+  const float* dsigma;
+  const float* drgb;
+  const float* dsem;
+  float* dfeat;
+  float* dapp;  // [R,A], accumulated with atomics
+  float* gpart;
+};
+
+template <int KS0_, int HB_, int HBC_>
+struct MainCfg {
+  using Base = MlpT<KS0_, HB_, 5, 2>;
+  using Sem = MlpT<16, 4, 4, 3>;
+  using Rgb = MlpT<12, HBC_, 1, 3>;
+  static constexpr int P_BASE = 0, P_SEM = Base::PACKED, P_RGB = P_SEM + Sem::PACKED, PACKED = P_RGB + Rgb::PACKED;
+  static constexpr int G_BASE = 0, G_SEM = Base::GPACKED, G_RGB = G_SEM + Sem::GPACKED, GPACKED = G_RGB + Rgb::GPACKED;
+  static constexpr int FW_BASE = 0, FW_SEM = Base::FW, FW_RGB = FW_SEM + Sem::FW, FW = FW_RGB + Rgb::FW;
+  static constexpr int SCR_ROWS = Base::SCRATCH_ROWS > Sem::SCRATCH_ROWS
+                                      ? (Base::SCRATCH_ROWS > Rgb::SCRATCH_ROWS ? Base::SCRATCH_ROWS : Rgb::SCRATCH_ROWS)
+                                      : (Sem::SCRATCH_ROWS > Rgb::SCRATCH_ROWS ? Sem::SCRATCH_ROWS : Rgb::SCRATCH_ROWS);
+};
+
+// colour-head input: k-steps 0-3 SH16 of (d+1)/2, 4-7 base-output block 0 (sigma_raw slot has zero weight),
+// 8-11 appearance embedding
+template <int PB>
+__device__ __forceinline__ void build_colour_input(const MainArgs& a, int64_t first, const float (&zb)[PB][20],
+                                                   float (&cin)[PB][12], int64_t (&ray_of)[PB]) {
+  const int lane = ps_lane(), j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int64_t p = first + pb * 16 + j;
+    const int64_t r = (p < a.N ? p : a.N - 1) / a.S;
+    ray_of[pb] = r;
+    float sh[16];
+    sh4((a.dirs[r * 3] + 1.0f) / 2.0f, (a.dirs[r * 3 + 1] + 1.0f) / 2.0f, (a.dirs[r * 3 + 2] + 1.0f) / 2.0f, sh);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      // select component 4t+g without dynamic register indexing
+      const float v0 = sh[4 * t], v1 = sh[4 * t + 1], v2 = sh[4 * t + 2], v3 = sh[4 * t + 3];
+      cin[pb][t] = g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
+      cin[pb][4 + t] = zb[pb][t];
+      const int c = 4 * t + g;
+      cin[pb][8 + t] = (a.app != nullptr && c < a.A) ? a.app[r * a.A + c] : 0.0f;
+    }
+  }
+}
+
+template <class C, int PB>
+__global__ __launch_bounds__(256) void main_fwd_kernel(MainArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[C::FW];
+  // forward blocks of the three MLPs, contiguous in LDS
+  for (int i = threadIdx.x * 4; i < C::Base::FW; i += 1024)
+    *reinterpret_cast<f32x4*>(lds + C::FW_BASE + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_BASE + i);
+  for (int i = threadIdx.x * 4; i < C::Sem::FW; i += 1024)
+    *reinterpret_cast<f32x4*>(lds + C::FW_SEM + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_SEM + i);
+  for (int i = threadIdx.x * 4; i < C::Rgb::FW; i += 1024)
+    *reinterpret_cast<f32x4*>(lds + C::FW_RGB + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_RGB + i);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  const int64_t tiles = (a.N + 16 * PB - 1) / (16 * PB);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t first = tile * 16 * PB;
+    float zb[PB][20];
+    {
+      float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], h2[PB][C::Base::HB * 4];
+      load_feat<C::Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
+      mlp_forward<typename C::Base, PB>(LdsW{lds + C::FW_BASE}, x, h1, h2, zb);
+    }
+    if (a.sigma != nullptr && g == 0) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j;
+        if (p < a.N) a.sigma[p] = expf(zb[pb][0]) * a.sel[p];
+      }
+    }
+    if (a.sem != nullptr) {
+      float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][4 + t];
+      mlp_forward<typename C::Sem, PB>(LdsW{lds + C::FW_SEM}, sin_, s1, s2, so);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j;
+        if (p < a.N) {
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+            *reinterpret_cast<f32x4*>(a.sem + p * 64 + 16 * nb + 4 * g) =
+                (f32x4){so[pb][4 * nb], so[pb][4 * nb + 1], so[pb][4 * nb + 2], so[pb][4 * nb + 3]};
+        }
+      }
+    }
+    if (a.rgb != nullptr) {
+      float cin[PB][12], c1[PB][C::Rgb::HB * 4], c2[PB][C::Rgb::HB * 4], co[PB][4];
+      int64_t ray_of[PB];
+      build_colour_input<PB>(a, first, zb, cin, ray_of);
+      mlp_forward<typename C::Rgb, PB>(LdsW{lds + C::FW_RGB}, cin, c1, c2, co);
+      if (g == 0) {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+          const int64_t p = first + pb * 16 + j;
+          if (p < a.N) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.rgb[p * 3 + k] = 1.0f / (1.0f + expf(-co[pb][k]));
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class C, int PB>
+__global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
+  constexpr int SCR = C::SCR_ROWS * kScratchLd;
+  __shared__ __attribute__((aligned(16))) float lds[C::GPACKED + 4 * SCR];
+  float* gacc = lds;
+  for (int i = threadIdx.x; i < C::GPACKED; i += 256) gacc[i] = 0.0f;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  float* scratch = lds + C::GPACKED + wave * SCR;
+  const GlobalW pk_all = make_global_w(a.packed, C::PACKED);
+  const GlobalW pk_base = pk_all.at(C::P_BASE), pk_sem = pk_all.at(C::P_SEM), pk_rgb = pk_all.at(C::P_RGB);
+  const int64_t tiles = (a.N + 16 * PB - 1) / (16 * PB);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t first = tile * 16 * PB;
+    // ---- recompute base
+    float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], hdummy[PB][C::Base::HB * 4], zb[PB][20];
+    load_feat<C::Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
+    mlp_forward<typename C::Base, PB>(pk_base, x, h1, hdummy, zb);
+    float dzb[PB][20];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t p = first + pb * 16 + j;
+#pragma unroll
+      for (int t = 0; t < 20; ++t) dzb[pb][t] = 0.0f;
+      if (a.dsigma != nullptr && g == 0 && p < a.N) dzb[pb][0] = a.dsigma[p] * a.sel[p] * trunc_exp_grad(zb[pb][0]);
+    }
+    // ---- semantic head
+    if (a.dsem != nullptr) {
+      float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][4 + t];
+      mlp_forward<typename C::Sem, PB>(pk_sem, sin_, s1, s2, so);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (p < a.N) d = *reinterpret_cast<const f32x4*>(a.dsem + p * 64 + 16 * nb + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = d[r];
+        }
+      }
+      float dsin[PB][16];
+      mlp_backward<typename C::Sem, PB, true>(pk_sem, scratch, gacc + C::G_SEM, sin_, s1, s2, so, dsin);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dzb[pb][4 + t] += dsin[pb][t];
+    }
+    // ---- colour head
+    if (a.drgb != nullptr) {
+      float cin[PB][12], c1[PB][C::Rgb::HB * 4], c2[PB][C::Rgb::HB * 4], co[PB][4];
+      int64_t ray_of[PB];
+      build_colour_input<PB>(a, first, zb, cin, ray_of);
+      mlp_forward<typename C::Rgb, PB>(pk_rgb, cin, c1, c2, co);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float d = 0.0f;
+          if (k < 3 && g == 0 && p < a.N) {
+            const float s = 1.0f / (1.0f + expf(-co[pb][k]));
+            d = a.drgb[p * 3 + k] * s * (1.0f - s);
+          }
+          co[pb][k] = d;
+        }
+      }
+      float dcin[PB][12];
+      mlp_backward<typename C::Rgb, PB, true>(pk_rgb, scratch, gacc + C::G_RGB, cin, c1, c2, co, dcin);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          dzb[pb][t] += dcin[pb][4 + t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
+          if (a.dapp != nullptr) {
+            const int c = 4 * t + g;
+            if (p < a.N && c < a.A) unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, dcin[pb][8 + t]);
+          }
+        }
+      }
+    }
+    // ---- base MLP backward -> d(features)
+    float dx[PB][C::Base::L0::IB * 4];
+    mlp_backward<typename C::Base, PB, true>(pk_base, scratch, gacc + C::G_BASE, x, h1, hdummy, dzb, dx);
+    store_dfeat<C::Base::KS0, PB>(a.dfeat, a.plane_stride, a.LF, a.F, first, a.N, dx);
+  }
+  __syncthreads();
+  float* out = a.gpart + (size_t)blockIdx.x * C::GPACKED;
+  for (int i = threadIdx.x; i < C::GPACKED; i += 256) out[i] = gacc[i];
+}
+
+int grid_for_tiles(int64_t N, int pts_per_tile, int max_blocks) {
+  const int64_t tiles = (N + pts_per_tile - 1) / pts_per_tile;
+  int64_t g = (tiles + 3) / 4;
+  if (g > max_blocks) g = max_blocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 4, kMainBwdPB = 1;
+
+// (L*F, hidden) of the proposal nets
+#define PS_PROP_CFGS(X) \
+  X(8, 64)              \
+  X(2, 32)
+// (L*F, hidden, hidden_color) of the main field
+#define PS_MAIN_CFGS(X) \
+  X(32, 64, 64)         \
+  X(40, 64, 64)         \
+  X(4, 32, 32)
+
+}  // namespace
+
+extern "C" int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats, int64_t* grad_floats, int* n_parts) {
+#define X(lf, h)                                            \
+  if (LF == lf && hidden == h) {                            \
+    using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;         \
+    *packed_floats = M::PACKED;                             \
+    *grad_floats = M::GPACKED;                              \
+    *n_parts = grid_for_tiles(N, 16 * kPropBwdPB, 256);     \
+    return 0;                                               \
+  }
+  PS_PROP_CFGS(X)
+#undef X
+  ps_set_error("ps_prop_field: unsupported (L*F, hidden)");
+  return -2;
+}
+
+extern "C" int ps_prop_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
+                                 const float* packed, int64_t N, float* sigma, void* stream) {
+  if (N == 0) return 0;
+#define X(lf, h)                                                                                                     \
+  if (LF == lf && hidden == h) {                                                                                     \
+    using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;                                                                  \
+    prop_fwd_kernel<M, kPropFwdPB><<<grid_for_tiles(N, 16 * kPropFwdPB, 512), 256, 0, (hipStream_t)stream>>>(         \
+        feat, plane_stride, LF, F, sel, packed, N, sigma);                                                           \
+    PS_CHECK_LAUNCH();                                                                                               \
+  }
+  PS_PROP_CFGS(X)
+#undef X
+  ps_set_error("ps_prop_field_fwd: unsupported (L*F, hidden)");
+  return -2;
+}
+
+extern "C" int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
+                                 const float* packed, const float* dsigma, int64_t N, float* dfeat, float* gpart,
+                                 void* stream) {
+  if (N == 0) return 0;
+#define X(lf, h)                                                                                                     \
+  if (LF == lf && hidden == h) {                                                                                     \
+    using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;                                                                  \
+    prop_bwd_kernel<M, kPropBwdPB><<<grid_for_tiles(N, 16 * kPropBwdPB, 256), 256, 0, (hipStream_t)stream>>>(         \
+        feat, plane_stride, LF, F, sel, packed, dsigma, N, dfeat, gpart);                                            \
+    PS_CHECK_LAUNCH();                                                                                               \
+  }
+  PS_PROP_CFGS(X)
+#undef X
+  ps_set_error("ps_prop_field_bwd: unsupported (L*F, hidden)");
+  return -2;
+}
+
+extern "C" int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t* packed_floats,
+                                   int64_t* grad_floats, int* n_parts, int64_t* offsets /*[6]: P_SEM,P_RGB,G_SEM,G_RGB,..*/) {
+#define X(lf, h, hc)                                               \
+  if (LF == lf && hidden == h && hidden_color == hc) {             \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;              \
+    *packed_floats = C::PACKED;                                    \
+    *grad_floats = C::GPACKED;                                     \
+    *n_parts = grid_for_tiles(N, 16 * kMainBwdPB, 256);            \
+    if (offsets) {                                                 \
+      offsets[0] = C::P_BASE;                                      \
+      offsets[1] = C::P_SEM;                                       \
+      offsets[2] = C::P_RGB;                                       \
+      offsets[3] = C::G_BASE;                                      \
+      offsets[4] = C::G_SEM;                                       \
+      offsets[5] = C::G_RGB;                                       \
+    }                                                              \
+    return 0;                                                      \
+  }
+  PS_MAIN_CFGS(X)
+#undef X
+  ps_set_error("ps_main_field: unsupported (L*F, hidden, hidden_color)");
+  return -2;
+}
+
+extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                 const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                 int64_t N, float* sigma, float* rgb, float* sem, void* stream) {
+  if (N == 0) return 0;
+  PS_REQUIRE(A <= 16 && S > 0, "ps_main_field_fwd: appearance dim must be <= 16");
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem;
+#define X(lf, h, hc)                                                                                                  \
+  if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
+    main_fwd_kernel<C, kMainFwdPB><<<grid_for_tiles(N, 16 * kMainFwdPB, 256), 256, 0, (hipStream_t)stream>>>(a);      \
+    PS_CHECK_LAUNCH();                                                                                                \
+  }
+  PS_MAIN_CFGS(X)
+#undef X
+  ps_set_error("ps_main_field_fwd: unsupported (L*F, hidden, hidden_color)");
+  return -2;
+}
+
+extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                 const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                 const float* dsigma, const float* drgb, const float* dsem, int64_t N, float* dfeat,
+                                 float* dapp, float* gpart, void* stream) {
+  if (N == 0) return 0;
+  PS_REQUIRE(A <= 16 && S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart;
+#define X(lf, h, hc)                                                                                                  \
+  if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
+    main_bwd_kernel<C, kMainBwdPB><<<grid_for_tiles(N, 16 * kMainBwdPB, 256), 256, 0, (hipStream_t)stream>>>(a);      \
+    PS_CHECK_LAUNCH();                                                                                                \
+  }
+  PS_MAIN_CFGS(X)
+#undef X
+  ps_set_error("ps_main_field_bwd: unsupported (L*F, hidden, hidden_color)");
+  return -2;
+}

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const float* __restrict__ 
     const int64_t first = tile * 16 * PB;
     float xin[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
     load_rows_linear<M, PB>(x, first, N, in_dim, xin);
-    mlp_forward<M, PB>(lds, xin, h1, h2, z);
+    mlp_forward<M, PB>(LdsW{lds}, xin, h1, h2, z);
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t p = first + pb * 16 + j;
@@ -123,12 +123,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const float* __restrict__ 
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
   float* scratch = lds + M::GPACKED + wave * SCR;
+  const GlobalW gw = make_global_w(packed, M::PACKED);
   const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t first = tile * 16 * PB;
     float xin[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
     load_rows_linear<M, PB>(x, first, N, in_dim, xin);
-    mlp_forward<M, PB>(packed, xin, h1, h2, z);
+    mlp_forward<M, PB>(gw, xin, h1, h2, z);
     // dz = dy (* sigmoid') in D layout
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const float* __restrict__ 
       }
     }
     float dxin[PB][M::L0::IB * 4];
-    mlp_backward<M, PB, WANT_DX>(packed, scratch, gacc, xin, h1, h2, z, dxin);
+    mlp_backward<M, PB, WANT_DX>(gw, scratch, gacc, xin, h1, h2, z, dxin);
     if constexpr (WANT_DX) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {

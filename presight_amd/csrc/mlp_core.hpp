@@ -23,6 +23,7 @@
 // accumulated in registers over the wave's points, then added into workgroup-level LDS
 // accumulators (ds_add_f32) and finally written as one partial per workgroup.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace ps {
@@ -48,27 +49,59 @@ struct LayerT {
 
 constexpr int kScratchLd = 20;  // floats per scratch row: 16 points + 4 pad (keeps 16-B alignment)
 
+// ---- where weight fragments come from --------------------------------------------------------
+// Forward-only kernels keep the packed forward blocks in LDS (ds_read with an immediate offset).
+struct LdsW {
+  const float* base;
+  __device__ __forceinline__ float frag(int float_off) const { return base[float_off + ps_lane()]; }
+  __device__ __forceinline__ f32x4 vec4(int float_off) const { return *reinterpret_cast<const f32x4*>(base + float_off); }
+  __device__ __forceinline__ LdsW at(int float_off) const { return LdsW{base + float_off}; }
+};
+// Backward kernels need LDS for the gradient accumulators, so they stream fragments from L2 through a
+// buffer resource: address = SGPR descriptor + (lane*4 in ONE VGPR) + SGPR/immediate fragment offset.
+// (Plain pointer arithmetic makes hipcc materialise a 64-bit per-lane pointer for every 4 KiB of
+// fragments, hoist them out of the tile loop and spill them.)
+struct GlobalW {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int base;  // float offset inside the buffer
+  __device__ __forceinline__ float frag(int float_off) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)ps_lane() * 4u, (base + float_off) * 4, 0));
+  }
+  __device__ __forceinline__ f32x4 vec4(int float_off) const {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0u, (base + float_off) * 4, 0));
+  }
+  __device__ __forceinline__ f32x4 vec4_lane(int float_off, unsigned lane_float_off) const {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_float_off * 4u, (base + float_off) * 4, 0));
+  }
+  __device__ __forceinline__ GlobalW at(int float_off) const { return GlobalW{rsrc, base + float_off}; }
+};
+__device__ __forceinline__ GlobalW make_global_w(const float* p, unsigned n_floats) {
+  return GlobalW{__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, n_floats * 4u, 0x00020000), 0};
+}
+
 // ---- forward -------------------------------------------------------------------------------
 // v[pb][t] is the B-operand array of a 16-point block: for D-chained data t = 4*nb + r.
-template <class LT, int PB>
-__device__ __forceinline__ void layer_fwd(const float* __restrict__ params, const float (&vin)[PB][LT::KS],
-                                          float (&vout)[PB][LT::NB * 4]) {
+template <class LT, int PB, class W>
+__device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB][LT::KS], float (&vout)[PB][LT::NB * 4]) {
   const int lane = ps_lane();
   const int g = lane >> 4;
   f32x4 acc[LT::NB][PB];
 #pragma unroll
   for (int nb = 0; nb < LT::NB; ++nb) {
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(params + LT::BIAS_OFF + 16 * nb + 4 * g);
+    f32x4 b4;
+    if constexpr (std::is_same<W, LdsW>::value)
+      b4 = params.vec4(LT::BIAS_OFF + 16 * nb + 4 * g);
+    else
+      b4 = params.vec4_lane(LT::BIAS_OFF + 16 * nb, 4u * (unsigned)g);
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = b4;
   }
-  const float* wf = params + LT::WF_OFF + lane;
 #pragma unroll
   for (int nb = 0; nb < LT::NB; ++nb) {
     __builtin_amdgcn_sched_barrier(0);  // keep the weight-fragment loads of later blocks from being hoisted
 #pragma unroll
     for (int t = 0; t < LT::KS; ++t) {
-      const float a = wf[(nb * LT::KS + t) * 64];
+      const float a = params.frag(LT::WF_OFF + (nb * LT::KS + t) * 64);
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = ps_mfma16(a, vin[pb][t], acc[nb][pb]);
     }
@@ -100,11 +133,9 @@ __device__ __forceinline__ void relu_mask(float (&dv)[PB][N], const float (&h)[P
 
 // ---- backward (data) -----------------------------------------------------------------------
 // dvin[pb][t], t = 4*ib + r, comes out in the layout the forward input of this layer had.
-template <class LT, int PB>
-__device__ __forceinline__ void layer_bwd_data(const float* __restrict__ wt_block, const float (&dvout)[PB][LT::NB * 4],
+template <class LT, int PB, class W>
+__device__ __forceinline__ void layer_bwd_data(const W& wt_block, const float (&dvout)[PB][LT::NB * 4],
                                                float (&dvin)[PB][LT::IB * 4]) {
-  const int lane = ps_lane();
-  const float* wtf = wt_block + lane;
 #pragma unroll
   for (int ib = 0; ib < LT::IB; ++ib) {
     __builtin_amdgcn_sched_barrier(0);
@@ -113,7 +144,7 @@ __device__ __forceinline__ void layer_bwd_data(const float* __restrict__ wt_bloc
     for (int pb = 0; pb < PB; ++pb) acc[pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < LT::KSO; ++t) {
-      const float a = wtf[(ib * LT::KSO + t) * 64];
+      const float a = wt_block.frag((ib * LT::KSO + t) * 64);
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) acc[pb] = ps_mfma16(a, dvout[pb][t], acc[pb]);
     }
@@ -133,11 +164,6 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
                                                   const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS]) {
   const int lane = ps_lane();
   const int j = lane & 15, g = lane >> 4;
-  f32x4 dw[LT::NB][LT::IB];
-#pragma unroll
-  for (int ob = 0; ob < LT::NB; ++ob)
-#pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float* sy = scratch;                               // dY tile rows [NB*16]
   float* sh = scratch + LT::NB * 16 * kScratchLd;    // H tile rows  [IB*16]
 #pragma unroll
@@ -156,21 +182,24 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
     for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(sh + (16 * ib + j) * kScratchLd + 4 * g);
 #pragma unroll
     for (int ob = 0; ob < LT::NB; ++ob) {
+      __builtin_amdgcn_sched_barrier(0);
       const f32x4 afrag = *reinterpret_cast<const f32x4*>(sy + (16 * ob + j) * kScratchLd + 4 * g);
+      f32x4 dw[LT::IB];
+#pragma unroll
+      for (int ib = 0; ib < LT::IB; ++ib) dw[ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ib = 0; ib < LT::IB; ++ib) dw[ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ib]);
+      // add the 16x16 tiles of this output block into the workgroup accumulators (ds_add_f32)
 #pragma unroll
       for (int ib = 0; ib < LT::IB; ++ib)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dw[ob][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ob][ib]);
+        for (int r = 0; r < 4; ++r) atomicAdd(gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 4 + r) * 64 + lane, dw[ib][r]);
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // flush the register tiles into the workgroup accumulators
-#pragma unroll
-  for (int ob = 0; ob < LT::NB; ++ob)
-#pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 4 + r) * 64 + lane, dw[ob][ib][r]);
+  __builtin_amdgcn_sched_barrier(0);
   // bias gradient: sum over the wave's points
 #pragma unroll
   for (int t = 0; t < LT::NB * 4; ++t) {
@@ -180,6 +209,7 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
     s = ps_row16_sum(s);
     if (j == 0) atomicAdd(gacc + LT::GB_OFF + 16 * (t >> 2) + 4 * g + (t & 3), s);
   }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---- whole-MLP description -----------------------------------------------------------------
@@ -211,46 +241,46 @@ struct MlpT {
 };
 
 // forward through all layers, keeping the post-ReLU hidden activations (needed by backward)
-template <class M, int PB>
-__device__ __forceinline__ void mlp_forward(const float* __restrict__ params, const float (&x)[PB][M::KS0],
+template <class M, int PB, class W>
+__device__ __forceinline__ void mlp_forward(const W& params, const float (&x)[PB][M::KS0],
                                             float (&h1)[PB][M::HB * 4], float (&h2)[PB][M::HB * 4],
                                             float (&z)[PB][M::NBO * 4]) {
-  layer_fwd<typename M::L0, PB>(params + M::OFF0, x, h1);
+  layer_fwd<typename M::L0, PB>(params.at(M::OFF0), x, h1);
   relu_inplace<PB, M::HB * 4>(h1);
   if constexpr (M::NL == 3) {
-    layer_fwd<typename M::L1, PB>(params + M::OFF1, h1, h2);
+    layer_fwd<typename M::L1, PB>(params.at(M::OFF1), h1, h2);
     relu_inplace<PB, M::HB * 4>(h2);
-    layer_fwd<typename M::LZ, PB>(params + M::OFFZ, h2, z);
+    layer_fwd<typename M::LZ, PB>(params.at(M::OFFZ), h2, z);
   } else {
-    layer_fwd<typename M::LZ, PB>(params + M::OFFZ, h1, z);
+    layer_fwd<typename M::LZ, PB>(params.at(M::OFFZ), h1, z);
   }
 }
 
 // backward through all layers given dz (gradient w.r.t. the last layer's pre-activation output).
 // WANT_DX selects whether dX (layout of x) is produced.
 // `params` is the global packed block (transposed fragments are read from it through L2).
-template <class M, int PB, bool WANT_DX>
-__device__ __forceinline__ void mlp_backward(const float* __restrict__ params, float* __restrict__ scratch,
+template <class M, int PB, bool WANT_DX, class W>
+__device__ __forceinline__ void mlp_backward(const W& params, float* __restrict__ scratch,
                                              float* __restrict__ gacc, const float (&x)[PB][M::KS0],
                                              const float (&h1)[PB][M::HB * 4], const float (&h2)[PB][M::HB * 4],
                                              const float (&dz)[PB][M::NBO * 4], float (&dx)[PB][M::L0::IB * 4]) {
   float dh[PB][M::HB * 4];
   if constexpr (M::NL == 3) {
     layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, dz, h2);
-    layer_bwd_data<typename M::LZ, PB>(params + M::TOFFZ, dz, dh);
+    layer_bwd_data<typename M::LZ, PB>(params.at(M::TOFFZ), dz, dh);
     relu_mask<PB, M::HB * 4>(dh, h2);
     float dh1[PB][M::HB * 4];
     layer_bwd_weights<typename M::L1, PB>(scratch, gacc + M::GOFF1, dh, h1);
-    layer_bwd_data<typename M::L1, PB>(params + M::TOFF1, dh, dh1);
+    layer_bwd_data<typename M::L1, PB>(params.at(M::TOFF1), dh, dh1);
     relu_mask<PB, M::HB * 4>(dh1, h1);
     layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, dh1, x);
-    if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params + M::TOFF0, dh1, dx);
+    if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params.at(M::TOFF0), dh1, dx);
   } else {
     layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, dz, h1);
-    layer_bwd_data<typename M::LZ, PB>(params + M::TOFFZ, dz, dh);
+    layer_bwd_data<typename M::LZ, PB>(params.at(M::TOFFZ), dz, dh);
     relu_mask<PB, M::HB * 4>(dh, h1);
     layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, dh, x);
-    if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params + M::TOFF0, dh, dx);
+    if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params.at(M::TOFF0), dh, dx);
   }
 }
 

@@ -39,6 +39,7 @@ __global__ void route_kernel(const float* __restrict__ p, int64_t M, const float
 
 __global__ void positions_kernel(const float* __restrict__ origins, const float* __restrict__ dirs,
                                  const float* __restrict__ ebins, int64_t R, int S, float* __restrict__ pos) {
+#pragma clang fp contract(off)
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= R * S) return;
   const int64_t r = i / S;

@@ -8,6 +8,7 @@ namespace ps {
 // aabb = {min.xyz, max.xyz}.  Returns the selector.
 __device__ __forceinline__ bool normalize_contract(float px, float py, float pz, const float* __restrict__ aabb,
                                                    bool contract, float (&u)[3]) {
+#pragma clang fp contract(off)  // keep the reference's separately rounded mul/add so that u is bit-identical to torch
   float q[3] = {(px - aabb[0]) / (aabb[3] - aabb[0]), (py - aabb[1]) / (aabb[4] - aabb[1]),
                 (pz - aabb[2]) / (aabb[5] - aabb[2])};
   if (contract) {

@@ -1,0 +1,253 @@
+"""Field-level fused operators (autograd glue over ps_field_points / ps_grid_encode / ps_*_field_fwd|bwd /
+ps_grid_scatter).  One call evaluates a whole PreSight field for a batch of points:
+
+    prop_field : ns/fields/PreSight/prop_density_field.py:129-153
+    main_field : ns/fields/PreSight/ingp_field.py:168-237 (density_fn + get_outputs)
+
+Positions carry no gradient (the reference detaches the sampled bins, ray_samplers.py:360)."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from ._lib import check, lib
+from .ops import MlpSpec, _f32, _p, _stream, chain_colmap, linear_colmap
+
+
+@dataclass(frozen=True)
+class GridCfg:
+    num_levels: int
+    features_per_level: int
+    log2_hashmap_size: int
+
+    @property
+    def out_dim(self) -> int:
+        return self.num_levels * self.features_per_level
+
+
+def field_points(aabb: Tensor, contract: bool, pos: Optional[Tensor] = None, origins: Optional[Tensor] = None,
+                 dirs: Optional[Tensor] = None, ebins: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """-> (u [N,3] in [0,1] (masked), sel [N] float 0/1).  Either world positions or a ray batch + bin edges."""
+    aabb = _f32(aabb)
+    if pos is not None:
+        pos = _f32(pos).view(-1, 3)
+        N, S, dev = pos.shape[0], 0, pos.device
+    else:
+        origins, dirs, ebins = _f32(origins), _f32(dirs), _f32(ebins)
+        S = ebins.shape[1] - 1
+        N, dev = ebins.shape[0] * S, ebins.device
+    u = torch.empty(N, 3, device=dev)
+    sel = torch.empty(N, device=dev)
+    check(lib().ps_field_points(_p(pos), _p(origins), _p(dirs), _p(ebins), S, _p(aabb), int(contract), N, _p(u), _p(sel),
+                                _stream()), "ps_field_points")
+    return u, sel
+
+
+def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg) -> Tensor:
+    N = u.shape[0]
+    feat = torch.empty(g.num_levels, N, g.features_per_level, device=u.device)
+    check(lib().ps_grid_encode(_p(u), _p(table), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
+                               N * g.features_per_level, _p(feat), _stream()), "ps_grid_encode")
+    return feat
+
+
+def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape) -> Tensor:
+    N = u.shape[0]
+    dtable = torch.empty(table_shape, device=u.device, dtype=torch.float32)
+    check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
+                                N * g.features_per_level, _p(dtable), 0, _stream()), "ps_grid_scatter")
+    return dtable
+
+
+def _layers(flat: Sequence[Tensor]) -> List[Tuple[Tensor, Tensor]]:
+    return [(flat[2 * i], flat[2 * i + 1]) for i in range(len(flat) // 2)]
+
+
+# ------------------------------------------------------------------------------------------------ proposal field
+_PROP_SPECS = {}
+
+
+def _prop_spec(LF: int, hidden: int) -> MlpSpec:
+    key = (LF, hidden)
+    if key not in _PROP_SPECS:
+        _PROP_SPECS[key] = MlpSpec([LF, hidden, 1])
+    return _PROP_SPECS[key]
+
+
+class _PropField(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, sel, table, scalings, g: GridCfg, *wb):
+        layers = _layers(wb)
+        hidden = layers[0][0].shape[0]
+        spec = _prop_spec(g.out_dim, hidden)
+        N = u.shape[0]
+        table = _f32(table, "hash table")
+        feat = _encode(u, table, scalings, g)
+        packed = spec.pack(layers, u.device)
+        sigma = torch.empty(N, device=u.device)
+        check(lib().ps_prop_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
+                                      _p(packed), N, _p(sigma), _stream()), "ps_prop_field_fwd")
+        ctx.save_for_backward(u, sel, scalings, feat, packed)
+        ctx.meta = (g, hidden, tuple(table.shape), [tuple(W.shape) for W, _ in layers])
+        return sigma
+
+    @staticmethod
+    def backward(ctx, dsigma):
+        u, sel, scalings, feat, packed = ctx.saved_tensors
+        g, hidden, tshape, shapes = ctx.meta
+        spec = _prop_spec(g.out_dim, hidden)
+        N = u.shape[0]
+        pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        check(lib().ps_prop_field_sizes(g.out_dim, hidden, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart)),
+              "ps_prop_field_sizes")
+        assert pf.value == spec.packed and gf.value == spec.g_total
+        gpart = torch.empty(npart.value, spec.g_total, device=u.device)
+        dfeat = torch.empty_like(feat)
+        check(lib().ps_prop_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
+                                      _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _stream()), "ps_prop_field_bwd")
+        dtable = _scatter(u, dfeat, scalings, g, tshape)
+        grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes)
+        flat = []
+        for gW, gb in grads:
+            flat += [gW, gb]
+        return (None, None, dtable, None, None, *flat)
+
+
+def prop_field(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g: GridCfg,
+               layers: Sequence[Tuple[Tensor, Tensor]]) -> Tensor:
+    """density [N] = trunc_exp(MLP(hash(u))) * sel."""
+    flat = []
+    for W, b in layers:
+        flat += [W, b]
+    return _PropField.apply(u, sel, table, scalings, g, *flat)
+
+
+# ------------------------------------------------------------------------------------------------ main field
+GEO_DIM = 15
+SEM_DIM = 64
+BASE_OUT = 1 + GEO_DIM + SEM_DIM
+
+
+def colour_colmap(app_dim: int) -> List[int]:
+    """First layer of the colour head: k-steps 0-3 = SH16 (linear), 4-7 = base-output block 0 straight from the MFMA
+    D registers (neuron 0 = sigma_raw has no column), 8-11 = appearance embedding (linear)."""
+    cm = []
+    for t in range(12):
+        for g in range(4):
+            if t < 4:
+                cm.append(4 * t + g)
+            elif t < 8:
+                n = 4 * g + (t - 4)
+                cm.append(-1 if n == 0 else 15 + n)
+            else:
+                c = 4 * (t - 8) + g
+                cm.append(31 + c if c < app_dim else -1)
+    return cm
+
+
+class MainSpec:
+    def __init__(self, LF: int, hidden: int, hidden_color: int, app_dim: int):
+        self.key = (LF, hidden, hidden_color)
+        self.app_dim = app_dim
+        self.base = MlpSpec([LF, hidden, BASE_OUT])
+        self.sem = MlpSpec([SEM_DIM, 64, 64, SEM_DIM], first_colmap=chain_colmap(16, SEM_DIM), ks0=16)
+        self.rgb = MlpSpec([16 + GEO_DIM + app_dim, hidden_color, hidden_color, 3], first_colmap=colour_colmap(app_dim), ks0=12)
+        self.p_off = [0, self.base.packed, self.base.packed + self.sem.packed]
+        self.packed = self.p_off[2] + self.rgb.packed
+        self.g_off = [0, self.base.g_total, self.base.g_total + self.sem.g_total]
+        self.g_total = self.g_off[2] + self.rgb.g_total
+
+    def pack(self, base, sem, rgb, device) -> Tensor:
+        packed = torch.empty(self.packed, device=device)
+        for spec, layers, off in ((self.base, base, self.p_off[0]), (self.sem, sem, self.p_off[1]), (self.rgb, rgb, self.p_off[2])):
+            spec.pack_into(layers, packed[off: off + spec.packed])
+        return packed
+
+
+_MAIN_SPECS = {}
+
+
+def _main_spec(LF, hidden, hidden_color, app_dim) -> MainSpec:
+    key = (LF, hidden, hidden_color, app_dim)
+    if key not in _MAIN_SPECS:
+        _MAIN_SPECS[key] = MainSpec(LF, hidden, hidden_color, app_dim)
+    return _MAIN_SPECS[key]
+
+
+class _MainField(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, sel, dirs, app, S, table, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, *wb):
+        layers = _layers(wb)
+        base, sem_l, rgb_l = layers[:n_base], layers[n_base:n_base + n_sem], layers[n_base + n_sem:]
+        hidden, hidden_color = base[0][0].shape[0], rgb_l[0][0].shape[0]
+        A = rgb_l[0][0].shape[1] - 16 - GEO_DIM  # appearance columns the colour head was built with
+        if want_rgb and (0 if app is None else app.shape[1]) != A:
+            raise ValueError(f"colour head expects SH16 + geo15 + app{A} inputs, got an appearance embedding of width "
+                             f"{0 if app is None else app.shape[1]}")
+        spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+        N = u.shape[0]
+        dev = u.device
+        table = _f32(table, "hash table")
+        feat = _encode(u, table, scalings, g)
+        packed = spec.pack(base, sem_l, rgb_l, dev)
+        sigma = torch.empty(N, device=dev)
+        rgb = torch.empty(N, 3, device=dev) if want_rgb else None
+        sem = torch.empty(N, SEM_DIM, device=dev) if want_sem else None
+        dirs = _f32(dirs) if dirs is not None else torch.zeros(1, 3, device=dev)
+        app_c = _f32(app) if (app is not None and want_rgb) else None
+        check(lib().ps_main_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                      _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb), _p(sem),
+                                      _stream()), "ps_main_field_fwd")
+        ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed)
+        ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
+                    want_rgb, want_sem)
+        empty = torch.empty(0, device=dev)
+        return sigma, (rgb if want_rgb else empty), (sem if want_sem else empty)
+
+    @staticmethod
+    def backward(ctx, dsigma, drgb, dsem):
+        u, sel, dirs, app, scalings, feat, packed = ctx.saved_tensors
+        g, hidden, hidden_color, A, S, tshape, shapes, n_base, n_sem, want_rgb, want_sem = ctx.meta
+        spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+        N = u.shape[0]
+        dev = u.device
+        pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        offs = (ctypes.c_int64 * 6)()
+        check(lib().ps_main_field_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart),
+                                        offs), "ps_main_field_sizes")
+        assert pf.value == spec.packed and gf.value == spec.g_total, (pf.value, spec.packed, gf.value, spec.g_total)
+        assert list(offs) == spec.p_off + spec.g_off, (list(offs), spec.p_off, spec.g_off)
+        gpart = torch.empty(npart.value, spec.g_total, device=dev)
+        dfeat = torch.empty_like(feat)
+        dapp = torch.zeros_like(app) if app is not None else None
+        d_sigma = _f32(dsigma) if dsigma is not None else None
+        d_rgb = _f32(drgb) if (want_rgb and drgb is not None) else None
+        d_sem = _f32(dsem) if (want_sem and dsem is not None) else None
+        check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                      _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem), N,
+                                      _p(dfeat), _p(dapp), _p(gpart), _stream()), "ps_main_field_bwd")
+        dtable = _scatter(u, dfeat, scalings, g, tshape)
+        n_rgb = len(shapes) - n_base - n_sem
+        grads = []
+        for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
+                            (spec.rgb, spec.g_off[2], shapes[n_base + n_sem:])):
+            grads += sp.unpack_grads(gpart, npart.value, spec.g_total, off, sh)
+        flat = []
+        for gW, gb in grads:
+            flat += [gW, gb]
+        assert len(flat) == 2 * (n_base + n_sem + n_rgb)
+        return (None, None, None, dapp, None, dtable, None, None, None, None, None, None, *flat)
+
+
+def main_field(u: Tensor, sel: Tensor, dirs: Optional[Tensor], app: Optional[Tensor], S: int, table: Tensor, scalings: Tensor,
+               g: GridCfg, base: Sequence[Tuple[Tensor, Tensor]], sem: Sequence[Tuple[Tensor, Tensor]],
+               rgb: Sequence[Tuple[Tensor, Tensor]], want_rgb: bool = True, want_sem: bool = True):
+    """-> (density [N], rgb [N,3], semantics [N,64]).  Point n belongs to ray n // S; dirs [R,3], app [R,A]."""
+    flat = []
+    for W, b in list(base) + list(sem) + list(rgb):
+        flat += [W, b]
+    return _MainField.apply(u, sel, dirs, app, S, table, scalings, g, want_rgb, want_sem, len(base), len(sem), *flat)

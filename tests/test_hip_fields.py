@@ -1,0 +1,195 @@
+"""GPU parity tests of the fused field kernels (points -> encode -> MFMA MLP stack -> outputs, and the full
+backward incl. the LDS slice-owner table scatter) against the reference-generated fixtures and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import model_fixture_setup, t
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def F():
+    from presight_amd import field_ops
+
+    return field_ops
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    b = t(b) if isinstance(b, np.ndarray) else b.detach().cpu()
+    torch.testing.assert_close(a.to(b.dtype).reshape(b.shape), b, rtol=rtol, atol=atol)
+
+
+def close_scaled(a, b, rtol=2e-4, atol=2e-5):
+    b = t(b) if isinstance(b, np.ndarray) else b.detach().cpu()
+    s = float(b.abs().max()) + 1e-20
+    close(a.detach().cpu() / s, b / s, rtol=rtol, atol=atol)
+
+
+def _layers(P, prefix, dev, grad=True):
+    out, i = [], 0
+    while f"{prefix}.layers.{i}.weight" in P:
+        out.append((P[f"{prefix}.layers.{i}.weight"].to(dev).requires_grad_(grad), P[f"{prefix}.layers.{i}.bias"].to(dev).requires_grad_(grad)))
+        i += 1
+    return out
+
+
+def test_main_field_golden(F, dev, gold_model):
+    """Sub-field 1 of the reference model fixture: density/embedding-derived outputs and every parameter gradient."""
+    G = gold_model
+    cfg, scene, P, _ = model_fixture_setup(G)
+    m = cfg["main"]
+    g = F.GridCfg(m["num_levels"], m["features_per_level"], m["log2_hashmap_size"])
+    sc = O.hash_scalings(m["num_levels"], m["base_res"], m["max_res"]).to(dev)
+    pre = "field.fields.1"
+    table = P[f"{pre}.mlp_base_grid.hash_table"].to(dev).requires_grad_(True)
+    base, sem, rgb = _layers(P, f"{pre}.mlp_base_mlp", dev), _layers(P, f"{pre}.semantic_head", dev), _layers(P, f"{pre}.rgb_head", dev)
+    pos, dirs, app = t(G["F_pos"]).to(dev), t(G["F_dirs"]).to(dev), t(G["F_app"]).to(dev).requires_grad_(True)
+    u, sel = F.field_points(scene["aabbs"][1].to(dev), True, pos=pos)
+    uo, so = O.normalize_contract(t(G["F_pos"]), scene["aabbs"][1])
+    assert torch.equal(sel.cpu() > 0, so)
+    close(u, uo, rtol=1e-6, atol=1e-7)
+    sigma, c, s = F.main_field(u, sel, dirs, app, 1, table, sc, g, base, sem, rgb)
+    close(sigma, G["F_density"][:, 0], rtol=1e-4, atol=1e-6)
+    close(c, G["F_rgb"])
+    close(s, G["F_sem"])
+    scalar = (sigma * t(G["F_cot_density"])[:, 0].to(dev)).sum() + (c * t(G["F_cot_rgb"]).to(dev)).sum() + (s * t(G["F_cot_sem"]).to(dev)).sum()
+    params = [table] + [p for wb in base + sem + rgb for p in wb]
+    names = ["mlp_base_grid.hash_table"] + [f"mlp_base_mlp.layers.{i}.{k}" for i in range(2) for k in ("weight", "bias")] + \
+        [f"semantic_head.layers.{i}.{k}" for i in range(3) for k in ("weight", "bias")] + \
+        [f"rgb_head.layers.{i}.{k}" for i in range(3) for k in ("weight", "bias")]
+    grads = torch.autograd.grad(scalar, params + [app])
+    for n, gr in zip(names, grads):
+        close_scaled(gr, G["Fg_" + n])
+    # appearance gradient vs the oracle (the reference fixture does not store it)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    appc = t(G["F_app"]).clone().requires_grad_(True)
+    dens, emb = O.main_density(Pg, cfg, 1, t(G["F_pos"]), scene["aabbs"][1])
+    rgb_o, sem_o = O.main_heads(Pg, cfg, 1, t(G["F_dirs"]), emb, appc)
+    so_ = (dens * t(G["F_cot_density"])[:, 0]).sum() + (rgb_o * t(G["F_cot_rgb"])).sum() + (sem_o * t(G["F_cot_sem"])).sum()
+    (ga,) = torch.autograd.grad(so_, appc)
+    close_scaled(grads[-1], ga)
+
+
+def test_prop_field_golden(F, dev, gold_model):
+    G = gold_model
+    cfg, scene, P, _ = model_fixture_setup(G)
+    pc = cfg["props"][0]
+    g = F.GridCfg(pc["num_levels"], pc["features_per_level"], pc["log2_hashmap_size"])
+    sc = O.hash_scalings(pc["num_levels"], pc["base_res"], pc["max_res"]).to(dev)
+    pre = "proposal_networks.0.fields.1"
+    table = P[f"{pre}.encoding.hash_table"].to(dev).requires_grad_(True)
+    layers = _layers(P, f"{pre}.mlp_base.1", dev)
+    u, sel = F.field_points(scene["aabbs"][1].to(dev), True, pos=t(G["F_pos"]).to(dev))
+    sigma = F.prop_field(u, sel, table, sc, g, layers)
+    close(sigma, G["Pp_density"][:, 0], rtol=1e-4, atol=1e-6)
+    grads = torch.autograd.grad((sigma * t(G["Pp_cot"])[:, 0].to(dev)).sum(), [table] + [p for wb in layers for p in wb])
+    names = ["encoding.hash_table"] + [f"mlp_base.1.layers.{i}.{k}" for i in range(2) for k in ("weight", "bias")]
+    for n, gr in zip(names, grads):
+        close_scaled(gr, G["Ppg_" + n])
+
+
+@pytest.mark.parametrize("which", ["cfg2", "prod"])
+def test_main_field_vs_oracle_ray_batch(F, dev, which):
+    """cfg-2 / production shaped field on a ray batch (positions generated in-kernel from rays + bins)."""
+    cfg = O.default_config()
+    if which == "prod":
+        cfg["main"].update(num_levels=10, features_per_level=4, log2_hashmap_size=14, max_res=16384)
+    else:
+        cfg["main"]["log2_hashmap_size"] = 15
+    for p in cfg["props"]:
+        p["log2_hashmap_size"] = 12
+    cfg["num_cameras"] = 60
+    P = O.make_params(cfg, seed=9, table_scale=0.2)
+    P["field.fields.0.mlp_base_mlp.layers.1.bias"][0] = 1.0
+    scene = O.make_scene(cfg)
+    m = cfg["main"]
+    R, S = 50, 64
+    batch = O.make_batch(cfg, scene, R, step=2)
+    o, d, _, _ = O.generate_rays(batch["ray_indices"], scene["c2w"], scene["fx"], scene["fy"], scene["cx"], scene["cy"])
+    bins = O.spaced_bins(R, S, batch["jitter"][0])
+    eb = O.s_to_euclid(bins, torch.full((R, 1), 0.005), torch.full((R, 1), 50.0), 5.0)
+    mid = (eb[:, :-1] + eb[:, 1:]) / 2
+    pos = (o[:, None] + d[:, None] * mid[..., None]).reshape(-1, 3)
+    app = torch.randn(R, 16)
+    cots = [torch.rand(R * S), torch.rand(R * S, 3) - 0.5, torch.rand(R * S, 64) - 0.5]
+    # oracle
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    appo = app.clone().requires_grad_(True)
+    app_s = appo[:, None, :].expand(R, S, 16).reshape(R * S, 16)
+    dir_s = d[:, None, :].expand(R, S, 3).reshape(-1, 3)
+    dens, emb = O.main_density(Pg, cfg, 0, pos, scene["aabbs"][0])
+    rgb_o, sem_o = O.main_heads(Pg, cfg, 0, dir_s, emb, app_s)
+    ((dens * cots[0]).sum() + (rgb_o * cots[1]).sum() + (sem_o * cots[2]).sum()).backward()
+    # HIP
+    g = F.GridCfg(m["num_levels"], m["features_per_level"], m["log2_hashmap_size"])
+    sc = O.hash_scalings(m["num_levels"], m["base_res"], m["max_res"]).to(dev)
+    pre = "field.fields.0"
+    table = P[f"{pre}.mlp_base_grid.hash_table"].to(dev).requires_grad_(True)
+    base, sem, rgb = _layers(P, f"{pre}.mlp_base_mlp", dev), _layers(P, f"{pre}.semantic_head", dev), _layers(P, f"{pre}.rgb_head", dev)
+    appd = app.to(dev).requires_grad_(True)
+    u, sel = F.field_points(scene["aabbs"][0].to(dev), True, origins=o.to(dev), dirs=d.to(dev), ebins=eb.to(dev))
+    sigma, c, s = F.main_field(u, sel, d.to(dev), appd, S, table, sc, g, base, sem, rgb)
+    close(sigma, dens, rtol=2e-4, atol=1e-6)
+    close(c, rgb_o)
+    close(s, sem_o)
+    scalar = (sigma * cots[0].to(dev)).sum() + (c * cots[1].to(dev)).sum() + (s * cots[2].to(dev)).sum()
+    params = [table] + [p for wb in base + sem + rgb for p in wb] + [appd]
+    names = [f"{pre}.mlp_base_grid.hash_table"] + [f"{pre}.mlp_base_mlp.layers.{i}.{k}" for i in range(2) for k in ("weight", "bias")] + \
+        [f"{pre}.semantic_head.layers.{i}.{k}" for i in range(3) for k in ("weight", "bias")] + \
+        [f"{pre}.rgb_head.layers.{i}.{k}" for i in range(3) for k in ("weight", "bias")]
+    grads = torch.autograd.grad(scalar, params)
+    for n, gr in zip(names, grads[:-1]):
+        close_scaled(gr, Pg[n].grad, rtol=5e-4, atol=5e-5)
+    close_scaled(grads[-1], appo.grad, rtol=5e-4, atol=5e-5)
+    # density-only query (extraction path): heads skipped
+    with torch.no_grad():
+        s2, _, sem2 = F.main_field(u, sel, None, None, 1, table, sc, g, base, sem, rgb, want_rgb=False, want_sem=True)
+    close(s2, dens, rtol=2e-4, atol=1e-6)
+    close(sem2, sem_o)
+
+
+def test_prop_field_vs_oracle_full_size_table(F, dev):
+    cfg = O.default_config()
+    P = {}
+    gen = torch.Generator().manual_seed(21)
+    pc = cfg["props"][1]
+    T = 1 << pc["log2_hashmap_size"]
+    table = (torch.rand(T * pc["num_levels"], 1, generator=gen) * 2 - 1) * 0.3
+    layers = [O._linear_init(gen, 64, 8), O._linear_init(gen, 1, 64)]
+    aabb = torch.tensor([[-1.0, -1.0, -0.2], [1.0, 1.0, 0.4]])
+    N = 20011
+    pos = (torch.rand(N, 3, generator=gen) - 0.5) * 6
+    P["proposal_networks.1.fields.0.encoding.hash_table"] = table.clone().requires_grad_(True)
+    for i, (W, b) in enumerate(layers):
+        P[f"proposal_networks.1.fields.0.mlp_base.1.layers.{i}.weight"] = W.clone().requires_grad_(True)
+        P[f"proposal_networks.1.fields.0.mlp_base.1.layers.{i}.bias"] = b.clone().requires_grad_(True)
+    ref = O.prop_density(P, cfg, 1, 0, pos, aabb)
+    cot = torch.rand(N, generator=gen)
+    (ref * cot).sum().backward()
+    g = F.GridCfg(pc["num_levels"], 1, pc["log2_hashmap_size"])
+    sc = O.hash_scalings(pc["num_levels"], pc["base_res"], pc["max_res"]).to(dev)
+    td = table.to(dev).requires_grad_(True)
+    ld = [(W.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)) for W, b in layers]
+    u, sel = F.field_points(aabb.to(dev), True, pos=pos.to(dev))
+    sigma = F.prop_field(u, sel, td, sc, g, ld)
+    close(sigma, ref, rtol=2e-4, atol=1e-6)
+    grads = torch.autograd.grad((sigma * cot.to(dev)).sum(), [td] + [p for wb in ld for p in wb])
+    close_scaled(grads[0], P["proposal_networks.1.fields.0.encoding.hash_table"].grad, rtol=5e-4, atol=5e-5)
+    for i in range(2):
+        close_scaled(grads[1 + 2 * i], P[f"proposal_networks.1.fields.0.mlp_base.1.layers.{i}.weight"].grad, rtol=5e-4, atol=5e-5)
+        close_scaled(grads[2 + 2 * i], P[f"proposal_networks.1.fields.0.mlp_base.1.layers.{i}.bias"].grad, rtol=5e-4, atol=5e-5)
+    # checksum-of-checksums: the table gradient of sum(features) is the total interpolation weight = N*L exactly
+    feat_ones = torch.ones(pc["num_levels"], N, 1, device=dev)
+    from presight_amd.field_ops import _scatter
+    dt = _scatter(u, feat_ones, sc, g, tuple(td.shape))
+    torch.testing.assert_close(dt.sum().cpu(), torch.tensor(float(N * pc["num_levels"])), rtol=1e-4, atol=0)
