@@ -95,6 +95,15 @@ int ps_composite_bwd(const float* weights, const float* ebins, const float* rgb_
                      const float* d_acc, const float* d_sem, const float* d_exp, int64_t R, int S, int C,
                      float* d_weights, float* d_rgb_s, float* d_sem_s, void* stream);
 
+/* ---- a16 per-ray losses: value per ray + gradient w.r.t. the weights in one pass ---------------------
+ * distortion (ns/model_components/losses.py:130-149): sbins [R,S+1], w [R,S] -> per_ray [R], dw [R,S] */
+int ps_distortion_loss(const float* sbins, const float* w, int64_t R, int S, float* per_ray, float* dw, void* stream);
+/* z-anti-aliased interlevel loss (ns/model_components/PreSight/losses.py:127-206): final-level histogram
+ * (c [R,S+1], w [R,S]) blurred with `pulse_width`, resampled on the proposal edges cp [R,Sp+1] and compared with
+ * wp [R,Sp]; per_ray [R] = sum_k max(ws-wp,0)^2/(wp+1e-5), dwp [R,Sp] its gradient */
+int ps_interlevel_loss(const float* c, const float* w, const float* cp, const float* wp, int64_t R, int S, int Sp,
+                       float pulse_width, float* per_ray, float* dwp, void* stream);
+
 /* ---- field level (fused) -------------------------------------------------------------------------
  * A field evaluation is:  ps_field_points -> ps_grid_encode -> ps_{prop,main}_field_fwd, and backward
  * ps_{prop,main}_field_bwd -> ps_grid_scatter.  Features travel as level planes feat[l][n][f]

@@ -1,0 +1,352 @@
+"""Fields of the PreSight model on the HIP kernels; same class names, constructor arguments, method names and
+state-dict keys as the reference:
+
+    iNGPField / iNGPFieldMS                ns/fields/PreSight/ingp_field.py:47-267, ingp_field_ms.py:46-185
+    PropNetDensityField / ...FieldMS       ns/fields/PreSight/prop_density_field.py:38-156, prop_density_field_ms.py:46-105
+    SkyField / SkyFieldMS                  ns/fields/PreSight/sky_field.py:40-120, sky_field_ms.py:47-117
+
+Two call levels exist.  The plugin-surface methods (`density_fn`, `get_outputs`, `forward`, `semantic_fn`) keep the
+reference's signatures.  `forward`, `semantic_fn` and the proposal `density_fn` run the fused field kernels
+(field_ops); `iNGPField.density_fn` / `get_outputs`, which expose the intermediate 79-d embedding, are composed from
+the operator-level kernels.  The *MS routers replace the reference's 16 masked python loops + host syncs by one
+nearest-centroid kernel and (for K > 1) gather / scatter around the per-sub-field fused calls."""
+from __future__ import annotations
+
+from copy import deepcopy
+from enum import Enum
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import field_ops as F
+from . import ops
+from .components import MLP, HashEncoding, SHEncoding, trunc_exp
+from .rays import RaySamples
+
+
+class FieldHeadNames(Enum):
+    """ns/field_components/field_heads.py:30-42"""
+    RGB = "rgb"
+    SH = "sh"
+    DENSITY = "density"
+    NORMALS = "normals"
+    PRED_NORMALS = "pred_normals"
+    UNCERTAINTY = "uncertainty"
+    BACKGROUND_RGB = "background_rgb"
+    TRANSIENT_RGB = "transient_rgb"
+    TRANSIENT_DENSITY = "transient_density"
+    SEMANTICS = "semantics"
+    SDF = "sdf"
+    ALPHA = "alpha"
+    GRADIENT = "gradient"
+
+
+def get_normalized_directions(directions: Tensor) -> Tensor:
+    """ns/fields/base_field.py:136-142"""
+    return (directions + 1.0) / 2.0
+
+
+def _grid_cfg(enc: HashEncoding) -> F.GridCfg:
+    return F.GridCfg(enc.num_levels, enc.features_per_level, enc.log2_hashmap_size)
+
+
+# ------------------------------------------------------------------------------------------------------------ main
+class iNGPField(nn.Module):
+    def __init__(self, aabb: Tensor, num_layers: int = 2, hidden_dim: int = 64, geo_feat_dim: int = 15, num_levels: int = 16,
+                 base_res: int = 16, max_res: int = 2048, log2_hashmap_size: int = 19, num_layers_color: int = 3,
+                 features_per_level: int = 2, hidden_dim_color: int = 64, appearance_embedding_dim: int = 32,
+                 use_semantics: bool = False, hidden_dim_semantic_head: int = 64, semantic_dim: int = 64,
+                 spatial_distortion: Optional[nn.Module] = None, implementation: str = "tcnn+fp32", field_type: str = "iNGP",
+                 **kwargs) -> None:
+        super().__init__()
+        if field_type != "iNGP":
+            raise ValueError(f"Unknown `field_type`: {field_type}")
+        self.register_buffer("aabb", deepcopy(aabb))
+        self.geo_feat_dim = geo_feat_dim
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
+        self.spatial_distortion = spatial_distortion
+        self.appearance_embedding_dim = appearance_embedding_dim
+        self.use_semantics = use_semantics
+        self.semantic_dim = semantic_dim if use_semantics else 0
+        self.base_res = base_res
+        self.direction_encoding = SHEncoding(levels=4, implementation=implementation)
+        self.mlp_base_grid = HashEncoding(num_levels=num_levels, min_res=base_res, max_res=max_res,
+                                          log2_hashmap_size=log2_hashmap_size, features_per_level=features_per_level,
+                                          implementation=implementation)
+        self.mlp_base_mlp = MLP(in_dim=self.mlp_base_grid.get_out_dim(), num_layers=num_layers, layer_width=hidden_dim,
+                                out_dim=1 + self.geo_feat_dim + self.semantic_dim, activation=nn.ReLU(), out_activation=None)
+        self.mlp_base = torch.nn.Sequential(self.mlp_base_grid, self.mlp_base_mlp)  # same aliasing as the reference
+        if self.use_semantics:
+            self.semantic_head = MLP(in_dim=self.semantic_dim, num_layers=3, layer_width=hidden_dim_semantic_head,
+                                     out_dim=semantic_dim, activation=nn.ReLU(), out_activation=None)
+        self.rgb_head = MLP(in_dim=self.direction_encoding.get_out_dim() + self.geo_feat_dim + self.appearance_embedding_dim,
+                            num_layers=num_layers_color, layer_width=hidden_dim_color, out_dim=3, activation=nn.ReLU(),
+                            out_activation=nn.Sigmoid())
+        self._fusable = (use_semantics and semantic_dim == 64 and geo_feat_dim == 15 and num_layers == 2 and num_layers_color == 3
+                         and hidden_dim_semantic_head == 64 and appearance_embedding_dim <= 16)
+
+    # -- fused fast path -------------------------------------------------------------------------------------
+    def _require_fused(self):
+        if not self._fusable:
+            raise NotImplementedError("presight_amd iNGPField: the fused kernels cover the PreSight layout (2-layer base MLP "
+                                      "-> 1+15+64, 3-layer 64-wide semantic head, 3-layer colour head, app dim <= 16)")
+
+    def points(self, pos=None, origins=None, dirs=None, ebins=None):
+        return F.field_points(self.aabb, self.spatial_distortion is not None, pos=pos, origins=origins, dirs=dirs, ebins=ebins)
+
+    def evaluate(self, u: Tensor, sel: Tensor, ray_dirs: Optional[Tensor], app: Optional[Tensor], S: int, want_rgb: bool = True,
+                 want_sem: bool = True):
+        """Fused field evaluation on prepared points: -> (density [N], rgb [N,3], semantics [N,64])."""
+        self._require_fused()
+        g = self.mlp_base_grid
+        return F.main_field(u, sel, ray_dirs, app, S, g.hash_table, g.scalings_on(u.device), _grid_cfg(g),
+                            self.mlp_base_mlp.layer_params(), self.semantic_head.layer_params(), self.rgb_head.layer_params(),
+                            want_rgb=want_rgb, want_sem=want_sem)
+
+    # -- reference plugin surface ------------------------------------------------------------------------------
+    def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
+        return self.density_fn(ray_samples.frustums.get_positions())
+
+    def density_fn(self, positions: Tensor, times=None) -> Tuple[Tensor, Tensor]:
+        """-> (density [*bs,1], embedding [*bs, geo+sem]); composed from operator-level kernels because the embedding is
+        an API output here (ns/fields/PreSight/ingp_field.py:168-191)."""
+        flat = positions.reshape(-1, 3)
+        u, sel = ops.contract(flat, self.aabb, self.spatial_distortion is not None)
+        h = self.mlp_base_mlp(self.mlp_base_grid(u))
+        raw, emb = torch.split(h, [1, self.geo_feat_dim + self.semantic_dim], dim=-1)
+        self._density_before_activation = raw
+        density = trunc_exp(raw) * sel[:, None]
+        return density.view(*positions.shape[:-1], 1), emb.reshape(*positions.shape[:-1], -1)
+
+    def get_outputs(self, directions: Tensor, density_embedding: Tensor, appearance_embedding: Optional[Tensor]):
+        """ns/fields/PreSight/ingp_field.py:193-237"""
+        assert density_embedding is not None
+        outputs = {}
+        shape = directions.shape[:-1]
+        if self.use_semantics:
+            density_embedding, sem_emb = torch.split(density_embedding, [self.geo_feat_dim, self.semantic_dim], dim=-1)
+            outputs[FieldHeadNames.SEMANTICS] = self.semantic_head(sem_emb.reshape(-1, self.semantic_dim)).view(*shape, -1)
+        d = self.direction_encoding(get_normalized_directions(directions).reshape(-1, 3))
+        parts = [d, density_embedding.reshape(-1, self.geo_feat_dim)]
+        if appearance_embedding is not None:
+            parts.append(appearance_embedding.reshape(-1, self.appearance_embedding_dim))
+        outputs[FieldHeadNames.RGB] = self.rgb_head(torch.cat(parts, dim=-1)).view(*shape, 3)
+        return outputs
+
+    def forward(self, ray_samples: RaySamples, appearance_embedding=None) -> Dict[FieldHeadNames, Tensor]:
+        rb = ray_samples.ray_bundle
+        R, S = ray_samples.ebins.shape[0], ray_samples.num_samples
+        u, sel = self.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        sigma, rgb, sem = self.evaluate(u, sel, rb.directions, app, S)
+        return {FieldHeadNames.DENSITY: sigma.view(R, S, 1), FieldHeadNames.RGB: rgb.view(R, S, 3),
+                FieldHeadNames.SEMANTICS: sem.view(R, S, -1)}
+
+    def semantic_fn(self, positions: Tensor) -> Tensor:
+        assert self.use_semantics, "Cannot query semantics when `self.use_semantics` is set to False"
+        u, sel = self.points(pos=positions.reshape(-1, 3))
+        _, _, sem = self.evaluate(u, sel, None, None, 1, want_rgb=False, want_sem=True)
+        return sem.view(*positions.shape[:-1], -1)
+
+
+def _route_groups(points: Tensor, centroids: Tensor) -> List[Tuple[int, Tensor]]:
+    """nearest-centroid router (ns/fields/PreSight/ingp_field_ms.py:97): [(k, indices of the points of sub-field k)]."""
+    assign = ops.route(points, centroids)
+    order = torch.argsort(assign, stable=True)
+    counts = torch.bincount(assign, minlength=centroids.shape[0]).tolist()  # one host sync instead of K torch.any()
+    groups, start = [], 0
+    for k, c in enumerate(counts):
+        if c > 0:
+            groups.append((k, order[start:start + c]))
+        start += c
+    return groups
+
+
+class iNGPFieldMS(nn.Module):
+    def __init__(self, fields: List[iNGPField], centroids: Tensor) -> None:
+        super().__init__()
+        self.register_buffer("centroids", deepcopy(centroids))
+        self.fields = nn.ModuleList(fields)
+
+    def _routed(self, positions: Tensor, fn, widths: List[int]) -> List[Tensor]:
+        flat = positions.reshape(-1, 3)
+        outs = [torch.zeros(flat.shape[0], w, device=flat.device) for w in widths]
+        for k, idx in _route_groups(flat, self.centroids):
+            vals = fn(self.fields[k], flat[idx], idx)
+            outs = [o.index_copy(0, idx, v.reshape(idx.shape[0], -1)) for o, v in zip(outs, vals)]
+        return outs
+
+    def forward(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor]) -> Dict[FieldHeadNames, Tensor]:
+        R, S = ray_samples.ebins.shape[0], ray_samples.num_samples
+        rb = ray_samples.ray_bundle
+        if len(self.fields) == 1:
+            return self.fields[0](ray_samples, appearance_embedding)
+        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        positions = ops.sample_positions(rb.origins, rb.directions, ray_samples.ebins)
+
+        def run(field: iNGPField, pos, idx):
+            ray = torch.div(idx, S, rounding_mode="floor")
+            u, sel = field.points(pos=pos)
+            return field.evaluate(u, sel, rb.directions[ray], None if app is None else app[ray], 1)
+
+        sigma, rgb, sem = self._routed(positions, run, [1, 3, 64])
+        return {FieldHeadNames.DENSITY: sigma.view(R, S, 1), FieldHeadNames.RGB: rgb.view(R, S, 3),
+                FieldHeadNames.SEMANTICS: sem.view(R, S, -1)}
+
+    def density_fn(self, positions: Tensor) -> Tuple[Tensor, Tensor]:
+        if len(self.fields) == 1:
+            return self.fields[0].density_fn(positions)
+        w = self.fields[0].geo_feat_dim + self.fields[0].semantic_dim
+        d, e = self._routed(positions, lambda f, pos, idx: f.density_fn(pos), [1, w])
+        return d.view(*positions.shape[:-1], 1), e.view(*positions.shape[:-1], -1)
+
+    def density_only(self, positions: Tensor) -> Tensor:
+        """density [*bs,1] through the fused kernel (heads skipped); used by get_depth and prior extraction."""
+        def run(f: iNGPField, pos, idx):
+            u, sel = f.points(pos=pos)
+            return (f.evaluate(u, sel, None, None, 1, want_rgb=False, want_sem=False)[0],)
+
+        if len(self.fields) == 1:
+            (d,) = run(self.fields[0], positions.reshape(-1, 3), None)
+        else:
+            (d,) = self._routed(positions, run, [1])
+        return d.view(*positions.shape[:-1], 1)
+
+    def get_density(self, ray_samples: RaySamples):
+        return self.density_fn(ray_samples.frustums.get_positions())
+
+    def semantic_fn(self, positions: Tensor) -> Tensor:
+        if len(self.fields) == 1:
+            return self.fields[0].semantic_fn(positions)
+        (s,) = self._routed(positions, lambda f, pos, idx: (f.semantic_fn(pos),), [64])
+        return s.view(*positions.shape[:-1], -1)
+
+
+# ------------------------------------------------------------------------------------------------------------ proposal
+class PropNetDensityField(nn.Module):
+    def __init__(self, aabb: Tensor, num_layers: int = 2, hidden_dim: int = 64, spatial_distortion: Optional[nn.Module] = None,
+                 use_linear: bool = False, num_levels: int = 8, max_res: int = 1024, base_res: int = 16,
+                 log2_hashmap_size: int = 18, features_per_level: int = 2, implementation: str = "tcnn+fp32",
+                 field_type: str = "iNGP") -> None:
+        super().__init__()
+        if field_type != "iNGP":
+            raise ValueError(f"Unknown `field_type`: {field_type}")
+        if use_linear or num_layers != 2:
+            raise NotImplementedError("presight_amd PropNetDensityField: PreSight uses the 2-layer MLP variant")
+        self.register_buffer("aabb", deepcopy(aabb))
+        self.spatial_distortion = spatial_distortion
+        self.use_linear = use_linear
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
+        self.encoding = HashEncoding(num_levels=num_levels, min_res=base_res, max_res=max_res,
+                                     log2_hashmap_size=log2_hashmap_size, features_per_level=features_per_level,
+                                     implementation=implementation)
+        network = MLP(in_dim=self.encoding.get_out_dim(), num_layers=num_layers, layer_width=hidden_dim, out_dim=1,
+                      activation=nn.ReLU(), out_activation=None)
+        self.mlp_base = torch.nn.Sequential(self.encoding, network)
+
+    def points(self, pos=None, origins=None, dirs=None, ebins=None):
+        return F.field_points(self.aabb, self.spatial_distortion is not None, pos=pos, origins=origins, dirs=dirs, ebins=ebins)
+
+    def evaluate(self, u: Tensor, sel: Tensor) -> Tensor:
+        e = self.encoding
+        return F.prop_field(u, sel, e.hash_table, e.scalings_on(u.device), _grid_cfg(e), self.mlp_base[1].layer_params())
+
+    def density_fn(self, positions: Tensor) -> Tensor:
+        """ns/fields/PreSight/prop_density_field.py:129-153 -> [*bs,1]"""
+        u, sel = self.points(pos=positions.reshape(-1, 3))
+        return self.evaluate(u, sel).view(*positions.shape[:-1], 1)
+
+    def density_of_samples(self, ray_samples: RaySamples) -> Tensor:
+        rb = ray_samples.ray_bundle
+        u, sel = self.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        return self.evaluate(u, sel).view(ray_samples.ebins.shape[0], ray_samples.num_samples, 1)
+
+    def get_density(self, ray_samples: RaySamples):
+        return self.density_of_samples(ray_samples), None
+
+    def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None) -> dict:
+        return {}
+
+
+class PropNetDensityFieldMS(nn.Module):
+    def __init__(self, fields: List[PropNetDensityField], centroids: Tensor) -> None:
+        super().__init__()
+        self.register_buffer("centroids", deepcopy(centroids))
+        self.fields = nn.ModuleList(fields)
+
+    def density_fn(self, positions: Tensor) -> Tensor:
+        if len(self.fields) == 1:
+            return self.fields[0].density_fn(positions)
+        flat = positions.reshape(-1, 3)
+        out = torch.zeros(flat.shape[0], 1, device=flat.device)
+        for k, idx in _route_groups(flat, self.centroids):
+            out = out.index_copy(0, idx, self.fields[k].density_fn(flat[idx]))
+        return out.view(*positions.shape[:-1], 1)
+
+    def density_of_samples(self, ray_samples: RaySamples) -> Tensor:
+        if len(self.fields) == 1:
+            return self.fields[0].density_of_samples(ray_samples)
+        return self.density_fn(ray_samples.frustums.get_positions())
+
+    def get_density(self, ray_samples: RaySamples):
+        return self.density_of_samples(ray_samples), None
+
+
+# ------------------------------------------------------------------------------------------------------------ sky
+class SkyField(nn.Module):
+    def __init__(self, direction_encoding: str = "SHEncoding", mlp_num_layers: int = 3, mlp_layer_width: int = 64,
+                 appearance_embedding_dim: int = 32, use_semantics: bool = False, semantic_dim: int = 64,
+                 implementation: str = "tcnn+fp32") -> None:
+        super().__init__()
+        self.use_semantics = use_semantics
+        self.appearance_embedding_dim = appearance_embedding_dim
+        self.direction_encoding = SHEncoding(levels=4, implementation=implementation)
+        self.rgb_head = MLP(in_dim=self.direction_encoding.get_out_dim() + self.appearance_embedding_dim,
+                            num_layers=mlp_num_layers, layer_width=mlp_layer_width, out_dim=3, activation=nn.ReLU(),
+                            out_activation=nn.Sigmoid())
+        if self.use_semantics:
+            self.semantic_head = MLP(in_dim=self.direction_encoding.get_out_dim(), num_layers=mlp_num_layers,
+                                     layer_width=mlp_layer_width, out_dim=semantic_dim, activation=nn.ReLU(), out_activation=None)
+
+    def get_outputs(self, directions: Tensor, appearance_embedding: Optional[Tensor]):
+        """ns/fields/PreSight/sky_field.py:95-110"""
+        d = self.direction_encoding(get_normalized_directions(directions))
+        outputs = {}
+        x = torch.cat([d, appearance_embedding], dim=-1) if appearance_embedding is not None else d
+        outputs[FieldHeadNames.RGB] = self.rgb_head(x)
+        if self.use_semantics:
+            outputs[FieldHeadNames.SEMANTICS] = self.semantic_head(d)
+        return outputs
+
+    def forward(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor]):
+        R = ray_samples.ebins.shape[0]
+        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        return self.get_outputs(ray_samples.ray_bundle.directions, app)
+
+
+class SkyFieldMS(nn.Module):
+    def __init__(self, fields: List[SkyField], centroids: Tensor) -> None:
+        super().__init__()
+        self.register_buffer("centroids", deepcopy(centroids))
+        self.fields = nn.ModuleList(fields)
+
+    def forward(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor]):
+        """routed by ray ORIGIN (ns/fields/PreSight/sky_field_ms.py:97-114)"""
+        rb = ray_samples.ray_bundle
+        R = rb.origins.shape[0]
+        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        if len(self.fields) == 1:
+            return self.fields[0].get_outputs(rb.directions, app)
+        outs: Dict[FieldHeadNames, Tensor] = {}
+        for k, idx in _route_groups(rb.origins, self.centroids):
+            o = self.fields[k].get_outputs(rb.directions[idx], None if app is None else app[idx])
+            for name, v in o.items():
+                if name not in outs:
+                    outs[name] = torch.zeros(R, v.shape[-1], device=v.device)
+                outs[name] = outs[name].index_copy(0, idx, v)
+        return outs

@@ -1,0 +1,352 @@
+"""NerfactoNuscMSModel on the HIP kernels — the caller of the hot path.
+
+Same config field names, module attribute names and state-dict keys as
+ns/models/PreSight/nerfacto_nusc_ms.py:75-760, so PreSight's prior-building configs and checkpoints
+(`implementation="torch"` layout: `...mlp_base_grid.hash_table`, `...layers.{i}.weight`) load unmodified."""
+from __future__ import annotations
+
+import functools
+from collections import defaultdict
+from dataclasses import dataclass, field
+from typing import Dict, List, Literal, Optional, Tuple, Type
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+from torch.nn import Parameter
+
+from . import ops
+from .components import Embedding, SceneContraction
+from .fields import (FieldHeadNames, PropNetDensityField, PropNetDensityFieldMS, SkyField, SkyFieldMS, iNGPField,
+                     iNGPFieldMS)
+from .losses import distortion_loss, semantic_loss, sky_loss, z_anti_aliasing_interlevel_loss
+from .rays import RayBundle, RaySamples
+from .renderers import AccumulationRenderer, DepthRenderer, NearFarCollider, RGBRenderer, render_all
+from .samplers import ProposalNetworkSampler, SpacedSampler
+
+RGB, FEATURES, SKY, DEPTH, VIDEO_ID = "rgb", "features", "sky", "depth", "video_id"  # ns/data/PreSight/constants.py
+
+
+@dataclass
+class NerfactoNuscMSModelConfig:
+    """Field-for-field copy of the reference config dataclass (nerfacto_nusc_ms.py:75-200)."""
+    _target: Type = field(default_factory=lambda: NerfactoNuscMSModel)
+    enable_collider: bool = True
+    collider_params: Optional[Dict[str, float]] = None
+    loss_coefficients: Dict[str, float] = field(default_factory=lambda: {"rgb_loss_coarse": 1.0, "rgb_loss_fine": 1.0})
+    eval_num_rays_per_chunk: int = 1 << 15
+    prompt: Optional[str] = None
+    near_plane: float = 0.1
+    far_plane: float = 1000.0
+    background_color: Literal["random", "last_sample", "black", "white"] = "black"
+    hidden_dim: int = 64
+    hidden_dim_color: int = 64
+    num_levels: int = 10
+    base_res: int = 16
+    max_res: int = 16384
+    log2_hashmap_size: int = 20
+    features_per_level: int = 4
+    num_proposal_samples_per_ray: Tuple[int, ...] = (128, 64)
+    num_nerf_samples_per_ray: int = 64
+    proposal_update_every: int = 5
+    proposal_warmup: int = 1000
+    num_proposal_iterations: int = 2
+    use_same_proposal_network: bool = False
+    proposal_net_args_list: List[Dict] = field(default_factory=lambda: [
+        {"features_per_level": 1, "log2_hashmap_size": 20, "num_levels": 8, "base_res": 16, "max_res": 1024, "use_linear": False},
+        {"features_per_level": 1, "log2_hashmap_size": 20, "num_levels": 8, "base_res": 16, "max_res": 4096, "use_linear": False},
+    ])
+    proposal_initial_sampler: Literal["piecewise", "uniform"] = "piecewise"
+    piecewise_sampler_threshold: float = 1.0
+    interlevel_loss_mult: float = 1.0
+    enable_z_anti_aliasing: bool = True
+    pulse_width: Tuple[float, ...] = (0.03, 0.003)
+    distortion_loss_mult: float = 0.002
+    orientation_loss_mult: float = 0.0001
+    pred_normal_loss_mult: float = 0.001
+    use_proposal_weight_anneal: bool = True
+    use_average_appearance_embedding: bool = True
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    use_single_jitter: bool = True
+    disable_scene_contraction: bool = False
+    use_gradient_scaling: bool = False
+    implementation: Literal["tcnn", "torch", "tcnn+fp32", "hip"] = "tcnn+fp32"
+    appearance_embed_dim: int = 4
+    video_embed_dim: int = 12
+    use_sky_model: bool = True
+    use_ms_sky_model: bool = True
+    num_sky_mlp_layers: int = 3
+    sky_mlp_dims: int = 32
+    sky_loss_mult: float = 0.001
+    use_lidar_loss: bool = True
+    expected_depth_loss_mult: float = 1.0
+    lidar_depth_upperbound: float = 75.0
+    line_of_sight_mult: float = 0.1
+    line_of_sight_decay_steps: int = 5000
+    line_of_sight_start_step: int = 1000
+    line_of_sight_end_step: int = 30000
+    line_of_sight_max_sigma: float = 5.0
+    line_of_sight_min_sigma: float = 2.0
+    use_semantics: bool = True
+    semantic_dim: int = 64
+    semantic_loss_mult: float = 0.5
+    use_monodepth_loss: bool = False
+    monodepth_loss_inverse: bool = False
+    monodepth_depth_upperbound: float = 40.0
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class _PropDensityFn:
+    """density_fn handed to the ProposalNetworkSampler; accepts RaySamples so positions are made in-kernel."""
+    takes_ray_samples = True
+
+    def __init__(self, net: PropNetDensityFieldMS):
+        self.net = net
+
+    def __call__(self, x):
+        if isinstance(x, RaySamples):
+            return self.net.density_of_samples(x)
+        return self.net.density_fn(x)
+
+
+class NerfactoNuscMSModel(nn.Module):
+    config: NerfactoNuscMSModelConfig
+
+    def __init__(self, config: NerfactoNuscMSModelConfig, scene_box=None, num_train_data: int = -1, **kwargs) -> None:
+        super().__init__()
+        self.config = config
+        self.scene_box = scene_box
+        self.render_aabb = None
+        self.num_train_data = num_train_data
+        self.kwargs = kwargs
+        self.collider = None
+        self.populate_modules()
+        self.callbacks = None
+        self.device_indicator_param = nn.Parameter(torch.empty(0))
+
+    @property
+    def device(self):
+        return self.device_indicator_param.device
+
+    # ------------------------------------------------------------------------------------------------ construction
+    def populate_modules(self):
+        c = self.config
+        if c.use_lidar_loss or c.use_monodepth_loss:
+            raise NotImplementedError("presight_amd: depth-supervised configs (lidar / monodepth losses) are not built yet; "
+                                      "the camera-dino prior-building configs set use_lidar_loss=False")
+        contraction = None if c.disable_scene_contraction else SceneContraction(order=float("inf"))
+        self.centroids = self.kwargs["centroids"]
+        self.aabbs = self.kwargs["aabbs"]
+        app_dim = c.appearance_embed_dim + c.video_embed_dim
+        fields = [iNGPField(aabb, hidden_dim=c.hidden_dim, num_levels=c.num_levels, max_res=c.max_res, base_res=c.base_res,
+                            features_per_level=c.features_per_level, log2_hashmap_size=c.log2_hashmap_size,
+                            hidden_dim_color=c.hidden_dim_color, spatial_distortion=contraction, num_images=self.num_train_data,
+                            use_semantics=c.use_semantics, semantic_dim=c.semantic_dim, appearance_embedding_dim=app_dim,
+                            implementation=c.implementation) for aabb in self.aabbs]
+        self.field = iNGPFieldMS(fields, self.centroids)
+        if c.appearance_embed_dim > 0:
+            self.appearance_embedding = Embedding(self.kwargs["num_train_cameras"], c.appearance_embed_dim)
+        if c.video_embed_dim > 0:
+            self.video_embedding = Embedding(self.kwargs["num_train_videos"], c.video_embed_dim)
+        self.dino_to_rgb = self.kwargs.get("dino_to_rgb")
+
+        self.proposal_networks = torch.nn.ModuleList()
+        n_prop = c.num_proposal_iterations
+        n_nets = 1 if c.use_same_proposal_network else n_prop
+        for i in range(n_nets):
+            args = c.proposal_net_args_list[min(i, len(c.proposal_net_args_list) - 1)]
+            pf = [PropNetDensityField(aabb, spatial_distortion=contraction, **args, implementation=c.implementation)
+                  for aabb in self.aabbs]
+            self.proposal_networks.append(PropNetDensityFieldMS(pf, self.centroids))
+        nets = [self.proposal_networks[0]] * n_prop if c.use_same_proposal_network else list(self.proposal_networks)
+        self.density_fns = [_PropDensityFn(n) for n in nets]
+
+        if not c.enable_z_anti_aliasing:
+            raise NotImplementedError("presight_amd: only the z-anti-aliased interlevel loss (PreSight default) is built")
+        self.interlevel_loss = functools.partial(z_anti_aliasing_interlevel_loss, pulse_width=c.pulse_width)
+
+        def update_schedule(step):
+            return np.clip(np.interp(step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1, c.proposal_update_every)
+
+        if c.proposal_initial_sampler != "piecewise":
+            raise NotImplementedError("presight_amd: only the piecewise initial sampler (PreSight default) is built")
+        initial_sampler = SpacedSampler(piecewise_threshold=c.piecewise_sampler_threshold, single_jitter=c.use_single_jitter)
+        self.proposal_sampler = ProposalNetworkSampler(
+            num_nerf_samples_per_ray=c.num_nerf_samples_per_ray, num_proposal_samples_per_ray=c.num_proposal_samples_per_ray,
+            num_proposal_network_iterations=c.num_proposal_iterations, single_jitter=c.use_single_jitter,
+            update_sched=update_schedule, initial_sampler=initial_sampler)
+        self.collider = NearFarCollider(near_plane=c.near_plane, far_plane=c.far_plane)
+
+        if c.use_sky_model:
+            c.background_color = "black"
+            mk = lambda: SkyField(mlp_num_layers=c.num_sky_mlp_layers, mlp_layer_width=c.sky_mlp_dims,  # noqa: E731
+                                  appearance_embedding_dim=app_dim, use_semantics=c.use_semantics, semantic_dim=c.semantic_dim,
+                                  implementation=c.implementation)
+            self.sky_model = SkyFieldMS([mk() for _ in self.aabbs], centroids=self.centroids) if c.use_ms_sky_model else mk()
+            self.sky_loss = sky_loss
+        self.renderer_rgb = RGBRenderer(background_color=c.background_color)
+        self.renderer_accumulation = AccumulationRenderer()
+        self.renderer_depth = DepthRenderer(method="threshold")
+        self.renderer_expected_depth = DepthRenderer(method="expected")
+        self.rgb_loss = nn.MSELoss()
+        if c.use_semantics:
+            self.semantic_loss = semantic_loss
+        self.step = 0
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        groups = {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
+        if self.config.use_sky_model:
+            groups["fields"] += list(self.sky_model.parameters())
+        if self.config.appearance_embed_dim > 0:
+            groups["fields"] += list(self.appearance_embedding.parameters())
+        if self.config.video_embed_dim > 0:
+            groups["fields"] += list(self.video_embedding.parameters())
+        return groups
+
+    def anneal_for_step(self, step: int) -> float:
+        """nerfacto_nusc_ms.py:423-434"""
+        N = self.config.proposal_weights_anneal_max_num_iters
+        x = np.clip(step / N, 0, 1)
+        b = self.config.proposal_weights_anneal_slope
+        return float(b * x / ((b - 1) * x + 1))
+
+    def before_train_iteration(self, step: int):
+        self.step = step
+        if self.config.use_proposal_weight_anneal:
+            self.proposal_sampler.set_anneal(self.anneal_for_step(step))
+
+    def after_train_iteration(self, step: int):
+        self.proposal_sampler.step_cb(step)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, ray_bundle: RayBundle, jitters: Optional[List[Tensor]] = None):
+        if self.collider is not None:
+            ray_bundle = self.collider(ray_bundle)
+        return self.get_outputs(ray_bundle, jitters=jitters)
+
+    def _appearance(self, ray_bundle: RayBundle) -> Optional[Tensor]:
+        """per-RAY appearance embedding [R, app+video] (the reference expands it per sample; the kernels index by ray)"""
+        c = self.config
+        cam = ray_bundle.camera_indices.reshape(-1)
+        R = cam.shape[0]
+        parts = []
+        if self.training:
+            if c.appearance_embed_dim > 0:
+                parts.append(self.appearance_embedding(cam))
+            if c.video_embed_dim > 0:
+                parts.append(self.video_embedding(ray_bundle.metadata[VIDEO_ID].reshape(-1)))
+        elif c.use_average_appearance_embedding:
+            if c.appearance_embed_dim > 0:
+                parts.append(self.appearance_embedding.mean(dim=0)[None].expand(R, -1))
+            if c.video_embed_dim > 0:
+                parts.append(self.video_embedding.mean(dim=0)[None].expand(R, -1))
+        else:
+            parts.append(torch.zeros(R, c.appearance_embed_dim + c.video_embed_dim, device=cam.device))
+        if not parts:
+            return None
+        app = torch.cat(parts, dim=-1)
+        return app if app.shape[-1] > 0 else None
+
+    def get_outputs(self, ray_bundle: RayBundle, jitters: Optional[List[Tensor]] = None):
+        """nerfacto_nusc_ms.py:452-546"""
+        c = self.config
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns, jitters=jitters)
+        app = self._appearance(ray_bundle)
+        field_outputs = self.field.forward(ray_samples, appearance_embedding=None if app is None else app[:, None, :])
+        weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
+        weights_list.append(weights)
+        ray_samples_list.append(ray_samples)
+        sem_s = field_outputs[FieldHeadNames.SEMANTICS] if c.use_semantics else None
+        rgb_s = field_outputs[FieldHeadNames.RGB]
+        if not self.training:
+            rgb_s = torch.nan_to_num(rgb_s)
+        rgb, acc_raw, depth, expected_depth, semantics = render_all(weights, ray_samples, rgb_s, sem_s)
+        if not self.training:
+            rgb = torch.clamp(rgb, min=0.0, max=1.0)
+        accumulation = torch.clamp(acc_raw, min=0.0, max=1.0)
+        sky_outputs = {}
+        if c.use_sky_model:
+            sky_outputs = self.sky_model(ray_samples, appearance_embedding=None if app is None else app[:, None, :])
+            rgb = rgb + (1.0 - accumulation) * sky_outputs[FieldHeadNames.RGB]
+        outputs = {"rgb": rgb, "accumulation": accumulation, "depth": depth.detach(), "expected_depth": expected_depth}
+        if c.use_semantics:
+            if FieldHeadNames.SEMANTICS in sky_outputs:
+                semantics = semantics + (1.0 - accumulation) * sky_outputs[FieldHeadNames.SEMANTICS]
+            outputs["semantics"] = semantics
+            if not self.training and self.dino_to_rgb is not None:
+                outputs["dino_rgb"] = apply_feature_colormap(semantics, self.dino_to_rgb)
+        if self.training:
+            outputs["weights_list"] = weights_list
+            outputs["ray_samples_list"] = ray_samples_list
+        with torch.no_grad():
+            for i in range(c.num_proposal_iterations):
+                outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
+        return outputs
+
+    def get_metrics_dict(self, outputs, batch):
+        mse = torch.mean((outputs["rgb"] - batch["rgb"][..., :3]) ** 2)
+        return {"psnr": 10.0 * torch.log10(1.0 / mse)}  # torchmetrics PSNR(data_range=1.0), nerfacto_nusc_ms.py:382,554
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None):
+        """nerfacto_nusc_ms.py:558-645 (camera-only)"""
+        c = self.config
+        loss_dict = {}
+        if RGB in batch:
+            loss_dict["rgb_loss"] = self.rgb_loss(batch[RGB][..., :3], outputs["rgb"])
+        if c.use_sky_model and SKY in batch:
+            loss_dict["sky_loss"] = c.sky_loss_mult * self.sky_loss(outputs["accumulation"].view(-1, 1), batch[SKY].view(-1, 1))
+        if c.use_semantics and FEATURES in batch:
+            loss_dict["semantic_loss"] = c.semantic_loss_mult * self.semantic_loss(pred=outputs["semantics"], target=batch[FEATURES], clip=True)
+        if self.training:
+            loss_dict["interlevel_loss"] = c.interlevel_loss_mult * self.interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"])
+            loss_dict["distortion_loss"] = c.distortion_loss_mult * distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+        return loss_dict
+
+    # ------------------------------------------------------------------------------------------------ depth / eval
+    def get_depth(self, ray_bundle: RayBundle, threshold=0.5):
+        """nerfacto_nusc_ms.py:688-708"""
+        if self.collider is not None:
+            ray_bundle = self.collider(ray_bundle)
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns)
+        if len(self.field.fields) == 1:
+            f = self.field.fields[0]
+            u, sel = f.points(origins=ray_bundle.origins, dirs=ray_bundle.directions, ebins=ray_samples.ebins)
+            density = f.evaluate(u, sel, None, None, 1, want_rgb=False, want_sem=False)[0].view(ray_samples.ebins.shape[0], -1, 1)
+        else:
+            density = self.field.density_only(ray_samples.frustums.get_positions())
+        weights = ray_samples.get_weights(density)
+        _, _, depth, expected_depth, _ = render_all(weights, ray_samples, None, None, threshold)
+        outputs = {"depth": depth.detach(), "expected_depth": expected_depth}
+        if self.training:
+            outputs["weights_list"] = weights_list
+            outputs["ray_samples_list"] = ray_samples_list
+        return outputs
+
+    def _chunked(self, camera_ray_bundle: RayBundle, fn):
+        n = self.config.eval_num_rays_per_chunk
+        lists = defaultdict(list)
+        for i in range(0, len(camera_ray_bundle), n):
+            out = fn(camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + n))
+            for k, v in out.items():
+                if torch.is_tensor(v):
+                    lists[k].append(v)
+        return {k: torch.cat(v) for k, v in lists.items()}
+
+    @torch.no_grad()
+    def get_depth_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle, threshold=0.5):
+        return self._chunked(camera_ray_bundle, lambda rb: self.get_depth(ray_bundle=rb, threshold=threshold))
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle):
+        return self._chunked(camera_ray_bundle, lambda rb: self.forward(ray_bundle=rb))
+
+
+def apply_feature_colormap(image: Tensor, dino_to_rgb: dict) -> Tensor:
+    """ns/utils/colormaps.py:212-234"""
+    red = dino_to_rgb["reduction_matrix"].to(image)
+    lo, hi, mean = dino_to_rgb["rgb_min"].to(image), dino_to_rgb["rgb_max"].to(image), dino_to_rgb["mean"].to(image)
+    x = (image - mean) @ red
+    return torch.clamp((x - lo) / (hi - lo), 0, 1)

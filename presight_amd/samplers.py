@@ -1,0 +1,156 @@
+"""Samplers of the PreSight model on the HIP kernels (same names / arguments / call protocol as
+ns/model_components/ray_samplers.py: SpacedSampler :53-128, PDFSampler :251-372, ProposalNetworkSampler :523-614).
+
+The piecewise spacing of ns/models/PreSight/nerfacto_nusc_ms.py:312-317 is built into the kernels; it is selected
+with `piecewise_threshold` instead of a pair of python lambdas (a python callable cannot run inside a HIP kernel)."""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .rays import RayBundle, RaySamples
+
+
+class Sampler(nn.Module):
+    def __init__(self, num_samples: Optional[int] = None) -> None:
+        super().__init__()
+        self.num_samples = num_samples
+
+    def forward(self, *args, **kwargs):
+        return self.generate_ray_samples(*args, **kwargs)
+
+
+def _near_far(ray_bundle: RayBundle) -> Tuple[float, float]:
+    """The collider of the PreSight model sets one near/far for the whole batch (scene_colliders.py:182-187); the
+    kernels take them as scalars.  Stored as python floats by NearFarCollider to avoid a device sync."""
+    nf = ray_bundle.metadata.get("_near_far")
+    if nf is None:
+        raise ValueError("ray bundle has no near/far: run the NearFarCollider first")
+    return nf
+
+
+class SpacedSampler(Sampler):
+    """Piecewise spaced sampler: s(t) = t/(2 thr) for t < thr, 1 - thr/(2 t) otherwise."""
+
+    def __init__(self, piecewise_threshold: float = 1.0, num_samples: Optional[int] = None, train_stratified=True,
+                 single_jitter=False, spacing_fn: Optional[Callable] = None, spacing_fn_inv: Optional[Callable] = None) -> None:
+        super().__init__(num_samples=num_samples)
+        if not single_jitter:
+            raise NotImplementedError("presight_amd SpacedSampler: PreSight uses single_jitter=True")
+        self.train_stratified = train_stratified
+        self.single_jitter = single_jitter
+        self.thr = float(piecewise_threshold)
+
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, num_samples: Optional[int] = None,
+                             jitter: Optional[Tensor] = None) -> RaySamples:
+        assert ray_bundle is not None
+        num_samples = num_samples or self.num_samples
+        assert num_samples is not None
+        near, far = _near_far(ray_bundle)
+        R, dev = ray_bundle.origins.shape[0], ray_bundle.origins.device
+        if self.train_stratified and self.training:
+            if jitter is None:
+                jitter = torch.rand((R, 1), device=dev)
+        else:
+            jitter = None
+        sb, eb = ops.spaced_bins(R, num_samples, near, far, self.thr, jitter, dev)
+        return RaySamples(ray_bundle, eb, sb, spacing_to_euclidean_fn=(near, far, self.thr))
+
+
+class PDFSampler(Sampler):
+    def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = False,
+                 include_original: bool = True, histogram_padding: float = 0.01) -> None:
+        super().__init__(num_samples=num_samples)
+        if include_original or not single_jitter:
+            raise NotImplementedError("presight_amd PDFSampler: PreSight uses include_original=False, single_jitter=True")
+        self.train_stratified = train_stratified
+        self.include_original = include_original
+        self.histogram_padding = histogram_padding
+        self.single_jitter = single_jitter
+
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, ray_samples: Optional[RaySamples] = None,
+                             weights: Optional[Tensor] = None, num_samples: Optional[int] = None, eps: float = 1e-5,
+                             anneal: float = 1.0, jitter: Optional[Tensor] = None) -> RaySamples:
+        if ray_samples is None or ray_bundle is None:
+            raise ValueError("ray_samples and ray_bundle must be provided")
+        assert weights is not None, "weights must be provided"
+        num_samples = num_samples or self.num_samples
+        assert num_samples is not None
+        assert ray_samples.spacing_to_euclidean_fn is not None, "ray_samples.spacing_to_euclidean_fn must be provided"
+        near, far, thr = ray_samples.spacing_to_euclidean_fn
+        R, dev = weights.shape[0], weights.device
+        if self.train_stratified and self.training:
+            if jitter is None:
+                jitter = torch.rand((R, 1), device=dev)
+        else:
+            jitter = None
+        w = weights[..., 0] if weights.dim() == 3 else weights
+        nsb, neb = ops.pdf_resample(w, ray_samples.sbins, num_samples, jitter, anneal, near, far, thr,
+                                    pad=self.histogram_padding, eps=eps)
+        return RaySamples(ray_bundle, neb, nsb, spacing_to_euclidean_fn=ray_samples.spacing_to_euclidean_fn)
+
+
+class ProposalNetworkSampler(Sampler):
+    def __init__(self, num_proposal_samples_per_ray: Tuple[int, ...] = (64,), num_nerf_samples_per_ray: int = 32,
+                 num_proposal_network_iterations: int = 2, single_jitter: bool = False, update_sched: Callable = lambda x: 1,
+                 initial_sampler: Optional[Sampler] = None) -> None:
+        super().__init__()
+        self.num_proposal_samples_per_ray = num_proposal_samples_per_ray
+        self.num_nerf_samples_per_ray = num_nerf_samples_per_ray
+        self.num_proposal_network_iterations = num_proposal_network_iterations
+        self.update_sched = update_sched
+        if self.num_proposal_network_iterations < 1:
+            raise ValueError("num_proposal_network_iterations must be >= 1")
+        if initial_sampler is None:
+            raise NotImplementedError("presight_amd: pass the piecewise SpacedSampler as initial_sampler")
+        self.initial_sampler = initial_sampler
+        self.pdf_sampler = PDFSampler(include_original=False, single_jitter=single_jitter)
+        self._anneal = 1.0
+        self._steps_since_update = 0
+        self._step = 0
+
+    def set_anneal(self, anneal: float) -> None:
+        self._anneal = anneal
+
+    def step_cb(self, step):
+        self._step = step
+        self._steps_since_update += 1
+
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, density_fns: Optional[List[Callable]] = None,
+                             jitters: Optional[List[Tensor]] = None) -> Tuple[RaySamples, List, List]:
+        """ns/model_components/ray_samplers.py:572-614.  `density_fns[i]` receives a RaySamples when it has the
+        attribute `takes_ray_samples` (fused path: positions are generated inside the field kernel), else positions."""
+        assert ray_bundle is not None and density_fns is not None
+        weights_list, ray_samples_list = [], []
+        n = self.num_proposal_network_iterations
+        weights, ray_samples = None, None
+        updated = self._steps_since_update > self.update_sched(self._step) or self._step < 10
+        eps = float(torch.finfo(torch.float32).eps)
+        for i_level in range(n + 1):
+            is_prop = i_level < n
+            num_samples = self.num_proposal_samples_per_ray[i_level] if is_prop else self.num_nerf_samples_per_ray
+            jit = None if jitters is None else jitters[i_level]
+            if i_level == 0:
+                ray_samples = self.initial_sampler(ray_bundle, num_samples=num_samples, jitter=jit)
+            else:
+                assert weights is not None
+                ray_samples = self.pdf_sampler(ray_bundle, ray_samples, weights, num_samples=num_samples, eps=eps,
+                                               anneal=self._anneal, jitter=jit)
+            if is_prop:
+                fn = density_fns[i_level]
+                arg = ray_samples if getattr(fn, "takes_ray_samples", False) else ray_samples.frustums.get_positions()
+                if updated and torch.is_grad_enabled():
+                    density = fn(arg)
+                else:
+                    with torch.no_grad():
+                        density = fn(arg)
+                weights = ray_samples.get_weights(density)
+                weights_list.append(weights)
+                ray_samples_list.append(ray_samples)
+        if updated:
+            self._steps_since_update = 0
+        assert ray_samples is not None
+        return ray_samples, weights_list, ray_samples_list
