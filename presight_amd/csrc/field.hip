@@ -99,8 +99,9 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
   float* scratch = lds + M::GPACKED + wave * SCR;
   const GlobalW gw = make_global_w(packed, M::PACKED);
   const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t first = tile * 16 * PB;
+  // workgroup-uniform trip count (the dW flush contains workgroup barriers); out-of-range tiles are fully masked
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < tiles; base += (int64_t)gridDim.x * 4) {
+    const int64_t first = (base + wave) * 16 * PB;
     float x[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
     load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
     mlp_forward<M, PB>(gw, x, h1, h2, z);
@@ -260,8 +261,9 @@ __global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
   const GlobalW pk_all = make_global_w(a.packed, C::PACKED);
   const GlobalW pk_base = pk_all.at(C::P_BASE), pk_sem = pk_all.at(C::P_SEM), pk_rgb = pk_all.at(C::P_RGB);
   const int64_t tiles = (a.N + 16 * PB - 1) / (16 * PB);
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t first = tile * 16 * PB;
+  // workgroup-uniform trip count (the dW flush contains workgroup barriers); out-of-range tiles are fully masked
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < tiles; base += (int64_t)gridDim.x * 4) {
+    const int64_t first = (base + wave) * 16 * PB;
     // ---- recompute base
     float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], hdummy[PB][C::Base::HB * 4], zb[PB][20];
     load_feat<C::Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
@@ -352,7 +354,7 @@ int grid_for_tiles(int64_t N, int pts_per_tile, int max_blocks) {
   return (int)g;
 }
 
-constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 4, kMainBwdPB = 1;
+constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 4, kMainBwdPB = 2;
 
 // (L*F, hidden) of the proposal nets
 #define PS_PROP_CFGS(X) \

@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const float* __restrict__ 
   float* scratch = lds + M::GPACKED + wave * SCR;
   const GlobalW gw = make_global_w(packed, M::PACKED);
   const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t first = tile * 16 * PB;
+  // workgroup-uniform trip count (the dW flush contains workgroup barriers); out-of-range tiles are fully masked
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < tiles; base += (int64_t)gridDim.x * 4) {
+    const int64_t first = (base + wave) * 16 * PB;
     float xin[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
     load_rows_linear<M, PB>(x, first, N, in_dim, xin);
     mlp_forward<M, PB>(gw, xin, h1, h2, z);

@@ -85,33 +85,55 @@ template <class LT, int PB, class W>
 __device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB][LT::KS], float (&vout)[PB][LT::NB * 4]) {
   const int lane = ps_lane();
   const int g = lane >> 4;
-  f32x4 acc[LT::NB][PB];
+  // Weight fragments are fetched one output block ahead: the loads of block nb+1 are issued (and fenced with a
+  // scheduling barrier) BEFORE the MFMAs of block nb, so their L2/LDS latency hides under 16*PB matrix ops.
+  // (Left to itself hipcc serialises  load -> s_waitcnt vmcnt(0) -> mfma  per k-step: 12x slower, measured.)
+  float a_cur[LT::KS], a_nxt[LT::KS];
+#pragma unroll
+  for (int t = 0; t < LT::KS; ++t) a_cur[t] = params.frag(LT::WF_OFF + t * 64);
 #pragma unroll
   for (int nb = 0; nb < LT::NB; ++nb) {
+    f32x4 acc[PB];
     f32x4 b4;
     if constexpr (std::is_same<W, LdsW>::value)
       b4 = params.vec4(LT::BIAS_OFF + 16 * nb + 4 * g);
     else
       b4 = params.vec4_lane(LT::BIAS_OFF + 16 * nb, 4u * (unsigned)g);
+    if (nb + 1 < LT::NB) {
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = b4;
-  }
-#pragma unroll
-  for (int nb = 0; nb < LT::NB; ++nb) {
-    __builtin_amdgcn_sched_barrier(0);  // keep the weight-fragment loads of later blocks from being hoisted
-#pragma unroll
-    for (int t = 0; t < LT::KS; ++t) {
-      const float a = params.frag(LT::WF_OFF + (nb * LT::KS + t) * 64);
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = ps_mfma16(a, vin[pb][t], acc[nb][pb]);
+      for (int t = 0; t < LT::KS; ++t) a_nxt[t] = params.frag(LT::WF_OFF + ((nb + 1) * LT::KS + t) * 64);
     }
-  }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PB == 1) {
+      // a single accumulator would serialise on the 40-cycle MFMA dependency: split the k-steps over two
+      f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[0] = b4;
 #pragma unroll
-  for (int nb = 0; nb < LT::NB; ++nb)
+      for (int t = 0; t < LT::KS; ++t) {
+        if (t & 1)
+          acc2 = ps_mfma16(a_cur[t], vin[0][t], acc2);
+        else
+          acc[0] = ps_mfma16(a_cur[t], vin[0][t], acc[0]);
+      }
+      acc[0] += acc2;
+    } else {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) acc[pb] = b4;
+#pragma unroll
+      for (int t = 0; t < LT::KS; ++t)
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) acc[pb] = ps_mfma16(a_cur[t], vin[pb][t], acc[pb]);
+    }
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vout[pb][4 * nb + r] = acc[nb][pb][r];
+      for (int r = 0; r < 4; ++r) vout[pb][4 * nb + r] = acc[pb][r];
+    if (nb + 1 < LT::NB) {
+#pragma unroll
+      for (int t = 0; t < LT::KS; ++t) a_cur[t] = a_nxt[t];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 template <int PB, int N>
@@ -136,22 +158,44 @@ __device__ __forceinline__ void relu_mask(float (&dv)[PB][N], const float (&h)[P
 template <class LT, int PB, class W>
 __device__ __forceinline__ void layer_bwd_data(const W& wt_block, const float (&dvout)[PB][LT::NB * 4],
                                                float (&dvin)[PB][LT::IB * 4]) {
+  float a_cur[LT::KSO], a_nxt[LT::KSO];
+#pragma unroll
+  for (int t = 0; t < LT::KSO; ++t) a_cur[t] = wt_block.frag(t * 64);
 #pragma unroll
   for (int ib = 0; ib < LT::IB; ++ib) {
+    if (ib + 1 < LT::IB) {
+#pragma unroll
+      for (int t = 0; t < LT::KSO; ++t) a_nxt[t] = wt_block.frag(((ib + 1) * LT::KSO + t) * 64);
+    }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[PB];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) acc[pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (PB == 1) {
+      f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < LT::KSO; ++t) {
-      const float a = wt_block.frag((ib * LT::KSO + t) * 64);
+      for (int t = 0; t < LT::KSO; ++t) {
+        if (t & 1)
+          acc2 = ps_mfma16(a_cur[t], dvout[0][t], acc2);
+        else
+          acc[0] = ps_mfma16(a_cur[t], dvout[0][t], acc[0]);
+      }
+      acc[0] += acc2;
+    } else {
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) acc[pb] = ps_mfma16(a, dvout[pb][t], acc[pb]);
+      for (int t = 0; t < LT::KSO; ++t)
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) acc[pb] = ps_mfma16(a_cur[t], dvout[pb][t], acc[pb]);
     }
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dvin[pb][4 * ib + r] = acc[pb][r];
+    if (ib + 1 < LT::IB) {
+#pragma unroll
+      for (int t = 0; t < LT::KSO; ++t) a_cur[t] = a_nxt[t];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -159,6 +203,12 @@ __device__ __forceinline__ void layer_bwd_data(const W& wt_block, const float (&
 // Accumulates dW += dY^T H and db += sum_p dY over the PB*16 points held by this wave.
 //   scratch : per-wave LDS, LT::SCRATCH_ROWS * kScratchLd floats
 //   gacc    : workgroup LDS accumulator block of this layer, LT::GPACKED floats
+// select v[r] for a runtime r without dynamic register indexing
+__device__ __forceinline__ float ps_sel4(const f32x4& v, int r) {
+  return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3]));
+}
+
+// NOTE: contains workgroup barriers -> must be reached by all 4 waves of the workgroup the same number of times.
 template <class LT, int PB>
 __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, float* __restrict__ gacc,
                                                   const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS]) {
@@ -166,6 +216,11 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
   const int j = lane & 15, g = lane >> 4;
   float* sy = scratch;                               // dY tile rows [NB*16]
   float* sh = scratch + LT::NB * 16 * kScratchLd;    // H tile rows  [IB*16]
+  f32x4 dw[LT::NB][LT::IB];
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     __builtin_amdgcn_sched_barrier(0);
@@ -182,32 +237,45 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
     for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(sh + (16 * ib + j) * kScratchLd + 4 * g);
 #pragma unroll
     for (int ob = 0; ob < LT::NB; ++ob) {
-      __builtin_amdgcn_sched_barrier(0);
       const f32x4 afrag = *reinterpret_cast<const f32x4*>(sy + (16 * ob + j) * kScratchLd + 4 * g);
-      f32x4 dw[LT::IB];
-#pragma unroll
-      for (int ib = 0; ib < LT::IB; ++ib) dw[ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int ib = 0; ib < LT::IB; ++ib) dw[ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ib]);
-      // add the 16x16 tiles of this output block into the workgroup accumulators (ds_add_f32)
-#pragma unroll
-      for (int ib = 0; ib < LT::IB; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 4 + r) * 64 + lane, dw[ib][r]);
+        for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ob][ib]);
     }
     __builtin_amdgcn_wave_barrier();
   }
-  __builtin_amdgcn_sched_barrier(0);
-  // bias gradient: sum over the wave's points
+  // bias gradient partials: sum over the wave's points, reduced over the 16 lanes of a row
+  f32x4 db[LT::NB];
 #pragma unroll
-  for (int t = 0; t < LT::NB * 4; ++t) {
-    float s = 0.f;
+  for (int nb = 0; nb < LT::NB; ++nb)
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) s += dvout[pb][t];
-    s = ps_row16_sum(s);
-    if (j == 0) atomicAdd(gacc + LT::GB_OFF + 16 * (t >> 2) + 4 * g + (t & 3), s);
+    for (int r = 0; r < 4; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) s += dvout[pb][4 * nb + r];
+      db[nb][r] = ps_row16_sum(s);
+    }
+  // Flush into the workgroup accumulators WITHOUT LDS float atomics (ds_add_f32 retires ~1 lane per 10 cycles on
+  // gfx950, measured 20x slower than integer LDS atomics or plain LDS traffic): four phases separated by workgroup
+  // barriers; in phase p wave w read-modify-writes only register slot r = (w+p)%4 of every 16x16 tile, so the four
+  // waves always touch disjoint LDS words.
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    __syncthreads();
+    const int rsel = (w + p) & 3;
+#pragma unroll
+    for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+      for (int ib = 0; ib < LT::IB; ++ib) {
+        float* dst = gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 4) * 64 + rsel * 64 + lane;
+        *dst += ps_sel4(dw[ob][ib], rsel);
+      }
+    if (j == 0) {
+#pragma unroll
+      for (int nb = 0; nb < LT::NB; ++nb) gacc[LT::GB_OFF + 16 * nb + 4 * g + rsel] += ps_sel4(db[nb], rsel);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 }

@@ -14,6 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
+from . import prof
 from ._lib import check, lib
 from .ops import MlpSpec, _f32, _p, _stream, chain_colmap, linear_colmap
 
@@ -50,16 +51,18 @@ def field_points(aabb: Tensor, contract: bool, pos: Optional[Tensor] = None, ori
 def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg) -> Tensor:
     N = u.shape[0]
     feat = torch.empty(g.num_levels, N, g.features_per_level, device=u.device)
-    check(lib().ps_grid_encode(_p(u), _p(table), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
-                               N * g.features_per_level, _p(feat), _stream()), "ps_grid_encode")
+    with prof.region(f"grid_encode_L{g.num_levels}F{g.features_per_level}"):
+        check(lib().ps_grid_encode(_p(u), _p(table), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
+                                   N * g.features_per_level, _p(feat), _stream()), "ps_grid_encode")
     return feat
 
 
 def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape) -> Tensor:
     N = u.shape[0]
     dtable = torch.empty(table_shape, device=u.device, dtype=torch.float32)
-    check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
-                                N * g.features_per_level, _p(dtable), 0, _stream()), "ps_grid_scatter")
+    with prof.region(f"grid_scatter_L{g.num_levels}F{g.features_per_level}"):
+        check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
+                                    N * g.features_per_level, _p(dtable), 0, _stream()), "ps_grid_scatter")
     return dtable
 
 
@@ -89,8 +92,9 @@ class _PropField(torch.autograd.Function):
         feat = _encode(u, table, scalings, g)
         packed = spec.pack(layers, u.device)
         sigma = torch.empty(N, device=u.device)
-        check(lib().ps_prop_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
-                                      _p(packed), N, _p(sigma), _stream()), "ps_prop_field_fwd")
+        with prof.region("prop_field_fwd"):
+            check(lib().ps_prop_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
+                                          _p(packed), N, _p(sigma), _stream()), "ps_prop_field_fwd")
         ctx.save_for_backward(u, sel, scalings, feat, packed)
         ctx.meta = (g, hidden, tuple(table.shape), [tuple(W.shape) for W, _ in layers])
         return sigma
@@ -107,8 +111,9 @@ class _PropField(torch.autograd.Function):
         assert pf.value == spec.packed and gf.value == spec.g_total
         gpart = torch.empty(npart.value, spec.g_total, device=u.device)
         dfeat = torch.empty_like(feat)
-        check(lib().ps_prop_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
-                                      _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _stream()), "ps_prop_field_bwd")
+        with prof.region("prop_field_bwd"):
+            check(lib().ps_prop_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
+                                          _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _stream()), "ps_prop_field_bwd")
         dtable = _scatter(u, dfeat, scalings, g, tshape)
         grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes)
         flat = []
@@ -199,9 +204,10 @@ class _MainField(torch.autograd.Function):
         sem = torch.empty(N, SEM_DIM, device=dev) if want_sem else None
         dirs = _f32(dirs) if dirs is not None else torch.zeros(1, 3, device=dev)
         app_c = _f32(app) if (app is not None and want_rgb) else None
-        check(lib().ps_main_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                      _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb), _p(sem),
-                                      _stream()), "ps_main_field_fwd")
+        with prof.region("main_field_fwd"):
+            check(lib().ps_main_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                          _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb), _p(sem),
+                                          _stream()), "ps_main_field_fwd")
         ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed)
         ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
                     want_rgb, want_sem)
@@ -227,9 +233,10 @@ class _MainField(torch.autograd.Function):
         d_sigma = _f32(dsigma) if dsigma is not None else None
         d_rgb = _f32(drgb) if (want_rgb and drgb is not None) else None
         d_sem = _f32(dsem) if (want_sem and dsem is not None) else None
-        check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                      _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem), N,
-                                      _p(dfeat), _p(dapp), _p(gpart), _stream()), "ps_main_field_bwd")
+        with prof.region("main_field_bwd"):
+            check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                          _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem), N,
+                                          _p(dfeat), _p(dapp), _p(gpart), _stream()), "ps_main_field_bwd")
         dtable = _scatter(u, dfeat, scalings, g, tshape)
         n_rgb = len(shapes) - n_base - n_sem
         grads = []

@@ -343,11 +343,12 @@ def gold_model():
         p["log2_hashmap_size"] = 9
     scene = O.make_scene(cfg)
     P = O.make_params(cfg, seed=5, table_scale=0.3)
-    # make density non-trivial: bias the density heads
+    # density heads biased so that accumulations spread over (0,1) instead of saturating at 1 - 2^-23 (a saturated
+    # ray sits on the bound of sky_loss' clip and makes (1-acc) a pure rounding artefact)
     for k in range(cfg["num_fields"]):
-        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = 2.0
+        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = -2.5
         for i in range(2):
-            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = 1.5
+            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = -2.0
     model, mod = _build_ref_model(cfg, scene, P)
     R_ = 64
     batch = O.make_batch(cfg, scene, R_, step=1)

@@ -73,15 +73,11 @@ def test_training_step_matches_reference(gold_model):
         assert mism.float().mean() <= 0.05, k
     gt = {"rgb": batch["rgb"].to(dev), "features": batch["features"].to(dev), "sky": batch["sky"].to(dev)}
     ld = model.get_loss_dict(out, gt)
-    # sky BCE takes log(acc) of rays whose accumulation is ~1e-7 (1-exp(-x) cancellation noise on both sides) and the
-    # interlevel loss divides fp32 cumsums by ~1e-5-wide bins: both amplify last-ulp differences, hence 1e-2 there
-    loose = {"sky_loss": 1e-2, "interlevel_loss": 1e-2}
+    # the interlevel loss divides fp32 cumsums by very narrow PDF-resampled bins, which amplifies summation-order
+    # differences (see tests/test_hip_losses.py), hence 1e-2 there
+    loose = {"interlevel_loss": 1e-2}
     for k, v in ld.items():
         close(v, G["TL_" + k], rtol=loose.get(k, 5e-4), atol=1e-7)
-    # Gradients: every fixture ray is saturated (accumulation == 1 - 2^-23), i.e. sits exactly ON the upper bound of
-    # sky_loss' clip(acc, 1e-7, 1-1e-7); torch passes the gradient at the bound and blocks it one ulp above, so the
-    # sky-loss share of the density gradients (~0.6 % of the total) is switched by last-ulp rounding.  The tolerance
-    # (1 % of each tensor's scale) covers exactly that; the per-field tests in test_hip_fields.py are the tight ones.
     sum(ld.values()).backward()
     named = dict(model.named_parameters())
     n = 0
@@ -96,7 +92,7 @@ def test_training_step_matches_reference(gold_model):
         if scale == 0:
             assert float(got.abs().max()) == 0, name
         else:
-            torch.testing.assert_close(got / scale, ref / scale, rtol=2e-2, atol=1e-2, msg=lambda m: f"{name}: {m}")
+            torch.testing.assert_close(got / scale, ref / scale, rtol=5e-3, atol=1e-3, msg=lambda m: f"{name}: {m}")
         n += 1
     assert n == len(P)
     psnr = float(model.get_metrics_dict(out, gt)["psnr"])

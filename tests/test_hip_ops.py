@@ -100,7 +100,8 @@ def test_mlp_golden(ops, dev, gold_ops, tag):
 
 
 @pytest.mark.parametrize("dims,act,N", [([32, 64, 80], None, 100003), ([47, 64, 64, 3], "sigmoid", 65537), ([64, 64, 64, 64], None, 40000),
-                                        ([8, 64, 1], None, 1), ([8, 64, 1], None, 17), ([16, 32, 32, 64], None, 4097)])
+                                        ([8, 64, 1], None, 1), ([8, 64, 1], None, 17), ([16, 32, 32, 64], None, 4097),
+                                        ([32, 32, 32, 3], "sigmoid", 23), ([16, 32, 32, 64], None, 23), ([32, 32, 32, 3], "sigmoid", 300)])
 def test_mlp_vs_oracle_ragged_sizes(ops, dev, dims, act, N):
     g = torch.Generator().manual_seed(sum(dims) + N)
     layers = [((torch.rand(dims[i + 1], dims[i], generator=g) - 0.5) * (2.0 / dims[i] ** 0.5), torch.rand(dims[i + 1], generator=g) - 0.5)
