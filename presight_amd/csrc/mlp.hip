@@ -38,30 +38,37 @@ __global__ void mlp_pack_layer_kernel(const float* __restrict__ W, const float* 
   }
 }
 
-// unpack: sum the per-workgroup partial gradient blocks and add into torch-layout grads
+// unpack: sum the per-workgroup partial gradient blocks and add into torch-layout grads.
+// grid = (elements/256, part chunks): each thread sums a chunk of <= kUnpackChunk partials (coalesced across the
+// 256 threads of a block) and adds it to the destination; with one chunk the result is a plain deterministic sum.
+constexpr int kUnpackChunk = 32;
 __global__ void mlp_unpack_grad_layer_kernel(const float* __restrict__ gpart, int n_parts, int64_t part_stride, int out_dim,
                                              int in_dim, const int* __restrict__ colmap, int KS, int NB,
                                              float* __restrict__ gW, float* __restrict__ gb) {
   const int IB = (KS + 3) / 4;
   const int n_w = NB * IB * 256, n_b = NB * 16;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_w + n_b; i += gridDim.x * blockDim.x) {
-    float* dst = nullptr;
-    if (i < n_w) {
-      const int lane = i & 63, r = (i >> 6) & 3, ib = (i >> 8) % IB, ob = (i >> 8) / IB;
-      const int o = 16 * ob + 4 * (lane >> 4) + r;
-      const int row = lane & 15;
-      const int tin = 4 * ib + (row & 3);
-      const int col = (tin < KS) ? colmap[tin * 4 + (row >> 2)] : -1;
-      if (o < out_dim && col >= 0 && col < in_dim) dst = gW + (size_t)o * in_dim + col;
-    } else {
-      const int o = i - n_w;
-      if (o < out_dim) dst = gb + o;
-    }
-    if (dst == nullptr) continue;
-    float s = 0.f;
-    for (int p = 0; p < n_parts; ++p) s += gpart[(size_t)p * part_stride + i];
-    *dst += s;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_w + n_b) return;
+  float* dst = nullptr;
+  if (i < n_w) {
+    const int lane = i & 63, r = (i >> 6) & 3, ib = (i >> 8) % IB, ob = (i >> 8) / IB;
+    const int o = 16 * ob + 4 * (lane >> 4) + r;
+    const int row = lane & 15;
+    const int tin = 4 * ib + (row & 3);
+    const int col = (tin < KS) ? colmap[tin * 4 + (row >> 2)] : -1;
+    if (o < out_dim && col >= 0 && col < in_dim) dst = gW + (size_t)o * in_dim + col;
+  } else {
+    const int o = i - n_w;
+    if (o < out_dim) dst = gb + o;
   }
+  if (dst == nullptr) return;
+  const int p0 = blockIdx.y * kUnpackChunk, p1 = min(n_parts, p0 + kUnpackChunk);
+  float s = 0.f;
+  for (int p = p0; p < p1; ++p) s += gpart[(size_t)p * part_stride + i];
+  if (gridDim.y == 1)
+    *dst += s;
+  else
+    unsafeAtomicAdd(dst, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -269,8 +276,9 @@ extern "C" int ps_mlp_unpack_grad_layer(const float* gpart, int n_parts, int64_t
                                         const int* colmap, int KS, int NB, float* gW, float* gb, void* stream) {
   const int IB = (KS + 3) / 4;
   const int total = NB * IB * 256 + NB * 16;
-  mlp_unpack_grad_layer_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(gpart, n_parts, part_stride, out_dim,
-                                                                                    in_dim, colmap, KS, NB, gW, gb);
+  dim3 grid((total + 255) / 256, (n_parts + kUnpackChunk - 1) / kUnpackChunk);
+  mlp_unpack_grad_layer_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gpart, n_parts, part_stride, out_dim, in_dim, colmap, KS,
+                                                                     NB, gW, gb);
   PS_CHECK_LAUNCH();
 }
 

@@ -354,6 +354,17 @@ class _Composite(torch.autograd.Function):
         return dw, None, d_rgb_s, d_sem_s, None
 
 
+def threshold_depth(weights: Tensor, ebins: Tensor, threshold: float = 0.5) -> Tensor:
+    """Depth of the first sample whose cumulative weight reaches `threshold` ([R,1], no gradient);
+    ns/model_components/renderers.py:352-362."""
+    w, eb = _f32(weights.detach()), _f32(ebins)
+    R, S = w.shape
+    depth = torch.empty(R, 1, device=w.device)
+    check(lib().ps_composite_fwd(_p(w), _p(eb), None, None, R, S, 0, threshold, None, None, _p(depth), None, None, None, _stream()),
+          "ps_composite_fwd")
+    return depth
+
+
 def composite(weights: Tensor, ebins: Tensor, rgb_s: Optional[Tensor], sem_s: Optional[Tensor], threshold: float = 0.5):
     """-> (rgb [R,3], acc [R,1] (unclamped), threshold depth [R,1], expected depth [R,1] (batch-clipped), sem [R,C])."""
     return _Composite.apply(weights, ebins, rgb_s, sem_s, threshold)

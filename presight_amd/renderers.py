@@ -78,5 +78,6 @@ class DepthRenderer(nn.Module):
         self.method = method
 
     def forward(self, weights: Tensor, ray_samples: RaySamples, ray_indices=None, num_rays=None, threshold: float = 0.5) -> Tensor:
-        _, _, depth, expd, _ = ops.composite(weights[..., 0], ray_samples.ebins, None, None, threshold)
-        return depth if self.method == "threshold" else expd
+        if self.method == "threshold":
+            return ops.threshold_depth(weights[..., 0], ray_samples.ebins, threshold)
+        return ops.composite(weights[..., 0], ray_samples.ebins, None, None, threshold)[3]
