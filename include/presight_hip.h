@@ -138,6 +138,17 @@ int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, in
                       const float* dsigma, const float* drgb, const float* dsem, int64_t N, float* dfeat, float* dapp,
                       float* gpart, void* stream);
 
+/* ---- a18 prior extraction ---------------------------------------------------------------------------
+ * voxel index of Open3D's voxel_down_sample_and_trace as called by ns/scripts/extract_priors.py:216-245:
+ * idx = floor((p - (min_bound - voxel/2)) / voxel), fp64 arithmetic, int64 [n,3] (bit exact); min_bound is a HOST array */
+int ps_voxel_index(const float* pts, int64_t n, double voxel, const double* min_bound /*host[3]*/, int64_t* idx,
+                   void* stream);
+/* cell centres of the dense res^3 query lattice over aabb (HOST array min xyz, max xyz), z fastest;
+ * writes points [start, start+count) -> pts [count,3] */
+int ps_lattice_points(const float* aabb /*host[6]*/, int res, int64_t start, int64_t count, float* pts, void* stream);
+/* (a + b + c) / 3: mean of proposal-net and main-field densities, extract_priors.py:133-137 */
+int ps_mean_density(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

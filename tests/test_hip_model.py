@@ -123,3 +123,41 @@ def test_eval_render_depth_and_extraction_queries(gold_model):
         close(torch.stack(dens, 0).mean(0), G["X_density_mean"], rtol=2e-4, atol=1e-6)
         feats = model.field.semantic_fn(pts).clip(0.0, 1.0).to(torch.float16)
         assert (feats.float().cpu() - t(G["X_feats"]).float()).abs().max() <= 2 ** -10
+
+
+def test_voxel_index_and_dense_lattice_query(gold_model):
+    """BASELINE config 5 path: lattice points, fused field queries, bit-exact voxel index, voxel grouping."""
+    from oracle import nerf_oracle as O
+    from presight_amd import extract
+
+    G = gold_model
+    dev = torch.device("cuda:0")
+    model, cfg, scene, P, batch, bundle = build(G, dev)
+    model.eval()
+    aabb = scene["aabbs"][1]
+    res = 24
+    pts = extract.lattice_points(aabb, res, 0, res ** 3, dev)
+    ax = [aabb[0][k] + (aabb[1][k] - aabb[0][k]) * ((torch.arange(res, dtype=torch.float32) + 0.5) / res) for k in range(3)]
+    ref_pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3)  # z fastest
+    torch.testing.assert_close(pts.cpu(), ref_pts, rtol=0, atol=1e-6)
+    dens, feats = extract.query_priors(model, pts)
+    d_ref, f_ref = O.prior_query(P, cfg, scene, pts.cpu())
+    close(dens, d_ref, rtol=2e-4, atol=1e-6)
+    assert (feats.float().cpu() - f_ref.float()).abs().max() <= 2 ** -10
+    # integer voxel index: bit exact against the oracle's fp64 rule, including negative coordinates
+    world = (pts / 0.05).cpu()
+    mn = world.min(0).values - 1.0
+    idx = extract.voxel_index(world.to(dev), 0.4, mn)
+    assert torch.equal(idx.cpu(), O.voxel_index(world, 0.4, mn))
+    # dense tile query in two slabs == one pass (sharding the lattice needs no exchange)
+    full = extract.dense_tile_query(model, aabb, res=res, chunk=5000, density_threshold=-1.0)
+    half = res ** 3 // 2
+    a = extract.dense_tile_query(model, aabb, res=res, chunk=5000, start=0, count=half, density_threshold=-1.0)
+    b = extract.dense_tile_query(model, aabb, res=res, chunk=5000, start=half, count=res ** 3 - half, density_threshold=-1.0)
+    assert torch.equal(torch.cat([a["points"], b["points"]]), full["points"])
+    assert torch.equal(torch.cat([a["densities"], b["densities"]]), full["densities"])
+    # voxel grouping: hits sum to n, per-voxel mean of points lies inside its voxel
+    vox = extract.voxelize(full["points"], full["features"], None, voxel=0.4)
+    assert int(vox["hits"].sum()) == full["points"].shape[0]
+    lo = (vox["min_bound"] - 0.2) + vox["index"].double() * 0.4
+    assert bool(((vox["points"].double() >= lo - 1e-4) & (vox["points"].double() <= lo + 0.4 + 1e-4)).all())
