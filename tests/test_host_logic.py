@@ -1,0 +1,144 @@
+"""CPU tests of the host-side logic: packed-layout bookkeeping, column maps, config / state-dict compatibility with the
+reference, dotted-path aliases for YAML configs, and the N > 1 gradient exchange (gloo, world_size 2)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+import yaml
+
+from conftest import ROOT, load_golden
+
+
+def test_colmaps_are_permutations():
+    from presight_amd.field_ops import colour_colmap
+    from presight_amd.ops import chain_colmap, linear_colmap
+
+    for n in (8, 32, 40, 47, 64):
+        ks = (n + 3) // 4
+        cm = [c for c in linear_colmap(ks, n) if c >= 0]
+        assert sorted(cm) == list(range(n))
+    for n in (16, 32, 64, 80):
+        cm = [c for c in chain_colmap(n // 4, n) if c >= 0]
+        assert sorted(cm) == list(range(n))
+    for a in (0, 4, 16):
+        cm = [c for c in colour_colmap(a) if c >= 0]
+        assert sorted(cm) == list(range(31 + a))  # SH16 + geo15 + app
+
+
+def test_model_state_dict_matches_reference_checkpoint_keys(gold_model):
+    """Every parameter key of the reference's (torch-implementation) NerfactoNuscMSModel exists with the same shape."""
+    from conftest import model_fixture_setup
+    from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
+
+    cfg, scene, P, _ = model_fixture_setup(gold_model)
+    m = cfg["main"]
+    conf = NerfactoNuscMSModelConfig(
+        hidden_dim=m["hidden_dim"], hidden_dim_color=m["hidden_dim_color"], num_levels=m["num_levels"], max_res=m["max_res"],
+        log2_hashmap_size=m["log2_hashmap_size"], features_per_level=m["features_per_level"], use_lidar_loss=False,
+        proposal_net_args_list=[dict(features_per_level=p["features_per_level"], log2_hashmap_size=p["log2_hashmap_size"],
+                                     num_levels=p["num_levels"], base_res=p["base_res"], max_res=p["max_res"],
+                                     hidden_dim=p["hidden_dim"], use_linear=False) for p in cfg["props"]])
+    model = NerfactoNuscMSModel(conf, num_train_cameras=cfg["num_cameras"], num_train_videos=cfg["num_videos"], dino_to_rgb=None,
+                                centroids=scene["centroids"], aabbs=scene["aabbs"])
+    sd = model.state_dict()
+    for k, v in P.items():
+        assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
+    # the reference aliases mlp_base = Sequential(grid, mlp): those duplicate keys exist too
+    assert "field.fields.0.mlp_base.0.hash_table" in sd and "proposal_networks.0.fields.0.mlp_base.1.layers.0.weight" in sd
+    assert set(model.get_param_groups()) == {"proposal_networks", "fields"}
+
+
+def test_yaml_config_with_reference_dotted_path_loads():
+    from presight_amd import compat
+
+    compat.install()
+    text = textwrap.dedent("""
+        !!python/object:nerfstudio.models.PreSight.nerfacto_nusc_ms.NerfactoNuscMSModelConfig
+        near_plane: 0.005
+        far_plane: 50.0
+        piecewise_sampler_threshold: 5.0
+        num_levels: 10
+        features_per_level: 4
+        log2_hashmap_size: 20
+        max_res: 16384
+        use_lidar_loss: false
+        implementation: tcnn+fp32
+        num_proposal_samples_per_ray: !!python/tuple [128, 64]
+        pulse_width: !!python/tuple [0.03, 0.003]
+    """)
+    conf = yaml.load(text, Loader=yaml.Loader)
+    from presight_amd.model import NerfactoNuscMSModelConfig
+
+    assert isinstance(conf, NerfactoNuscMSModelConfig)
+    assert conf.far_plane == 50.0 and conf.num_levels == 10 and conf.implementation == "tcnn+fp32"
+    import nerfstudio.fields.PreSight.ingp_field as ref_path
+
+    assert hasattr(ref_path, "iNGPField")
+
+
+def test_anneal_and_update_schedule_match_reference_formulas():
+    """SURVEY Appendix A.7."""
+    import numpy as np
+
+    from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
+
+    conf = NerfactoNuscMSModelConfig(use_lidar_loss=False, num_levels=2, features_per_level=2, log2_hashmap_size=4, max_res=64,
+                                     hidden_dim=32, hidden_dim_color=32, proposal_weights_anneal_max_num_iters=1000,
+                                     proposal_net_args_list=[dict(features_per_level=1, log2_hashmap_size=4, num_levels=2,
+                                                                  base_res=16, max_res=32, hidden_dim=32, use_linear=False)])
+    m = NerfactoNuscMSModel(conf, num_train_cameras=2, num_train_videos=1, dino_to_rgb=None, centroids=torch.zeros(1, 3),
+                            aabbs=torch.tensor([[[-1.0, -1, -1], [1, 1, 1]]]))
+    for step in (0, 100, 500, 1000, 5000):
+        x = np.clip(step / 1000, 0, 1)
+        assert abs(m.anneal_for_step(step) - 10 * x / (9 * x + 1)) < 1e-12
+    s = m.proposal_sampler
+    assert s.update_sched(0) == 1 and s.update_sched(500) == 2.5 and s.update_sched(5000) == 5
+
+
+_WORKER = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from presight_amd.dist import FlatGrads, init_from_env
+    rank, local, world = init_from_env("cpu")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2, 2))]
+    fg = FlatGrads(params)
+    for i, p in enumerate(params):
+        (p * (rank + 1) * (i + 1)).sum().backward()
+    assert all(p.grad.data_ptr() >= fg.flat.data_ptr() for p in params)  # grads are views of the flat buffer
+    fg.all_reduce_mean()
+    expect = [(1 + 2) / 2 * (i + 1) for i in range(3)]
+    for p, e in zip(params, expect):
+        assert torch.allclose(p.grad, torch.full_like(p, e)), (rank, p.grad, e)
+    # "unused parameter" case: rank 1 contributes nothing for params[1]
+    fg.zero_()
+    if rank == 0:
+        (params[1] * 4).sum().backward()
+    fg.all_reduce_mean()
+    assert torch.allclose(params[1].grad, torch.full_like(params[1], 2.0))
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_gradient_exchange_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
+
+
+def test_hip_ops_refuse_cpu_tensors():
+    """No CPU fallback: the product path fails loudly when handed CPU tensors."""
+    from presight_amd import field_ops, ops
+
+    with pytest.raises(RuntimeError):
+        ops.hashgrid_encode(torch.zeros(4, 3), torch.zeros(32, 2), torch.ones(1), 1, 2, 5)
+    with pytest.raises(RuntimeError):
+        field_ops.field_points(torch.zeros(2, 3), True, pos=torch.zeros(4, 3))
