@@ -118,6 +118,13 @@ int ps_grid_encode(const float* u, const float* table, const float* scalings, in
 /* table gradient without HBM atomics (LDS slice owners); accumulate=0 overwrites dtable, 1 adds to it */
 int ps_grid_scatter(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                     int64_t plane_stride, float* dtable, int accumulate, void* stream);
+/* Fast path of the same gradient (used by the fused fields): every corner contribution is computed once, binned
+ * through `workspace` (ps_grid_scatter_workspace bytes, caller-allocated device memory) into the record stream of the
+ * table slice that owns its row, and reduced with fixed-point int64 LDS atomics -> bit-reproducible; dtable is
+ * overwritten. */
+int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N);
+int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
+                           int64_t plane_stride, float* dtable, void* workspace, void* stream);
 /* proposal field: MLP (L*F -> hidden -> 1), packed with ps_mlp_pack_layer (LINEAR first-layer colmap) */
 int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
                         int* n_parts /*host*/);

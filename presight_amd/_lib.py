@@ -29,10 +29,11 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(ps_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(ps_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
-        protos[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int, argtypes)
+        restype = ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int)
+        protos[name] = (restype, argtypes)
     return protos
 
 

@@ -200,3 +200,299 @@ extern "C" int ps_grid_scatter(const float* u, const float* dfeat, const float* 
 #undef PS_LAUNCH_SCATTER
   PS_CHECK_LAUNCH();
 }
+
+// =================================================================================================
+// Binned table backward (ps_grid_scatter_binned) — the fast path.
+//
+// The slice-owner scan above makes all ~32 owners of a level recompute every point's hashes, and its LDS *float*
+// atomics retire ~1 lane / 10 cycles (profiles/r01_microbench_atomics.txt).  Here every corner contribution is
+// computed ONCE, shuffled through HBM into the record stream of the slice that owns its table row, and each slice is
+// then reduced by one workgroup with dense 64-bit INTEGER LDS atomics (3.3 T lane-ops/s chip-wide) on fixed-point
+// values:  fixed = rint(w*g * 2^e),  e = 36 - ceil(log2(max|g|))  (max|g| per level, from a reduction over d(features)).
+// |fixed| <= 2^36 and a row receives at most 8N <= 2^26 contributions, so the int64 sums cannot overflow; the
+// resolution is 2^-36 of the largest feature gradient, i.e. finer than the fp32 sums of the reference for anything
+// that matters, and — integer addition being associative — the gradient is bit-reproducible run to run.
+//   phase 0  per-level absmax over d(features)                         (streams N*L*F floats)
+//   phase A  bin_kernel x2: count pass (records per (level, slice)) -> exclusive prefix -> write pass: hashes +
+//            weights, LDS counting sort of the workgroup's records by slice, one global cursor reservation per
+//            (workgroup, slice), coalesced record runs to HBM at their exact final position
+//   phase B  accumulate_kernel: one workgroup per (level, slice); records in, 128 KiB of int64 accumulators in LDS,
+//            slice out (+= into the pre-zeroed table gradient)
+// Stream sizes are exact (count pass -> prefix sum -> write pass), so nothing is ever dropped or capped.
+// =================================================================================================
+namespace {
+
+constexpr int kBinThreads = 256;
+constexpr int kBinPointsPerThread = 2;
+constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
+constexpr int kMaxSlices = 256;
+constexpr int kAccBytes = 128 * 1024;
+
+// one maximum per level plane (blockIdx.y = level): levels can differ by orders of magnitude in gradient scale
+__global__ void absmax_kernel(const float* __restrict__ v_all, int64_t n, int64_t plane_stride, unsigned* __restrict__ out_all) {
+  const float* v = v_all + blockIdx.y * plane_stride;
+  unsigned* out_bits = out_all + blockIdx.y;
+  float m = 0.f;
+  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(v + i);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
+    } else {
+      for (int64_t k = i; k < n; ++k) m = fmaxf(m, fabsf(v[k]));
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+  if (ps_lane() == 0 && m > 0.f && isfinite(m)) atomicMax(out_bits, __float_as_uint(m));  // positive floats order like uints
+}
+
+// scale exponent from the max-|g| bit pattern: 2^e * gmax in [2^35, 2^36)
+__device__ __forceinline__ float fixed_scale(unsigned gmax_bits, int headroom_log2) {
+  if (gmax_bits == 0u) return 1.0f;
+  const int ex = (int)((gmax_bits >> 23) & 0xffu) - 127;  // floor(log2 gmax)
+  return ldexpf(1.0f, headroom_log2 - (ex + 1));
+}
+
+// COUNT_ONLY = true : pass 1, per-(level, slice) record counts (cursors[] += bucket sizes)
+// COUNT_ONLY = false: pass 2, cursors[] hold the exclusive prefix (stream start) of every (level, slice) and are
+//                     advanced by the reservations; records are written at their exact final position.
+template <int F, bool COUNT_ONLY>
+__global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restrict__ u, const float* __restrict__ dfeat,
+                                                          const float* __restrict__ scalings, int L, int log2T,
+                                                          int log2_slice, int64_t N, int64_t plane_stride, int64_t n_rec_max,
+                                                          unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
+                                                          float* __restrict__ rec_val) {
+  // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record
+  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * 8;
+  __shared__ unsigned cnt[kMaxSlices], off[kMaxSlices + 1], gbase[kMaxSlices];
+  __shared__ unsigned s_idx[kRec];
+  __shared__ float s_val[F][kRec];
+  __shared__ unsigned char s_slice[kRec];
+  const int n_slices = 1 << (log2T - log2_slice);
+  const int64_t chunks = (N + kBinPoints - 1) / kBinPoints;
+  const int level = (int)(blockIdx.x / chunks);
+  const int64_t first = (blockIdx.x % chunks) * kBinPoints;
+  for (int i = threadIdx.x; i < n_slices; i += kBinThreads) cnt[i] = 0u;
+  __syncthreads();
+  const float s = scalings[level];
+  const uint32_t mask = (1u << log2T) - 1u, low = (1u << log2_slice) - 1u;
+  const float* g_plane = dfeat + level * plane_stride;
+  // hashes, weights, local position inside the slice bucket
+  uint32_t r_slice[kBinPointsPerThread][8], r_pos[kBinPointsPerThread][8], r_idx[kBinPointsPerThread][8];
+  float r_val[kBinPointsPerThread][8][F];
+#pragma unroll
+  for (int q = 0; q < kBinPointsPerThread; ++q) {
+    const int64_t n = first + q * kBinThreads + threadIdx.x;
+    const bool ok = n < N;
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) g[f] = 0.f;
+    ps::Cell c = ps::make_cell(ok ? u[n * 3] : 0.f, ok ? u[n * 3 + 1] : 0.f, ok ? u[n * 3 + 2] : 0.f, s);
+    if (ok) {
+      if constexpr (F == 1) g[0] = g_plane[n];
+      if constexpr (F == 2) {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(g_plane + n * 2);
+        g[0] = t.x;
+        g[1] = t.y;
+      }
+      if constexpr (F == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(g_plane + n * 4);
+        g[0] = t.x;
+        g[1] = t.y;
+        g[2] = t.z;
+        g[3] = t.w;
+      }
+    }
+    uint32_t h[8];
+    ps::corner_hashes(c, mask, h);
+    const float ox = c.ox, oy = c.oy, oz = c.oz, ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
+    const float w[8] = {ox * oy * oz, ox * uy * oz, ux * uy * oz, ux * oy * oz,
+                        ox * oy * uz, ox * uy * uz, ux * uy * uz, ux * oy * uz};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      bool any = false;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        r_val[q][k][f] = w[k] * g[f];
+        any |= (r_val[q][k][f] != 0.0f);
+      }
+      r_slice[q][k] = h[k] >> log2_slice;
+      r_idx[q][k] = h[k] & low;
+      r_pos[q][k] = (ok && any) ? atomicAdd(&cnt[r_slice[q][k]], 1u) : 0xffffffffu;  // ds_add_rtn_u32
+    }
+  }
+  __syncthreads();
+  if constexpr (COUNT_ONLY) {
+    if ((int)threadIdx.x < n_slices && cnt[threadIdx.x]) atomicAdd(&cursors[level * n_slices + threadIdx.x], cnt[threadIdx.x]);
+    return;
+  } else {
+    // exclusive scan of the bucket sizes (n_slices <= 256: one thread per slice, Hillis-Steele in LDS)
+    if (threadIdx.x < kMaxSlices) off[threadIdx.x + 1] = ((int)threadIdx.x < n_slices) ? cnt[threadIdx.x] : 0u;
+    if (threadIdx.x == 0) off[0] = 0u;
+    __syncthreads();
+    for (int d = 1; d < kMaxSlices; d <<= 1) {
+      unsigned v = 0u;
+      if (threadIdx.x < kMaxSlices && (int)threadIdx.x + 1 > d) v = off[threadIdx.x + 1 - d];
+      __syncthreads();
+      if (threadIdx.x < kMaxSlices) off[threadIdx.x + 1] += v;
+      __syncthreads();
+    }
+    // one global reservation per (workgroup, slice): absolute position in the record arrays
+    if ((int)threadIdx.x < n_slices) {
+      const unsigned c = cnt[threadIdx.x];
+      gbase[threadIdx.x] = c ? atomicAdd(&cursors[level * n_slices + threadIdx.x], c) : 0u;
+    }
+    // stage the records in bucket order
+#pragma unroll
+    for (int q = 0; q < kBinPointsPerThread; ++q)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (r_pos[q][k] != 0xffffffffu) {
+          const unsigned p = off[r_slice[q][k]] + r_pos[q][k];
+          s_idx[p] = r_idx[q][k];
+          s_slice[p] = (unsigned char)r_slice[q][k];
+#pragma unroll
+          for (int f = 0; f < F; ++f) s_val[f][p] = r_val[q][k][f];
+        }
+      }
+    __syncthreads();
+    // coalesced runs to the slice streams
+    const unsigned total = off[n_slices];
+    for (unsigned p = threadIdx.x; p < total; p += kBinThreads) {
+      const unsigned sl = s_slice[p];
+      const int64_t dst = (int64_t)gbase[sl] + (p - off[sl]);
+      rec_idx[dst] = s_idx[p];
+#pragma unroll
+      for (int f = 0; f < F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = s_val[f][p];
+    }
+  }
+}
+
+// exclusive prefix over the (level, slice) counts: starts[i], and cursors[i] := starts[i] for the second pass
+__global__ __launch_bounds__(1024) void stream_offsets_kernel(unsigned* __restrict__ cursors, unsigned* __restrict__ counts,
+                                                              unsigned* __restrict__ starts, int n) {
+  __shared__ unsigned part[1024];
+  const int per = (n + 1023) / 1024;
+  const int b = threadIdx.x * per;
+  unsigned sum = 0;
+  for (int i = 0; i < per; ++i)
+    if (b + i < n) sum += cursors[b + i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    unsigned v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = part[threadIdx.x] - sum;
+  for (int i = 0; i < per; ++i)
+    if (b + i < n) {
+      const unsigned c = cursors[b + i];
+      counts[b + i] = c;
+      starts[b + i] = run;
+      cursors[b + i] = run;
+      run += c;
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __restrict__ counts, const unsigned* __restrict__ starts,
+                                                          const unsigned* __restrict__ rec_idx,
+                                                          const float* __restrict__ rec_val, const unsigned* __restrict__ gmax_bits,
+                                                          int L, int log2T, int log2_slice, int64_t n_rec_max, int headroom_log2,
+                                                          float* __restrict__ dtable) {
+  extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F]
+  const int entries = 1 << log2_slice;
+  const int n_slices = 1 << (log2T - log2_slice);
+  const int item = blockIdx.x;  // level * n_slices + slice
+  const int level = item / n_slices, sl = item % n_slices;
+  for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
+  __syncthreads();
+  const int64_t n = counts[item];
+  const float scale = fixed_scale(gmax_bits[level], headroom_log2);
+  const int64_t base = starts[item];
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const unsigned e = rec_idx[base + i];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const long long fx = __float2ll_rn(rec_val[f * n_rec_max + base + i] * scale);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&acc[e * F + f]), (unsigned long long)fx);  // ds_add_u64
+    }
+  }
+  __syncthreads();
+  const float inv = 1.0f / scale;
+  float* out = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
+  for (int i = threadIdx.x; i < entries * F; i += 1024) out[i] = (float)((double)acc[i] * (double)inv);
+}
+
+int binned_log2_slice(int F, int log2T) {
+  int ls = 0;
+  while ((int64_t)(1 << (ls + 1)) * F * 8 <= kAccBytes) ++ls;
+  if (ls > log2T) ls = log2T;
+  while ((log2T - ls) > 8) ++ls;  // at most 256 slices (cannot happen for T <= 2^22)
+  return ls;
+}
+
+}  // namespace
+
+// bytes of scratch needed by ps_grid_scatter_binned
+extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N) {
+  const int ls = binned_log2_slice(F, log2T);
+  const int n_slices = 1 << (log2T - ls);
+  const int64_t n_rec_max = N * L * 8;
+  return 4096 + (int64_t)L * n_slices * 4 * 3 + n_rec_max * 4 * (1 + F) + 256;
+}
+
+extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
+                                      int64_t N, int64_t plane_stride, float* dtable, void* workspace, void* stream) {
+  PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
+  PS_REQUIRE(N * L * 8 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
+  hipStream_t s = (hipStream_t)stream;
+  const int ls = binned_log2_slice(F, log2T);
+  const int n_slices = 1 << (log2T - ls);
+  PS_REQUIRE(n_slices <= kMaxSlices, "ps_grid_scatter_binned: too many slices");
+  const int64_t n_rec_max = N * L * 8;
+  const int n_items = L * n_slices;
+  char* ws = (char*)workspace;
+  unsigned* gmax_bits = (unsigned*)ws;            // [L] (+ padding to 4096)
+  unsigned* cursors = (unsigned*)(ws + 4096);     // [n_items]
+  unsigned* counts = cursors + n_items;           // [n_items]
+  unsigned* starts = counts + n_items;            // [n_items]
+  unsigned* rec_idx = starts + n_items;           // [n_rec_max]
+  float* rec_val = (float*)(rec_idx + n_rec_max); // [F][n_rec_max]
+  hipError_t e = hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
+  if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
+  int headroom = 62 - 26;  // 8N <= 2^26 contributions per row
+  {
+    int bits = 0;
+    while (((int64_t)1 << bits) < N * 8) ++bits;
+    if (bits > 26) headroom = 62 - bits;
+  }
+  const int64_t chunks = (N + kBinPoints - 1) / kBinPoints;
+  const size_t lds = (size_t)(1 << ls) * F * 8;
+#define PS_LAUNCH_BINNED(FF)                                                                                              \
+  {                                                                                                                       \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      hipFuncSetAttribute((const void*)accumulate_kernel<FF>, hipFuncAttributeMaxDynamicSharedMemorySize, kAccBytes);     \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    if (N > 0) {                                                                                                          \
+      absmax_kernel<<<dim3(128, L), 256, 0, s>>>(dfeat, N * FF, plane_stride, gmax_bits);                                 \
+      bin_kernel<FF, true><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,            \
+                                                                          plane_stride, n_rec_max, cursors, rec_idx, rec_val); \
+    }                                                                                                                     \
+    stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                           \
+    if (N > 0)                                                                                                            \
+      bin_kernel<FF, false><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,           \
+                                                                           plane_stride, n_rec_max, cursors, rec_idx, rec_val); \
+    accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(counts, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
+                                                               n_rec_max, headroom, dtable);                              \
+  }
+  if (F == 1) PS_LAUNCH_BINNED(1)
+  if (F == 2) PS_LAUNCH_BINNED(2)
+  if (F == 4) PS_LAUNCH_BINNED(4)
+#undef PS_LAUNCH_BINNED
+  PS_CHECK_LAUNCH();
+}

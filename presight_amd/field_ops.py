@@ -57,12 +57,33 @@ def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg) -> Tensor:
     return feat
 
 
+_WORKSPACES = {}
+SCATTER_IMPL = "binned"  # "binned" (records + int64 LDS accumulation) or "owner" (LDS slice-owner scan)
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    """Scratch for the binned scatter, grown on demand and reused across steps (stream-ordered reuse is safe: every
+    consumer of the previous contents was enqueued on the same stream before the next producer)."""
+    key = str(device)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.05) + 4096, device=device, dtype=torch.uint8)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape) -> Tensor:
     N = u.shape[0]
     dtable = torch.empty(table_shape, device=u.device, dtype=torch.float32)
-    with prof.region(f"grid_scatter_L{g.num_levels}F{g.features_per_level}"):
-        check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
-                                    N * g.features_per_level, _p(dtable), 0, _stream()), "ps_grid_scatter")
+    L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
+    with prof.region(f"grid_scatter_L{L}F{F}"):
+        if SCATTER_IMPL == "binned" and N * 8 < (1 << 31):
+            ws = _workspace(lib().ps_grid_scatter_workspace(L, F, l2t, N), u.device)
+            check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), _p(ws), _stream()),
+                  "ps_grid_scatter_binned")
+        else:
+            check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), 0, _stream()),
+                  "ps_grid_scatter")
     return dtable
 
 
