@@ -7,7 +7,7 @@ import re
 from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpresight_hip.so")
+LIB_PATH = os.environ.get("PRESIGHT_HIP_LIB", os.path.join(_HERE, "libpresight_hip.so"))  # env override: ablation builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "presight_hip.h")
 
 

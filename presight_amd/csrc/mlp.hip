@@ -124,9 +124,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ packed, float* __restrict__ dx,
                                                       float* __restrict__ gpart, int64_t N, int in_dim, int out_dim) {
   constexpr int SCR = M::SCRATCH_ROWS * kScratchLd;
-  __shared__ __attribute__((aligned(16))) float lds[M::GPACKED + 4 * SCR];
+  __shared__ __attribute__((aligned(16))) float lds[M::GPACKED + 4 * SCR + 16];
   float* gacc = lds;
+  int* locks = reinterpret_cast<int*>(lds + M::GPACKED + 4 * SCR);
   for (int i = threadIdx.x; i < M::GPACKED; i += 256) gacc[i] = 0.0f;
+  if (threadIdx.x < 16) locks[threadIdx.x] = 0;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
   float* scratch = lds + M::GPACKED + wave * SCR;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const float* __restrict__ 
       }
     }
     float dxin[PB][M::L0::IB * 4];
-    mlp_backward<M, PB, WANT_DX>(gw, scratch, gacc, xin, h1, h2, z, dxin);
+    mlp_backward<M, PB, WANT_DX>(gw, scratch, gacc, locks, xin, h1, h2, z, dxin);
     if constexpr (WANT_DX) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {

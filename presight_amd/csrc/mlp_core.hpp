@@ -208,10 +208,13 @@ __device__ __forceinline__ float ps_sel4(const f32x4& v, int r) {
   return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3]));
 }
 
-// NOTE: contains workgroup barriers -> must be reached by all 4 waves of the workgroup the same number of times.
+// `lock` is this layer's LDS spin-lock word (zero-initialised by the kernel).
 template <class LT, int PB>
-__device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, float* __restrict__ gacc,
+__device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, float* __restrict__ gacc, int* __restrict__ lock,
                                                   const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS]) {
+#if defined(PS_ABLATE) && PS_ABLATE == 4
+  return;
+#endif
   const int lane = ps_lane();
   const int j = lane & 15, g = lane >> 4;
   float* sy = scratch;                               // dY tile rows [NB*16]
@@ -245,6 +248,10 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
     }
     __builtin_amdgcn_wave_barrier();
   }
+#if defined(PS_ABLATE) && PS_ABLATE == 3
+  asm volatile("" ::"v"(dw[0][0][0]));
+  return;
+#endif
   // bias gradient partials: sum over the wave's points, reduced over the 16 lanes of a row
   f32x4 db[LT::NB];
 #pragma unroll
@@ -254,29 +261,39 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
       float s = 0.f;
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) s += dvout[pb][4 * nb + r];
+#if defined(PS_ABLATE) && PS_ABLATE == 2
+      db[nb][r] = s;
+#else
       db[nb][r] = ps_row16_sum(s);
+#endif
     }
+#if defined(PS_ABLATE) && PS_ABLATE == 1
+  asm volatile("" ::"v"(dw[0][0][0]), "v"(db[0][0]));
+  return;
+#endif
   // Flush into the workgroup accumulators WITHOUT LDS float atomics (ds_add_f32 retires ~1 lane per 10 cycles on
-  // gfx950, measured 20x slower than integer LDS atomics or plain LDS traffic): four phases separated by workgroup
-  // barriers; in phase p wave w read-modify-writes only register slot r = (w+p)%4 of every 16x16 tile, so the four
-  // waves always touch disjoint LDS words.
-  const int w = threadIdx.x >> 6;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    __syncthreads();
-    const int rsel = (w + p) & 3;
-#pragma unroll
-    for (int ob = 0; ob < LT::NB; ++ob)
-#pragma unroll
-      for (int ib = 0; ib < LT::IB; ++ib) {
-        float* dst = gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 4) * 64 + rsel * 64 + lane;
-        *dst += ps_sel4(dw[ob][ib], rsel);
-      }
-    if (j == 0) {
-#pragma unroll
-      for (int nb = 0; nb < LT::NB; ++nb) gacc[LT::GB_OFF + 16 * nb + 4 * g + rsel] += ps_sel4(db[nb], rsel);
-    }
+  // gfx950, measured 20x slower than integer LDS atomics or plain LDS traffic): the wave takes this layer's LDS
+  // spin lock (integer compare-and-swap, fast), does plain read-modify-writes and releases.  The four waves of a
+  // workgroup drift apart after the first collision, so the lock is almost always free; there is no workgroup
+  // barrier on this path.
+  if (lane == 0) {
+    while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gacc[LT::GW_OFF + ((ob * LT::IB + ib) * 4 + r) * 64 + lane] += dw[ob][ib][r];
+  if (j == 0) {
+#pragma unroll
+    for (int nb = 0; nb < LT::NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gacc[LT::GB_OFF + 16 * nb + 4 * g + r] += db[nb][r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) atomicExch(lock, 0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -329,25 +346,26 @@ __device__ __forceinline__ void mlp_forward(const W& params, const float (&x)[PB
 // `params` is the global packed block (transposed fragments are read from it through L2).
 template <class M, int PB, bool WANT_DX, class W>
 __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict__ scratch,
-                                             float* __restrict__ gacc, const float (&x)[PB][M::KS0],
+                                             float* __restrict__ gacc, int* __restrict__ locks /*[3]*/,
+                                             const float (&x)[PB][M::KS0],
                                              const float (&h1)[PB][M::HB * 4], const float (&h2)[PB][M::HB * 4],
                                              const float (&dz)[PB][M::NBO * 4], float (&dx)[PB][M::L0::IB * 4]) {
   float dh[PB][M::HB * 4];
   if constexpr (M::NL == 3) {
-    layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, dz, h2);
+    layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, locks + 2, dz, h2);
     layer_bwd_data<typename M::LZ, PB>(params.at(M::TOFFZ), dz, dh);
     relu_mask<PB, M::HB * 4>(dh, h2);
     float dh1[PB][M::HB * 4];
-    layer_bwd_weights<typename M::L1, PB>(scratch, gacc + M::GOFF1, dh, h1);
+    layer_bwd_weights<typename M::L1, PB>(scratch, gacc + M::GOFF1, locks + 1, dh, h1);
     layer_bwd_data<typename M::L1, PB>(params.at(M::TOFF1), dh, dh1);
     relu_mask<PB, M::HB * 4>(dh1, h1);
-    layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, dh1, x);
+    layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, locks + 0, dh1, x);
     if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params.at(M::TOFF0), dh1, dx);
   } else {
-    layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, dz, h1);
+    layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, locks + 2, dz, h1);
     layer_bwd_data<typename M::LZ, PB>(params.at(M::TOFFZ), dz, dh);
     relu_mask<PB, M::HB * 4>(dh, h1);
-    layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, dh, x);
+    layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, locks + 0, dh, x);
     if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params.at(M::TOFF0), dh, dx);
   }
 }
