@@ -326,17 +326,30 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     if ((int)threadIdx.x < n_slices && cnt[threadIdx.x]) atomicAdd(&cursors[level * n_slices + threadIdx.x], cnt[threadIdx.x]);
     return;
   } else {
-    // exclusive scan of the bucket sizes (n_slices <= 256: one thread per slice, Hillis-Steele in LDS)
-    if (threadIdx.x < kMaxSlices) off[threadIdx.x + 1] = ((int)threadIdx.x < n_slices) ? cnt[threadIdx.x] : 0u;
-    if (threadIdx.x == 0) off[0] = 0u;
-    __syncthreads();
-    for (int d = 1; d < kMaxSlices; d <<= 1) {
-      unsigned v = 0u;
-      if (threadIdx.x < kMaxSlices && (int)threadIdx.x + 1 > d) v = off[threadIdx.x + 1 - d];
-      __syncthreads();
-      if (threadIdx.x < kMaxSlices) off[threadIdx.x + 1] += v;
-      __syncthreads();
+    // exclusive scan of the bucket sizes by the first wavefront (4 slices per lane + one wave scan, no block barriers)
+    if (threadIdx.x < 64) {
+      const int b = threadIdx.x * 4;
+      unsigned c4[4], sum = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c4[i] = (b + i < n_slices) ? cnt[b + i] : 0u;
+        sum += c4[i];
+      }
+      unsigned incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, 64);
+        if ((int)threadIdx.x >= d) incl += o;
+      }
+      unsigned run = incl - sum;
+      if (threadIdx.x == 0) off[0] = 0u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        run += c4[i];
+        off[b + i + 1] = run;
+      }
     }
+    __syncthreads();
     // one global reservation per (workgroup, slice): absolute position in the record arrays
     if ((int)threadIdx.x < n_slices) {
       const unsigned c = cnt[threadIdx.x];
@@ -412,12 +425,27 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   const int64_t n = counts[item];
   const float scale = fixed_scale(gmax_bits[level], headroom_log2);
   const int64_t base = starts[item];
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
-    const unsigned e = rec_idx[base + i];
+  // 4 records per thread per iteration, all loads issued before the first LDS atomic (memory-level parallelism)
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
+    unsigned e[4];
+    float v[4][F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-      const long long fx = __float2ll_rn(rec_val[f * n_rec_max + base + i] * scale);
-      atomicAdd(reinterpret_cast<unsigned long long*>(&acc[e * F + f]), (unsigned long long)fx);  // ds_add_u64
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * 1024;
+      const bool ok = i < n;
+      e[k] = ok ? rec_idx[base + i] : 0u;
+#pragma unroll
+      for (int f = 0; f < F; ++f) v[k][f] = ok ? rec_val[f * n_rec_max + base + i] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k * 1024 < n) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const long long fx = __float2ll_rn(v[k][f] * scale);
+          atomicAdd(reinterpret_cast<unsigned long long*>(&acc[e[k] * F + f]), (unsigned long long)fx);  // ds_add_u64
+        }
+      }
     }
   }
   __syncthreads();

@@ -51,7 +51,7 @@ __global__ void mlp_unpack_grad_layer_kernel(const float* __restrict__ gpart, in
   if (i >= n_w + n_b) return;
   float* dst = nullptr;
   if (i < n_w) {
-    const int lane = i & 63, r = (i >> 6) & 3, ib = (i >> 8) % IB, ob = (i >> 8) / IB;
+    const int r = i & 3, lane = (i >> 2) & 63, ib = (i >> 8) % IB, ob = (i >> 8) / IB;  // [tile][lane][r]
     const int o = 16 * ob + 4 * (lane >> 4) + r;
     const int row = lane & 15;
     const int tin = 4 * ib + (row & 3);

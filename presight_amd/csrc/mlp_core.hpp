@@ -40,7 +40,7 @@ struct LayerT {
   static constexpr int WF_OFF = NB_ * 16;
   static constexpr int FW = WF_OFF + NB_ * KS_ * 64;
   static constexpr int WT = IB * KSO * 64;
-  // packed gradient block: dW tiles in MFMA D layout, then the bias gradient
+  // packed gradient block: dW tiles in MFMA D layout ([tile = ob*IB+ib][lane][r]), then the bias gradient
   static constexpr int GW_OFF = 0;
   static constexpr int GB_OFF = NB_ * IB * 256;
   static constexpr int GPACKED = GB_OFF + NB_ * 16;
@@ -280,12 +280,14 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
     while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // accumulator layout [tile][lane][4]: one 16-byte LDS read + write per 16x16 tile and lane
 #pragma unroll
   for (int ob = 0; ob < LT::NB; ++ob)
 #pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gacc[LT::GW_OFF + ((ob * LT::IB + ib) * 4 + r) * 64 + lane] += dw[ob][ib][r];
+    for (int ib = 0; ib < LT::IB; ++ib) {
+      f32x4* dst = reinterpret_cast<f32x4*>(gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 64 + lane) * 4);
+      *dst = *dst + dw[ob][ib];
+    }
   if (j == 0) {
 #pragma unroll
     for (int nb = 0; nb < LT::NB; ++nb)
