@@ -263,10 +263,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
                                                           float* __restrict__ rec_val) {
   // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record
-  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * 8;
+  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * 8;  // worst case: every pair split
   __shared__ unsigned cnt[kMaxSlices], off[kMaxSlices + 1], gbase[kMaxSlices];
   __shared__ unsigned s_idx[kRec];
-  __shared__ float s_val[F][kRec];
+  __shared__ float s_val[F + 1][kRec];  // plane F holds ox
   __shared__ unsigned char s_slice[kRec];
   const int n_slices = 1 << (log2T - log2_slice);
   const int64_t chunks = (N + kBinPoints - 1) / kBinPoints;
@@ -277,9 +277,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
   const float s = scalings[level];
   const uint32_t mask = (1u << log2T) - 1u, low = (1u << log2_slice) - 1u;
   const float* g_plane = dfeat + level * plane_stride;
-  // hashes, weights, local position inside the slice bucket
-  uint32_t r_slice[kBinPointsPerThread][8], r_pos[kBinPointsPerThread][8], r_idx[kBinPointsPerThread][8];
-  float r_val[kBinPointsPerThread][8][F];
+  // hashes, weights, local position inside the slice bucket.  The two corners of an x-pair (ceil/floor in x) have
+  // hashes that differ by cx^fx = 2^(t+1)-1 (low bits only), so they almost always live in the same slice: they travel
+  // as ONE record {row of the floor corner, t, q[F] = w_yz * g[F], ox}; the accumulate kernel expands it.  A pair whose
+  // xor reaches the slice bits (probability ~2^-log2_slice) is split into two single-corner records (t = 31).
+  constexpr int NP = 4;  // pairs per point-level, in (y,z) corner order: (c,c) (f,c) (c,f) (f,f)
+  uint32_t r_slice[kBinPointsPerThread][2 * NP], r_pos[kBinPointsPerThread][2 * NP], r_idx[kBinPointsPerThread][2 * NP];
+  float r_val[kBinPointsPerThread][2 * NP][F], r_ox[kBinPointsPerThread][2 * NP];
 #pragma unroll
   for (int q = 0; q < kBinPointsPerThread; ++q) {
     const int64_t n = first + q * kBinThreads + threadIdx.x;
@@ -303,22 +307,40 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
         g[3] = t.w;
       }
     }
-    uint32_t h[8];
-    ps::corner_hashes(c, mask, h);
-    const float ox = c.ox, oy = c.oy, oz = c.oz, ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
-    const float w[8] = {ox * oy * oz, ox * uy * oz, ux * uy * oz, ux * oy * oz,
-                        ox * oy * uz, ox * uy * uz, ux * uy * uz, ux * oy * uz};
+    const uint32_t yc = (uint32_t)c.cy * 2654435761u, yf = (uint32_t)c.fy * 2654435761u;
+    const uint32_t zc = (uint32_t)c.cz * 805459861u, zf = (uint32_t)c.fz * 805459861u;
+    const uint32_t hyz[NP] = {yc ^ zc, yf ^ zc, yc ^ zf, yf ^ zf};
+    const float oy = c.oy, oz = c.oz, uy = 1.0f - oy, uz = 1.0f - oz;
+    const float wyz[NP] = {oy * oz, uy * oz, oy * uz, uy * uz};
+    const uint32_t xdiff = ((uint32_t)c.cx ^ (uint32_t)c.fx) & mask;  // 0 (exact integer) or 2^(t+1)-1
+    const bool together = (xdiff >> log2_slice) == 0u;
+    const uint32_t tcode = xdiff == 0u ? 30u : (uint32_t)(31 - __clz((int)xdiff));  // t (xdiff = 2^(t+1)-1), 30 = same row
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t hf = ((uint32_t)c.fx ^ hyz[k]) & mask, hc = ((uint32_t)c.cx ^ hyz[k]) & mask;
       bool any = false;
+      float qv[F];
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        r_val[q][k][f] = w[k] * g[f];
-        any |= (r_val[q][k][f] != 0.0f);
+        qv[f] = wyz[k] * g[f];
+        any |= (qv[f] != 0.0f);
       }
-      r_slice[q][k] = h[k] >> log2_slice;
-      r_idx[q][k] = h[k] & low;
-      r_pos[q][k] = (ok && any) ? atomicAdd(&cnt[r_slice[q][k]], 1u) : 0xffffffffu;  // ds_add_rtn_u32
+      // slot 2k: the pair (or the floor corner of a split pair); slot 2k+1: the ceil corner of a split pair
+      r_slice[q][2 * k] = hf >> log2_slice;
+      r_idx[q][2 * k] = (hf & low) | ((together ? tcode : 31u) << 16) ;
+      r_ox[q][2 * k] = together ? c.ox : 0.0f;  // single floor corner: weight (1-ox) folded into the values below
+      r_slice[q][2 * k + 1] = hc >> log2_slice;
+      r_idx[q][2 * k + 1] = (hc & low) | (31u << 16);
+      r_ox[q][2 * k + 1] = 0.0f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        r_val[q][2 * k][f] = together ? qv[f] : qv[f] * (1.0f - c.ox);
+        r_val[q][2 * k + 1][f] = qv[f] * c.ox;
+      }
+      const bool emit0 = ok && any;
+      const bool emit1 = ok && any && !together && c.ox != 0.0f;
+      r_pos[q][2 * k] = emit0 ? atomicAdd(&cnt[r_slice[q][2 * k]], 1u) : 0xffffffffu;  // ds_add_rtn_u32
+      r_pos[q][2 * k + 1] = emit1 ? atomicAdd(&cnt[r_slice[q][2 * k + 1]], 1u) : 0xffffffffu;
     }
   }
   __syncthreads();
@@ -366,6 +388,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
           s_slice[p] = (unsigned char)r_slice[q][k];
 #pragma unroll
           for (int f = 0; f < F; ++f) s_val[f][p] = r_val[q][k][f];
+          s_val[F][p] = r_ox[q][k];
         }
       }
     __syncthreads();
@@ -376,7 +399,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
       const int64_t dst = (int64_t)gbase[sl] + (p - off[sl]);
       rec_idx[dst] = s_idx[p];
 #pragma unroll
-      for (int f = 0; f < F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = s_val[f][p];
+      for (int f = 0; f <= F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = s_val[f][p];
     }
   }
 }
@@ -425,25 +448,37 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   const int64_t n = counts[item];
   const float scale = fixed_scale(gmax_bits[level], headroom_log2);
   const int64_t base = starts[item];
-  // 4 records per thread per iteration, all loads issued before the first LDS atomic (memory-level parallelism)
+  // 4 records per thread per iteration, all loads issued before the first LDS atomic (memory-level parallelism).
+  // record = {row | t<<16, ox, q[F]}: t < 30 -> pair (rows e and e ^ (2^(t+1)-1), weights 1-ox / ox), t == 30 -> both
+  // corners on the same row (exact integer x), t == 31 -> single corner with its weight already applied.
+  const unsigned low = (unsigned)entries - 1u;
   for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
     unsigned e[4];
-    float v[4][F];
+    float v[4][F], ox[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t i = i0 + k * 1024;
       const bool ok = i < n;
-      e[k] = ok ? rec_idx[base + i] : 0u;
+      e[k] = ok ? rec_idx[base + i] : (31u << 16);
+      ox[k] = ok ? rec_val[(int64_t)F * n_rec_max + base + i] : 0.0f;
 #pragma unroll
       for (int f = 0; f < F; ++f) v[k][f] = ok ? rec_val[f * n_rec_max + base + i] : 0.0f;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (i0 + k * 1024 < n) {
+        const unsigned row = e[k] & 0xffffu, t = e[k] >> 16;
+        const bool pair = t < 30u;
+        const unsigned row_c = pair ? ((row ^ ((2u << t) - 1u)) & low) : row;
+        const float wf = (t == 31u) ? 1.0f : (pair ? 1.0f - ox[k] : 1.0f);  // t == 30: c and f coincide, ox == 0
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-          const long long fx = __float2ll_rn(v[k][f] * scale);
-          atomicAdd(reinterpret_cast<unsigned long long*>(&acc[e[k] * F + f]), (unsigned long long)fx);  // ds_add_u64
+          const long long ff = __float2ll_rn(v[k][f] * wf * scale);
+          atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row * F + f]), (unsigned long long)ff);  // ds_add_u64
+          if (pair) {
+            const long long fc = __float2ll_rn(v[k][f] * ox[k] * scale);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row_c * F + f]), (unsigned long long)fc);
+          }
         }
       }
     }
@@ -469,7 +504,7 @@ extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N)
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
   const int64_t n_rec_max = N * L * 8;
-  return 4096 + (int64_t)L * n_slices * 4 * 3 + n_rec_max * 4 * (1 + F) + 256;
+  return 4096 + (int64_t)L * n_slices * 4 * 3 + n_rec_max * 4 * (2 + F) + 256;
 }
 
 extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
@@ -488,7 +523,7 @@ extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const 
   unsigned* counts = cursors + n_items;           // [n_items]
   unsigned* starts = counts + n_items;            // [n_items]
   unsigned* rec_idx = starts + n_items;           // [n_rec_max]
-  float* rec_val = (float*)(rec_idx + n_rec_max); // [F][n_rec_max]
+  float* rec_val = (float*)(rec_idx + n_rec_max); // [F+1][n_rec_max] (plane F = ox)
   hipError_t e = hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
   if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
   int headroom = 62 - 26;  // 8N <= 2^26 contributions per row
