@@ -473,12 +473,19 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
         const float wf = (t == 31u) ? 1.0f : (pair ? 1.0f - ox[k] : 1.0f);  // t == 30: c and f coincide, ox == 0
 #pragma unroll
         for (int f = 0; f < F; ++f) {
+#if defined(PS_ABLATE) && PS_ABLATE == 6
+          const long long ff = (long long)(int)(v[k][f] * wf);
+          const long long fc = (long long)(int)(v[k][f] * ox[k]);
+#else
           const long long ff = __float2ll_rn(v[k][f] * wf * scale);
+          const long long fc = __float2ll_rn(v[k][f] * ox[k] * scale);
+#endif
+#if defined(PS_ABLATE) && PS_ABLATE == 5
+          if (ff == 0x7fffffffffffffffLL || fc == 0x7fffffffffffffffLL) acc[row * F + f] = ff + fc;
+#else
           atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row * F + f]), (unsigned long long)ff);  // ds_add_u64
-          if (pair) {
-            const long long fc = __float2ll_rn(v[k][f] * ox[k] * scale);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row_c * F + f]), (unsigned long long)fc);
-          }
+          if (pair) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row_c * F + f]), (unsigned long long)fc);
+#endif
         }
       }
     }

@@ -81,8 +81,26 @@ __device__ __forceinline__ GlobalW make_global_w(const float* p, unsigned n_floa
 
 // ---- forward -------------------------------------------------------------------------------
 // v[pb][t] is the B-operand array of a 16-point block: for D-chained data t = 4*nb + r.
-template <class LT, int PB, class W>
-__device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB][LT::KS], float (&vout)[PB][LT::NB * 4]) {
+// fragments of output block 0 (issued early by the caller so that their latency hides under earlier work)
+template <class LT, class W>
+__device__ __forceinline__ void first_frags_fwd(const W& params, float (&a)[LT::KS]) {
+#pragma unroll
+  for (int t = 0; t < LT::KS; ++t) a[t] = params.frag(LT::WF_OFF + t * 64);
+}
+template <class LT, class W>
+__device__ __forceinline__ void first_frags_bwd(const W& wt_block, float (&a)[LT::KSO]) {
+#pragma unroll
+  for (int t = 0; t < LT::KSO; ++t) a[t] = wt_block.frag(t * 64);
+}
+struct NoPrefetch {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// `a_first`: fragments of block 0, already requested.  `next()` is invoked before the MFMAs of the LAST block and may
+// issue the first fragment loads of whatever runs next.
+template <class LT, int PB, class W, class Next>
+__device__ __forceinline__ void layer_fwd_pf(const W& params, const float (&a_first)[LT::KS], const float (&vin)[PB][LT::KS],
+                                             float (&vout)[PB][LT::NB * 4], const Next& next) {
   const int lane = ps_lane();
   const int g = lane >> 4;
   // Weight fragments are fetched one output block ahead: the loads of block nb+1 are issued (and fenced with a
@@ -90,7 +108,7 @@ __device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB
   // (Left to itself hipcc serialises  load -> s_waitcnt vmcnt(0) -> mfma  per k-step: 12x slower, measured.)
   float a_cur[LT::KS], a_nxt[LT::KS];
 #pragma unroll
-  for (int t = 0; t < LT::KS; ++t) a_cur[t] = params.frag(LT::WF_OFF + t * 64);
+  for (int t = 0; t < LT::KS; ++t) a_cur[t] = a_first[t];
 #pragma unroll
   for (int nb = 0; nb < LT::NB; ++nb) {
     f32x4 acc[PB];
@@ -102,6 +120,8 @@ __device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB
     if (nb + 1 < LT::NB) {
 #pragma unroll
       for (int t = 0; t < LT::KS; ++t) a_nxt[t] = params.frag(LT::WF_OFF + ((nb + 1) * LT::KS + t) * 64);
+    } else {
+      next();
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PB == 1) {
@@ -136,6 +156,13 @@ __device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB
   }
 }
 
+template <class LT, int PB, class W>
+__device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB][LT::KS], float (&vout)[PB][LT::NB * 4]) {
+  float a0[LT::KS];
+  first_frags_fwd<LT>(params, a0);
+  layer_fwd_pf<LT, PB>(params, a0, vin, vout, NoPrefetch());
+}
+
 template <int PB, int N>
 __device__ __forceinline__ void relu_inplace(float (&v)[PB][N]) {
 #pragma unroll
@@ -155,17 +182,20 @@ __device__ __forceinline__ void relu_mask(float (&dv)[PB][N], const float (&h)[P
 
 // ---- backward (data) -----------------------------------------------------------------------
 // dvin[pb][t], t = 4*ib + r, comes out in the layout the forward input of this layer had.
-template <class LT, int PB, class W>
-__device__ __forceinline__ void layer_bwd_data(const W& wt_block, const float (&dvout)[PB][LT::NB * 4],
-                                               float (&dvin)[PB][LT::IB * 4]) {
+template <class LT, int PB, class W, class Next>
+__device__ __forceinline__ void layer_bwd_data_pf(const W& wt_block, const float (&a_first)[LT::KSO],
+                                                  const float (&dvout)[PB][LT::NB * 4], float (&dvin)[PB][LT::IB * 4],
+                                                  const Next& next) {
   float a_cur[LT::KSO], a_nxt[LT::KSO];
 #pragma unroll
-  for (int t = 0; t < LT::KSO; ++t) a_cur[t] = wt_block.frag(t * 64);
+  for (int t = 0; t < LT::KSO; ++t) a_cur[t] = a_first[t];
 #pragma unroll
   for (int ib = 0; ib < LT::IB; ++ib) {
     if (ib + 1 < LT::IB) {
 #pragma unroll
       for (int t = 0; t < LT::KSO; ++t) a_nxt[t] = wt_block.frag(((ib + 1) * LT::KSO + t) * 64);
+    } else {
+      next();
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[PB];
@@ -197,6 +227,14 @@ __device__ __forceinline__ void layer_bwd_data(const W& wt_block, const float (&
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+template <class LT, int PB, class W>
+__device__ __forceinline__ void layer_bwd_data(const W& wt_block, const float (&dvout)[PB][LT::NB * 4],
+                                               float (&dvin)[PB][LT::IB * 4]) {
+  float a0[LT::KSO];
+  first_frags_bwd<LT>(wt_block, a0);
+  layer_bwd_data_pf<LT, PB>(wt_block, a0, dvout, dvin, NoPrefetch());
 }
 
 // ---- backward (weights) --------------------------------------------------------------------
@@ -332,14 +370,23 @@ template <class M, int PB, class W>
 __device__ __forceinline__ void mlp_forward(const W& params, const float (&x)[PB][M::KS0],
                                             float (&h1)[PB][M::HB * 4], float (&h2)[PB][M::HB * 4],
                                             float (&z)[PB][M::NBO * 4]) {
-  layer_fwd<typename M::L0, PB>(params.at(M::OFF0), x, h1);
-  relu_inplace<PB, M::HB * 4>(h1);
+  using L0 = typename M::L0;
+  using L1 = typename M::L1;
+  using LZ = typename M::LZ;
+  const W p0 = params.at(M::OFF0), p1 = params.at(M::OFF1), pz = params.at(M::OFFZ);
+  float a0[L0::KS], az[LZ::KS];
+  first_frags_fwd<L0>(p0, a0);
   if constexpr (M::NL == 3) {
-    layer_fwd<typename M::L1, PB>(params.at(M::OFF1), h1, h2);
+    float a1[L1::KS];
+    layer_fwd_pf<L0, PB>(p0, a0, x, h1, [&]() { first_frags_fwd<L1>(p1, a1); });
+    relu_inplace<PB, M::HB * 4>(h1);
+    layer_fwd_pf<L1, PB>(p1, a1, h1, h2, [&]() { first_frags_fwd<LZ>(pz, az); });
     relu_inplace<PB, M::HB * 4>(h2);
-    layer_fwd<typename M::LZ, PB>(params.at(M::OFFZ), h2, z);
+    layer_fwd_pf<LZ, PB>(pz, az, h2, z, NoPrefetch());
   } else {
-    layer_fwd<typename M::LZ, PB>(params.at(M::OFFZ), h1, z);
+    layer_fwd_pf<L0, PB>(p0, a0, x, h1, [&]() { first_frags_fwd<LZ>(pz, az); });
+    relu_inplace<PB, M::HB * 4>(h1);
+    layer_fwd_pf<LZ, PB>(pz, az, h1, z, NoPrefetch());
   }
 }
 
@@ -352,23 +399,37 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
                                              const float (&x)[PB][M::KS0],
                                              const float (&h1)[PB][M::HB * 4], const float (&h2)[PB][M::HB * 4],
                                              const float (&dz)[PB][M::NBO * 4], float (&dx)[PB][M::L0::IB * 4]) {
+  using L0 = typename M::L0;
+  using L1 = typename M::L1;
+  using LZ = typename M::LZ;
+  const W tz = params.at(M::TOFFZ), t1 = params.at(M::TOFF1), t0 = params.at(M::TOFF0);
   float dh[PB][M::HB * 4];
+  // the first transposed fragments of every data-backward layer are requested before the (long, fragment-free)
+  // weight-gradient phase that precedes it
+  float az[LZ::KSO];
+  first_frags_bwd<LZ>(tz, az);
   if constexpr (M::NL == 3) {
-    layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, locks + 2, dz, h2);
-    layer_bwd_data<typename M::LZ, PB>(params.at(M::TOFFZ), dz, dh);
+    layer_bwd_weights<LZ, PB>(scratch, gacc + M::GOFFZ, locks + 2, dz, h2);
+    layer_bwd_data_pf<LZ, PB>(tz, az, dz, dh, NoPrefetch());
     relu_mask<PB, M::HB * 4>(dh, h2);
     float dh1[PB][M::HB * 4];
-    layer_bwd_weights<typename M::L1, PB>(scratch, gacc + M::GOFF1, locks + 1, dh, h1);
-    layer_bwd_data<typename M::L1, PB>(params.at(M::TOFF1), dh, dh1);
+    float a1[L1::KSO];
+    first_frags_bwd<L1>(t1, a1);
+    layer_bwd_weights<L1, PB>(scratch, gacc + M::GOFF1, locks + 1, dh, h1);
+    layer_bwd_data_pf<L1, PB>(t1, a1, dh, dh1, NoPrefetch());
     relu_mask<PB, M::HB * 4>(dh1, h1);
-    layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, locks + 0, dh1, x);
-    if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params.at(M::TOFF0), dh1, dx);
+    float a0[L0::KSO];
+    if constexpr (WANT_DX) first_frags_bwd<L0>(t0, a0);
+    layer_bwd_weights<L0, PB>(scratch, gacc + M::GOFF0, locks + 0, dh1, x);
+    if constexpr (WANT_DX) layer_bwd_data_pf<L0, PB>(t0, a0, dh1, dx, NoPrefetch());
   } else {
-    layer_bwd_weights<typename M::LZ, PB>(scratch, gacc + M::GOFFZ, locks + 2, dz, h1);
-    layer_bwd_data<typename M::LZ, PB>(params.at(M::TOFFZ), dz, dh);
+    layer_bwd_weights<LZ, PB>(scratch, gacc + M::GOFFZ, locks + 2, dz, h1);
+    layer_bwd_data_pf<LZ, PB>(tz, az, dz, dh, NoPrefetch());
     relu_mask<PB, M::HB * 4>(dh, h1);
-    layer_bwd_weights<typename M::L0, PB>(scratch, gacc + M::GOFF0, locks + 0, dh, x);
-    if constexpr (WANT_DX) layer_bwd_data<typename M::L0, PB>(params.at(M::TOFF0), dh, dx);
+    float a0[L0::KSO];
+    if constexpr (WANT_DX) first_frags_bwd<L0>(t0, a0);
+    layer_bwd_weights<L0, PB>(scratch, gacc + M::GOFF0, locks + 0, dh, x);
+    if constexpr (WANT_DX) layer_bwd_data_pf<L0, PB>(t0, a0, dh, dx, NoPrefetch());
   }
 }
 

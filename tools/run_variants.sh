@@ -1,7 +1,6 @@
 #!/bin/bash
-# run bench.py against each ablation build (and the real library) and print the kernel timings
 cd $GRAFT_REPO_ROOT
-for v in "" noflush nobperm nodwflush_nobias nodw; do
+for v in "" "$@"; do
   if [ -z "$v" ]; then unset PRESIGHT_HIP_LIB; name=baseline; else export PRESIGHT_HIP_LIB=$PWD/presight_amd/_variants/lib_$v.so; name=$v; fi
-  timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms']; print('$name', round(d['ms_per_step'],2), 'main_bwd', k['main_field_bwd'], 'prop_bwd', k['prop_field_bwd'])"
+  timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms']; print('$name', round(d['ms_per_step'],2), {a:round(b,2) for a,b in k.items()})"
 done
