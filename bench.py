@@ -113,7 +113,9 @@ class Trainer:
                 seen.add(id(p))
                 uniq.append(p)
         self.grads = FlatGrads(uniq)
-        self.opt = torch.optim.Adam(uniq, lr=1e-2, eps=1e-15, weight_decay=1e-5, fused=True)
+        from presight_amd.optim import HipAdam
+
+        self.opt = HipAdam(uniq, lr=1e-2, eps=1e-15, weight_decay=1e-5)
         self.step_idx = 0
         self.loss_scale = 2.0 ** 10
         self.update_props_every_step = True

@@ -156,6 +156,12 @@ int ps_lattice_points(const float* aabb /*host[6]*/, int res, int64_t start, int
 /* (a + b + c) / 3: mean of proposal-net and main-field densities, extract_priors.py:133-137 */
 int ps_mean_density(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
 
+/* ---- f1 optimizer: torch.optim.Adam semantics (L2 weight decay added to the gradient, bias-corrected), in place.
+ * Reference configuration: ns/configs/method_configs.py:158-168 (lr 1e-2, eps 1e-15, weight_decay 1e-5).
+ * p, g, m, v: [n] fp32, 16-byte aligned; step counts from 1. */
+int ps_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,14 +18,15 @@ from torch import Tensor
 class FlatGrads:
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and p.numel() > 0]
-        total = sum(p.numel() for p in self.params)
+        pad = lambda n: (n + 3) // 4 * 4  # noqa: E731  keep every view 16-byte aligned (vectorised optimizer kernels)
+        total = sum(pad(p.numel()) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         off = 0
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+            off += pad(n)
 
     def zero_(self):
         self.flat.zero_()

@@ -1,0 +1,51 @@
+"""Adam on the HIP kernel (ps_adam_step), torch.optim.Adam-compatible numerics for the reference's settings
+(ns/engine/optimizers.py:73-170: one Adam per parameter group, lr 1e-2, eps 1e-15, weight_decay 1e-5)."""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+from ._lib import check, lib
+from .ops import _p, _stream
+
+
+class HipAdam:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-15,
+                 weight_decay: float = 1e-5):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and p.numel() > 0]
+        for p in self.params:
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("HipAdam: parameters must be contiguous fp32 CUDA tensors")
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.step_count = 0
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        s = _stream()
+        for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq):
+            g = p.grad
+            if g is None:
+                continue
+            if not g.is_contiguous():
+                g = g.contiguous()
+            check(lib().ps_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                     self.weight_decay, self.step_count, s), "ps_adam_step")
+
+    def zero_grad(self):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        for a, b in zip(self.exp_avg, sd["exp_avg"]):
+            a.copy_(b)
+        for a, b in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+            a.copy_(b)

@@ -262,3 +262,24 @@ def test_weights_large_batch_properties(ops, dev):
     r_u, _ = ops.pdf_resample(ones, sb_u, 64, None, 1.0, 0.0, 50.0, 5.0)
     expect = torch.linspace(0.0, 1.0 - 1.0 / 65, 65, device=dev) + 1.0 / 130
     torch.testing.assert_close(r_u, expect.expand(8, 65), rtol=1e-5, atol=1e-6)
+
+
+def test_adam_matches_torch_optim(dev):
+    """ps_adam_step against torch.optim.Adam (CPU, fp32) with the reference's hyper-parameters, 5 steps, ragged sizes."""
+    from presight_amd.optim import HipAdam
+
+    g = torch.Generator().manual_seed(8)
+    shapes = [(1000, 2), (7,), (33, 5), (1,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    hip_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+    hip = HipAdam(hip_p, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+    for step in range(5):
+        for a, b in zip(ref_p, hip_p):
+            gr = torch.randn(a.shape, generator=g) * (10.0 ** (step - 2))
+            a.grad = gr.clone()
+            b.grad = gr.to(dev)
+        ref.step()
+        hip.step()
+    for a, b in zip(ref_p, hip_p):
+        close(b, a.detach(), rtol=2e-5, atol=1e-6)
