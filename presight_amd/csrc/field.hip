@@ -85,25 +85,38 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const float* __restrict__
   }
 }
 
+// 2-layer proposal MLP: all weight/bias gradients live in registers for the whole kernel (no LDS accumulators, no
+// per-tile flush); every wave writes its own partial block at the end (gpart has 4 blocks per workgroup).
 template <class M, int PB>
 __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__ feat, int64_t plane_stride, int LF, int F,
                                                        const float* __restrict__ sel, const float* __restrict__ packed,
                                                        const float* __restrict__ dsigma, int64_t N, float* __restrict__ dfeat,
                                                        float* __restrict__ gpart) {
+  static_assert(M::NL == 2, "proposal MLP has two linear layers");
+  using L0 = typename M::L0;
+  using LZ = typename M::LZ;
   constexpr int SCR = M::SCRATCH_ROWS * kScratchLd;
-  __shared__ __attribute__((aligned(16))) float lds[M::GPACKED + 4 * SCR + 16];
-  float* gacc = lds;
-  int* locks = reinterpret_cast<int*>(lds + M::GPACKED + 4 * SCR);
-  for (int i = threadIdx.x; i < M::GPACKED; i += 256) gacc[i] = 0.0f;
-  if (threadIdx.x < 16) locks[threadIdx.x] = 0;
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) float lds[4 * SCR];
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
-  float* scratch = lds + M::GPACKED + wave * SCR;
+  float* scratch = lds + wave * SCR;
   const GlobalW gw = make_global_w(packed, M::PACKED);
+  const GlobalW tz = gw.at(M::TOFFZ), t0 = gw.at(M::TOFF0);
+  f32x4 dw0[L0::NB][L0::IB], db0[L0::NB], dwz[LZ::NB][LZ::IB], dbz[LZ::NB];
+#pragma unroll
+  for (int a = 0; a < L0::NB; ++a) {
+    db0[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < L0::IB; ++b) dw0[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int a = 0; a < LZ::NB; ++a) {
+    dbz[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < LZ::IB; ++b) dwz[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
-  // workgroup-uniform trip count (the dW flush contains workgroup barriers); out-of-range tiles are fully masked
-  for (int64_t base = (int64_t)blockIdx.x * 4; base < tiles; base += (int64_t)gridDim.x * 4) {
-    const int64_t first = (base + wave) * 16 * PB;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t first = tile * 16 * PB;
     float x[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
     load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
     mlp_forward<M, PB>(gw, x, h1, h2, z);
@@ -115,13 +128,17 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
       for (int t = 0; t < M::NBO * 4; ++t) z[pb][t] = 0.0f;
       z[pb][0] = d;
     }
-    float dx[PB][M::L0::IB * 4];
-    mlp_backward<M, PB, true>(gw, scratch, gacc, locks, x, h1, h2, z, dx);
+    float dh[PB][M::HB * 4], dx[PB][L0::IB * 4];
+    layer_bwd_weights_acc<LZ, PB>(scratch, dwz, dbz, z, h1);
+    layer_bwd_data<LZ, PB>(tz, z, dh);
+    relu_mask<PB, M::HB * 4>(dh, h1);
+    layer_bwd_weights_acc<L0, PB>(scratch, dw0, db0, dh, x);
+    layer_bwd_data<L0, PB>(t0, dh, dx);
     store_dfeat<M::KS0, PB>(dfeat, plane_stride, LF, F, first, N, dx);
   }
-  __syncthreads();
-  float* out = gpart + (size_t)blockIdx.x * M::GPACKED;
-  for (int i = threadIdx.x; i < M::GPACKED; i += 256) out[i] = gacc[i];
+  float* out = gpart + ((size_t)blockIdx.x * 4 + wave) * M::GPACKED;
+  store_layer_acc<L0>(out + M::GOFF0, dw0, db0);
+  store_layer_acc<LZ>(out + M::GOFFZ, dwz, dbz);
 }
 
 // ------------------------------------------------------------------------------------------ main field
@@ -387,7 +404,7 @@ extern "C" int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packe
     using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;         \
     *packed_floats = M::PACKED;                             \
     *grad_floats = M::GPACKED;                              \
-    *n_parts = grid_for_tiles(N, 16 * kPropBwdPB, 256);     \
+    *n_parts = 4 * grid_for_tiles(N, 16 * kPropBwdPB, 256); \
     return 0;                                               \
   }
   PS_PROP_CFGS(X)

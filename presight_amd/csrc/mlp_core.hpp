@@ -337,6 +337,63 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Register-resident variant for small MLPs (proposal nets: 2128 gradient words = 52 registers per lane): the dW / db
+// tiles stay in the caller's registers over ALL tiles of the kernel, so there is no per-tile flush at all.
+template <class LT, int PB>
+__device__ __forceinline__ void layer_bwd_weights_acc(float* __restrict__ scratch, f32x4 (&dw)[LT::NB][LT::IB], f32x4 (&db)[LT::NB],
+                                                      const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS]) {
+  const int lane = ps_lane();
+  const int j = lane & 15, g = lane >> 4;
+  float* sy = scratch;
+  float* sh = scratch + LT::NB * 16 * kScratchLd;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < LT::NB * 4; ++t) sy[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = dvout[pb][t];
+#pragma unroll
+    for (int t = 0; t < LT::IB * 4; ++t)
+      sh[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = (t < LT::KS) ? vin[pb][t < LT::KS ? t : 0] : 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    f32x4 bfrag[LT::IB];
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(sh + (16 * ib + j) * kScratchLd + 4 * g);
+#pragma unroll
+    for (int ob = 0; ob < LT::NB; ++ob) {
+      const f32x4 afrag = *reinterpret_cast<const f32x4*>(sy + (16 * ob + j) * kScratchLd + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ob][ib]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nb = 0; nb < LT::NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) db[nb][r] += dvout[pb][4 * nb + r];  // per-lane partial; reduced over lanes at the end
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// write one wave's register accumulators of a layer as a partial gradient block (same layout as the LDS accumulators)
+template <class LT>
+__device__ __forceinline__ void store_layer_acc(float* __restrict__ gblock, const f32x4 (&dw)[LT::NB][LT::IB], const f32x4 (&db)[LT::NB]) {
+  const int lane = ps_lane();
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib)
+      *reinterpret_cast<f32x4*>(gblock + LT::GW_OFF + ((ob * LT::IB + ib) * 64 + lane) * 4) = dw[ob][ib];
+#pragma unroll
+  for (int nb = 0; nb < LT::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = ps_row16_sum(db[nb][r]);
+      if (j == 0) gblock[LT::GB_OFF + 16 * nb + 4 * g + r] = s;
+    }
+}
+
 // ---- whole-MLP description -----------------------------------------------------------------
 // NL linear layers: KS0*4 inputs -> HB*16 hidden (NL-1 times) -> NBO*16 outputs.
 template <int KS0_, int HB_, int NBO_, int NL_>
