@@ -104,6 +104,16 @@ int ps_distortion_loss(const float* sbins, const float* w, int64_t R, int S, flo
 int ps_interlevel_loss(const float* c, const float* w, const float* cp, const float* wp, int64_t R, int S, int Sp,
                        float pulse_width, float* per_ray, float* dwp, void* stream);
 
+/* depth supervision of the lidar / monodepth configs (ns/model_components/PreSight/losses.py:28-103, called from
+ * nerfacto_nusc_ms.py:576-629).  depth [R] metres, sky [R] or NULL (1 = sky), ebins [R,S+1] / pred [R] in scene
+ * units (divided by pose_scale inside).  keep[r] = 1 < depth < upper_bound (and not sky); per_ray, dw, dpred are zero
+ * for the other rays; the reference's masked mean is sum(per_ray) / sum(keep) (NaN when no ray is kept). */
+int ps_line_of_sight_loss(const float* w, const float* ebins, const float* depth, const float* sky, int64_t R, int S,
+                          float sigma, float upper_bound, float pose_scale, float* per_ray, float* dw, float* keep,
+                          void* stream);
+int ps_expected_depth_loss(const float* depth, const float* pred, const float* sky, int64_t R, float upper_bound,
+                           int inverse, float pose_scale, float* per_ray, float* dpred, float* keep, void* stream);
+
 /* ---- field level (fused) -------------------------------------------------------------------------
  * A field evaluation is:  ps_field_points -> ps_grid_encode -> ps_{prop,main}_field_fwd, and backward
  * ps_{prop,main}_field_bwd -> ps_grid_scatter.  Features travel as level planes feat[l][n][f]

@@ -299,6 +299,57 @@ def distortion_loss(bins_s: Tensor, w: Tensor) -> Tensor:
     return (inter + intra).mean()
 
 
+def line_of_sight_loss(w: Tensor, depth: Tensor, steps: Tensor, sigma: float, sky_mask: Optional[Tensor] = None,
+                       upper_bound: float = 75.0) -> Tensor:
+    """URF line-of-sight loss, ns/model_components/PreSight/losses.py:28-65.  w, steps [R,S]; depth, sky_mask [R]
+    (metres: the caller divides steps by pose_scale_factor, nerfacto_nusc_ms.py:576-629).  Mean over the rays with
+    1 < depth < upper_bound (and not sky); NaN when no ray qualifies (torch.mean of an empty selection)."""
+    keep = (depth > 1.0) & (depth < upper_bound)
+    if sky_mask is not None:
+        keep = keep & (sky_mask == 0.0)
+    steps = steps.detach()
+    d = depth[:, None]
+    s = sigma / 3.0  # URF_SIGMA_SCALE_FACTOR
+    x = steps - d
+    target = torch.exp(-(x * x) / (2 * s * s) - math.log(s) - 0.5 * math.log(2 * math.pi))
+    near = (steps <= d + sigma) & (steps >= d - sigma)
+    empty = steps < d - sigma
+    per_ray = (near * (w - target) ** 2).sum(-1) + (empty * w**2).sum(-1)
+    return per_ray[keep].mean()
+
+
+def normalize_depth(depth: Tensor, upper_bound: float) -> Tensor:
+    """ns/model_components/PreSight/losses.py:25-26."""
+    return torch.clip(depth / upper_bound, 0.0, 1.0)
+
+
+def expected_depth_loss(depth: Tensor, pred: Tensor, upper_bound: float = 75.0, sky_mask: Optional[Tensor] = None,
+                        inverse: bool = False) -> Tensor:
+    """expected_depth_loss (lidar: sky_mask None, inverse False) and expected_monodepth_loss,
+    ns/model_components/PreSight/losses.py:67-103.  depth, pred, sky_mask [R] in metres."""
+    keep = (depth > 1.0) & (depth < upper_bound)
+    if sky_mask is not None:
+        keep = keep & (sky_mask == 0.0)
+    if inverse:
+        t, p = 1 / (depth + 5), 1 / (pred + 5)
+    else:
+        t, p = normalize_depth(depth, upper_bound), normalize_depth(pred, upper_bound)
+    return ((t - p) ** 2)[keep].mean()
+
+
+def line_of_sight_sigma(step: int, start_step=1000, end_step=30000, max_sigma=5.0, min_sigma=2.0) -> float:
+    """nerfacto_nusc_ms.py:387-396."""
+    frac = min(max((step - start_step) / (end_step - start_step), 0.0), 1.0)
+    return max_sigma - frac * (max_sigma - min_sigma)
+
+
+def line_of_sight_mult(step: int, mult=0.1, start_step=1000, decay_steps=5000) -> float:
+    """nerfacto_nusc_ms.py:398-403."""
+    if step <= start_step:
+        return 0.0
+    return mult / (2.0 ** (step // decay_steps))
+
+
 def _blur_stepfun(x: Tensor, y: Tensor, r: float):
     """ns/model_components/PreSight/losses.py:127-139."""
     xr, order = torch.sort(torch.cat([x - r, x + r], dim=-1))

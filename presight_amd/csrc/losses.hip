@@ -177,6 +177,72 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
   if (lane == 0) per_ray[ray] = total;
 }
 
+// ---- depth supervision (lidar / monodepth configs): ns/model_components/PreSight/losses.py:28-103 -----------------
+// One wavefront per ray.  steps = sample midpoints / pose_scale (metres); keep[ray] = 1 < depth < upper_bound (and not
+// sky); per_ray and dw are zero for rays that are not kept, so the caller's mean is sum(per_ray) / sum(keep).
+__global__ __launch_bounds__(256) void line_of_sight_kernel(const float* __restrict__ w, const float* __restrict__ ebins,
+                                                            const float* __restrict__ depth, const float* __restrict__ sky,
+                                                            int64_t R, int S, float sigma, float upper_bound, float pose_scale,
+                                                            float var2, float log_norm, float* __restrict__ per_ray,
+                                                            float* __restrict__ dw, float* __restrict__ keep) {
+  const int wv = threadIdx.x >> 6, lane = ps_lane();
+  const int64_t ray = blockIdx.x * 4 + wv;
+  if (ray >= R) return;
+  const float d = depth[ray];
+  const bool k = d > 1.0f && d < upper_bound && (sky == nullptr || sky[ray] == 0.0f);
+  const float* b = ebins + ray * (S + 1);
+  float total = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float step = ((b[s] + b[s + 1]) / 2.0f) / pose_scale;
+    const float wk = w[ray * S + s];
+    const float x = step - d;
+    const bool near = step <= d + sigma && step >= d - sigma;
+    const bool empty = step < d - sigma;
+    const float diff = wk - expf(-(x * x) / var2 - log_norm);
+    float l = 0.f, g = 0.f;
+    if (near) {
+      l += diff * diff;
+      g += 2.0f * diff;
+    }
+    if (empty) {
+      l += wk * wk;
+      g += 2.0f * wk;
+    }
+    total += l;
+    dw[ray * S + s] = k ? g : 0.0f;
+  }
+  total = ps_wave_sum(total);
+  if (lane == 0) {
+    per_ray[ray] = k ? total : 0.0f;
+    keep[ray] = k ? 1.0f : 0.0f;
+  }
+}
+
+__global__ void expected_depth_kernel(const float* __restrict__ depth, const float* __restrict__ pred, const float* __restrict__ sky,
+                                      int64_t R, float upper_bound, int inverse, float pose_scale, float* __restrict__ per_ray,
+                                      float* __restrict__ dpred, float* __restrict__ keep) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const float d = depth[i];
+  const bool k = d > 1.0f && d < upper_bound && (sky == nullptr || sky[i] == 0.0f);
+  const float p_m = pred[i] / pose_scale;  // metres
+  float t, p, dp;
+  if (inverse) {
+    t = 1.0f / (d + 5.0f);
+    p = 1.0f / (p_m + 5.0f);
+    dp = -(p * p);
+  } else {
+    const float tn = d / upper_bound, pn = p_m / upper_bound;
+    t = fminf(fmaxf(tn, 0.0f), 1.0f);
+    p = fminf(fmaxf(pn, 0.0f), 1.0f);
+    dp = (pn >= 0.0f && pn <= 1.0f) ? 1.0f / upper_bound : 0.0f;
+  }
+  const float e = t - p;
+  per_ray[i] = k ? e * e : 0.0f;
+  dpred[i] = k ? -2.0f * e * dp / pose_scale : 0.0f;
+  keep[i] = k ? 1.0f : 0.0f;
+}
+
 }  // namespace
 
 extern "C" int ps_distortion_loss(const float* sbins, const float* w, int64_t R, int S, float* per_ray, float* dw,
@@ -192,5 +258,27 @@ extern "C" int ps_interlevel_loss(const float* c, const float* w, const float* c
   PS_REQUIRE(S <= kMaxS && Sp <= kMaxSp, "ps_interlevel_loss: S must be <= 128 and Sp <= 256");
   if (R == 0) return 0;
   interlevel_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(c, w, cp, wp, R, S, Sp, pulse_width, per_ray, dwp);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_line_of_sight_loss(const float* w, const float* ebins, const float* depth, const float* sky, int64_t R, int S,
+                                     float sigma, float upper_bound, float pose_scale, float* per_ray, float* dw, float* keep,
+                                     void* stream) {
+  PS_REQUIRE(sigma > 0.f && pose_scale > 0.f, "ps_line_of_sight_loss: sigma and pose_scale must be positive");
+  if (R == 0) return 0;
+  const float sd = sigma / 3.0f;  // URF_SIGMA_SCALE_FACTOR
+  const float log_norm = (float)(log((double)sd) + 0.5 * log(2.0 * 3.14159265358979323846));
+  line_of_sight_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(w, ebins, depth, sky, R, S, sigma, upper_bound,
+                                                                               pose_scale, 2.0f * (sd * sd), log_norm, per_ray,
+                                                                               dw, keep);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_expected_depth_loss(const float* depth, const float* pred, const float* sky, int64_t R, float upper_bound,
+                                      int inverse, float pose_scale, float* per_ray, float* dpred, float* keep, void* stream) {
+  PS_REQUIRE(upper_bound > 0.f && pose_scale > 0.f, "ps_expected_depth_loss: upper_bound and pose_scale must be positive");
+  if (R == 0) return 0;
+  expected_depth_kernel<<<(unsigned)((R + 255) / 256), 256, 0, (hipStream_t)stream>>>(depth, pred, sky, R, upper_bound, inverse,
+                                                                                    pose_scale, per_ray, dpred, keep);
   PS_CHECK_LAUNCH();
 }

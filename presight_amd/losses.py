@@ -6,7 +6,7 @@ loss and its gradient w.r.t. the weights in one pass; the per-ray scalar losses 
 element-wise reductions."""
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 from torch import Tensor
@@ -84,3 +84,63 @@ def z_anti_aliasing_interlevel_loss(weights_list: Sequence[Tensor], ray_samples_
         wp = wp[..., 0] if wp.dim() == 3 else wp
         total = total + _Interlevel.apply(c, w, rs.sbins, wp, pulse_width[i])
     return total
+
+
+class _LineOfSight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, ebins, depth, sky, sigma, upper_bound, pose_scale):
+        w, ebins, depth = _f32(w), _f32(ebins), _f32(depth)
+        sky = None if sky is None else _f32(sky)
+        R, S = w.shape
+        per_ray, keep, dw = torch.empty(R, device=w.device), torch.empty(R, device=w.device), torch.empty_like(w)
+        check(lib().ps_line_of_sight_loss(_p(w), _p(ebins), _p(depth), _p(sky), R, S, float(sigma), float(upper_bound),
+                                          float(pose_scale), _p(per_ray), _p(dw), _p(keep), _stream()), "ps_line_of_sight_loss")
+        n = keep.sum()
+        ctx.save_for_backward(dw, n)
+        return per_ray.sum() / n  # NaN when no ray qualifies, like torch.mean of an empty selection
+
+    @staticmethod
+    def backward(ctx, g):
+        dw, n = ctx.saved_tensors
+        return dw * (g / n), None, None, None, None, None, None
+
+
+def line_of_sight_loss(weights: Tensor, termination_depth: Tensor, ray_samples, sigma: float, sky_mask: Optional[Tensor] = None,
+                       upper_bound: float = 75.0, pose_scale_factor: float = 1.0) -> Tensor:
+    """URF line-of-sight loss (ns/model_components/PreSight/losses.py:28-65).  Takes the RaySamples (bin edges in scene
+    units) + pose_scale_factor instead of the pre-divided `steps` tensor: the midpoints are formed inside the kernel."""
+    w = weights[..., 0] if weights.dim() == 3 else weights
+    sky = None if sky_mask is None else sky_mask.reshape(-1)
+    return _LineOfSight.apply(w, ray_samples.ebins, termination_depth.reshape(-1), sky, sigma, upper_bound, pose_scale_factor)
+
+
+class _ExpectedDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, pred, sky, upper_bound, inverse, pose_scale):
+        depth, pred = _f32(depth), _f32(pred)
+        sky = None if sky is None else _f32(sky)
+        R = depth.shape[0]
+        per_ray, keep, dpred = (torch.empty(R, device=depth.device) for _ in range(3))
+        check(lib().ps_expected_depth_loss(_p(depth), _p(pred), _p(sky), R, float(upper_bound), int(bool(inverse)), float(pose_scale),
+                                           _p(per_ray), _p(dpred), _p(keep), _stream()), "ps_expected_depth_loss")
+        n = keep.sum()
+        ctx.save_for_backward(dpred, n)
+        return per_ray.sum() / n
+
+    @staticmethod
+    def backward(ctx, g):
+        dpred, n = ctx.saved_tensors
+        return None, dpred * (g / n), None, None, None, None
+
+
+def expected_depth_loss(termination_depth: Tensor, predicted_depth: Tensor, upper_bound: float = 75.0,
+                        pose_scale_factor: float = 1.0) -> Tensor:
+    """ns/model_components/PreSight/losses.py:67-81; predicted_depth in scene units (divided by pose_scale_factor inside)."""
+    return _ExpectedDepth.apply(termination_depth.reshape(-1), predicted_depth.reshape(-1), None, upper_bound, False, pose_scale_factor)
+
+
+def expected_monodepth_loss(termination_depth: Tensor, predicted_depth: Tensor, sky_mask: Tensor, upper_bound: float = 50.0,
+                            inverse: bool = False, pose_scale_factor: float = 1.0) -> Tensor:
+    """ns/model_components/PreSight/losses.py:83-103."""
+    return _ExpectedDepth.apply(termination_depth.reshape(-1), predicted_depth.reshape(-1), sky_mask.reshape(-1), upper_bound, inverse,
+                                pose_scale_factor)

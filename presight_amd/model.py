@@ -19,7 +19,8 @@ from . import ops
 from .components import Embedding, SceneContraction
 from .fields import (FieldHeadNames, PropNetDensityField, PropNetDensityFieldMS, SkyField, SkyFieldMS, iNGPField,
                      iNGPFieldMS)
-from .losses import distortion_loss, semantic_loss, sky_loss, z_anti_aliasing_interlevel_loss
+from .losses import (distortion_loss, expected_depth_loss, expected_monodepth_loss, line_of_sight_loss, semantic_loss, sky_loss,
+                     z_anti_aliasing_interlevel_loss)
 from .rays import RayBundle, RaySamples
 from .renderers import AccumulationRenderer, DepthRenderer, NearFarCollider, RGBRenderer, render_all
 from .samplers import ProposalNetworkSampler, SpacedSampler
@@ -134,9 +135,7 @@ class NerfactoNuscMSModel(nn.Module):
     # ------------------------------------------------------------------------------------------------ construction
     def populate_modules(self):
         c = self.config
-        if c.use_lidar_loss or c.use_monodepth_loss:
-            raise NotImplementedError("presight_amd: depth-supervised configs (lidar / monodepth losses) are not built yet; "
-                                      "the camera-dino prior-building configs set use_lidar_loss=False")
+        assert not (c.use_lidar_loss and c.use_monodepth_loss)  # nerfacto_nusc_ms.py:361-365
         contraction = None if c.disable_scene_contraction else SceneContraction(order=float("inf"))
         self.centroids = self.kwargs["centroids"]
         self.aabbs = self.kwargs["aabbs"]
@@ -298,12 +297,50 @@ class NerfactoNuscMSModel(nn.Module):
             loss_dict["rgb_loss"] = self.rgb_loss(batch[RGB][..., :3], outputs["rgb"])
         if c.use_sky_model and SKY in batch:
             loss_dict["sky_loss"] = c.sky_loss_mult * self.sky_loss(outputs["accumulation"].view(-1, 1), batch[SKY].view(-1, 1))
+        if (c.use_monodepth_loss or c.use_lidar_loss) and DEPTH in batch:  # nerfacto_nusc_ms.py:576-629
+            rs = outputs["ray_samples_list"][-1]
+            scale = self._pose_scale_factor(rs)
+            mono = c.use_monodepth_loss
+            ub = c.monodepth_depth_upperbound if mono else c.lidar_depth_upperbound
+            sky_mask = batch[SKY].view(-1, 1) if mono else None  # the reference reuses the sky branch's mask
+            if mono:
+                ed = expected_monodepth_loss(batch[DEPTH], outputs["expected_depth"], sky_mask, upper_bound=ub,
+                                             inverse=c.monodepth_loss_inverse, pose_scale_factor=scale)
+            else:
+                ed = expected_depth_loss(batch[DEPTH], outputs["expected_depth"], upper_bound=ub, pose_scale_factor=scale)
+            loss_dict["expected_depth_loss"] = c.expected_depth_loss_mult * ed
+            loss_dict["line_of_sight_loss"] = self.get_line_of_sight_mult(self.step) * line_of_sight_loss(
+                outputs["weights_list"][-1], batch[DEPTH], rs, sigma=self.get_line_of_sight_sigma(self.step), sky_mask=sky_mask,
+                upper_bound=ub, pose_scale_factor=scale)
         if c.use_semantics and FEATURES in batch:
             loss_dict["semantic_loss"] = c.semantic_loss_mult * self.semantic_loss(pred=outputs["semantics"], target=batch[FEATURES], clip=True)
         if self.training:
             loss_dict["interlevel_loss"] = c.interlevel_loss_mult * self.interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"])
             loss_dict["distortion_loss"] = c.distortion_loss_mult * distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
         return loss_dict
+
+    def get_line_of_sight_sigma(self, step):
+        """nerfacto_nusc_ms.py:387-396"""
+        c = self.config
+        frac = np.clip((step - c.line_of_sight_start_step) / (c.line_of_sight_end_step - c.line_of_sight_start_step), 0.0, 1.0)
+        return c.line_of_sight_max_sigma - frac * (c.line_of_sight_max_sigma - c.line_of_sight_min_sigma)
+
+    def get_line_of_sight_mult(self, step):
+        """nerfacto_nusc_ms.py:398-403"""
+        c = self.config
+        if step <= c.line_of_sight_start_step:
+            return 0.0
+        return c.line_of_sight_mult / (2.0 ** (step // c.line_of_sight_decay_steps))
+
+    def _pose_scale_factor(self, ray_samples) -> float:
+        """metadata["pose_scale_factor"] is a per-ray copy of one dataset constant (nerfacto_nusc_ms.py:582 reads element
+        [0,0,0]); it is a kernel argument here, so it is fetched from the device once and cached."""
+        v = ray_samples.metadata["pose_scale_factor"]
+        if not torch.is_tensor(v):
+            return float(v)
+        if getattr(self, "_pose_scale_cache", None) is None:
+            self._pose_scale_cache = float(v.reshape(-1)[0])  # one host sync for the lifetime of the model
+        return self._pose_scale_cache
 
     # ------------------------------------------------------------------------------------------------ depth / eval
     def get_depth(self, ray_bundle: RayBundle, threshold=0.5):

@@ -304,6 +304,16 @@ def pdf_resample(weights: Tensor, sbins: Tensor, n_new: int, jitter: Optional[Te
     return nsb, neb
 
 
+_MINMAX_INIT = {}
+
+
+def _minmax_init(dev):
+    """{+inf, 0} on `dev`, created once (a host->device copy per call would also break hipGraph capture of a step)"""
+    if dev not in _MINMAX_INIT:
+        _MINMAX_INIT[dev] = torch.tensor([float("inf"), 0.0], device=dev)
+    return _MINMAX_INIT[dev]
+
+
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, ebins, rgb_s, sem_s, threshold):
@@ -318,7 +328,7 @@ class _Composite(torch.autograd.Function):
         acc = torch.empty(R, 1, device=dev)
         depth = torch.empty(R, 1, device=dev)
         expd = torch.empty(R, 1, device=dev)
-        minmax = torch.tensor([float("inf"), 0.0], device=dev)
+        minmax = _minmax_init(dev).clone()
         check(lib().ps_composite_fwd(_p(weights), _p(ebins), _p(rgb_s), _p(sem_s), R, S, C, threshold, _p(rgb), _p(acc), _p(depth),
                                      _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
         raw = expd.clone()

@@ -307,6 +307,36 @@ def gold_losses():
          acc=acc, sky_mask=skym, sky_loss=sl, g_sky=g_sl, sem_pred=pred, sem_tgt=tgt, sem_loss=sm, g_sem=g_sm)
 
 
+def gold_depth_losses():
+    """lidar / monodepth supervision (ns/model_components/PreSight/losses.py:28-103), exactly as get_loss_dict calls them
+    (nerfacto_nusc_ms.py:576-629): depth [R,1] in metres, steps and predicted depth divided by pose_scale_factor."""
+    g = torch.Generator().manual_seed(15)
+    R_, S = 48, 64
+    scale = 0.05
+    edges = torch.sort(torch.rand(R_, S + 1, generator=g) * 60.0 * scale, dim=-1).values
+    steps = ((edges[:, :-1] + edges[:, 1:]) / 2)[..., None] / scale  # [R,S,1] metres
+    w = (torch.rand(R_, S, 1, generator=g) * 0.1).requires_grad_(True)
+    depth = torch.rand(R_, 1, generator=g) * 90.0  # some < 1, some > upper bound
+    depth[0], depth[1], depth[2] = 0.5, 76.0, 39.9
+    sky = (torch.rand(R_, 1, generator=g) < 0.25).float()
+    pred = (torch.rand(R_, 1, generator=g) * 80.0).requires_grad_(True)
+    out = dict(edges=edges, steps=steps, w=w, depth=depth, sky=sky, pred=pred, pose_scale_factor=np.float32(scale))
+    for tag, sigma, ub, use_sky in (("lidar", 5.0, 75.0, False), ("mono", 2.6, 40.0, True)):
+        los = ns.ps_losses.line_of_sight_loss(weights=w, termination_depth=depth, steps=steps, sigma=sigma,
+                                              sky_mask=sky if use_sky else None, upper_bound=ub)
+        (g_los,) = torch.autograd.grad(los, w)
+        out.update({f"los_{tag}": los, f"g_los_{tag}": g_los, f"sigma_{tag}": np.float32(sigma), f"ub_{tag}": np.float32(ub)})
+    ed = ns.ps_losses.expected_depth_loss(termination_depth=depth, predicted_depth=pred, upper_bound=75.0)
+    (g_ed,) = torch.autograd.grad(ed, pred)
+    out.update(ed_lidar=ed, g_ed_lidar=g_ed)
+    for tag, inv in (("mono", False), ("mono_inv", True)):
+        em = ns.ps_losses.expected_monodepth_loss(termination_depth=depth, predicted_depth=pred, sky_mask=sky, upper_bound=40.0,
+                                                  inverse=inv)
+        (g_em,) = torch.autograd.grad(em, pred)
+        out.update({f"ed_{tag}": em, f"g_ed_{tag}": g_em})
+    save("depth_losses", **out)
+
+
 # ---------------------------------------------------------------------------- fields + whole model
 def _build_ref_model(cfg, scene, P):
     mod = __import__("importlib").import_module("nerfstudio.models.PreSight.nerfacto_nusc_ms")
@@ -444,6 +474,6 @@ def _with_meta(rb, batch):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "model"]
+    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "depth_losses", "model"]
     for w in which:
         globals()["gold_" + w]()

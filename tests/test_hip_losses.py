@@ -95,3 +95,80 @@ def test_interlevel_vs_oracle_well_conditioned():
     d_ref = O.distortion_loss(bl[2], ref_w[2])
     d_out = L.distortion_loss(dw, [_RS(b.to(dev)) for b in bl])
     close(d_out, d_ref, rtol=2e-4)
+
+
+class _RSE:
+    def __init__(self, ebins):
+        self.ebins = ebins
+
+
+def test_depth_losses_golden():
+    """lidar / monodepth supervision kernels vs the reference-generated fixture (tests/golden/depth_losses.npz)"""
+    from conftest import load_golden
+    from presight_amd import losses as L
+
+    G = load_golden("depth_losses")
+    dev = torch.device("cuda:0")
+    scale = float(G["pose_scale_factor"])
+    w = t(G["w"])[..., 0].to(dev).requires_grad_(True)
+    rs = _RSE(t(G["edges"]).to(dev))
+    depth, sky = t(G["depth"]).to(dev), t(G["sky"]).to(dev)
+    for tag, use_sky in (("lidar", False), ("mono", True)):
+        los = L.line_of_sight_loss(w[..., None], depth, rs, sigma=float(G[f"sigma_{tag}"]), sky_mask=sky if use_sky else None,
+                                   upper_bound=float(G[f"ub_{tag}"]), pose_scale_factor=scale)
+        close(los, G[f"los_{tag}"], rtol=1e-5)
+        close(torch.autograd.grad(los, w)[0], G[f"g_los_{tag}"][..., 0], rtol=1e-4, atol=1e-8)
+    pred_m = t(G["pred"]).to(dev)  # metres in the fixture; the model hands scene units
+    pred = (pred_m * scale).requires_grad_(True)
+    cases = (("lidar", lambda: L.expected_depth_loss(depth, pred, upper_bound=75.0, pose_scale_factor=scale)),
+             ("mono", lambda: L.expected_monodepth_loss(depth, pred, sky, upper_bound=40.0, pose_scale_factor=scale)),
+             ("mono_inv", lambda: L.expected_monodepth_loss(depth, pred, sky, upper_bound=40.0, inverse=True, pose_scale_factor=scale)))
+    for tag, fn in cases:
+        ed = fn()
+        close(ed, G[f"ed_{tag}"], rtol=1e-5)
+        close(torch.autograd.grad(ed, pred)[0] * scale, G[f"g_ed_{tag}"], rtol=1e-4, atol=1e-9)
+    # no ray qualifies -> NaN, like torch.mean of an empty selection
+    none = L.expected_depth_loss(torch.zeros_like(depth), pred, pose_scale_factor=scale)
+    assert bool(torch.isnan(none))
+
+
+def test_model_depth_supervised_step():
+    """use_lidar_loss=True config: loss dict carries expected_depth_loss + line_of_sight_loss and they match the oracle
+    on the model's own outputs; gradients reach the tables."""
+    from oracle import nerf_oracle as O
+    from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
+    import bench
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    scene = bench.make_scene(60, 6)
+    conf = NerfactoNuscMSModelConfig(near_plane=0.005, far_plane=50.0, piecewise_sampler_threshold=5.0, num_levels=4,
+                                     features_per_level=2, log2_hashmap_size=12, base_res=16, max_res=128, hidden_dim=32,
+                                     hidden_dim_color=32, implementation="hip", use_lidar_loss=True, line_of_sight_start_step=0)
+    model = NerfactoNuscMSModel(conf, num_train_cameras=60, num_train_videos=6, dino_to_rgb=None, centroids=scene["centroids"],
+                                aabbs=scene["aabbs"]).to(dev)
+    scene = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    batch = bench.make_batches(scene, dev, 1, 0, rays=256)[0]
+    batch["depth"] = torch.rand(256, 1, device=dev) * 80.0
+    from presight_amd import ops
+    from presight_amd.rays import RayBundle
+
+    o, d, pa, dn = ops.generate_rays(batch["ray_indices"], scene["c2w"], scene["fx"], scene["fy"], scene["cx"], scene["cy"])
+    rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1],
+                   metadata={"video_id": batch["video_ids"][:, None], "directions_norm": dn,
+                             "pose_scale_factor": torch.full((256, 1), 0.05, device=dev)})
+    model.train()
+    model.before_train_iteration(6000)
+    out = model(rb)
+    ld = model.get_loss_dict(out, batch)
+    assert {"expected_depth_loss", "line_of_sight_loss"} <= set(ld)
+    rs, w = out["ray_samples_list"][-1], out["weights_list"][-1]
+    steps = ((rs.ebins[:, :-1] + rs.ebins[:, 1:]) / 2 / 0.05).cpu()
+    ref_los = O.line_of_sight_mult(6000) * O.line_of_sight_loss(w[..., 0].detach().cpu(), batch["depth"][:, 0].cpu(), steps,
+                                                                 O.line_of_sight_sigma(6000))
+    ref_ed = O.expected_depth_loss(batch["depth"][:, 0].cpu(), out["expected_depth"][:, 0].detach().cpu() / 0.05)
+    close(ld["line_of_sight_loss"], ref_los, rtol=1e-4)
+    close(ld["expected_depth_loss"], ref_ed, rtol=1e-4)
+    sum(ld.values()).backward()
+    gt = model.field.fields[0].mlp_base_grid.hash_table.grad
+    assert gt is not None and bool(torch.isfinite(gt).all()) and float(gt.abs().sum()) > 0

@@ -3,7 +3,7 @@
 import numpy as np
 import torch
 
-from conftest import model_fixture_setup, t
+from conftest import load_golden, model_fixture_setup, t
 from oracle import nerf_oracle as O
 
 F32 = dict(rtol=1e-5, atol=1e-6)
@@ -226,6 +226,25 @@ def test_losses(gold_losses):
     sm = O.semantic_loss(pred, t(G["sem_tgt"]))
     close(sm, G["sem_loss"])
     close(torch.autograd.grad(sm, pred)[0], G["g_sem"])
+
+
+def test_depth_losses():
+    """lidar / monodepth supervision vs the reference (tests/golden/make_golden.py::gold_depth_losses)"""
+    G = load_golden("depth_losses")
+    w = t(G["w"])[..., 0].clone().requires_grad_(True)
+    steps, depth, sky = t(G["steps"])[..., 0], t(G["depth"])[:, 0], t(G["sky"])[:, 0]
+    for tag, use_sky in (("lidar", False), ("mono", True)):
+        los = O.line_of_sight_loss(w, depth, steps, float(G[f"sigma_{tag}"]), sky if use_sky else None, float(G[f"ub_{tag}"]))
+        close(los, G[f"los_{tag}"])
+        close(torch.autograd.grad(los, w)[0], G[f"g_los_{tag}"][..., 0], rtol=1e-4)
+    pred = t(G["pred"])[:, 0].clone().requires_grad_(True)
+    for tag, kw in (("lidar", dict(upper_bound=75.0)), ("mono", dict(upper_bound=40.0, sky_mask=sky)),
+                    ("mono_inv", dict(upper_bound=40.0, sky_mask=sky, inverse=True))):
+        ed = O.expected_depth_loss(depth, pred, **kw)
+        close(ed, G[f"ed_{tag}"])
+        close(torch.autograd.grad(ed, pred)[0], G[f"g_ed_{tag}"][:, 0], rtol=1e-4)
+    assert O.line_of_sight_mult(1000) == 0.0 and O.line_of_sight_mult(1001) == 0.1 and O.line_of_sight_mult(12000) == 0.025
+    assert O.line_of_sight_sigma(0) == 5.0 and O.line_of_sight_sigma(30000) == 2.0 and abs(O.line_of_sight_sigma(15500) - 3.5) < 1e-12
 
 
 # ------------------------------------------------------------------------------ fields + whole model
