@@ -105,7 +105,10 @@ class Trainer:
         from presight_amd.dist import FlatGrads
 
         self.model, self.scene, self.world = model, scene, world
-        params = [p for p in model.parameters() if p.requires_grad and p.numel() > 0]
+        groups = model.get_param_groups()  # group-major order: a group that receives no gradient in a step (proposal nets
+        params = [p for k in sorted(groups, reverse=True) for p in groups[k]]  # off-schedule) is one contiguous range to skip
+        params = [p for p in params if p.requires_grad and p.numel() > 0]
+        assert {id(p) for p in params} == {id(p) for p in model.parameters() if p.requires_grad and p.numel() > 0}
         # the reference registers mlp_base = Sequential(grid, mlp): the same tensors appear twice in parameters() -> dedup
         seen, uniq = set(), []
         for p in params:
@@ -115,7 +118,7 @@ class Trainer:
         self.grads = FlatGrads(uniq)
         from presight_amd.optim import HipAdam
 
-        self.opt = HipAdam(uniq, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+        self.opt = HipAdam(uniq, lr=1e-2, eps=1e-15, weight_decay=1e-5, flat_grads=self.grads)
         self.step_idx = 0
         self.loss_scale = 2.0 ** 10
         self.update_props_every_step = True

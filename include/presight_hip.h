@@ -49,6 +49,14 @@ int ps_mlp_pack_layer(const float* W, const float* b, int out_dim, int in_dim, c
 /* gW [out,in] += sum_parts dW ; gb [out] += sum_parts db */
 int ps_mlp_unpack_grad_layer(const float* gpart, int n_parts, int64_t part_stride, int out_dim, int in_dim,
                              const int* colmap, int KS, int NB, float* gW, float* gb, void* stream);
+/* The same two operations for all layers (<= 8) of one fused stack in ONE launch.  Every array argument is a HOST
+ * array of n_layers entries (device pointers / ints); gpart[i] points at layer i's block inside the first partial. */
+int ps_mlp_pack_layers(int n_layers, const float* const* W, const float* const* b, const int* out_dim, const int* in_dim,
+                       const int* const* colmap, const int* KS, const int* NB, float* const* fw_block,
+                       float* const* wt_block, void* stream);
+int ps_mlp_unpack_grad_layers(int n_layers, const float* const* gpart, int n_parts, int64_t part_stride,
+                              const int* out_dim, const int* in_dim, const int* const* colmap, const int* KS,
+                              const int* NB, float* const* gW, float* const* gb, void* stream);
 /* y [N,out] = MLP(x [N,in]); out_act: 0 none, 1 sigmoid */
 int ps_mlp_fwd(const float* x, const float* packed, float* y, int64_t N, int in_dim, int hidden, int out_dim,
                int num_layers, int out_act, void* stream);
@@ -130,11 +138,11 @@ int ps_grid_scatter(const float* u, const float* dfeat, const float* scalings, i
                     int64_t plane_stride, float* dtable, int accumulate, void* stream);
 /* Fast path of the same gradient (used by the fused fields): every corner contribution is computed once, binned
  * through `workspace` (ps_grid_scatter_workspace bytes, caller-allocated device memory) into the record stream of the
- * table slice that owns its row, and reduced with fixed-point int64 LDS atomics -> bit-reproducible; dtable is
- * overwritten. */
+ * table slice that owns its row, and reduced with fixed-point int64 LDS atomics -> bit-reproducible;
+ * accumulate=0 overwrites dtable, 1 adds to it. */
 int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N);
 int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
-                           int64_t plane_stride, float* dtable, void* workspace, void* stream);
+                           int64_t plane_stride, float* dtable, int accumulate, void* workspace, void* stream);
 /* proposal field: MLP (L*F -> hidden -> 1), packed with ps_mlp_pack_layer (LINEAR first-layer colmap) */
 int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
                         int* n_parts /*host*/);

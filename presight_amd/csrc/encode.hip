@@ -437,7 +437,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
                                                           const unsigned* __restrict__ rec_idx,
                                                           const float* __restrict__ rec_val, const unsigned* __restrict__ gmax_bits,
                                                           int L, int log2T, int log2_slice, int64_t n_rec_max, int headroom_log2,
-                                                          float* __restrict__ dtable) {
+                                                          int accumulate, float* __restrict__ dtable) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F]
   const int entries = 1 << log2_slice;
   const int n_slices = 1 << (log2T - log2_slice);
@@ -493,7 +493,10 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   __syncthreads();
   const float inv = 1.0f / scale;
   float* out = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
-  for (int i = threadIdx.x; i < entries * F; i += 1024) out[i] = (float)((double)acc[i] * (double)inv);
+  for (int i = threadIdx.x; i < entries * F; i += 1024) {
+    const float v = (float)((double)acc[i] * (double)inv);
+    out[i] = accumulate ? out[i] + v : v;
+  }
 }
 
 int binned_log2_slice(int F, int log2T) {
@@ -515,7 +518,8 @@ extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N)
 }
 
 extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
-                                      int64_t N, int64_t plane_stride, float* dtable, void* workspace, void* stream) {
+                                      int64_t N, int64_t plane_stride, float* dtable, int accumulate, void* workspace,
+                                      void* stream) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
   PS_REQUIRE(N * L * 8 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
   hipStream_t s = (hipStream_t)stream;
@@ -558,7 +562,7 @@ extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const 
       bin_kernel<FF, false><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,           \
                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val); \
     accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(counts, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
-                                                               n_rec_max, headroom, dtable);                              \
+                                                               n_rec_max, headroom, accumulate, dtable);                  \
   }
   if (F == 1) PS_LAUNCH_BINNED(1)
   if (F == 2) PS_LAUNCH_BINNED(2)

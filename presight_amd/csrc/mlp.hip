@@ -12,9 +12,9 @@ using namespace ps;
 // pack: torch layout W[out][in], b[out]  ->  forward fragments + transposed fragments
 // colmap[t*4+g] = torch input column supplied by lane group g at k-step t (-1 = zero pad)
 // ------------------------------------------------------------------------------------------
-__global__ void mlp_pack_layer_kernel(const float* __restrict__ W, const float* __restrict__ b, int out_dim, int in_dim,
-                                      const int* __restrict__ colmap, int KS, int NB, float* __restrict__ fw_block,
-                                      float* __restrict__ wt_block) {
+__device__ __forceinline__ void pack_layer(const float* __restrict__ W, const float* __restrict__ b, int out_dim, int in_dim,
+                                           const int* __restrict__ colmap, int KS, int NB, float* __restrict__ fw_block,
+                                           float* __restrict__ wt_block) {
   const int IB = (KS + 3) / 4, KSO = NB * 4;
   const int n_bias = NB * 16, n_wf = NB * KS * 64, n_wt = IB * KSO * 64;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_bias + n_wf + n_wt; i += gridDim.x * blockDim.x) {
@@ -38,13 +38,39 @@ __global__ void mlp_pack_layer_kernel(const float* __restrict__ W, const float* 
   }
 }
 
+__global__ void mlp_pack_layer_kernel(const float* __restrict__ W, const float* __restrict__ b, int out_dim, int in_dim,
+                                      const int* __restrict__ colmap, int KS, int NB, float* __restrict__ fw_block,
+                                      float* __restrict__ wt_block) {
+  pack_layer(W, b, out_dim, in_dim, colmap, KS, NB, fw_block, wt_block);
+}
+
+// batched variants: all layers of one fused stack in ONE launch (blockIdx.y / blockIdx.z = layer); the per-layer
+// descriptors travel by value in the kernel arguments
+constexpr int kMaxBatchedLayers = 8;
+struct LayerDesc {
+  const float* W;     // pack: torch weight [out,in]       unpack: partial blocks of this layer
+  const float* b;     // pack: torch bias [out]            unpack: unused
+  const int* colmap;
+  float* dst0;        // pack: forward fragments           unpack: dW [out,in] (accumulated)
+  float* dst1;        // pack: transposed fragments        unpack: db [out]    (accumulated)
+  int out_dim, in_dim, KS, NB;
+};
+struct LayerBatch {
+  LayerDesc l[kMaxBatchedLayers];
+};
+
+__global__ void mlp_pack_layers_kernel(LayerBatch a) {
+  const LayerDesc& d = a.l[blockIdx.y];
+  pack_layer(d.W, d.b, d.out_dim, d.in_dim, d.colmap, d.KS, d.NB, d.dst0, d.dst1);
+}
+
 // unpack: sum the per-workgroup partial gradient blocks and add into torch-layout grads.
 // grid = (elements/256, part chunks): each thread sums a chunk of <= kUnpackChunk partials (coalesced across the
 // 256 threads of a block) and adds it to the destination; with one chunk the result is a plain deterministic sum.
 constexpr int kUnpackChunk = 32;
-__global__ void mlp_unpack_grad_layer_kernel(const float* __restrict__ gpart, int n_parts, int64_t part_stride, int out_dim,
-                                             int in_dim, const int* __restrict__ colmap, int KS, int NB,
-                                             float* __restrict__ gW, float* __restrict__ gb) {
+__device__ __forceinline__ void unpack_layer(const float* __restrict__ gpart, int n_parts, int64_t part_stride, int out_dim,
+                                             int in_dim, const int* __restrict__ colmap, int KS, int NB, float* __restrict__ gW,
+                                             float* __restrict__ gb, int chunk, int n_chunks) {
   const int IB = (KS + 3) / 4;
   const int n_w = NB * IB * 256, n_b = NB * 16;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,13 +88,24 @@ __global__ void mlp_unpack_grad_layer_kernel(const float* __restrict__ gpart, in
     if (o < out_dim) dst = gb + o;
   }
   if (dst == nullptr) return;
-  const int p0 = blockIdx.y * kUnpackChunk, p1 = min(n_parts, p0 + kUnpackChunk);
+  const int p0 = chunk * kUnpackChunk, p1 = min(n_parts, p0 + kUnpackChunk);
   float s = 0.f;
   for (int p = p0; p < p1; ++p) s += gpart[(size_t)p * part_stride + i];
-  if (gridDim.y == 1)
+  if (n_chunks == 1)
     *dst += s;
   else
     unsafeAtomicAdd(dst, s);
+}
+
+__global__ void mlp_unpack_grad_layer_kernel(const float* __restrict__ gpart, int n_parts, int64_t part_stride, int out_dim,
+                                             int in_dim, const int* __restrict__ colmap, int KS, int NB,
+                                             float* __restrict__ gW, float* __restrict__ gb) {
+  unpack_layer(gpart, n_parts, part_stride, out_dim, in_dim, colmap, KS, NB, gW, gb, blockIdx.y, gridDim.y);
+}
+
+__global__ void mlp_unpack_grad_layers_kernel(LayerBatch a, int n_parts, int64_t part_stride) {
+  const LayerDesc& d = a.l[blockIdx.z];
+  unpack_layer(d.W, n_parts, part_stride, d.out_dim, d.in_dim, d.colmap, d.KS, d.NB, d.dst0, d.dst1, blockIdx.y, gridDim.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -281,6 +318,36 @@ extern "C" int ps_mlp_unpack_grad_layer(const float* gpart, int n_parts, int64_t
   dim3 grid((total + 255) / 256, (n_parts + kUnpackChunk - 1) / kUnpackChunk);
   mlp_unpack_grad_layer_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gpart, n_parts, part_stride, out_dim, in_dim, colmap, KS,
                                                                      NB, gW, gb);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_mlp_pack_layers(int n_layers, const float* const* W, const float* const* b, const int* out_dim,
+                                  const int* in_dim, const int* const* colmap, const int* KS, const int* NB,
+                                  float* const* fw_block, float* const* wt_block, void* stream) {
+  PS_REQUIRE(n_layers >= 1 && n_layers <= kMaxBatchedLayers, "ps_mlp_pack_layers: 1..8 layers per call");
+  LayerBatch a{};
+  int total = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    a.l[i] = LayerDesc{W[i], b[i], colmap[i], fw_block[i], wt_block[i], out_dim[i], in_dim[i], KS[i], NB[i]};
+    const int IB = (KS[i] + 3) / 4;
+    total = max(total, NB[i] * 16 + NB[i] * KS[i] * 64 + IB * NB[i] * 4 * 64);
+  }
+  mlp_pack_layers_kernel<<<dim3((total + 255) / 256, n_layers), 256, 0, (hipStream_t)stream>>>(a);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_mlp_unpack_grad_layers(int n_layers, const float* const* gpart, int n_parts, int64_t part_stride,
+                                         const int* out_dim, const int* in_dim, const int* const* colmap, const int* KS,
+                                         const int* NB, float* const* gW, float* const* gb, void* stream) {
+  PS_REQUIRE(n_layers >= 1 && n_layers <= kMaxBatchedLayers, "ps_mlp_unpack_grad_layers: 1..8 layers per call");
+  LayerBatch a{};
+  int total = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    a.l[i] = LayerDesc{gpart[i], nullptr, colmap[i], gW[i], gb[i], out_dim[i], in_dim[i], KS[i], NB[i]};
+    total = max(total, NB[i] * ((KS[i] + 3) / 4) * 256 + NB[i] * 16);
+  }
+  dim3 grid((total + 255) / 256, (n_parts + kUnpackChunk - 1) / kUnpackChunk, n_layers);
+  mlp_unpack_grad_layers_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, n_parts, part_stride);
   PS_CHECK_LAUNCH();
 }
 

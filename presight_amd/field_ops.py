@@ -16,7 +16,8 @@ from torch import Tensor
 
 from . import prof
 from ._lib import check, lib
-from .ops import MlpSpec, _f32, _p, _stream, chain_colmap, linear_colmap
+from .ops import (MlpSpec, _f32, _p, _stream, chain_colmap, direct_params, flatten_grads, grad_sink, layer_sinks, linear_colmap,
+                  mark_touched, pack_layers, unpack_layers)
 
 
 @dataclass(frozen=True)
@@ -72,19 +73,21 @@ def _workspace(nbytes: int, device) -> Tensor:
     return ws
 
 
-def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape) -> Tensor:
+def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape, sink: Optional[Tensor] = None) -> Optional[Tensor]:
+    """table gradient; with `sink` (the parameter's pre-allocated .grad, ops.grad_sink) it is ADDED there and None is returned"""
     N = u.shape[0]
-    dtable = torch.empty(table_shape, device=u.device, dtype=torch.float32)
+    acc = int(sink is not None)
+    dtable = sink if sink is not None else torch.empty(table_shape, device=u.device, dtype=torch.float32)
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
     with prof.region(f"grid_scatter_L{L}F{F}"):
         if SCATTER_IMPL == "binned" and N * 8 < (1 << 31):
             ws = _workspace(lib().ps_grid_scatter_workspace(L, F, l2t, N), u.device)
-            check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), _p(ws), _stream()),
-                  "ps_grid_scatter_binned")
+            check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(ws),
+                                               _stream()), "ps_grid_scatter_binned")
         else:
-            check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), 0, _stream()),
+            check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _stream()),
                   "ps_grid_scatter")
-    return dtable
+    return None if sink is not None else dtable
 
 
 def _layers(flat: Sequence[Tensor]) -> List[Tuple[Tensor, Tensor]]:
@@ -118,6 +121,8 @@ class _PropField(torch.autograd.Function):
                                           _p(packed), N, _p(sigma), _stream()), "ps_prop_field_fwd")
         ctx.save_for_backward(u, sel, scalings, feat, packed)
         ctx.meta = (g, hidden, tuple(table.shape), [tuple(W.shape) for W, _ in layers])
+        ctx.sinks = (grad_sink(table), layer_sinks(layers))
+        ctx.direct = direct_params(table, *wb)
         return sigma
 
     @staticmethod
@@ -135,12 +140,10 @@ class _PropField(torch.autograd.Function):
         with prof.region("prop_field_bwd"):
             check(lib().ps_prop_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
                                           _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _stream()), "ps_prop_field_bwd")
-        dtable = _scatter(u, dfeat, scalings, g, tshape)
-        grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes)
-        flat = []
-        for gW, gb in grads:
-            flat += [gW, gb]
-        return (None, None, dtable, None, None, *flat)
+        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0])
+        grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes, ctx.sinks[1])
+        mark_touched(ctx.direct)
+        return (None, None, dtable, None, None, *flatten_grads(grads))
 
 
 def prop_field(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g: GridCfg,
@@ -189,8 +192,10 @@ class MainSpec:
 
     def pack(self, base, sem, rgb, device) -> Tensor:
         packed = torch.empty(self.packed, device=device)
+        descs = []
         for spec, layers, off in ((self.base, base, self.p_off[0]), (self.sem, sem, self.p_off[1]), (self.rgb, rgb, self.p_off[2])):
-            spec.pack_into(layers, packed[off: off + spec.packed])
+            descs += spec.pack_descs(layers, packed[off: off + spec.packed])
+        pack_layers(descs)  # all 8 layers of the three stacks in one launch
         return packed
 
 
@@ -232,6 +237,8 @@ class _MainField(torch.autograd.Function):
         ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed)
         ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
                     want_rgb, want_sem)
+        ctx.sinks = (grad_sink(table), layer_sinks(layers))
+        ctx.direct = direct_params(table, *wb)
         empty = torch.empty(0, device=dev)
         return sigma, (rgb if want_rgb else empty), (sem if want_sem else empty)
 
@@ -258,16 +265,15 @@ class _MainField(torch.autograd.Function):
             check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                           _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem), N,
                                           _p(dfeat), _p(dapp), _p(gpart), _stream()), "ps_main_field_bwd")
-        dtable = _scatter(u, dfeat, scalings, g, tshape)
-        n_rgb = len(shapes) - n_base - n_sem
-        grads = []
+        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0])
+        descs = []
         for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
                             (spec.rgb, spec.g_off[2], shapes[n_base + n_sem:])):
-            grads += sp.unpack_grads(gpart, npart.value, spec.g_total, off, sh)
-        flat = []
-        for gW, gb in grads:
-            flat += [gW, gb]
-        assert len(flat) == 2 * (n_base + n_sem + n_rgb)
+            descs += sp.unpack_descs(gpart, off, sh)
+        grads = unpack_layers(descs, npart.value, spec.g_total, dev, ctx.sinks[1])  # all layers in one launch
+        flat = flatten_grads(grads)
+        mark_touched(ctx.direct)
+        assert len(flat) == 2 * len(shapes)
         return (None, None, None, dapp, None, dtable, None, None, None, None, None, None, *flat)
 
 

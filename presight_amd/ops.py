@@ -116,33 +116,101 @@ class MlpSpec:
             self._dev_colmaps[key] = [torch.tensor(c, dtype=torch.int32, device=device) for c in self.colmaps]
         return self._dev_colmaps[key]
 
-    def pack_into(self, layers: Sequence[Tuple[Tensor, Tensor]], packed: Tensor):
-        """layers: [(W [out,in], b [out])] in torch layout -> packed fragment buffer (device)."""
+    def pack_descs(self, layers: Sequence[Tuple[Tensor, Tensor]], packed: Tensor) -> list:
+        """per-layer descriptors (W, b, out, in, colmap, KS, NB, fw_block ptr, wt_block ptr) for pack_layers()"""
         cms = self.dev_colmaps(packed.device)
         base = packed.data_ptr()
-        for i, (W, b) in enumerate(layers):
-            W, b = _f32(W), _f32(b)
-            check(lib().ps_mlp_pack_layer(_p(W), _p(b), W.shape[0], W.shape[1], _p(cms[i]), self.ks[i], self.nb[i],
-                                          base + 4 * self.fw_off[i], base + 4 * self.wt_off[i], _stream()), "ps_mlp_pack_layer")
+        return [(_f32(W), _f32(b), W.shape[0], W.shape[1], cms[i], self.ks[i], self.nb[i], base + 4 * self.fw_off[i],
+                 base + 4 * self.wt_off[i]) for i, (W, b) in enumerate(layers)]
+
+    def pack_into(self, layers: Sequence[Tuple[Tensor, Tensor]], packed: Tensor):
+        """layers: [(W [out,in], b [out])] in torch layout -> packed fragment buffer (device), one launch."""
+        pack_layers(self.pack_descs(layers, packed))
 
     def pack(self, layers, device) -> Tensor:
         packed = torch.empty(self.packed, device=device, dtype=torch.float32)
         self.pack_into(layers, packed)
         return packed
 
-    def unpack_grads(self, gpart: Tensor, n_parts: int, part_stride: int, part_offset: int,
-                     shapes: Sequence[Tuple[int, int]]) -> List[Tuple[Tensor, Tensor]]:
-        """Sum per-workgroup partial blocks into torch-layout (dW, db) per layer."""
+    def unpack_descs(self, gpart: Tensor, part_offset: int, shapes: Sequence[Tuple[int, int]]) -> list:
         cms = self.dev_colmaps(gpart.device)
-        grads = []
-        for i, (o, n_in) in enumerate(shapes):
-            gW = torch.zeros(o, n_in, device=gpart.device, dtype=torch.float32)
-            gb = torch.zeros(o, device=gpart.device, dtype=torch.float32)
-            check(lib().ps_mlp_unpack_grad_layer(gpart.data_ptr() + 4 * (part_offset + self.g_off[i]), n_parts, part_stride, o,
-                                                 n_in, _p(cms[i]), self.ks[i], self.nb[i], _p(gW), _p(gb), _stream()),
-                  "ps_mlp_unpack_grad_layer")
-            grads.append((gW, gb))
-        return grads
+        return [(gpart.data_ptr() + 4 * (part_offset + self.g_off[i]), o, n_in, cms[i], self.ks[i], self.nb[i])
+                for i, (o, n_in) in enumerate(shapes)]
+
+    def unpack_grads(self, gpart: Tensor, n_parts: int, part_stride: int, part_offset: int, shapes: Sequence[Tuple[int, int]],
+                     sinks: Optional[Sequence[Optional[Tuple[Tensor, Tensor]]]] = None) -> List[Optional[Tuple[Tensor, Tensor]]]:
+        """Sum per-workgroup partial blocks into torch-layout (dW, db) per layer (one launch)."""
+        return unpack_layers(self.unpack_descs(gpart, part_offset, shapes), n_parts, part_stride, gpart.device, sinks)
+
+
+def _ptr_array(vals):
+    import ctypes
+
+    return (ctypes.c_void_p * len(vals))(*[int(v) for v in vals])
+
+
+def _int_array(vals):
+    import ctypes
+
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def pack_layers(descs: list):
+    """ps_mlp_pack_layers over descriptors from MlpSpec.pack_descs (<= 8 layers per launch)."""
+    for i in range(0, len(descs), 8):
+        d = descs[i:i + 8]
+        check(lib().ps_mlp_pack_layers(len(d), _ptr_array([_p(x[0]) for x in d]), _ptr_array([_p(x[1]) for x in d]),
+                                       _int_array([x[2] for x in d]), _int_array([x[3] for x in d]),
+                                       _ptr_array([_p(x[4]) for x in d]), _int_array([x[5] for x in d]),
+                                       _int_array([x[6] for x in d]), _ptr_array([x[7] for x in d]), _ptr_array([x[8] for x in d]),
+                                       _stream()), "ps_mlp_pack_layers")
+
+
+def grad_sink(t: Tensor) -> Optional[Tensor]:
+    """Destination for a parameter gradient that is accumulated IN PLACE by the backward kernels instead of being returned
+    to autograd: the parameter's pre-allocated `.grad` when its owner opted in (presight_amd.dist.FlatGrads marks its
+    parameters) — saves one zero-fill, one temporary and one `grad += tmp` launch per parameter and step."""
+    g = getattr(t, "grad", None)
+    if getattr(t, "_ps_direct_grad", False) and g is not None and g.is_contiguous() and g.dtype == torch.float32:
+        return g
+    return None
+
+
+def direct_params(*tensors) -> list:
+    """the tensors among `tensors` whose gradient the backward writes in place (see grad_sink)"""
+    return [t for t in tensors if t is not None and grad_sink(t) is not None]
+
+
+def mark_touched(params):
+    """tell the owner of the flat gradient buffer that these parameters received a gradient this step"""
+    for t in params:
+        t._ps_touched = True
+
+
+def unpack_layers(descs: list, n_parts: int, part_stride: int, device, sinks=None) -> list:
+    """ps_mlp_unpack_grad_layers over descriptors from MlpSpec.unpack_descs.  sinks[i] = (dW, db) buffers to accumulate
+    into (-> returns None for that layer) or None (-> fresh tensors are returned)."""
+    n = len(descs)
+    sinks = list(sinks) if sinks is not None else [None] * n
+    need = [i for i in range(n) if sinks[i] is None]
+    out: list = [None] * n
+    if need:
+        sizes = [descs[i][1] * descs[i][2] + descs[i][1] for i in need]
+        buf = torch.zeros(sum((s + 3) // 4 * 4 for s in sizes), device=device, dtype=torch.float32)
+        off = 0
+        for i, sz in zip(need, sizes):
+            o, n_in = descs[i][1], descs[i][2]
+            out[i] = (buf[off:off + o * n_in].view(o, n_in), buf[off + o * n_in:off + o * n_in + o])
+            off += (sz + 3) // 4 * 4
+    dst = [sinks[i] if sinks[i] is not None else out[i] for i in range(n)]
+    for i in range(0, n, 8):
+        d, t = descs[i:i + 8], dst[i:i + 8]
+        check(lib().ps_mlp_unpack_grad_layers(len(d), _ptr_array([x[0] for x in d]), n_parts, part_stride,
+                                              _int_array([x[1] for x in d]), _int_array([x[2] for x in d]),
+                                              _ptr_array([_p(x[3]) for x in d]), _int_array([x[4] for x in d]),
+                                              _int_array([x[5] for x in d]), _ptr_array([_p(g[0]) for g in t]),
+                                              _ptr_array([_p(g[1]) for g in t]), _stream()), "ps_mlp_unpack_grad_layers")
+    return out
 
 
 _SPEC_CACHE = {}
@@ -171,6 +239,8 @@ class _Mlp(torch.autograd.Function):
         check(lib().ps_mlp_fwd(_p(x), _p(packed), _p(y), N, dims[0], dims[1], dims[-1], spec.nl, out_act, _stream()), "ps_mlp_fwd")
         ctx.save_for_backward(x, packed)
         ctx.meta = (dims, out_act, [tuple(W.shape) for W, _ in layers])
+        ctx.sinks = layer_sinks(layers)
+        ctx.direct = direct_params(*wb)
         return y
 
     @staticmethod
@@ -190,11 +260,25 @@ class _Mlp(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         check(lib().ps_mlp_bwd(_p(x), _p(dy), _p(packed), _p(dx), _p(gpart), N, dims[0], dims[1], dims[-1], spec.nl, out_act,
                                _stream()), "ps_mlp_bwd")
-        grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes)
-        flat = []
-        for gW, gb in grads:
-            flat += [gW, gb]
-        return (dx, None, *flat)
+        grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes, ctx.sinks)
+        mark_touched(ctx.direct)
+        return (dx, None, *flatten_grads(grads))
+
+
+def layer_sinks(layers) -> list:
+    """[(dW sink, db sink) | None] per layer: direct accumulation needs both tensors of a layer to opt in"""
+    out = []
+    for W, b in layers:
+        gw, gb = grad_sink(W), grad_sink(b)
+        out.append((gw, gb) if gw is not None and gb is not None else None)
+    return out
+
+
+def flatten_grads(grads) -> list:
+    flat = []
+    for g in grads:
+        flat += [None, None] if g is None else [g[0], g[1]]
+    return flat
 
 
 def mlp(x: Tensor, layers: Sequence[Tuple[Tensor, Tensor]], out_act: Optional[str] = None) -> Tensor:

@@ -12,20 +12,50 @@ from .ops import _p, _stream
 
 class HipAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-15,
-                 weight_decay: float = 1e-5):
+                 weight_decay: float = 1e-5, flat_grads=None):
+        """flat_grads: a presight_amd.dist.FlatGrads over exactly `params` -> parameters and both moments are moved into
+        flat buffers of the same layout (every parameter's storage is re-pointed to a view of the flat buffer, values
+        kept) and the whole update is ONE kernel launch over the flat range instead of one per tensor."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and p.numel() > 0]
         for p in self.params:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("HipAdam: parameters must be contiguous fp32 CUDA tensors")
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.exp_avg = [torch.zeros_like(p) for p in self.params]
-        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.step_count = 0
+        self.flat = None
+        if flat_grads is not None:
+            if len(flat_grads.params) != len(self.params) or any(a is not b for a, b in zip(flat_grads.params, self.params)):
+                raise ValueError("HipAdam: flat_grads must cover exactly the optimizer's parameters, in the same order")
+            dev = self.params[0].device
+            fp = torch.zeros(flat_grads.total, device=dev, dtype=torch.float32)  # padding stays 0 (grad 0, decay of 0)
+            fm, fv = torch.zeros_like(fp), torch.zeros_like(fp)
+            self.exp_avg, self.exp_avg_sq = [], []
+            with torch.no_grad():
+                for p, off in zip(self.params, flat_grads.offsets):
+                    n = p.numel()
+                    view = fp[off:off + n].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+                    self.exp_avg.append(fm[off:off + n].view_as(p))
+                    self.exp_avg_sq.append(fv[off:off + n].view_as(p))
+            self.flat = (fp, flat_grads.flat, fm, fv)
+            self.flat_grads = flat_grads
+        else:
+            self.exp_avg = [torch.zeros_like(p) for p in self.params]
+            self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
 
     @torch.no_grad()
     def step(self):
         self.step_count += 1
         s = _stream()
+        if self.flat is not None:
+            # parameters without a gradient this step are skipped entirely (no decay, no moment update), like torch.optim
+            # with grad None; the others are updated range by range (all of them -> a single launch)
+            for a, b in self.flat_grads.touched_ranges():
+                ptrs = [t.data_ptr() + 4 * a for t in self.flat]
+                check(lib().ps_adam_step(ptrs[0], ptrs[1], ptrs[2], ptrs[3], b - a, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         self.weight_decay, self.step_count, s), "ps_adam_step")
+            return
         for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq):
             g = p.grad
             if g is None:

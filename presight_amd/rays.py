@@ -86,7 +86,7 @@ class RaySamples:
 
     @property
     def metadata(self):
-        return {k: v[:, None] for k, v in self.ray_bundle.metadata.items()}
+        return {k: v[:, None] for k, v in self.ray_bundle.metadata.items() if torch.is_tensor(v)}
 
     def get_weights(self, densities: Tensor) -> Tensor:
         """ns/cameras/rays.py:128-150: densities [R,S,1] -> weights [R,S,1]."""

@@ -142,7 +142,7 @@ def test_model_depth_supervised_step():
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
     scene = bench.make_scene(60, 6)
-    conf = NerfactoNuscMSModelConfig(near_plane=0.005, far_plane=50.0, piecewise_sampler_threshold=5.0, num_levels=4,
+    conf = NerfactoNuscMSModelConfig(near_plane=0.005, far_plane=50.0, piecewise_sampler_threshold=5.0, num_levels=2,
                                      features_per_level=2, log2_hashmap_size=12, base_res=16, max_res=128, hidden_dim=32,
                                      hidden_dim_color=32, implementation="hip", use_lidar_loss=True, line_of_sight_start_step=0)
     model = NerfactoNuscMSModel(conf, num_train_cameras=60, num_train_videos=6, dino_to_rgb=None, centroids=scene["centroids"],

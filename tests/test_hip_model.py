@@ -161,3 +161,69 @@ def test_voxel_index_and_dense_lattice_query(gold_model):
     assert int(vox["hits"].sum()) == full["points"].shape[0]
     lo = (vox["min_bound"] - 0.2) + vox["index"].double() * 0.4
     assert bool(((vox["points"].double() >= lo - 1e-4) & (vox["points"].double() <= lo + 0.4 + 1e-4)).all())
+
+
+def test_flat_gradients_and_fused_adam_match_autograd_path(gold_model):
+    """Trainer plumbing (dist.FlatGrads + optim.HipAdam(flat_grads=...)): the backward kernels accumulate parameter gradients
+    in place in one flat buffer and one Adam launch updates every parameter that received a gradient.  Must equal the
+    plain autograd path (gradients returned as tensors) + torch.optim.Adam with the reference's settings, and must leave
+    parameters without a gradient (sub-fields that saw no sample, proposal nets off-schedule) untouched like torch does."""
+    from presight_amd.dist import FlatGrads
+    from presight_amd.optim import HipAdam
+
+    G = gold_model
+    dev = torch.device("cuda:0")
+    jit = None
+
+    def run(model, batch, bundle):
+        model.train()
+        model.proposal_sampler.set_anneal(float(G["T_anneal"]))
+        out = model(bundle(), jitters=[j.to(dev) for j in batch["jitter"]])
+        gt = {"rgb": batch["rgb"].to(dev), "features": batch["features"].to(dev), "sky": batch["sky"].to(dev)}
+        (sum(model.get_loss_dict(out, gt).values()) * 1024.0).backward()
+
+    # A: plain autograd accumulation
+    mA, _, _, P, batch, bundle = build(G, dev)
+    run(mA, batch, bundle)
+    gA = {k: (None if p.grad is None else p.grad.clone()) for k, p in mA.named_parameters()}
+    # B: flat buffer, in-place accumulation
+    mB, _, _, _, _, bundleB = build(G, dev)
+    uniq, seen = [], set()
+    for p in mB.parameters():
+        if p.requires_grad and p.numel() > 0 and id(p) not in seen:
+            seen.add(id(p))
+            uniq.append(p)
+    fg = FlatGrads(uniq)
+    opt = HipAdam(uniq, lr=1e-2, eps=1e-15, weight_decay=1e-5, flat_grads=fg)
+    before = {k: p.detach().clone() for k, p in mB.named_parameters()}
+    fg.zero_()
+    run(mB, batch, bundleB)
+    touched = dict(zip([id(p) for p in uniq], fg.touched()))
+    n_untouched = 0
+    for k, p in mB.named_parameters():
+        if p.numel() == 0:
+            continue
+        assert p.grad.data_ptr() >= fg.flat.data_ptr() and p.grad.data_ptr() < fg.flat.data_ptr() + 4 * fg.total
+        if gA[k] is None:
+            assert not touched[id(p)] and float(p.grad.abs().max()) == 0.0, k
+            n_untouched += 1
+        else:
+            assert touched[id(p)], k
+            scale = float(gA[k].abs().max())
+            torch.testing.assert_close(p.grad / max(scale, 1e-30), gA[k] / max(scale, 1e-30), rtol=1e-5, atol=2e-6, msg=lambda m: f"{k}: {m}")
+    # optimizer: torch.optim.Adam on CPU copies of (param, grad) of the autograd path
+    ref_p = {k: torch.nn.Parameter(before[k].cpu().clone()) for k in before if before[k].numel() > 0 and gA[k] is not None}
+    for k, p in ref_p.items():
+        p.grad = gA[k].cpu()
+    torch.optim.Adam(list(ref_p.values()), lr=1e-2, eps=1e-15, weight_decay=1e-5).step()
+    opt.step()
+    for k, p in mB.named_parameters():
+        if p.numel() == 0:
+            continue
+        if k in ref_p:
+            # first Adam step moves every entry by ~lr*sign(g): compare the update, entries with |g| ~ 0 are ill-conditioned
+            big = gA[k].abs().cpu() > 1e-6 * float(gA[k].abs().max())
+            torch.testing.assert_close(p.detach().cpu()[big], ref_p[k].detach()[big], rtol=1e-4, atol=2e-5, msg=lambda m: f"{k}: {m}")
+        else:
+            assert torch.equal(p.detach(), before[k]), f"{k} has no gradient and must not move"
+    assert len(fg.touched_ranges()) >= 1

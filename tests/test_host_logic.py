@@ -119,6 +119,11 @@ _WORKER = textwrap.dedent("""
         (params[1] * 4).sum().backward()
     fg.all_reduce_mean()
     assert torch.allclose(params[1].grad, torch.full_like(params[1], 2.0))
+    # "received a gradient this step" flags: local by default, OR-ed over ranks on request (DDP semantics for routing)
+    assert fg.touched() == [False, rank == 0, False]
+    fg.flags_may_differ_across_ranks = True
+    assert fg.touched() == [False, True, False]
+    assert fg.touched_ranges() == [(16, 24)]  # 15 floats padded to 16, then 7 padded to 8
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
 """)
@@ -132,6 +137,23 @@ def test_gradient_exchange_gloo_world2(tmp_path):
                         "--master-port", "29731", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_flat_grads_touched_ranges():
+    """parameters without a gradient in a step are skipped by the optimizer (torch: grad None), adjacent ones merge"""
+    from presight_amd.dist import FlatGrads
+
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 8, 3, 16)]
+    fg = FlatGrads(ps)
+    assert fg.offsets == [0, 8, 16, 20] and fg.total == 36
+    assert fg.touched_ranges() == []
+    (ps[0].sum() + ps[1].sum() + ps[3].sum()).backward()
+    assert fg.touched() == [True, True, False, True]
+    assert fg.touched_ranges() == [(0, 16), (20, 36)]
+    ps[2]._ps_touched = True  # what a HIP backward does after writing into the parameter's .grad in place
+    assert fg.touched_ranges() == [(0, 36)]
+    fg.zero_()
+    assert fg.touched_ranges() == [] and float(fg.flat.abs().sum()) == 0.0
 
 
 def test_hip_ops_refuse_cpu_tensors():
