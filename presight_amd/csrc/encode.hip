@@ -262,8 +262,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
                                                           int log2_slice, int64_t N, int64_t plane_stride, int64_t n_rec_max,
                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
                                                           float* __restrict__ rec_val) {
-  // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record
-  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * 8;  // worst case: every pair split
+  // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record.
+  // The staging area holds the common case (4 pair records per point + slack); split pairs can push a workgroup past it
+  // (only where a level's resolution exceeds the slice size), those records go straight to their final position.
+  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * 4 + kBinPoints / 4;
   __shared__ unsigned cnt[kMaxSlices], off[kMaxSlices + 1], gbase[kMaxSlices];
   __shared__ unsigned s_idx[kRec];
   __shared__ float s_val[F + 1][kRec];  // plane F holds ox
@@ -384,16 +386,32 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
       for (int k = 0; k < 8; ++k) {
         if (r_pos[q][k] != 0xffffffffu) {
           const unsigned p = off[r_slice[q][k]] + r_pos[q][k];
-          s_idx[p] = r_idx[q][k];
-          s_slice[p] = (unsigned char)r_slice[q][k];
+          if (p < (unsigned)kRec) {
+            s_idx[p] = r_idx[q][k];
+            s_slice[p] = (unsigned char)r_slice[q][k];
 #pragma unroll
-          for (int f = 0; f < F; ++f) s_val[f][p] = r_val[q][k][f];
-          s_val[F][p] = r_ox[q][k];
+            for (int f = 0; f < F; ++f) s_val[f][p] = r_val[q][k][f];
+            s_val[F][p] = r_ox[q][k];
+          }
         }
       }
     __syncthreads();
+    if (off[n_slices] > (unsigned)kRec) {  // staging area full (workgroup-uniform): the rest goes out uncoalesced
+#pragma unroll
+      for (int q = 0; q < kBinPointsPerThread; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (r_pos[q][k] != 0xffffffffu && off[r_slice[q][k]] + r_pos[q][k] >= (unsigned)kRec) {
+            const int64_t dst = (int64_t)gbase[r_slice[q][k]] + r_pos[q][k];
+            rec_idx[dst] = r_idx[q][k];
+#pragma unroll
+            for (int f = 0; f < F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = r_val[q][k][f];
+            rec_val[(int64_t)F * n_rec_max + dst] = r_ox[q][k];
+          }
+        }
+    }
     // coalesced runs to the slice streams
-    const unsigned total = off[n_slices];
+    const unsigned total = min(off[n_slices], (unsigned)kRec);
     for (unsigned p = threadIdx.x; p < total; p += kBinThreads) {
       const unsigned sl = s_slice[p];
       const int64_t dst = (int64_t)gbase[sl] + (p - off[sl]);

@@ -228,3 +228,30 @@ def test_table_gradient_binned_vs_owner_vs_oracle(F, dev, L, nf, l2t, mx, N):
             a, b = got[l * T:(l + 1) * T], ref[l * T:(l + 1) * T]
             s = float(b.abs().max()) + 1e-30
             torch.testing.assert_close(a / s, b / s, rtol=2e-4, atol=2e-6, msg=lambda m: f"{impl} level {l}: {m}")
+
+
+def test_table_gradient_binned_split_pairs_and_accumulate(F, dev):
+    """Points whose x cell straddles a slice boundary of the binned scatter (floor and ceil corner hash into different
+    slices -> split records, more than the staging area of a bin workgroup holds -> overflow path), and accumulate=1
+    (gradient ADDED into a pre-filled buffer, the mode the trainer's flat gradient buffer uses)."""
+    from presight_amd import field_ops
+    from presight_amd._lib import check, lib
+
+    L, nf, l2t, mx, N = 10, 4, 14, 16384, 3000
+    gen = torch.Generator().manual_seed(5)
+    g = F.GridCfg(L, nf, l2t)
+    sc = O.hash_scalings(L, 16, mx)
+    u = torch.rand(N, 3, generator=gen)
+    # finest level: scaled x in (4095, 4096) -> fx = 4095, cx = 4096: the xor reaches bit 12 = above every slice size
+    u[:2048, 0] = (4095.0 + 0.05 + 0.9 * torch.rand(2048, generator=gen)) / float(sc[-1])
+    dfeat = torch.randn(L, N, nf, generator=gen)
+    table = torch.zeros((1 << l2t) * L, nf, requires_grad=True)
+    enc = O.hash_encode(u, table, sc, l2t)
+    (ref,) = torch.autograd.grad((enc * dfeat.permute(1, 0, 2).reshape(N, L * nf)).sum(), table)
+    got = field_ops._scatter(u.to(dev), dfeat.to(dev).contiguous(), sc.to(dev), g, tuple(table.shape)).cpu()
+    s = float(ref.abs().max())
+    torch.testing.assert_close(got / s, ref / s, rtol=2e-4, atol=2e-6)
+    base = torch.randn(table.shape, generator=gen).to(dev)
+    sink = base.clone()
+    assert field_ops._scatter(u.to(dev), dfeat.to(dev).contiguous(), sc.to(dev), g, tuple(table.shape), sink=sink) is None
+    torch.testing.assert_close(sink.cpu(), base.cpu() + got, rtol=0, atol=1e-6 * s)

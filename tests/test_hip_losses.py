@@ -165,7 +165,7 @@ def test_model_depth_supervised_step():
     rs, w = out["ray_samples_list"][-1], out["weights_list"][-1]
     steps = ((rs.ebins[:, :-1] + rs.ebins[:, 1:]) / 2 / 0.05).cpu()
     ref_los = O.line_of_sight_mult(6000) * O.line_of_sight_loss(w[..., 0].detach().cpu(), batch["depth"][:, 0].cpu(), steps,
-                                                                 O.line_of_sight_sigma(6000))
+                                                                 O.line_of_sight_sigma(6000, start_step=0))
     ref_ed = O.expected_depth_loss(batch["depth"][:, 0].cpu(), out["expected_depth"][:, 0].detach().cpu() / 0.05)
     close(ld["line_of_sight_loss"], ref_los, rtol=1e-4)
     close(ld["expected_depth_loss"], ref_ed, rtol=1e-4)
