@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define PS_WAVE 64

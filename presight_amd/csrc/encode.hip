@@ -430,7 +430,7 @@ __global__ __launch_bounds__(1024) void stream_offsets_kernel(unsigned* __restri
   const int b = threadIdx.x * per;
   unsigned sum = 0;
   for (int i = 0; i < per; ++i)
-    if (b + i < n) sum += cursors[b + i];
+    if (b + i < n) sum += (cursors[b + i] + 3u) & ~3u;  // every stream starts on a multiple of 4 records (vector loads)
   part[threadIdx.x] = sum;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(1024) void stream_offsets_kernel(unsigned* __restri
       counts[b + i] = c;
       starts[b + i] = run;
       cursors[b + i] = run;
-      run += c;
+      run += (c + 3u) & ~3u;
     }
 }
 
@@ -465,48 +465,70 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   __syncthreads();
   const int64_t n = counts[item];
   const float scale = fixed_scale(gmax_bits[level], headroom_log2);
-  const int64_t base = starts[item];
-  // 4 records per thread per iteration, all loads issued before the first LDS atomic (memory-level parallelism).
+  const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
+  // Every lane takes kChunk CONSECUTIVE records of the stream and merges neighbours that hit the same pair of rows in
+  // registers (int64 adds: associative, so merging does not change the result) before touching LDS.  The bin kernel
+  // emits the records of one wavefront instruction in lane order = consecutive samples of a ray, which share their
+  // cell on the coarse levels: there a handful of hot rows would otherwise serialise the LDS atomics of a whole wave.
   // record = {row | t<<16, ox, q[F]}: t < 30 -> pair (rows e and e ^ (2^(t+1)-1), weights 1-ox / ox), t == 30 -> both
   // corners on the same row (exact integer x), t == 31 -> single corner with its weight already applied.
+  constexpr int kChunk = 8;
   const unsigned low = (unsigned)entries - 1u;
-  for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
-    unsigned e[4];
-    float v[4][F], ox[4];
+  for (int64_t i0 = (int64_t)threadIdx.x * kChunk; i0 < n; i0 += 1024 * kChunk) {
+    unsigned e[kChunk];
+    float v[F][kChunk], ox[kChunk];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t i = i0 + k * 1024;
-      const bool ok = i < n;
-      e[k] = ok ? rec_idx[base + i] : (31u << 16);
-      ox[k] = ok ? rec_val[(int64_t)F * n_rec_max + base + i] : 0.0f;
+    for (int h = 0; h < kChunk; h += 4) {
+      const int64_t i = base + i0 + h;
+      const u32x4 t = *reinterpret_cast<const u32x4*>(rec_idx + i);  // reads past n stay inside the workspace
+      const f32x4 o = *reinterpret_cast<const f32x4*>(rec_val + (int64_t)F * n_rec_max + i);
 #pragma unroll
-      for (int f = 0; f < F; ++f) v[k][f] = ok ? rec_val[f * n_rec_max + base + i] : 0.0f;
+      for (int k = 0; k < 4; ++k) {
+        e[h + k] = t[k];
+        ox[h + k] = o[k];
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(rec_val + (int64_t)f * n_rec_max + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[f][h + k] = q[k];
+      }
     }
+    unsigned p_row = 0xffffffffu, p_rowc = 0xffffffffu;
+    long long p_f[F], p_c[F];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (i0 + k * 1024 < n) {
+    for (int f = 0; f < F; ++f) p_f[f] = p_c[f] = 0;
+    auto flush = [&]() {
+      if (p_row != 0xffffffffu) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p_row * F + f]), (unsigned long long)p_f[f]);  // ds_add_u64
+          if (p_rowc != p_row) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p_rowc * F + f]), (unsigned long long)p_c[f]);
+        }
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) {
+      if (i0 + k < n) {
         const unsigned row = e[k] & 0xffffu, t = e[k] >> 16;
         const bool pair = t < 30u;
         const unsigned row_c = pair ? ((row ^ ((2u << t) - 1u)) & low) : row;
-        const float wf = (t == 31u) ? 1.0f : (pair ? 1.0f - ox[k] : 1.0f);  // t == 30: c and f coincide, ox == 0
+        const float wf = pair ? 1.0f - ox[k] : 1.0f;  // t == 30: c and f coincide (ox == 0); t == 31: weight already applied
+        if (row != p_row || row_c != p_rowc) {
+          flush();
+          p_row = row;
+          p_rowc = row_c;
+#pragma unroll
+          for (int f = 0; f < F; ++f) p_f[f] = p_c[f] = 0;
+        }
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-#if defined(PS_ABLATE) && PS_ABLATE == 6
-          const long long ff = (long long)(int)(v[k][f] * wf);
-          const long long fc = (long long)(int)(v[k][f] * ox[k]);
-#else
-          const long long ff = __float2ll_rn(v[k][f] * wf * scale);
-          const long long fc = __float2ll_rn(v[k][f] * ox[k] * scale);
-#endif
-#if defined(PS_ABLATE) && PS_ABLATE == 5
-          if (ff == 0x7fffffffffffffffLL || fc == 0x7fffffffffffffffLL) acc[row * F + f] = ff + fc;
-#else
-          atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row * F + f]), (unsigned long long)ff);  // ds_add_u64
-          if (pair) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row_c * F + f]), (unsigned long long)fc);
-#endif
+          p_f[f] += __float2ll_rn(v[f][k] * wf * scale);
+          if (pair) p_c[f] += __float2ll_rn(v[f][k] * ox[k] * scale);
         }
       }
     }
+    flush();
   }
   __syncthreads();
   const float inv = 1.0f / scale;
@@ -516,6 +538,10 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
     out[i] = accumulate ? out[i] + v : v;
   }
 }
+
+// records the streams can hold: 8 per (point, level) worst case + every stream start rounded up to 4 records + the
+// vector-load overshoot of the last chunk; a multiple of 4 so that all planes stay 16-byte aligned
+int64_t binned_rec_capacity(int64_t N, int L, int n_slices) { return ((N * L * 8 + 4 * (int64_t)L * n_slices + 64) + 3) & ~(int64_t)3; }
 
 int binned_log2_slice(int F, int log2T) {
   int ls = 0;
@@ -531,27 +557,28 @@ int binned_log2_slice(int F, int log2T) {
 extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N) {
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
-  const int64_t n_rec_max = N * L * 8;
-  return 4096 + (int64_t)L * n_slices * 4 * 3 + n_rec_max * 4 * (2 + F) + 256;
+  const int64_t n_rec_max = binned_rec_capacity(N, L, n_slices);
+  return 4096 + (int64_t)L * n_slices * 4 * 3 + 16 + n_rec_max * 4 * (2 + F) + 256;
 }
 
 extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
                                       int64_t N, int64_t plane_stride, float* dtable, int accumulate, void* workspace,
                                       void* stream) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
-  PS_REQUIRE(N * L * 8 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
+  PS_REQUIRE(N * L * 8 + 4096 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
   hipStream_t s = (hipStream_t)stream;
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
   PS_REQUIRE(n_slices <= kMaxSlices, "ps_grid_scatter_binned: too many slices");
-  const int64_t n_rec_max = N * L * 8;
+  const int64_t n_rec_max = binned_rec_capacity(N, L, n_slices);
   const int n_items = L * n_slices;
+  PS_REQUIRE(((uintptr_t)workspace & 15) == 0, "ps_grid_scatter_binned: workspace must be 16-byte aligned");
   char* ws = (char*)workspace;
   unsigned* gmax_bits = (unsigned*)ws;            // [L] (+ padding to 4096)
   unsigned* cursors = (unsigned*)(ws + 4096);     // [n_items]
   unsigned* counts = cursors + n_items;           // [n_items]
   unsigned* starts = counts + n_items;            // [n_items]
-  unsigned* rec_idx = starts + n_items;           // [n_rec_max]
+  unsigned* rec_idx = starts + ((n_items + 3) & ~3);  // [n_rec_max], 16-byte aligned like every plane behind it
   float* rec_val = (float*)(rec_idx + n_rec_max); // [F+1][n_rec_max] (plane F = ox)
   hipError_t e = hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
   if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
