@@ -131,8 +131,12 @@ int ps_expected_depth_loss(const float* depth, const float* pred, const float* s
  * u [N,3] normalised+contracted+masked, sel [N] (1.0 / 0.0) */
 int ps_field_points(const float* pos, const float* origins, const float* dirs, const float* ebins, int S,
                     const float* aabb, int contract, int64_t N, float* u, float* sel, void* stream);
+/* slice_counts (nullable): uint32 [L, ps_grid_scatter_slices(F, log2T)], zeroed and filled with the number of records
+ * the binned table backward will emit per (level, table slice) for these points (upper bound) -- hand it to
+ * ps_grid_scatter_binned to save the backward its counting pass (training forward only) */
 int ps_grid_encode(const float* u, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
-                   int64_t plane_stride, float* feat, void* stream);
+                   int64_t plane_stride, float* feat, uint32_t* slice_counts, void* stream);
+int ps_grid_scatter_slices(int F, int log2T);
 /* table gradient without HBM atomics (LDS slice owners); accumulate=0 overwrites dtable, 1 adds to it */
 int ps_grid_scatter(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                     int64_t plane_stride, float* dtable, int accumulate, void* stream);
@@ -142,7 +146,8 @@ int ps_grid_scatter(const float* u, const float* dfeat, const float* scalings, i
  * accumulate=0 overwrites dtable, 1 adds to it. */
 int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N);
 int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
-                           int64_t plane_stride, float* dtable, int accumulate, void* workspace, void* stream);
+                           int64_t plane_stride, float* dtable, int accumulate, const uint32_t* slice_counts /*nullable*/,
+                           void* workspace, void* stream);
 /* proposal field: MLP (L*F -> hidden -> 1), packed with ps_mlp_pack_layer (LINEAR first-layer colmap) */
 int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
                         int* n_parts /*host*/);

@@ -22,7 +22,7 @@ def _ctype(decl: str):
     base = d.replace("const", "").split()
     ty = base[0]
     return {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "int32_t": ctypes.c_int32,
-            "uint8_t": ctypes.c_uint8, "double": ctypes.c_double}[ty]
+            "uint8_t": ctypes.c_uint8, "uint32_t": ctypes.c_uint32, "double": ctypes.c_double}[ty]
 
 
 def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object]]]:

@@ -58,29 +58,63 @@ __global__ void field_points_kernel(const float* __restrict__ pos, const float* 
   sel[n] = s_ ? 1.0f : 0.0f;
 }
 
-template <int F>
+// COUNT: the training forward also counts, per (level, table slice of the binned backward), the records the backward
+// will emit for these points (an upper bound: the backward drops records whose gradient is exactly zero), which saves
+// the backward its own counting pass over all hashes.  A workgroup then walks `group` consecutive 256-point chunks of
+// one level so that its LDS histogram is flushed with 1/group as many global atomics.
+constexpr int kEncMaxSlices = 256;
+template <int F, bool COUNT>
 __global__ __launch_bounds__(256) void grid_encode_kernel(const float* __restrict__ u, const float* __restrict__ table,
                                                           const float* __restrict__ scalings, int L, int log2T, int64_t N,
-                                                          int64_t plane_stride, float* __restrict__ feat) {
+                                                          int64_t plane_stride, float* __restrict__ feat,
+                                                          unsigned* __restrict__ slice_counts, int log2_slice, int group) {
+  __shared__ unsigned cnt[COUNT ? kEncMaxSlices : 1];
   const int64_t chunks = (N + 255) / 256;
+  const int64_t groups = (chunks + group - 1) / group;
   int64_t item;
   bool valid;
-  xcd_item(chunks * L, item, valid);
+  xcd_item(groups * L, item, valid);
   if (!valid) return;
-  const int level = (int)(item / chunks);
-  const int64_t n = (item % chunks) * 256 + threadIdx.x;
-  if (n >= N) return;
+  const int level = (int)(item / groups);
+  const int n_slices = COUNT ? (1 << (log2T - log2_slice)) : 0;
+  if constexpr (COUNT) {
+    for (int i = threadIdx.x; i < n_slices; i += 256) cnt[i] = 0u;
+    __syncthreads();
+  }
   const uint32_t mask = (1u << log2T) - 1u;
-  ps::Cell c = ps::make_cell(u[n * 3], u[n * 3 + 1], u[n * 3 + 2], scalings[level]);
-  float v[F];
-  ps::encode_level<F>(table + ((int64_t)level << log2T) * F, c, mask, v);
-  float* o = feat + level * plane_stride + n * F;
-  if constexpr (F == 1) o[0] = v[0];
-  if constexpr (F == 2) *reinterpret_cast<f32x2*>(o) = (f32x2){v[0], v[1]};
-  if constexpr (F == 4) *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+  const float scale = scalings[level];
+  const float* tl = table + ((int64_t)level << log2T) * F;
+  for (int64_t chunk = (item % groups) * group, end = min(chunks, chunk + group); chunk < end; ++chunk) {
+    const int64_t n = chunk * 256 + threadIdx.x;
+    if (n >= N) break;  // only the last chunk is ragged; no barrier inside the loop
+    ps::Cell c = ps::make_cell(u[n * 3], u[n * 3 + 1], u[n * 3 + 2], scale);
+    float v[F];
+    ps::encode_level<F>(tl, c, mask, v);
+    float* o = feat + level * plane_stride + n * F;
+    if constexpr (F == 1) o[0] = v[0];
+    if constexpr (F == 2) *reinterpret_cast<f32x2*>(o) = (f32x2){v[0], v[1]};
+    if constexpr (F == 4) *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+    if constexpr (COUNT) {
+      // same record rule as bin_kernel: one record per x-pair in the slice of its floor-x corner, plus one in the
+      // slice of the ceil-x corner when the pair straddles a slice boundary
+      uint32_t h[8];
+      ps::corner_hashes(c, mask, h);
+      const bool together = ((((uint32_t)c.cx ^ (uint32_t)c.fx) & mask) >> log2_slice) == 0u;
+      const uint32_t hf[4] = {h[3], h[2], h[7], h[6]}, hc[4] = {h[0], h[1], h[4], h[5]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(&cnt[hf[k] >> log2_slice], 1u);
+        if (!together) atomicAdd(&cnt[hc[k] >> log2_slice], 1u);
+      }
+    }
+  }
+  if constexpr (COUNT) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_slices; i += 256)
+      if (cnt[i]) atomicAdd(&slice_counts[level * n_slices + i], cnt[i]);
+  }
 }
 
-// ---- slice-owner scatter ---------------------------------------------------------------------
 constexpr int kSliceBytes = 128 * 1024;
 constexpr int kScatterThreads = 1024;
 
@@ -158,17 +192,38 @@ extern "C" int ps_field_points(const float* pos, const float* origins, const flo
   PS_CHECK_LAUNCH();
 }
 
+namespace {
+int binned_log2_slice(int F, int log2T);  // defined with the binned backward below
+}
+
+// number of table slices per level of the binned backward (= length of one level's row in `slice_counts`)
+extern "C" int ps_grid_scatter_slices(int F, int log2T) { return 1 << (log2T - binned_log2_slice(F, log2T)); }
+
 extern "C" int ps_grid_encode(const float* u, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
-                              int64_t plane_stride, float* feat, void* stream) {
+                              int64_t plane_stride, float* feat, uint32_t* slice_counts, void* stream) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_encode: features_per_level must be 1, 2 or 4");
-  if (N == 0) return 0;
-  const int64_t chunks = (N + 255) / 256;
-  const int64_t per = (chunks * L + 7) / 8;
-  dim3 grid((unsigned)(per * 8)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (F == 1) grid_encode_kernel<1><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat);
-  if (F == 2) grid_encode_kernel<2><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat);
-  if (F == 4) grid_encode_kernel<4><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat);
+  const int ls = binned_log2_slice(F, log2T);
+  if (slice_counts != nullptr) {
+    PS_REQUIRE((1 << (log2T - ls)) <= kEncMaxSlices, "ps_grid_encode: too many table slices");
+    hipError_t e = hipMemsetAsync(slice_counts, 0, (size_t)L * (1 << (log2T - ls)) * 4, s);
+    if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
+  }
+  if (N == 0) return 0;
+  const int group = 8;  // 2048 points of one level per workgroup (also measured faster than 256 without counting)
+  const int64_t chunks = (N + 255) / 256;
+  const int64_t groups = (chunks + group - 1) / group;
+  const int64_t per = (groups * L + 7) / 8;
+  dim3 grid((unsigned)(per * 8)), block(256);
+#define PS_ENC(FF)                                                                                                          \
+  if (F == FF) {                                                                                                            \
+    if (slice_counts != nullptr)                                                                                            \
+      grid_encode_kernel<FF, true><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat, slice_counts, ls, group); \
+    else                                                                                                                    \
+      grid_encode_kernel<FF, false><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat, nullptr, ls, group);     \
+  }
+  PS_ENC(1) PS_ENC(2) PS_ENC(4)
+#undef PS_ENC
   PS_CHECK_LAUNCH();
 }
 
@@ -451,7 +506,7 @@ __global__ __launch_bounds__(1024) void stream_offsets_kernel(unsigned* __restri
 }
 
 template <int F>
-__global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __restrict__ counts, const unsigned* __restrict__ starts,
+__global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __restrict__ cursors, const unsigned* __restrict__ starts,
                                                           const unsigned* __restrict__ rec_idx,
                                                           const float* __restrict__ rec_val, const unsigned* __restrict__ gmax_bits,
                                                           int L, int log2T, int log2_slice, int64_t n_rec_max, int headroom_log2,
@@ -463,7 +518,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   const int level = item / n_slices, sl = item % n_slices;
   for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
   __syncthreads();
-  const int64_t n = counts[item];
+  const int64_t n = cursors[item] - starts[item];  // the write pass advanced the cursor from the stream start to its end
   const float scale = fixed_scale(gmax_bits[level], headroom_log2);
   const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
   // Every lane takes kChunk CONSECUTIVE records of the stream and merges neighbours that hit the same pair of rows in
@@ -562,8 +617,8 @@ extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N)
 }
 
 extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
-                                      int64_t N, int64_t plane_stride, float* dtable, int accumulate, void* workspace,
-                                      void* stream) {
+                                      int64_t N, int64_t plane_stride, float* dtable, int accumulate,
+                                      const uint32_t* slice_counts, void* workspace, void* stream) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
   PS_REQUIRE(N * L * 8 + 4096 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
   hipStream_t s = (hipStream_t)stream;
@@ -582,6 +637,10 @@ extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const 
   float* rec_val = (float*)(rec_idx + n_rec_max); // [F+1][n_rec_max] (plane F = ox)
   hipError_t e = hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
   if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
+  if (slice_counts != nullptr && N > 0) {  // record counts (upper bounds) from the forward pass: ps_grid_encode
+    e = hipMemcpyAsync(cursors, slice_counts, (size_t)n_items * 4, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
+  }
   int headroom = 62 - 26;  // 8N <= 2^26 contributions per row
   {
     int bits = 0;
@@ -599,14 +658,15 @@ extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const 
     }                                                                                                                     \
     if (N > 0) {                                                                                                          \
       absmax_kernel<<<dim3(128, L), 256, 0, s>>>(dfeat, N * FF, plane_stride, gmax_bits);                                 \
-      bin_kernel<FF, true><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,            \
-                                                                          plane_stride, n_rec_max, cursors, rec_idx, rec_val); \
+      if (slice_counts == nullptr)                                                                                        \
+        bin_kernel<FF, true><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,          \
+                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val); \
     }                                                                                                                     \
     stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                           \
     if (N > 0)                                                                                                            \
       bin_kernel<FF, false><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,           \
                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val); \
-    accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(counts, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
+    accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
                                                                n_rec_max, headroom, accumulate, dtable);                  \
   }
   if (F == 1) PS_LAUNCH_BINNED(1)

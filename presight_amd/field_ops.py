@@ -49,13 +49,19 @@ def field_points(aabb: Tensor, contract: bool, pos: Optional[Tensor] = None, ori
     return u, sel
 
 
-def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg) -> Tensor:
+def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, count: bool = False):
+    """-> (feature planes [L,N,F], slice_counts | None).  count=True (a table backward will follow): the kernel also counts
+    the records of the binned backward per (level, table slice), see ps_grid_encode."""
     N = u.shape[0]
     feat = torch.empty(g.num_levels, N, g.features_per_level, device=u.device)
+    counts = None
+    if count and SCATTER_IMPL == "binned" and N * 8 < (1 << 31):
+        counts = torch.empty(g.num_levels * lib().ps_grid_scatter_slices(g.features_per_level, g.log2_hashmap_size), device=u.device,
+                             dtype=torch.int32)
     with prof.region(f"grid_encode_L{g.num_levels}F{g.features_per_level}"):
         check(lib().ps_grid_encode(_p(u), _p(table), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
-                                   N * g.features_per_level, _p(feat), _stream()), "ps_grid_encode")
-    return feat
+                                   N * g.features_per_level, _p(feat), _p(counts), _stream()), "ps_grid_encode")
+    return feat, counts
 
 
 _WORKSPACES = {}
@@ -73,8 +79,10 @@ def _workspace(nbytes: int, device) -> Tensor:
     return ws
 
 
-def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape, sink: Optional[Tensor] = None) -> Optional[Tensor]:
-    """table gradient; with `sink` (the parameter's pre-allocated .grad, ops.grad_sink) it is ADDED there and None is returned"""
+def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape, sink: Optional[Tensor] = None,
+             counts: Optional[Tensor] = None) -> Optional[Tensor]:
+    """table gradient; with `sink` (the parameter's pre-allocated .grad, ops.grad_sink) it is ADDED there and None is returned.
+    counts: slice record counts from the forward encode of the same points (_encode(count=True))."""
     N = u.shape[0]
     acc = int(sink is not None)
     dtable = sink if sink is not None else torch.empty(table_shape, device=u.device, dtype=torch.float32)
@@ -82,8 +90,8 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
     with prof.region(f"grid_scatter_L{L}F{F}"):
         if SCATTER_IMPL == "binned" and N * 8 < (1 << 31):
             ws = _workspace(lib().ps_grid_scatter_workspace(L, F, l2t, N), u.device)
-            check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(ws),
-                                               _stream()), "ps_grid_scatter_binned")
+            check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
+                                               _p(ws), _stream()), "ps_grid_scatter_binned")
         else:
             check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _stream()),
                   "ps_grid_scatter")
@@ -113,13 +121,13 @@ class _PropField(torch.autograd.Function):
         spec = _prop_spec(g.out_dim, hidden)
         N = u.shape[0]
         table = _f32(table, "hash table")
-        feat = _encode(u, table, scalings, g)
+        feat, counts = _encode(u, table, scalings, g, count=ctx.needs_input_grad[2])
         packed = spec.pack(layers, u.device)
         sigma = torch.empty(N, device=u.device)
         with prof.region("prop_field_fwd"):
             check(lib().ps_prop_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
                                           _p(packed), N, _p(sigma), _stream()), "ps_prop_field_fwd")
-        ctx.save_for_backward(u, sel, scalings, feat, packed)
+        ctx.save_for_backward(u, sel, scalings, feat, packed, counts)
         ctx.meta = (g, hidden, tuple(table.shape), [tuple(W.shape) for W, _ in layers])
         ctx.sinks = (grad_sink(table), layer_sinks(layers))
         ctx.direct = direct_params(table, *wb)
@@ -127,7 +135,7 @@ class _PropField(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dsigma):
-        u, sel, scalings, feat, packed = ctx.saved_tensors
+        u, sel, scalings, feat, packed, counts = ctx.saved_tensors
         g, hidden, tshape, shapes = ctx.meta
         spec = _prop_spec(g.out_dim, hidden)
         N = u.shape[0]
@@ -140,7 +148,7 @@ class _PropField(torch.autograd.Function):
         with prof.region("prop_field_bwd"):
             check(lib().ps_prop_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
                                           _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _stream()), "ps_prop_field_bwd")
-        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0])
+        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
         grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes, ctx.sinks[1])
         mark_touched(ctx.direct)
         return (None, None, dtable, None, None, *flatten_grads(grads))
@@ -223,7 +231,7 @@ class _MainField(torch.autograd.Function):
         N = u.shape[0]
         dev = u.device
         table = _f32(table, "hash table")
-        feat = _encode(u, table, scalings, g)
+        feat, counts = _encode(u, table, scalings, g, count=ctx.needs_input_grad[5])
         packed = spec.pack(base, sem_l, rgb_l, dev)
         sigma = torch.empty(N, device=dev)
         rgb = torch.empty(N, 3, device=dev) if want_rgb else None
@@ -234,7 +242,7 @@ class _MainField(torch.autograd.Function):
             check(lib().ps_main_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                           _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb), _p(sem),
                                           _stream()), "ps_main_field_fwd")
-        ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed)
+        ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed, counts)
         ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
                     want_rgb, want_sem)
         ctx.sinks = (grad_sink(table), layer_sinks(layers))
@@ -244,7 +252,7 @@ class _MainField(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dsigma, drgb, dsem):
-        u, sel, dirs, app, scalings, feat, packed = ctx.saved_tensors
+        u, sel, dirs, app, scalings, feat, packed, counts = ctx.saved_tensors
         g, hidden, hidden_color, A, S, tshape, shapes, n_base, n_sem, want_rgb, want_sem = ctx.meta
         spec = _main_spec(g.out_dim, hidden, hidden_color, A)
         N = u.shape[0]
@@ -265,7 +273,7 @@ class _MainField(torch.autograd.Function):
             check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                           _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem), N,
                                           _p(dfeat), _p(dapp), _p(gpart), _stream()), "ps_main_field_bwd")
-        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0])
+        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
         descs = []
         for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
                             (spec.rgb, spec.g_off[2], shapes[n_base + n_sem:])):

@@ -251,6 +251,14 @@ def test_table_gradient_binned_split_pairs_and_accumulate(F, dev):
     got = field_ops._scatter(u.to(dev), dfeat.to(dev).contiguous(), sc.to(dev), g, tuple(table.shape)).cpu()
     s = float(ref.abs().max())
     torch.testing.assert_close(got / s, ref / s, rtol=2e-4, atol=2e-6)
+    # record counts taken in the forward encode (upper bounds, incl. the split pairs) instead of the backward's own pass
+    td = torch.zeros(table.shape, device=dev)
+    feat, counts = field_ops._encode(u.to(dev), td, sc.to(dev), g, count=True)
+    assert counts is not None and int(counts.sum()) >= 4 * N * L
+    got_c = field_ops._scatter(u.to(dev), dfeat.to(dev).contiguous(), sc.to(dev), g, tuple(table.shape), counts=counts).cpu()
+    assert torch.equal(got_c, got)
+    feat0, none = field_ops._encode(u.to(dev), td, sc.to(dev), g)
+    assert none is None and torch.equal(feat0, feat)
     base = torch.randn(table.shape, generator=gen).to(dev)
     sink = base.clone()
     assert field_ops._scatter(u.to(dev), dfeat.to(dev).contiguous(), sc.to(dev), g, tuple(table.shape), sink=sink) is None

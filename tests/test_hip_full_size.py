@@ -28,7 +28,7 @@ def test_encode_scatter_adjoint_full_size(dev):
         u = torch.rand(N, 3, device=dev, generator=gen)
         table = torch.randn((1 << l2t) * L, nf, device=dev, generator=gen)
         cot = torch.randn(L, N, nf, device=dev, generator=gen)
-        feat = F._encode(u, table, sc, g)
+        feat, _ = F._encode(u, table, sc, g)
         lhs = (feat.double() * cot.double()).sum()
         dt = F._scatter(u, cot, sc, g, tuple(table.shape))
         rhs = (table.double() * dt.double()).sum()
