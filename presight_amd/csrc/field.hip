@@ -60,48 +60,87 @@ __device__ __forceinline__ void store_dfeat(float* __restrict__ dfeat, int64_t p
 __device__ __forceinline__ float trunc_exp_grad(float raw) { return expf(fminf(fmaxf(raw, -15.0f), 15.0f)); }
 
 // ------------------------------------------------------------------------------------------ proposal field
+// The proposal MLP ends in ONE output neuron.  As a 16x16 MFMA tile that layer would be 15/16 padding and, with its
+// data-backward and weight-gradient tiles, 48 of the 88 matrix ops per 16 points; it runs on the vector ALU instead.
+// In the D-register layout lane (j, g) already holds the 16 hidden neurons {16*nb + 4*g + r} of point j, so
+//     z_j   = b + sum over the 4 lane groups of  sum_t wz_g[t] * h_g[t]        (16 FMAs + 2 cross-lane adds)
+//     dh[t] = wz_g[t] * dz_j,      dWz_g[t] += h_g[t] * dz_j                   (no cross-lane traffic until the end)
+// wz_g[t] is element (lane 16*g) of the packed forward fragment t of that layer (row 0 of the A operand).
+template <class M, class W>
+__device__ __forceinline__ void load_scalar_head(const W& pz, float (&wz)[M::HB * 4], float& bz) {
+  using LZ = typename M::LZ;
+  const unsigned g = (unsigned)ps_lane() >> 4;
+#pragma unroll
+  for (int t = 0; t < M::HB * 4; ++t) wz[t] = pz.elem(LZ::WF_OFF + t * 64, 16u * g);
+  bz = pz.elem(LZ::BIAS_OFF, 0u);
+}
+
+template <int PB, int H>
+__device__ __forceinline__ void scalar_head_fwd(const float (&wz)[H], float bz, const float (&h)[PB][H], float (&z)[PB]) {
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < H; ++t) s = fmaf(wz[t], h[pb][t], s);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    z[pb] = s + bz;
+  }
+}
+
 template <class M, int PB>
 __global__ __launch_bounds__(256) void prop_fwd_kernel(const float* __restrict__ feat, int64_t plane_stride, int LF, int F,
                                                        const float* __restrict__ sel, const float* __restrict__ packed,
                                                        int64_t N, float* __restrict__ sigma) {
+  static_assert(M::NL == 2 && M::NBO == 1, "proposal MLP: two linear layers, scalar output");
+  using L0 = typename M::L0;
   __shared__ __attribute__((aligned(16))) float lds[M::FW];
   for (int i = threadIdx.x * 4; i < M::FW; i += 256 * 4)
     *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(packed + i);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  const LdsW pw{lds};
+  float wz[M::HB * 4], bz;
+  load_scalar_head<M>(pw.at(M::OFFZ), wz, bz);
   const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t first = tile * 16 * PB;
-    float x[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
+    float x[PB][M::KS0], h1[PB][M::HB * 4], z[PB];
     load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
-    mlp_forward<M, PB>(LdsW{lds}, x, h1, h2, z);
+    layer_fwd<L0, PB>(pw.at(M::OFF0), x, h1);
+    relu_inplace<PB, M::HB * 4>(h1);
+    scalar_head_fwd<PB, M::HB * 4>(wz, bz, h1, z);
     if (g == 0) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const int64_t p = first + pb * 16 + j;
-        if (p < N) sigma[p] = expf(z[pb][0]) * sel[p];
+        if (p < N) sigma[p] = expf(z[pb]) * sel[p];
       }
     }
   }
 }
 
-// 2-layer proposal MLP: all weight/bias gradients live in registers for the whole kernel (no LDS accumulators, no
-// per-tile flush); every wave writes its own partial block at the end (gpart has 4 blocks per workgroup).
+// All weight/bias gradients live in registers for the whole kernel (no LDS accumulators, no per-tile flush); every
+// wave writes its own partial block at the end (gpart has 4 blocks per workgroup).
 template <class M, int PB>
 __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__ feat, int64_t plane_stride, int LF, int F,
                                                        const float* __restrict__ sel, const float* __restrict__ packed,
                                                        const float* __restrict__ dsigma, int64_t N, float* __restrict__ dfeat,
                                                        float* __restrict__ gpart) {
-  static_assert(M::NL == 2, "proposal MLP has two linear layers");
+  static_assert(M::NL == 2 && M::NBO == 1, "proposal MLP: two linear layers, scalar output");
   using L0 = typename M::L0;
   using LZ = typename M::LZ;
-  constexpr int SCR = M::SCRATCH_ROWS * kScratchLd;
+  constexpr int H = M::HB * 4;
+  constexpr int SCR = L0::SCRATCH_ROWS * kScratchLd;
   __shared__ __attribute__((aligned(16))) float lds[4 * SCR];
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
   float* scratch = lds + wave * SCR;
   const GlobalW gw = make_global_w(packed, M::PACKED);
-  const GlobalW tz = gw.at(M::TOFFZ), t0 = gw.at(M::TOFF0);
-  f32x4 dw0[L0::NB][L0::IB], db0[L0::NB], dwz[LZ::NB][LZ::IB], dbz[LZ::NB];
+  const GlobalW p0 = gw.at(M::OFF0), t0 = gw.at(M::TOFF0);
+  float wz[H], bz;
+  load_scalar_head<M>(gw.at(M::OFFZ), wz, bz);
+  f32x4 dw0[L0::NB][L0::IB], db0[L0::NB];
+  float dwz[H], dbz = 0.f;
 #pragma unroll
   for (int a = 0; a < L0::NB; ++a) {
     db0[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -109,36 +148,42 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
     for (int b = 0; b < L0::IB; ++b) dw0[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int a = 0; a < LZ::NB; ++a) {
-    dbz[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < LZ::IB; ++b) dwz[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
+  for (int t = 0; t < H; ++t) dwz[t] = 0.f;
   const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t first = tile * 16 * PB;
-    float x[PB][M::KS0], h1[PB][M::HB * 4], h2[PB][M::HB * 4], z[PB][M::NBO * 4];
+    float x[PB][M::KS0], h1[PB][H], z[PB], dh[PB][H], dx[PB][L0::IB * 4];
     load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
-    mlp_forward<M, PB>(gw, x, h1, h2, z);
+    layer_fwd<L0, PB>(p0, x, h1);
+    relu_inplace<PB, H>(h1);
+    scalar_head_fwd<PB, H>(wz, bz, h1, z);
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t p = first + pb * 16 + j;
-      const float d = (g == 0 && p < N) ? dsigma[p] * sel[p] * trunc_exp_grad(z[pb][0]) : 0.0f;
+      const float d = (p < N) ? dsigma[p] * sel[p] * trunc_exp_grad(z[pb]) : 0.0f;  // the same value on the 4 lane groups
+      if (g == 0) dbz += d;
 #pragma unroll
-      for (int t = 0; t < M::NBO * 4; ++t) z[pb][t] = 0.0f;
-      z[pb][0] = d;
+      for (int t = 0; t < H; ++t) {
+        dwz[t] = fmaf(h1[pb][t], d, dwz[t]);
+        dh[pb][t] = h1[pb][t] > 0.0f ? wz[t] * d : 0.0f;
+      }
     }
-    float dh[PB][M::HB * 4], dx[PB][L0::IB * 4];
-    layer_bwd_weights_acc<LZ, PB>(scratch, dwz, dbz, z, h1);
-    layer_bwd_data<LZ, PB>(tz, z, dh);
-    relu_mask<PB, M::HB * 4>(dh, h1);
     layer_bwd_weights_acc<L0, PB>(scratch, dw0, db0, dh, x);
     layer_bwd_data<L0, PB>(t0, dh, dx);
     store_dfeat<M::KS0, PB>(dfeat, plane_stride, LF, F, first, N, dx);
   }
   float* out = gpart + ((size_t)blockIdx.x * 4 + wave) * M::GPACKED;
   store_layer_acc<L0>(out + M::GOFF0, dw0, db0);
-  store_layer_acc<LZ>(out + M::GOFFZ, dwz, dbz);
+  // head gradient in the packed layout of a [tile][lane][4] dW block: output row 0 lives in lanes 0..15 (= input row),
+  // register 0; input row 4*g' + r' of input block ib is the neuron of lane group g', k-step t = 4*ib + r'
+  float* oz = out + M::GOFFZ;
+#pragma unroll
+  for (int t = 0; t < H; ++t) {
+    const float s = ps_row16_sum(dwz[t]);
+    if (j == 0) oz[LZ::GW_OFF + (((t >> 2) * 64) + 4 * g + (t & 3)) * 4] = s;
+  }
+  dbz = ps_row16_sum(dbz);
+  if (lane == 0) oz[LZ::GB_OFF] = dbz;
 }
 
 // ------------------------------------------------------------------------------------------ main field
@@ -385,6 +430,7 @@ int grid_for_tiles(int64_t N, int pts_per_tile, int max_blocks) {
 }
 
 constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 4, kMainBwdPB = 2;
+constexpr int kPropBwdBlocks = 512;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
 
 // (L*F, hidden) of the proposal nets
 #define PS_PROP_CFGS(X) \
@@ -404,7 +450,7 @@ extern "C" int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packe
     using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;         \
     *packed_floats = M::PACKED;                             \
     *grad_floats = M::GPACKED;                              \
-    *n_parts = 4 * grid_for_tiles(N, 16 * kPropBwdPB, 256); \
+    *n_parts = 4 * grid_for_tiles(N, 16 * kPropBwdPB, kPropBwdBlocks); \
     return 0;                                               \
   }
   PS_PROP_CFGS(X)
@@ -419,7 +465,7 @@ extern "C" int ps_prop_field_fwd(const float* feat, int64_t plane_stride, int LF
 #define X(lf, h)                                                                                                     \
   if (LF == lf && hidden == h) {                                                                                     \
     using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;                                                                  \
-    prop_fwd_kernel<M, kPropFwdPB><<<grid_for_tiles(N, 16 * kPropFwdPB, 512), 256, 0, (hipStream_t)stream>>>(         \
+    prop_fwd_kernel<M, kPropFwdPB><<<grid_for_tiles(N, 16 * kPropFwdPB, 1024), 256, 0, (hipStream_t)stream>>>(         \
         feat, plane_stride, LF, F, sel, packed, N, sigma);                                                           \
     PS_CHECK_LAUNCH();                                                                                               \
   }
@@ -436,7 +482,7 @@ extern "C" int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF
 #define X(lf, h)                                                                                                     \
   if (LF == lf && hidden == h) {                                                                                     \
     using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;                                                                  \
-    prop_bwd_kernel<M, kPropBwdPB><<<grid_for_tiles(N, 16 * kPropBwdPB, 256), 256, 0, (hipStream_t)stream>>>(         \
+    prop_bwd_kernel<M, kPropBwdPB><<<grid_for_tiles(N, 16 * kPropBwdPB, kPropBwdBlocks), 256, 0, (hipStream_t)stream>>>(         \
         feat, plane_stride, LF, F, sel, packed, dsigma, N, dfeat, gpart);                                            \
     PS_CHECK_LAUNCH();                                                                                               \
   }

@@ -55,6 +55,7 @@ struct LdsW {
   const float* base;
   __device__ __forceinline__ float frag(int float_off) const { return base[float_off + ps_lane()]; }
   __device__ __forceinline__ f32x4 vec4(int float_off) const { return *reinterpret_cast<const f32x4*>(base + float_off); }
+  __device__ __forceinline__ float elem(int float_off, unsigned lane_float_off) const { return base[float_off + lane_float_off]; }
   __device__ __forceinline__ LdsW at(int float_off) const { return LdsW{base + float_off}; }
 };
 // Backward kernels need LDS for the gradient accumulators, so they stream fragments from L2 through a
@@ -72,6 +73,9 @@ struct GlobalW {
   }
   __device__ __forceinline__ f32x4 vec4_lane(int float_off, unsigned lane_float_off) const {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_float_off * 4u, (base + float_off) * 4, 0));
+  }
+  __device__ __forceinline__ float elem(int float_off, unsigned lane_float_off) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_float_off * 4u, (base + float_off) * 4, 0));
   }
   __device__ __forceinline__ GlobalW at(int float_off) const { return GlobalW{rsrc, base + float_off}; }
 };
