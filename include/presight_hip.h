@@ -163,10 +163,14 @@ int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t
 int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                       const float* sel, const float* dirs, const float* app, int S, int A, const float* packed, int64_t N,
                       float* sigma, float* rgb, float* sem, void* stream);
+/* weights == NULL: drgb [N,3] and dsem [N,64] are per-sample gradients.  weights [N] (the compositing weights of
+ * RaySamples.get_weights, point n = ray n/S): drgb [R,3] / dsem [R,64] are the gradients of the COMPOSITED per-ray outputs
+ * and the kernel forms weights[n] * d[n/S] itself -- the d_rgb_s / d_sem_s outputs of ps_composite_bwd are then not
+ * needed (pass NULL there). */
 int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                       const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
-                      const float* dsigma, const float* drgb, const float* dsem, int64_t N, float* dfeat, float* dapp,
-                      float* gpart, void* stream);
+                      const float* dsigma, const float* drgb, const float* dsem, const float* weights /*nullable*/, int64_t N,
+                      float* dfeat, float* dapp, float* gpart, void* stream);
 
 /* ---- a18 prior extraction ---------------------------------------------------------------------------
  * voxel index of Open3D's voxel_down_sample_and_trace as called by ns/scripts/extract_priors.py:216-245:

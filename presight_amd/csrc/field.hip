@@ -205,6 +205,8 @@ struct MainArgs {
   const float* dsigma;
   const float* drgb;
   const float* dsem;
+  const float* w;  // null: drgb [N,3] / dsem [N,64] per sample.  non-null [N]: they are per RAY ([R,3] / [R,64], gradients of
+                   // the composited outputs) and the per-sample gradient is w[n] * d[ray of n] (composite backward fused in)
   float* dfeat;
   float* dapp;  // [R,A], accumulated with atomics
   float* gpart;
@@ -353,12 +355,15 @@ __global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const int64_t p = first + pb * 16 + j;
+        const bool in = p < a.N;
+        const float wp = (a.w != nullptr && in) ? a.w[p] : 1.0f;
+        const float* src = a.dsem + ((a.w != nullptr) ? (in ? p / a.S : 0) : p) * 64 + 4 * g;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (p < a.N) d = *reinterpret_cast<const f32x4*>(a.dsem + p * 64 + 16 * nb + 4 * g);
+          if (in) d = *reinterpret_cast<const f32x4*>(src + 16 * nb);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = d[r];
+          for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = d[r] * wp;
         }
       }
       float dsin[PB][16];
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
           float d = 0.0f;
           if (k < 3 && g == 0 && p < a.N) {
             const float s = 1.0f / (1.0f + expf(-co[pb][k]));
-            d = a.drgb[p * 3 + k] * s * (1.0f - s);
+            const float up = (a.w != nullptr) ? a.w[p] * a.drgb[ray_of[pb] * 3 + k] : a.drgb[p * 3 + k];
+            d = up * s * (1.0f - s);
           }
           co[pb][k] = d;
         }
@@ -538,13 +544,13 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
 
 extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                  const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
-                                 const float* dsigma, const float* drgb, const float* dsem, int64_t N, float* dfeat,
-                                 float* dapp, float* gpart, void* stream) {
+                                 const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t N,
+                                 float* dfeat, float* dapp, float* gpart, void* stream) {
   if (N == 0) return 0;
   PS_REQUIRE(A <= 16 && S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
   MainArgs a{};
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
-  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart;
+  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart;
 #define X(lf, h, hc)                                                                                                  \
   if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \

@@ -359,6 +359,54 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
   }
 }
 
+// d_weights ONLY, for S <= 64 (the per-sample gradients d_rgb_s / d_sem_s are then formed inside the field backward from
+// the per-ray gradients, ps_main_field_bwd with `weights`).  One wavefront per ray; while streaming the sample rows the
+// lane is the channel (coalesced 256-byte rows, 64 independent loads in flight), then a recursive-halving
+// transpose-reduction (63 cross-lane exchanges instead of 64 six-step wave sums) leaves lane s with the dot product of
+// sample s.
+__global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __restrict__ weights, const float* __restrict__ ebins,
+                                                              const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
+                                                              const float* __restrict__ d_rgb, const float* __restrict__ d_acc,
+                                                              const float* __restrict__ d_sem, const float* __restrict__ d_exp,
+                                                              int64_t R, int S, int C, float* __restrict__ d_weights) {
+  const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  const float* w = weights + ray * S;
+  const float* e = ebins + ray * (S + 1);
+  const bool sem_on = sem_s != nullptr && d_sem != nullptr && lane < C;
+  const bool rgb_on = rgb_s != nullptr && d_rgb != nullptr && lane < 3;
+  const float gsem = sem_on ? d_sem[ray * C + lane] : 0.0f;
+  const float grgb = rgb_on ? d_rgb[ray * 3 + lane] : 0.0f;
+  float v[64];
+#pragma unroll
+  for (int s = 0; s < 64; ++s) {
+    float part = 0.f;
+    if (s < S) {
+      if (sem_on) part = sem_s[(ray * S + s) * C + lane] * gsem;
+      if (rgb_on) part += rgb_s[(ray * S + s) * 3 + lane] * grgb;
+    }
+    v[s] = part;
+  }
+#define PS_HALVE(M)                                     \
+  _Pragma("unroll") for (int i = 0; i < M; ++i) {       \
+    const bool up = (lane & M) != 0;                    \
+    const float keep = up ? v[i + M] : v[i];            \
+    const float send = up ? v[i] : v[i + M];            \
+    v[i] = keep + __shfl_xor(send, M, 64);              \
+  }
+  PS_HALVE(32) PS_HALVE(16) PS_HALVE(8) PS_HALVE(4) PS_HALVE(2) PS_HALVE(1)
+#undef PS_HALVE
+  const float ws = lane < S ? w[lane] : 0.0f;
+  const float mid = lane < S ? (e[lane] + e[lane + 1]) / 2.0f : 0.0f;
+  float g = v[0] + (d_acc ? d_acc[ray] : 0.0f);
+  if (d_exp != nullptr) {  // expected depth D = A/(B+eps): dD/dw_s = t_s/(B+eps) - A/(B+eps)^2
+    const float A = ps_wave_sum(ws * mid), B = ps_wave_sum(ws) + 1e-10f;
+    g += d_exp[ray] * (mid / B - A / (B * B));
+  }
+  if (lane < S) d_weights[ray * S + lane] = g;
+}
+
 template <class F>
 int by_chunk(int S, F f) {
   const int ch = (S + 63) / 64;
@@ -445,6 +493,11 @@ extern "C" int ps_composite_bwd(const float* weights, const float* ebins, const 
                                 int S, int C, float* d_weights, float* d_rgb_s, float* d_sem_s, void* stream) {
   PS_REQUIRE(S <= kMaxCh * 64 && C <= 64, "ps_composite_bwd: S must be <= 256 and C <= 64");
   if (R == 0) return 0;
+  if (d_rgb_s == nullptr && d_sem_s == nullptr && S <= 64) {
+    composite_bwd_w_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
+                                                                                    d_sem, d_exp, R, S, C, d_weights);
+    PS_CHECK_LAUNCH();
+  }
   composite_bwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
                                                                                 d_sem, d_exp, R, S, C, d_weights, d_rgb_s,
                                                                                 d_sem_s);

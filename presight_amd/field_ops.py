@@ -217,72 +217,152 @@ def _main_spec(LF, hidden, hidden_color, app_dim) -> MainSpec:
     return _MAIN_SPECS[key]
 
 
+def _main_forward(ctx, table_needs_grad, u, sel, dirs, app, S, table, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, wb):
+    """shared forward of the main-field nodes: encode (+ record counts for the table backward) -> fused MLP kernel.
+    Stores everything the shared backward needs on ctx (tensors are returned for save_for_backward)."""
+    layers = _layers(wb)
+    base, sem_l, rgb_l = layers[:n_base], layers[n_base:n_base + n_sem], layers[n_base + n_sem:]
+    hidden, hidden_color = base[0][0].shape[0], rgb_l[0][0].shape[0]
+    A = rgb_l[0][0].shape[1] - 16 - GEO_DIM  # appearance columns the colour head was built with
+    if want_rgb and (0 if app is None else app.shape[1]) != A:
+        raise ValueError(f"colour head expects SH16 + geo15 + app{A} inputs, got an appearance embedding of width "
+                         f"{0 if app is None else app.shape[1]}")
+    spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+    N = u.shape[0]
+    dev = u.device
+    table = _f32(table, "hash table")
+    feat, counts = _encode(u, table, scalings, g, count=table_needs_grad)
+    packed = spec.pack(base, sem_l, rgb_l, dev)
+    sigma = torch.empty(N, device=dev)
+    rgb = torch.empty(N, 3, device=dev) if want_rgb else None
+    sem = torch.empty(N, SEM_DIM, device=dev) if want_sem else None
+    dirs = _f32(dirs) if dirs is not None else torch.zeros(1, 3, device=dev)
+    app_c = _f32(app) if (app is not None and want_rgb) else None
+    with prof.region("main_field_fwd"):
+        check(lib().ps_main_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                      _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb), _p(sem),
+                                      _stream()), "ps_main_field_fwd")
+    ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
+                want_rgb, want_sem)
+    ctx.sinks = (grad_sink(table), layer_sinks(layers))
+    ctx.direct = direct_params(table, *wb)
+    return (u, sel, dirs, app_c, scalings, feat, packed, counts), (sigma, rgb, sem)
+
+
+def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
+    """shared backward: fused MLP backward -> table scatter -> weight-gradient reduction.  weights != None: d_rgb / d_sem are
+    per-RAY gradients (see ps_main_field_bwd).  -> (dapp, dtable | None, [dW0, db0, ...] with None for in-place gradients)"""
+    u, sel, dirs, app, scalings, feat, packed, counts = saved
+    g, hidden, hidden_color, A, S, tshape, shapes, n_base, n_sem, want_rgb, want_sem = ctx.meta
+    spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+    N = u.shape[0]
+    dev = u.device
+    pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    offs = (ctypes.c_int64 * 6)()
+    check(lib().ps_main_field_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart),
+                                    offs), "ps_main_field_sizes")
+    assert pf.value == spec.packed and gf.value == spec.g_total, (pf.value, spec.packed, gf.value, spec.g_total)
+    assert list(offs) == spec.p_off + spec.g_off, (list(offs), spec.p_off, spec.g_off)
+    gpart = torch.empty(npart.value, spec.g_total, device=dev)
+    dfeat = torch.empty_like(feat)
+    dapp = torch.zeros_like(app) if app is not None else None
+    with prof.region("main_field_bwd"):
+        check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                      _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
+                                      _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _stream()), "ps_main_field_bwd")
+    dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
+    descs = []
+    for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
+                        (spec.rgb, spec.g_off[2], shapes[n_base + n_sem:])):
+        descs += sp.unpack_descs(gpart, off, sh)
+    grads = unpack_layers(descs, npart.value, spec.g_total, dev, ctx.sinks[1])  # all layers in one launch
+    flat = flatten_grads(grads)
+    mark_touched(ctx.direct)
+    assert len(flat) == 2 * len(shapes)
+    return dapp, dtable, flat
+
+
 class _MainField(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, sel, dirs, app, S, table, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, *wb):
-        layers = _layers(wb)
-        base, sem_l, rgb_l = layers[:n_base], layers[n_base:n_base + n_sem], layers[n_base + n_sem:]
-        hidden, hidden_color = base[0][0].shape[0], rgb_l[0][0].shape[0]
-        A = rgb_l[0][0].shape[1] - 16 - GEO_DIM  # appearance columns the colour head was built with
-        if want_rgb and (0 if app is None else app.shape[1]) != A:
-            raise ValueError(f"colour head expects SH16 + geo15 + app{A} inputs, got an appearance embedding of width "
-                             f"{0 if app is None else app.shape[1]}")
-        spec = _main_spec(g.out_dim, hidden, hidden_color, A)
-        N = u.shape[0]
-        dev = u.device
-        table = _f32(table, "hash table")
-        feat, counts = _encode(u, table, scalings, g, count=ctx.needs_input_grad[5])
-        packed = spec.pack(base, sem_l, rgb_l, dev)
-        sigma = torch.empty(N, device=dev)
-        rgb = torch.empty(N, 3, device=dev) if want_rgb else None
-        sem = torch.empty(N, SEM_DIM, device=dev) if want_sem else None
-        dirs = _f32(dirs) if dirs is not None else torch.zeros(1, 3, device=dev)
-        app_c = _f32(app) if (app is not None and want_rgb) else None
-        with prof.region("main_field_fwd"):
-            check(lib().ps_main_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                          _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb), _p(sem),
-                                          _stream()), "ps_main_field_fwd")
-        ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed, counts)
-        ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
-                    want_rgb, want_sem)
-        ctx.sinks = (grad_sink(table), layer_sinks(layers))
-        ctx.direct = direct_params(table, *wb)
-        empty = torch.empty(0, device=dev)
+        saved, (sigma, rgb, sem) = _main_forward(ctx, ctx.needs_input_grad[5], u, sel, dirs, app, S, table, scalings, g, want_rgb,
+                                                 want_sem, n_base, n_sem, wb)
+        ctx.save_for_backward(*saved)
+        empty = torch.empty(0, device=u.device)
         return sigma, (rgb if want_rgb else empty), (sem if want_sem else empty)
 
     @staticmethod
     def backward(ctx, dsigma, drgb, dsem):
-        u, sel, dirs, app, scalings, feat, packed, counts = ctx.saved_tensors
-        g, hidden, hidden_color, A, S, tshape, shapes, n_base, n_sem, want_rgb, want_sem = ctx.meta
-        spec = _main_spec(g.out_dim, hidden, hidden_color, A)
-        N = u.shape[0]
-        dev = u.device
-        pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
-        offs = (ctypes.c_int64 * 6)()
-        check(lib().ps_main_field_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart),
-                                        offs), "ps_main_field_sizes")
-        assert pf.value == spec.packed and gf.value == spec.g_total, (pf.value, spec.packed, gf.value, spec.g_total)
-        assert list(offs) == spec.p_off + spec.g_off, (list(offs), spec.p_off, spec.g_off)
-        gpart = torch.empty(npart.value, spec.g_total, device=dev)
-        dfeat = torch.empty_like(feat)
-        dapp = torch.zeros_like(app) if app is not None else None
+        want_rgb, want_sem = ctx.meta[-2:]
         d_sigma = _f32(dsigma) if dsigma is not None else None
         d_rgb = _f32(drgb) if (want_rgb and drgb is not None) else None
         d_sem = _f32(dsem) if (want_sem and dsem is not None) else None
-        with prof.region("main_field_bwd"):
-            check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                          _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem), N,
-                                          _p(dfeat), _p(dapp), _p(gpart), _stream()), "ps_main_field_bwd")
-        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
-        descs = []
-        for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
-                            (spec.rgb, spec.g_off[2], shapes[n_base + n_sem:])):
-            descs += sp.unpack_descs(gpart, off, sh)
-        grads = unpack_layers(descs, npart.value, spec.g_total, dev, ctx.sinks[1])  # all layers in one launch
-        flat = flatten_grads(grads)
-        mark_touched(ctx.direct)
-        assert len(flat) == 2 * len(shapes)
+        dapp, dtable, flat = _main_backward(ctx, ctx.saved_tensors, d_sigma, d_rgb, d_sem, None)
         return (None, None, None, dapp, None, dtable, None, None, None, None, None, None, *flat)
+
+
+class _MainFieldRender(torch.autograd.Function):
+    """main field + RaySamples.get_weights + the renderers as ONE autograd node (training, one sub-field, S <= 64).
+    Versus the three separate nodes this never materialises the per-sample gradients d(rgb_s) [N,3] / d(sem_s) [N,64]
+    (1.1 GB written by the composite backward and read again by the field backward at cfg 2): the composite backward only
+    produces d(weights), the field backward forms w[n] * d(out)[ray] from the per-ray gradients in registers."""
+
+    @staticmethod
+    def forward(ctx, u, sel, dirs, app, S, ebins, threshold, table, scalings, g: GridCfg, n_base, n_sem, *wb):
+        from . import ops
+
+        saved, (sigma, rgb_s, sem_s) = _main_forward(ctx, ctx.needs_input_grad[7], u, sel, dirs, app, S, table, scalings, g, True, True,
+                                                     n_base, n_sem, wb)
+        R = ebins.shape[0]
+        dev = u.device
+        ebins = _f32(ebins)
+        w = torch.empty(R, S, device=dev)
+        check(lib().ps_weights_fwd(_p(ebins), _p(sigma), R, S, _p(w), _stream()), "ps_weights_fwd")
+        rgb, sem = torch.empty(R, 3, device=dev), torch.empty(R, SEM_DIM, device=dev)
+        acc, depth, expd = torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev)
+        minmax = ops._minmax_init(dev).clone()
+        check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), _p(sem_s), R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth),
+                                     _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
+        raw = expd.clone()
+        check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
+        ctx.save_for_backward(*saved, ebins, sigma, w, rgb_s, sem_s, raw, expd)
+        ctx.n_field_saved = len(saved)
+        ctx.mark_non_differentiable(depth)
+        return rgb, acc, depth, expd, sem, w
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, _d_depth, d_exp, d_sem, d_w_ext):
+        t = ctx.saved_tensors
+        saved, (ebins, sigma, w, rgb_s, sem_s, raw, expd) = t[:ctx.n_field_saved], t[ctx.n_field_saved:]
+        R, S = w.shape
+        d_rgb = _f32(d_rgb) if d_rgb is not None else None
+        d_sem = _f32(d_sem) if d_sem is not None else None
+        d_acc = _f32(d_acc) if d_acc is not None else None
+        if d_exp is not None:
+            d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
+        dw = torch.empty_like(w)
+        check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s) if d_rgb is not None else None,
+                                     _p(sem_s) if d_sem is not None else None, _p(d_rgb), _p(d_acc), _p(d_sem), _p(d_exp), R, S,
+                                     SEM_DIM, _p(dw), None, None, _stream()), "ps_composite_bwd")
+        if d_w_ext is not None:
+            dw.add_(_f32(d_w_ext))  # losses that act on the weights directly (distortion, line of sight)
+        dsig = torch.empty_like(sigma)
+        check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
+        dapp, dtable, flat = _main_backward(ctx, saved, dsig, d_rgb, d_sem, w)  # a missing head gradient skips that head
+        return (None, None, None, dapp, None, None, None, dtable, None, None, None, None, *flat)
+
+
+def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor], ebins: Tensor, table: Tensor, scalings: Tensor,
+                      g: GridCfg, base, sem, rgb, threshold: float = 0.5):
+    """-> (rgb [R,3], accumulation [R,1] (unclamped), threshold depth [R,1], expected depth [R,1], semantics [R,64],
+    weights [R,S]) of a ray batch whose S = ebins.shape[1]-1 <= 64 samples per ray are the points u (point n = ray n // S)."""
+    S = ebins.shape[1] - 1
+    if S > 64:
+        raise NotImplementedError("main_field_render: at most 64 samples per ray (use main_field + ops.composite)")
+    flat = []
+    for W, b in list(base) + list(sem) + list(rgb):
+        flat += [W, b]
+    return _MainFieldRender.apply(u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, len(base), len(sem), *flat)
 
 
 def main_field(u: Tensor, sel: Tensor, dirs: Optional[Tensor], app: Optional[Tensor], S: int, table: Tensor, scalings: Tensor,

@@ -106,6 +106,24 @@ class iNGPField(nn.Module):
                             self.mlp_base_mlp.layer_params(), self.semantic_head.layer_params(), self.rgb_head.layer_params(),
                             want_rgb=want_rgb, want_sem=want_sem)
 
+    def render(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor], threshold: float = 0.5):
+        """forward() + RaySamples.get_weights + the RGB / accumulation / depth / semantics renderers as one autograd node
+        (field_ops.main_field_render): -> (rgb, accumulation (unclamped), threshold depth, expected depth, semantics, weights
+        [R,S,1])."""
+        self._require_fused()
+        rb = ray_samples.ray_bundle
+        R = ray_samples.ebins.shape[0]
+        u, sel = self.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        g = self.mlp_base_grid
+        rgb, acc, depth, expd, sem, w = F.main_field_render(
+            u, sel, rb.directions, app, ray_samples.ebins, g.hash_table, g.scalings_on(u.device), _grid_cfg(g),
+            self.mlp_base_mlp.layer_params(), self.semantic_head.layer_params(), self.rgb_head.layer_params(), threshold)
+        return rgb, acc, depth, expd, sem, w[..., None]
+
+    def can_render(self, ray_samples: RaySamples) -> bool:
+        return self._fusable and ray_samples.num_samples <= 64
+
     # -- reference plugin surface ------------------------------------------------------------------------------
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
         return self.density_fn(ray_samples.frustums.get_positions())

@@ -194,6 +194,7 @@ class NerfactoNuscMSModel(nn.Module):
         if c.use_semantics:
             self.semantic_loss = semantic_loss
         self.step = 0
+        self.fused_render = True  # training, one sub-field, <= 64 samples: field + weights + renderers as one autograd node
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         groups = {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
@@ -254,15 +255,23 @@ class NerfactoNuscMSModel(nn.Module):
         c = self.config
         ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns, jitters=jitters)
         app = self._appearance(ray_bundle)
-        field_outputs = self.field.forward(ray_samples, appearance_embedding=None if app is None else app[:, None, :])
-        weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
-        weights_list.append(weights)
-        ray_samples_list.append(ray_samples)
-        sem_s = field_outputs[FieldHeadNames.SEMANTICS] if c.use_semantics else None
-        rgb_s = field_outputs[FieldHeadNames.RGB]
-        if not self.training:
-            rgb_s = torch.nan_to_num(rgb_s)
-        rgb, acc_raw, depth, expected_depth, semantics = render_all(weights, ray_samples, rgb_s, sem_s)
+        app3 = None if app is None else app[:, None, :]
+        if (self.training and self.fused_render and c.use_semantics and len(self.field.fields) == 1
+                and self.field.fields[0].can_render(ray_samples)):
+            # field + get_weights + renderers in one autograd node (never materialises the per-sample output gradients)
+            rgb, acc_raw, depth, expected_depth, semantics, weights = self.field.fields[0].render(ray_samples, app3)
+            weights_list.append(weights)
+            ray_samples_list.append(ray_samples)
+        else:
+            field_outputs = self.field.forward(ray_samples, appearance_embedding=app3)
+            weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
+            weights_list.append(weights)
+            ray_samples_list.append(ray_samples)
+            sem_s = field_outputs[FieldHeadNames.SEMANTICS] if c.use_semantics else None
+            rgb_s = field_outputs[FieldHeadNames.RGB]
+            if not self.training:
+                rgb_s = torch.nan_to_num(rgb_s)
+            rgb, acc_raw, depth, expected_depth, semantics = render_all(weights, ray_samples, rgb_s, sem_s)
         if not self.training:
             rgb = torch.clamp(rgb, min=0.0, max=1.0)
         accumulation = torch.clamp(acc_raw, min=0.0, max=1.0)

@@ -227,3 +227,52 @@ def test_flat_gradients_and_fused_adam_match_autograd_path(gold_model):
         else:
             assert torch.equal(p.detach(), before[k]), f"{k} has no gradient and must not move"
     assert len(fg.touched_ranges()) >= 1
+
+
+def test_fused_render_node_matches_separate_nodes():
+    """One sub-field: field + get_weights + renderers as one autograd node (field_ops.main_field_render, per-ray output
+    gradients expanded inside the field backward) against the three separate nodes, outputs and every parameter gradient."""
+    import bench
+    from presight_amd import ops
+    from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
+    from presight_amd.rays import RayBundle
+
+    dev = torch.device("cuda:0")
+    scene = bench.make_scene(60, 6)
+    conf = NerfactoNuscMSModelConfig(near_plane=0.005, far_plane=50.0, piecewise_sampler_threshold=5.0, num_levels=2,
+                                     features_per_level=2, log2_hashmap_size=12, base_res=16, max_res=128, hidden_dim=32,
+                                     hidden_dim_color=32, implementation="hip", use_lidar_loss=False)
+    torch.manual_seed(11)
+    model = NerfactoNuscMSModel(conf, num_train_cameras=60, num_train_videos=6, dino_to_rgb=None, centroids=scene["centroids"],
+                                aabbs=scene["aabbs"]).to(dev)
+    with torch.no_grad():  # lift the densities so that the weights are not vanishingly small
+        model.field.fields[0].mlp_base_mlp.layers[-1].bias[0] = 2.0
+    scene = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    R = 300
+    batch = bench.make_batches(scene, dev, 1, 0, rays=R)[0]
+    g = torch.Generator().manual_seed(2)
+    jit = [torch.rand(R, 1, generator=g).to(dev) for _ in range(3)]
+    results = {}
+    for fused in (False, True):
+        model.fused_render = fused
+        model.zero_grad(set_to_none=True)
+        model.train()
+        o, d, pa, dn = ops.generate_rays(batch["ray_indices"], scene["c2w"], scene["fx"], scene["fy"], scene["cx"], scene["cy"])
+        rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1], metadata={"video_id": batch["video_ids"][:, None],
+                                                                                       "directions_norm": dn})
+        out = model(rb, jitters=jit)
+        ld = model.get_loss_dict(out, batch)
+        (sum(ld.values()) + out["expected_depth"].mean() * 0.1).backward()
+        results[fused] = ({k: out[k].detach().clone() for k in ("rgb", "accumulation", "depth", "expected_depth", "semantics")},
+                          {k: v.detach().clone() for k, v in ld.items()},
+                          {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    (oa, la, ga), (ob, lb, gb) = results[False], results[True]
+    for k in oa:
+        torch.testing.assert_close(ob[k], oa[k], rtol=0, atol=0, msg=lambda m: f"{k}: {m}")  # same forward kernels
+    for k in la:
+        torch.testing.assert_close(lb[k], la[k], rtol=0, atol=0)
+    assert set(ga) == set(gb)
+    for k in ga:
+        s = float(ga[k].abs().max()) + 1e-30
+        torch.testing.assert_close(gb[k] / s, ga[k] / s, rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+    assert float(ga["field.fields.0.mlp_base_grid.hash_table"].abs().max()) > 0
