@@ -122,6 +122,30 @@ int ps_line_of_sight_loss(const float* w, const float* ebins, const float* depth
 int ps_expected_depth_loss(const float* depth, const float* pred, const float* sky, int64_t R, float upper_bound,
                            int inverse, float pose_scale, float* per_ray, float* dpred, float* keep, void* stream);
 
+/* ---- per-ray tail of the training step (one launch per operator and direction) ---------------------------
+ * nn.Embedding lookup into a column block of out [R, out_stride] and its scatter-add backward
+ * (ns/field_components/embedding.py:27-55; idx int64 [R], table [rows, D]) */
+int ps_embedding_fwd(const int64_t* idx, const float* table, int64_t R, int D, int out_stride, int col0, float* out,
+                     void* stream);
+int ps_embedding_bwd(const int64_t* idx, const float* dout, int64_t R, int D, int rows, int out_stride, int col0,
+                     float* dtable /* += */, void* stream);
+/* sky blending, ns/models/PreSight/nerfacto_nusc_ms.py:512-533: acc = clamp(acc_raw, 0, 1),
+ * rgb = rgb_f + (1-acc) sky_rgb, sem = sem_f + (1-acc) sky_sem (sky_* / sem may be NULL).  Backward: d(rgb_f) = d(rgb)
+ * and d(sem_f) = d(sem) are identities (not written); d_acc_raw [R], d_sky_rgb [R,3], d_sky_sem [R,C] are. */
+int ps_sky_blend_fwd(const float* rgb_f, const float* acc_raw, const float* sem_f, const float* sky_rgb,
+                     const float* sky_sem, int64_t R, int C, float* rgb, float* acc, float* sem, void* stream);
+int ps_sky_blend_bwd(const float* acc_raw, const float* sky_rgb, const float* sky_sem, const float* d_rgb,
+                     const float* d_acc, const float* d_sem, int64_t R, int C, float* d_acc_raw, float* d_sky_rgb,
+                     float* d_sky_sem, void* stream);
+/* scalar losses: partial [ps_loss_partials(n)] receives per-workgroup sums (the caller adds them and divides by n),
+ * dpred / dacc the gradient of the MEAN.  MSE: nn.MSELoss (nerfacto_nusc_ms.py:568) and semantic_loss with
+ * clip_target=1 (ns/model_components/PreSight/losses.py:117-125); sky BCE: losses.py:106-115 */
+int ps_loss_partials(int64_t n);
+int ps_mse_loss(const float* pred, const float* target, int64_t n, int clip_target, float* partial, float* dpred,
+                void* stream);
+int ps_sky_bce_loss(const float* acc, const float* sky_mask, int64_t R, float eps, float* partial, float* dacc,
+                    void* stream);
+
 /* ---- field level (fused) -------------------------------------------------------------------------
  * A field evaluation is:  ps_field_points -> ps_grid_encode -> ps_{prop,main}_field_fwd, and backward
  * ps_{prop,main}_field_bwd -> ps_grid_scatter.  Features travel as level planes feat[l][n][f]

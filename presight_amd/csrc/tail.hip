@@ -1,0 +1,193 @@
+// Per-ray "tail" of the training step: embedding lookup, sky blending and the scalar per-ray losses.  Each of these is a
+// chain of 5-15 element-wise torch kernels in the reference (a few microseconds of work each, but one dependent launch
+// each: ~10 us of GPU timeline apiece on MI355X); here every operator is one launch per direction.
+//   embedding      ns/field_components/embedding.py:27-55 (nn.Embedding lookup; backward = scatter-add of the rows)
+//   sky blend      ns/models/PreSight/nerfacto_nusc_ms.py:512-533  acc = clamp(acc,0,1); out += (1-acc) * sky_out
+//   rgb / semantic MSE, sky BCE   nerfacto_nusc_ms.py:568, ns/model_components/PreSight/losses.py:106-125
+#include "common.hpp"
+
+namespace {
+
+// out[r, col0 + d] = table[idx[r], d]
+__global__ void embedding_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table, int64_t R, int D,
+                                     int out_stride, int col0, float* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= R * D) return;
+  const int64_t r = i / D;
+  const int d = (int)(i - r * D);
+  out[r * out_stride + col0 + d] = table[idx[r] * D + d];
+}
+
+// dtable[idx[r], d] += dout[r, col0 + d].  Small tables (rows*D <= kEmbLds floats: the per-camera / per-video appearance
+// codes) are first reduced in LDS per workgroup, so that the global atomics are one per touched table entry and
+// workgroup instead of one per ray and column; large tables go straight to global atomics.
+constexpr int kEmbLds = 12288;
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ dout, int64_t R,
+                                                            int D, int rows, int out_stride, int col0, float* __restrict__ dtable) {
+  __shared__ float acc[kEmbLds];
+  const bool use_lds = (int64_t)rows * D <= kEmbLds;
+  const int n_tab = rows * D;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < n_tab; i += 256) acc[i] = 0.0f;
+    __syncthreads();
+  }
+  const int64_t per = (R * D + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = blockIdx.x * per, hi = min(R * D, lo + per);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const int64_t r = i / D;
+    const int d = (int)(i - r * D);
+    const float g = dout[r * out_stride + col0 + d];
+    const int64_t row = idx[r];
+    if (use_lds)
+      atomicAdd(&acc[row * D + d], g);
+    else
+      unsafeAtomicAdd(dtable + row * D + d, g);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_tab; i += 256)
+      if (acc[i] != 0.0f) unsafeAtomicAdd(dtable + i, acc[i]);
+  }
+}
+
+// One wavefront per ray, lane = channel.  sky_* may be null (no sky model): plain clamp of the accumulation.
+__global__ __launch_bounds__(256) void sky_blend_fwd_kernel(const float* __restrict__ rgb_f, const float* __restrict__ acc_raw,
+                                                            const float* __restrict__ sem_f, const float* __restrict__ sky_rgb,
+                                                            const float* __restrict__ sky_sem, int64_t R, int C,
+                                                            float* __restrict__ rgb, float* __restrict__ acc, float* __restrict__ sem) {
+  const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  const float a = fminf(fmaxf(acc_raw[ray], 0.0f), 1.0f);
+  if (lane == 0) acc[ray] = a;
+  if (lane < 3) rgb[ray * 3 + lane] = rgb_f[ray * 3 + lane] + (sky_rgb ? (1.0f - a) * sky_rgb[ray * 3 + lane] : 0.0f);
+  if (sem != nullptr && lane < C) sem[ray * C + lane] = sem_f[ray * C + lane] + (sky_sem ? (1.0f - a) * sky_sem[ray * C + lane] : 0.0f);
+}
+
+// d(rgb_f) = d(rgb), d(sem_f) = d(sem) (identity: the caller passes the same tensors on); here
+//   d(sky_rgb) = (1-acc) d(rgb), d(sky_sem) = (1-acc) d(sem),
+//   d(acc_raw) = [0 <= acc_raw <= 1] * (d(acc) - sum_c d(rgb) sky_rgb - sum_c d(sem) sky_sem)      (torch.clamp passes the bounds)
+__global__ __launch_bounds__(256) void sky_blend_bwd_kernel(const float* __restrict__ acc_raw, const float* __restrict__ sky_rgb,
+                                                            const float* __restrict__ sky_sem, const float* __restrict__ d_rgb,
+                                                            const float* __restrict__ d_acc, const float* __restrict__ d_sem,
+                                                            int64_t R, int C, float* __restrict__ d_acc_raw,
+                                                            float* __restrict__ d_sky_rgb, float* __restrict__ d_sky_sem) {
+  const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  const float ar = acc_raw[ray];
+  const float a = fminf(fmaxf(ar, 0.0f), 1.0f);
+  float dot = 0.f;
+  if (sky_rgb != nullptr && d_rgb != nullptr && lane < 3) {
+    const float g = d_rgb[ray * 3 + lane];
+    dot += g * sky_rgb[ray * 3 + lane];
+    d_sky_rgb[ray * 3 + lane] = (1.0f - a) * g;
+  } else if (d_sky_rgb != nullptr && lane < 3) {
+    d_sky_rgb[ray * 3 + lane] = 0.0f;
+  }
+  if (sky_sem != nullptr && d_sem != nullptr && lane < C) {
+    const float g = d_sem[ray * C + lane];
+    dot += g * sky_sem[ray * C + lane];
+    d_sky_sem[ray * C + lane] = (1.0f - a) * g;
+  } else if (d_sky_sem != nullptr && lane < C) {
+    d_sky_sem[ray * C + lane] = 0.0f;
+  }
+  dot = ps_wave_sum(dot);
+  if (lane == 0) d_acc_raw[ray] = (ar >= 0.0f && ar <= 1.0f) ? (d_acc ? d_acc[ray] : 0.0f) - dot : 0.0f;
+}
+
+// sum of squared errors of a block of elements (one partial per workgroup) + d/dpred of the MEAN over n elements
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t n,
+                                                  int clip_target, float* __restrict__ partial, float* __restrict__ dpred) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const float k = 2.0f / (float)n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float t = target[i];
+    if (clip_target) t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float e = pred[i] - t;
+    s += e * e;
+    dpred[i] = k * e;
+  }
+  s = ps_wave_sum(s);
+  if (ps_lane() == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// binary cross entropy of clip(acc, eps, 1-eps) against (1 - sky_mask), torch semantics (log clamped at -100)
+__global__ __launch_bounds__(256) void sky_bce_kernel(const float* __restrict__ acc, const float* __restrict__ sky_mask, int64_t R,
+                                                      float eps, float* __restrict__ partial, float* __restrict__ dacc) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const float inv = 1.0f / (float)R;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = acc[i], t = 1.0f - sky_mask[i];
+    const float a = fminf(fmaxf(x, eps), 1.0f - eps);
+    const float la = fmaxf(logf(a), -100.0f), lb = fmaxf(logf(1.0f - a), -100.0f);
+    s -= t * la + (1.0f - t) * lb;
+    // d/da = (a - t) / (a (1 - a)), through the clip only where eps <= acc <= 1-eps
+    dacc[i] = (x >= eps && x <= 1.0f - eps) ? inv * (a - t) / fmaxf(a * (1.0f - a), 1e-12f) : 0.0f;
+  }
+  s = ps_wave_sum(s);
+  if (ps_lane() == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace
+
+extern "C" int ps_embedding_fwd(const int64_t* idx, const float* table, int64_t R, int D, int out_stride, int col0, float* out,
+                                void* stream) {
+  if (R == 0 || D == 0) return 0;
+  embedding_fwd_kernel<<<(unsigned)((R * D + 255) / 256), 256, 0, (hipStream_t)stream>>>(idx, table, R, D, out_stride, col0, out);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_embedding_bwd(const int64_t* idx, const float* dout, int64_t R, int D, int rows, int out_stride, int col0,
+                                float* dtable, void* stream) {
+  if (R == 0 || D == 0) return 0;
+  const int64_t want = (R * D + 256 * 32 - 1) / (256 * 32);
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 128 ? 128 : want));
+  embedding_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(idx, dout, R, D, rows, out_stride, col0, dtable);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_sky_blend_fwd(const float* rgb_f, const float* acc_raw, const float* sem_f, const float* sky_rgb,
+                                const float* sky_sem, int64_t R, int C, float* rgb, float* acc, float* sem, void* stream) {
+  PS_REQUIRE(C <= 64, "ps_sky_blend_fwd: at most 64 semantic channels");
+  if (R == 0) return 0;
+  sky_blend_fwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(rgb_f, acc_raw, sem_f, sky_rgb, sky_sem, R, C, rgb,
+                                                                                acc, sem);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_sky_blend_bwd(const float* acc_raw, const float* sky_rgb, const float* sky_sem, const float* d_rgb,
+                                const float* d_acc, const float* d_sem, int64_t R, int C, float* d_acc_raw, float* d_sky_rgb,
+                                float* d_sky_sem, void* stream) {
+  PS_REQUIRE(C <= 64, "ps_sky_blend_bwd: at most 64 semantic channels");
+  if (R == 0) return 0;
+  sky_blend_bwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(acc_raw, sky_rgb, sky_sem, d_rgb, d_acc, d_sem, R, C,
+                                                                                d_acc_raw, d_sky_rgb, d_sky_sem);
+  PS_CHECK_LAUNCH();
+}
+
+// number of partial sums ps_mse_loss / ps_sky_bce_loss write for n elements
+extern "C" int ps_loss_partials(int64_t n) {
+  const int64_t b = (n + 256 * 8 - 1) / (256 * 8);
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int ps_mse_loss(const float* pred, const float* target, int64_t n, int clip_target, float* partial, float* dpred,
+                           void* stream) {
+  PS_REQUIRE(n > 0, "ps_mse_loss: empty input");
+  mse_kernel<<<ps_loss_partials(n), 256, 0, (hipStream_t)stream>>>(pred, target, n, clip_target, partial, dpred);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_sky_bce_loss(const float* acc, const float* sky_mask, int64_t R, float eps, float* partial, float* dacc,
+                               void* stream) {
+  PS_REQUIRE(R > 0, "ps_sky_bce_loss: empty input");
+  sky_bce_kernel<<<ps_loss_partials(R), 256, 0, (hipStream_t)stream>>>(acc, sky_mask, R, eps, partial, dacc);
+  PS_CHECK_LAUNCH();
+}

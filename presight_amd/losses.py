@@ -16,16 +16,51 @@ from ._lib import check, lib
 from .ops import _f32, _p, _stream
 
 
+class _ScalarLoss(torch.autograd.Function):
+    """mean-reduced element-wise loss in one launch: value (per-workgroup partial sums, added here) + gradient of the mean"""
+
+    @staticmethod
+    def forward(ctx, pred, other, kind, arg):
+        pred, other = _f32(pred), _f32(other)
+        if pred.shape != other.shape:
+            other = other.expand_as(pred).contiguous() if other.numel() != pred.numel() else other.reshape(pred.shape)
+        n = pred.numel()
+        partial = torch.empty(lib().ps_loss_partials(n), device=pred.device)
+        grad = torch.empty_like(pred)
+        if kind == "mse":
+            check(lib().ps_mse_loss(_p(pred), _p(other), n, int(arg), _p(partial), _p(grad), _stream()), "ps_mse_loss")
+        else:
+            check(lib().ps_sky_bce_loss(_p(pred), _p(other), n, float(arg), _p(partial), _p(grad), _stream()), "ps_sky_bce_loss")
+        ctx.save_for_backward(grad)
+        return partial.sum() / n
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def mse_loss(target: Tensor, pred: Tensor) -> Tensor:
+    """nn.MSELoss()(target, pred) of the reference (nerfacto_nusc_ms.py:568); the gradient flows to `pred` only."""
+    return _ScalarLoss.apply(pred, target.detach(), "mse", 0)
+
+
+class MSELoss(torch.nn.Module):
+    def forward(self, a: Tensor, b: Tensor) -> Tensor:
+        # the reference calls rgb_loss(gt, pred); keep nn.MSELoss's symmetry by differentiating whichever side needs it
+        if a.requires_grad and not b.requires_grad:
+            return _ScalarLoss.apply(a, b.detach(), "mse", 0)
+        return _ScalarLoss.apply(b, a.detach(), "mse", 0)
+
+
 def sky_loss(accumulation: Tensor, sky_mask: Tensor, eps: float = 1e-7) -> Tensor:
-    target = 1.0 - sky_mask
-    a = torch.clip(accumulation, min=eps, max=1 - eps)
-    return torch.nn.functional.binary_cross_entropy(a, target, reduction="none").mean()
+    """ns/model_components/PreSight/losses.py:106-115: BCE(clip(acc, eps, 1-eps), 1 - sky_mask), mean"""
+    return _ScalarLoss.apply(accumulation, sky_mask.detach(), "bce", eps)
 
 
 def semantic_loss(pred: Tensor, target: Tensor, clip: bool = True) -> Tensor:
-    if clip:
-        target = torch.clip(target, min=0.0, max=1.0)
-    return torch.nn.functional.mse_loss(pred, target, reduction="none").mean()
+    """ns/model_components/PreSight/losses.py:117-125: MSE against the (clipped) feature target, mean"""
+    return _ScalarLoss.apply(pred, target.detach(), "mse", int(clip))
 
 
 class _Distortion(torch.autograd.Function):

@@ -19,7 +19,7 @@ from . import ops
 from .components import Embedding, SceneContraction
 from .fields import (FieldHeadNames, PropNetDensityField, PropNetDensityFieldMS, SkyField, SkyFieldMS, iNGPField,
                      iNGPFieldMS)
-from .losses import (distortion_loss, expected_depth_loss, expected_monodepth_loss, line_of_sight_loss, semantic_loss, sky_loss,
+from .losses import (MSELoss, distortion_loss, expected_depth_loss, expected_monodepth_loss, line_of_sight_loss, semantic_loss, sky_loss,
                      z_anti_aliasing_interlevel_loss)
 from .rays import RayBundle, RaySamples
 from .renderers import AccumulationRenderer, DepthRenderer, NearFarCollider, RGBRenderer, render_all
@@ -190,7 +190,7 @@ class NerfactoNuscMSModel(nn.Module):
         self.renderer_accumulation = AccumulationRenderer()
         self.renderer_depth = DepthRenderer(method="threshold")
         self.renderer_expected_depth = DepthRenderer(method="expected")
-        self.rgb_loss = nn.MSELoss()
+        self.rgb_loss = MSELoss()
         if c.use_semantics:
             self.semantic_loss = semantic_loss
         self.step = 0
@@ -234,10 +234,14 @@ class NerfactoNuscMSModel(nn.Module):
         R = cam.shape[0]
         parts = []
         if self.training:
+            idx, tabs = [], []
             if c.appearance_embed_dim > 0:
-                parts.append(self.appearance_embedding(cam))
+                idx.append(cam)
+                tabs.append(self.appearance_embedding.embedding.weight)
             if c.video_embed_dim > 0:
-                parts.append(self.video_embedding(ray_bundle.metadata[VIDEO_ID].reshape(-1)))
+                idx.append(ray_bundle.metadata[VIDEO_ID].reshape(-1))
+                tabs.append(self.video_embedding.embedding.weight)
+            return ops.embed_cat(idx, tabs) if tabs else None  # lookups + concat (+ scatter-add backward) in one op
         elif c.use_average_appearance_embedding:
             if c.appearance_embed_dim > 0:
                 parts.append(self.appearance_embedding.mean(dim=0)[None].expand(R, -1))
@@ -274,15 +278,14 @@ class NerfactoNuscMSModel(nn.Module):
             rgb, acc_raw, depth, expected_depth, semantics = render_all(weights, ray_samples, rgb_s, sem_s)
         if not self.training:
             rgb = torch.clamp(rgb, min=0.0, max=1.0)
-        accumulation = torch.clamp(acc_raw, min=0.0, max=1.0)
         sky_outputs = {}
         if c.use_sky_model:
             sky_outputs = self.sky_model(ray_samples, appearance_embedding=None if app is None else app[:, None, :])
-            rgb = rgb + (1.0 - accumulation) * sky_outputs[FieldHeadNames.RGB]
+        # accumulation = clamp(acc, 0, 1); rgb/semantics += (1 - accumulation) * sky   (nerfacto_nusc_ms.py:512-533)
+        rgb, accumulation, semantics = ops.sky_blend(rgb, acc_raw, semantics if c.use_semantics else None,
+                                                     sky_outputs.get(FieldHeadNames.RGB), sky_outputs.get(FieldHeadNames.SEMANTICS))
         outputs = {"rgb": rgb, "accumulation": accumulation, "depth": depth.detach(), "expected_depth": expected_depth}
         if c.use_semantics:
-            if FieldHeadNames.SEMANTICS in sky_outputs:
-                semantics = semantics + (1.0 - accumulation) * sky_outputs[FieldHeadNames.SEMANTICS]
             outputs["semantics"] = semantics
             if not self.training and self.dino_to_rgb is not None:
                 outputs["dino_rgb"] = apply_feature_colormap(semantics, self.dino_to_rgb)

@@ -462,3 +462,89 @@ def threshold_depth(weights: Tensor, ebins: Tensor, threshold: float = 0.5) -> T
 def composite(weights: Tensor, ebins: Tensor, rgb_s: Optional[Tensor], sem_s: Optional[Tensor], threshold: float = 0.5):
     """-> (rgb [R,3], acc [R,1] (unclamped), threshold depth [R,1], expected depth [R,1] (batch-clipped), sem [R,C])."""
     return _Composite.apply(weights, ebins, rgb_s, sem_s, threshold)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-ray tail: embedding lookup, sky blending
+# ------------------------------------------------------------------------------------------------
+class _EmbedCat(torch.autograd.Function):
+    """cat([table_k[idx_k] for k], dim=-1) in one launch per table; backward scatter-adds the rows (in place into the
+    parameter's flat .grad when the owner opted in, see grad_sink)."""
+
+    @staticmethod
+    def forward(ctx, n_tab, *args):
+        idxs, tables = args[:n_tab], args[n_tab:]
+        R = idxs[0].shape[0]
+        dev = tables[0].device
+        widths = [t.shape[1] for t in tables]
+        out = torch.empty(R, sum(widths), device=dev)
+        idxs = [i.reshape(-1).to(torch.int64).contiguous() for i in idxs]
+        col = 0
+        for i, t in zip(idxs, tables):
+            check(lib().ps_embedding_fwd(_p(i), _p(_f32(t)), R, t.shape[1], out.shape[1], col, _p(out), _stream()), "ps_embedding_fwd")
+            col += t.shape[1]
+        ctx.save_for_backward(*idxs)
+        ctx.shapes = [tuple(t.shape) for t in tables]
+        ctx.sinks = [grad_sink(t) for t in tables]
+        ctx.direct = direct_params(*tables)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idxs = ctx.saved_tensors
+        dout = _f32(dout)
+        R = dout.shape[0]
+        grads, col = [], 0
+        for i, (rows, D), sink in zip(idxs, ctx.shapes, ctx.sinks):
+            dst = sink if sink is not None else torch.zeros(rows, D, device=dout.device)
+            check(lib().ps_embedding_bwd(_p(i), _p(dout), R, D, rows, dout.shape[1], col, _p(dst), _stream()), "ps_embedding_bwd")
+            grads.append(None if sink is not None else dst)
+            col += D
+        mark_touched(ctx.direct)
+        return (None, *([None] * len(idxs)), *grads)
+
+
+def embed_cat(indices: Sequence[Tensor], tables: Sequence[Tensor]) -> Tensor:
+    """[R, sum(D_k)] = concatenation of nn.Embedding lookups (ns/field_components/embedding.py:27-55)"""
+    return _EmbedCat.apply(len(tables), *indices, *tables)
+
+
+class _SkyBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_f, acc_raw, sem_f, sky_rgb, sky_sem):
+        rgb_f, acc_raw = _f32(rgb_f), _f32(acc_raw)
+        R = rgb_f.shape[0]
+        dev = rgb_f.device
+        sem_f = None if sem_f is None else _f32(sem_f)
+        sky_rgb = None if sky_rgb is None else _f32(sky_rgb)
+        sky_sem = None if (sky_sem is None or sem_f is None) else _f32(sky_sem)
+        C = 0 if sem_f is None else sem_f.shape[1]
+        rgb, acc = torch.empty(R, 3, device=dev), torch.empty(R, 1, device=dev)
+        sem = torch.empty(R, C, device=dev) if sem_f is not None else None
+        check(lib().ps_sky_blend_fwd(_p(rgb_f), _p(acc_raw), _p(sem_f), _p(sky_rgb), _p(sky_sem), R, C, _p(rgb), _p(acc), _p(sem),
+                                     _stream()), "ps_sky_blend_fwd")
+        ctx.save_for_backward(acc_raw, sky_rgb, sky_sem)
+        ctx.C = C
+        return rgb, acc, (sem if sem is not None else torch.empty(0, device=dev))
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, d_sem):
+        acc_raw, sky_rgb, sky_sem = ctx.saved_tensors
+        R = acc_raw.shape[0]
+        dev = acc_raw.device
+        d_rgb = None if d_rgb is None else _f32(d_rgb)
+        d_acc = None if d_acc is None else _f32(d_acc)
+        d_sem = None if (d_sem is None or ctx.C == 0) else _f32(d_sem)
+        d_acc_raw = torch.empty_like(acc_raw)
+        d_sky_rgb = torch.empty_like(sky_rgb) if sky_rgb is not None else None
+        d_sky_sem = torch.empty_like(sky_sem) if sky_sem is not None else None
+        check(lib().ps_sky_blend_bwd(_p(acc_raw), _p(sky_rgb), _p(sky_sem), _p(d_rgb), _p(d_acc), _p(d_sem), R, ctx.C, _p(d_acc_raw),
+                                     _p(d_sky_rgb), _p(d_sky_sem), _stream()), "ps_sky_blend_bwd")
+        return d_rgb, d_acc_raw, d_sem, d_sky_rgb, d_sky_sem
+
+
+def sky_blend(rgb_f: Tensor, acc_raw: Tensor, sem_f: Optional[Tensor], sky_rgb: Optional[Tensor], sky_sem: Optional[Tensor]):
+    """-> (rgb, accumulation = clamp(acc_raw, 0, 1), semantics | None): rgb_f + (1-acc) sky_rgb, sem_f + (1-acc) sky_sem
+    (ns/models/PreSight/nerfacto_nusc_ms.py:512-533); without sky tensors only the clamp is applied."""
+    rgb, acc, sem = _SkyBlend.apply(rgb_f, acc_raw, sem_f, sky_rgb, sky_sem)
+    return rgb, acc, (sem if sem_f is not None else None)
