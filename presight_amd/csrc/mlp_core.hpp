@@ -313,15 +313,26 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
   asm volatile("" ::"v"(dw[0][0][0]), "v"(db[0][0]));
   return;
 #endif
+#if defined(PS_ABLATE) && PS_ABLATE == 8  // all dW / db values stay live (no dead-code elimination), only the LDS flush is skipped
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob) {
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) asm volatile("" ::"v"(dw[ob][ib][0]), "v"(dw[ob][ib][1]), "v"(dw[ob][ib][2]), "v"(dw[ob][ib][3]));
+    asm volatile("" ::"v"(db[ob][0]), "v"(db[ob][1]), "v"(db[ob][2]), "v"(db[ob][3]));
+  }
+  return;
+#endif
   // Flush into the workgroup accumulators WITHOUT LDS float atomics (ds_add_f32 retires ~1 lane per 10 cycles on
   // gfx950, measured 20x slower than integer LDS atomics or plain LDS traffic): the wave takes this layer's LDS
   // spin lock (integer compare-and-swap, fast), does plain read-modify-writes and releases.  The four waves of a
   // workgroup drift apart after the first collision, so the lock is almost always free; there is no workgroup
   // barrier on this path.
+#if !(defined(PS_ABLATE) && PS_ABLATE == 7)  // 7: racy, timing only -- what do the lock and its contention cost?
   if (lane == 0) {
     while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
   // accumulator layout [tile][lane][4]: one 16-byte LDS read + write per 16x16 tile and lane
 #pragma unroll
   for (int ob = 0; ob < LT::NB; ++ob)
@@ -336,8 +347,10 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
 #pragma unroll
       for (int r = 0; r < 4; ++r) gacc[LT::GB_OFF + 16 * nb + 4 * g + r] += db[nb][r];
   }
+#if !(defined(PS_ABLATE) && PS_ABLATE == 7)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane == 0) atomicExch(lock, 0);
+#endif
   __builtin_amdgcn_sched_barrier(0);
 }
 
