@@ -116,6 +116,11 @@ class Trainer:
                 seen.add(id(p))
                 uniq.append(p)
         self.grads = FlatGrads(uniq)
+        if world > 1 and not model.config.use_same_proposal_network:
+            # one bucket per optimizer group: the "fields" bucket (main table + MLPs + sky + embeddings, 2/3 of the bytes) is
+            # complete before the proposal networks' backward starts and is exchanged underneath it
+            uid = {id(p) for p in uniq}
+            self.grads.enable_overlap([[p for p in groups[k] if id(p) in uid] for k in sorted(groups, reverse=True)])
         from presight_amd.optim import HipAdam
 
         self.opt = HipAdam(uniq, lr=1e-2, eps=1e-15, weight_decay=1e-5, flat_grads=self.grads)
@@ -140,7 +145,7 @@ class Trainer:
         loss_dict = m.get_loss_dict(out, batch)
         loss = sum(loss_dict.values())
         (loss * self.loss_scale).backward()
-        self.grads.all_reduce_mean()
+        self.grads.finish_exchange()
         self.opt.step()
         m.after_train_iteration(self.step_idx)
         self.step_idx += 1
@@ -239,10 +244,18 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt_sched = time.perf_counter() - t1
+    replica_diff = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+        # data-parallel consistency: every rank applied the same averaged gradients, so the replicas must still be identical
+        mine = trainer.opt.flat[0]
+        ref = mine.clone()
+        torch.distributed.broadcast(ref, src=0)
+        d = (mine - ref).abs().max().reshape(1)
+        torch.distributed.all_reduce(d, op=torch.distributed.ReduceOp.MAX)
+        replica_diff = float(d.item())
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -266,6 +279,7 @@ def main():
                          "avg_launch_ms": t_bwd, "launches": n_launch},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
             "value_reference_schedule": world * RAYS * n_sched / dt_sched,
+            "replicas_max_abs_diff": replica_diff,
             "psnr_vs_random_targets": psnr,
             "loss": float(sum(loss_dict.values())),
         }

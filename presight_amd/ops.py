@@ -184,6 +184,9 @@ def direct_params(*tensors) -> list:
 def mark_touched(params):
     """tell the owner of the flat gradient buffer that these parameters received a gradient this step"""
     for t in params:
+        cb = getattr(t, "_ps_on_touch", None)  # bucketed gradient exchange: FlatGrads.enable_overlap
+        if cb is not None:
+            cb(t)
         t._ps_touched = True
 
 

@@ -124,6 +124,27 @@ _WORKER = textwrap.dedent("""
     fg.flags_may_differ_across_ranks = True
     assert fg.touched() == [False, True, False]
     assert fg.touched_ranges() == [(16, 24)]  # 15 floats padded to 16, then 7 padded to 8
+    # bucketed exchange launched from the gradient hooks: bucket 0 = params[0:2], bucket 1 = params[2:3]
+    fg.flags_may_differ_across_ranks = False
+    fg.enable_overlap([params[0:2], params[2:3]])
+    fg.zero_()
+    for i, p in enumerate(params):
+        (p * (rank + 1) * (i + 1)).sum().backward()
+    assert all(b["launched"] for b in fg._buckets)  # both went out during backward
+    fg.finish_exchange()
+    for p, e in zip(params, expect):
+        assert torch.allclose(p.grad, torch.full_like(p, e)), (rank, p.grad, e)
+    fg.zero_()
+    (params[2] * 2.0).sum().backward()  # bucket 0 gets nothing on any rank -> skipped, bucket 1 exchanged
+    assert [b["launched"] for b in fg._buckets] == [False, True]
+    fg.finish_exchange()
+    assert torch.allclose(params[2].grad, torch.full_like(params[2], 2.0)) and float(params[0].grad.abs().sum()) == 0.0
+    from presight_amd.ops import mark_touched
+    try:
+        mark_touched([params[2]])  # what a HIP backward node does after adding a SECOND contribution in place
+        raise SystemExit("a second in-place contribution after the launch must raise")
+    except RuntimeError as e:
+        assert "second gradient" in str(e)
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
 """)
