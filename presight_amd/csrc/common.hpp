@@ -46,17 +46,32 @@ __device__ __forceinline__ f32x4 ps_mfma16(float a, float b, f32x4 c) {
 }
 
 // sum over the 16 lanes that share (lane >> 4); result valid in every lane of the row
+// sum over the 16 lanes of a row (lanes 16k..16k+15), result in every lane.  DPP modifiers on the vector ALU
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror): __shfl_xor lowers to ds_bpermute_b32, i.e. four trips
+// through the LDS crossbar per value -- the fused MLP backward does ~500 of these reductions per 32 points.
+__device__ __forceinline__ float ps_dpp_add(float v, const int ctrl_tag) {
+  // ctrl must be a compile-time constant for the builtin: dispatch on a small tag
+  int x = __builtin_bit_cast(int, v), y;
+  switch (ctrl_tag) {
+    case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); break;   // quad_perm:[1,0,3,2]
+    case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false); break;   // quad_perm:[2,3,0,1]
+    case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+    default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false); break; // row_mirror
+  }
+  return v + __builtin_bit_cast(float, y);
+}
 __device__ __forceinline__ float ps_row16_sum(float v) {
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
+  v = ps_dpp_add(v, 0);
+  v = ps_dpp_add(v, 1);
+  v = ps_dpp_add(v, 2);
+  v = ps_dpp_add(v, 3);
   return v;
 }
 
 __device__ __forceinline__ float ps_wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v = ps_row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 
