@@ -115,6 +115,86 @@ __global__ __launch_bounds__(256) void grid_encode_kernel(const float* __restric
   }
 }
 
+// Lane-paired variant: the two corners of an x-pair (floor-x / ceil-x, same y and z) hash to rows that differ only in
+// low bits, i.e. they almost always share a cache line, but as two separate gather instructions they cost two L1 tag
+// lookups per lane.  Here lanes 2i / 2i+1 fetch the floor-x / ceil-x corners of point i in the SAME instruction, so the
+// L1 sees 32 distinct lines per gather instead of 64; the x-blend takes the partner's product through a DPP quad swap
+// (a + b is commutative, so the reference's  v_ceil*ox + v_floor*(1-ox)  is reproduced bit for bit in both lanes).
+template <int F, bool COUNT>
+__global__ __launch_bounds__(256) void grid_encode_pair_kernel(const float* __restrict__ u, const float* __restrict__ table,
+                                                               const float* __restrict__ scalings, int L, int log2T, int64_t N,
+                                                               int64_t plane_stride, float* __restrict__ feat,
+                                                               unsigned* __restrict__ slice_counts, int log2_slice, int group) {
+#pragma clang fp contract(off)
+  __shared__ unsigned cnt[COUNT ? kEncMaxSlices : 1];
+  const int64_t chunks = (N + 127) / 128;  // 128 points per pass of a 256-thread workgroup
+  const int64_t groups = (chunks + group - 1) / group;
+  int64_t item;
+  bool valid;
+  xcd_item(groups * L, item, valid);
+  if (!valid) return;
+  const int level = (int)(item / groups);
+  const int n_slices = COUNT ? (1 << (log2T - log2_slice)) : 0;
+  if constexpr (COUNT) {
+    for (int i = threadIdx.x; i < n_slices; i += 256) cnt[i] = 0u;
+    __syncthreads();
+  }
+  const uint32_t mask = (1u << log2T) - 1u;
+  const float scale = scalings[level];
+  const float* tl = table + ((int64_t)level << log2T) * F;
+  const int side = threadIdx.x & 1;  // 0: floor-x corners, 1: ceil-x corners
+  for (int64_t chunk = (item % groups) * group, end = min(chunks, chunk + group); chunk < end; ++chunk) {
+    const int64_t n = chunk * 128 + (threadIdx.x >> 1);
+    const bool ok = n < N;  // both lanes of a pair agree; inactive pairs still take part in the DPP swap
+    const int64_t nn = ok ? n : N - 1;
+    ps::Cell c = ps::make_cell(u[nn * 3], u[nn * 3 + 1], u[nn * 3 + 2], scale);
+    const uint32_t xs = (uint32_t)(side ? c.cx : c.fx);
+    const uint32_t yc = (uint32_t)c.cy * 2654435761u, yf = (uint32_t)c.fy * 2654435761u;
+    const uint32_t zc = (uint32_t)c.cz * 805459861u, zf = (uint32_t)c.fz * 805459861u;
+    // (y,z) combos in the order of the reference's blend: (c,c) (f,c) | (c,f) (f,f)
+    const uint32_t h[4] = {(xs ^ yc ^ zc) & mask, (xs ^ yf ^ zc) & mask, (xs ^ yc ^ zf) & mask, (xs ^ yf ^ zf) & mask};
+    ps::Row<F> r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k].load(tl + (size_t)h[k] * F);
+    const float wx = side ? c.ox : 1.0f - c.ox;
+    const float oy = c.oy, oz = c.oz, uy = 1.0f - oy, uz = 1.0f - oz;
+    float v[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      float p[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float mine = r[k].v[f] * wx;
+        const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0xB1, 0xF, 0xF, false));
+        p[k] = side ? mine + other : other + mine;  // = v_ceil*ox + v_floor*(1-ox) in both lanes
+      }
+      const float f0312 = p[0] * oy + p[1] * uy;
+      const float f4756 = p[2] * oy + p[3] * uy;
+      v[f] = f0312 * oz + f4756 * uz;
+    }
+    if (ok && side == 0) {
+      float* o = feat + level * plane_stride + n * F;
+      if constexpr (F == 1) o[0] = v[0];
+      if constexpr (F == 2) *reinterpret_cast<f32x2*>(o) = (f32x2){v[0], v[1]};
+      if constexpr (F == 4) *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+    }
+    if constexpr (COUNT) {
+      // one record per x-pair in the slice of its floor-x corner (counted by the floor lane) + one in the slice of the
+      // ceil-x corner when the pair straddles a slice boundary (counted by the ceil lane): same rule as bin_kernel
+      const bool together = ((((uint32_t)c.cx ^ (uint32_t)c.fx) & mask) >> log2_slice) == 0u;
+      if (ok && (side == 0 || !together)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&cnt[h[k] >> log2_slice], 1u);
+      }
+    }
+  }
+  if constexpr (COUNT) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_slices; i += 256)
+      if (cnt[i]) atomicAdd(&slice_counts[level * n_slices + i], cnt[i]);
+  }
+}
+
 constexpr int kSliceBytes = 128 * 1024;
 constexpr int kScatterThreads = 1024;
 
@@ -210,11 +290,24 @@ extern "C" int ps_grid_encode(const float* u, const float* table, const float* s
     if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
   }
   if (N == 0) return 0;
-  const int group = 8;  // 2048 points of one level per workgroup (also measured faster than 256 without counting)
-  const int64_t chunks = (N + 255) / 256;
+  static const bool paired = getenv("PS_ENCODE_UNPAIRED") == nullptr;
+  const int group = paired ? 16 : 8;  // 2048 points of one level per workgroup (also measured faster than 256 without counting)
+  const int64_t chunks = paired ? (N + 127) / 128 : (N + 255) / 256;
   const int64_t groups = (chunks + group - 1) / group;
   const int64_t per = (groups * L + 7) / 8;
   dim3 grid((unsigned)(per * 8)), block(256);
+  if (paired) {
+#define PS_ENCP(FF)                                                                                                          \
+  if (F == FF) {                                                                                                            \
+    if (slice_counts != nullptr)                                                                                            \
+      grid_encode_pair_kernel<FF, true><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat, slice_counts, ls, group); \
+    else                                                                                                                    \
+      grid_encode_pair_kernel<FF, false><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat, nullptr, ls, group);     \
+  }
+    PS_ENCP(1) PS_ENCP(2) PS_ENCP(4)
+#undef PS_ENCP
+    PS_CHECK_LAUNCH();
+  }
 #define PS_ENC(FF)                                                                                                          \
   if (F == FF) {                                                                                                            \
     if (slice_counts != nullptr)                                                                                            \
