@@ -171,6 +171,7 @@ int ps_grid_scatter(const float* u, const float* dfeat, const float* scalings, i
 int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N);
 int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                            int64_t plane_stride, float* dtable, int accumulate, const uint32_t* slice_counts /*nullable*/,
+                           int absmax_ready /* workspace[0..L) already holds the level maxima, see ps_prop_field_bwd */,
                            void* workspace, void* stream);
 /* proposal field: MLP (L*F -> hidden -> 1), packed with ps_mlp_pack_layer (LINEAR first-layer colmap) */
 int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
@@ -178,7 +179,8 @@ int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats /*
 int ps_prop_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
                       const float* packed, int64_t N, float* sigma, void* stream);
 int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
-                      const float* packed, const float* dsigma, int64_t N, float* dfeat, float* gpart, void* stream);
+                      const float* packed, const float* dsigma, int64_t N, float* dfeat, float* gpart,
+                      uint32_t* level_absmax /* nullable: [L] float bits of max |dfeat| per level, zeroed + filled */, void* stream);
 /* main field: packed = [base | semantic head | colour head]; offsets[6] = packed offsets of the three MLPs then
  * their gradient-block offsets.  dirs [R,3], app [R,A] (A <= 16, may be NULL), point n belongs to ray n/S.
  * Outputs sigma [N], rgb [N,3], sem [N,64]; any of them may be NULL to skip that head. */

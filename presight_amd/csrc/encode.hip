@@ -718,7 +718,7 @@ extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N)
 
 extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
                                       int64_t N, int64_t plane_stride, float* dtable, int accumulate,
-                                      const uint32_t* slice_counts, void* workspace, void* stream) {
+                                      const uint32_t* slice_counts, int absmax_ready, void* workspace, void* stream) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
   PS_REQUIRE(N * L * 8 + 4096 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
   hipStream_t s = (hipStream_t)stream;
@@ -735,7 +735,9 @@ extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const 
   unsigned* starts = counts + n_items;            // [n_items]
   unsigned* rec_idx = starts + ((n_items + 3) & ~3);  // [n_rec_max], 16-byte aligned like every plane behind it
   float* rec_val = (float*)(rec_idx + n_rec_max); // [F+1][n_rec_max] (plane F = ox)
-  hipError_t e = hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
+  // absmax_ready: the first L words of the workspace already hold the per-level max |d(feature)| bits (written by the
+  // field backward kernel that produced dfeat) -> keep them and skip the absmax pass
+  hipError_t e = absmax_ready ? hipMemsetAsync(ws + 4096, 0, (int64_t)n_items * 4, s) : hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
   if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
   if (slice_counts != nullptr && N > 0) {  // record counts (upper bounds) from the forward pass: ps_grid_encode
     e = hipMemcpyAsync(cursors, slice_counts, (size_t)n_items * 4, hipMemcpyDeviceToDevice, s);
@@ -757,7 +759,7 @@ extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const 
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
     if (N > 0) {                                                                                                          \
-      absmax_kernel<<<dim3(128, L), 256, 0, s>>>(dfeat, N * FF, plane_stride, gmax_bits);                                 \
+      if (!absmax_ready) absmax_kernel<<<dim3(128, L), 256, 0, s>>>(dfeat, N * FF, plane_stride, gmax_bits);              \
       if (slice_counts == nullptr)                                                                                        \
         bin_kernel<FF, true><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,          \
                                                                             plane_stride, n_rec_max, cursors, rec_idx, rec_val); \

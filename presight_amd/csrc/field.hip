@@ -57,6 +57,30 @@ __device__ __forceinline__ void store_dfeat(float* __restrict__ dfeat, int64_t p
   }
 }
 
+// per-level max |d(feature)| for the fixed-point scale of the binned table backward (encode.hip), kept per lane over all
+// tiles of the kernel and published once per wave: saves that backward a separate pass over d(features)
+template <int KS0, int PB>
+__device__ __forceinline__ void track_absmax(const float (&dx)[PB][((KS0 + 3) / 4) * 4], float (&mx)[KS0]) {
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+    for (int t = 0; t < KS0; ++t) mx[t] = fmaxf(mx[t], fabsf(dx[pb][t]));
+}
+template <int KS0>
+__device__ __forceinline__ void publish_absmax(const float (&mx)[KS0], int LF, int F, unsigned* __restrict__ level_absmax) {
+  const int lane = ps_lane(), j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < KS0; ++t) {
+    float m = mx[t];
+    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    m = fmaxf(m, __shfl_xor(m, 4, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    const int col = 4 * t + g;
+    if (j == 0 && col < LF && m > 0.0f) atomicMax(level_absmax + col / F, __float_as_uint(m));  // non-negative floats order like uints
+  }
+}
+
 __device__ __forceinline__ float trunc_exp_grad(float raw) { return expf(fminf(fmaxf(raw, -15.0f), 15.0f)); }
 
 // ------------------------------------------------------------------------------------------ proposal field
@@ -126,11 +150,14 @@ template <class M, int PB>
 __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__ feat, int64_t plane_stride, int LF, int F,
                                                        const float* __restrict__ sel, const float* __restrict__ packed,
                                                        const float* __restrict__ dsigma, int64_t N, float* __restrict__ dfeat,
-                                                       float* __restrict__ gpart) {
+                                                       float* __restrict__ gpart, unsigned* __restrict__ level_absmax) {
   static_assert(M::NL == 2 && M::NBO == 1, "proposal MLP: two linear layers, scalar output");
   using L0 = typename M::L0;
   using LZ = typename M::LZ;
   constexpr int H = M::HB * 4;
+  float mx[M::KS0];
+#pragma unroll
+  for (int t = 0; t < M::KS0; ++t) mx[t] = 0.f;
   constexpr int SCR = L0::SCRATCH_ROWS * kScratchLd;
   __shared__ __attribute__((aligned(16))) float lds[4 * SCR];
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
@@ -171,7 +198,9 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
     layer_bwd_weights_acc<L0, PB>(scratch, dw0, db0, dh, x);
     layer_bwd_data<L0, PB>(t0, dh, dx);
     store_dfeat<M::KS0, PB>(dfeat, plane_stride, LF, F, first, N, dx);
+    track_absmax<M::KS0, PB>(dx, mx);
   }
+  if (level_absmax != nullptr) publish_absmax<M::KS0>(mx, LF, F, level_absmax);
   float* out = gpart + ((size_t)blockIdx.x * 4 + wave) * M::GPACKED;
   store_layer_acc<L0>(out + M::GOFF0, dw0, db0);
   // head gradient in the packed layout of a [tile][lane][4] dW block: output row 0 lives in lanes 0..15 (= input row),
@@ -483,13 +512,17 @@ extern "C" int ps_prop_field_fwd(const float* feat, int64_t plane_stride, int LF
 
 extern "C" int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
                                  const float* packed, const float* dsigma, int64_t N, float* dfeat, float* gpart,
-                                 void* stream) {
+                                 uint32_t* level_absmax, void* stream) {
   if (N == 0) return 0;
+  if (level_absmax != nullptr) {
+    hipError_t e = hipMemsetAsync(level_absmax, 0, (size_t)(LF / F) * 4, (hipStream_t)stream);
+    if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
+  }
 #define X(lf, h)                                                                                                     \
   if (LF == lf && hidden == h) {                                                                                     \
     using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;                                                                  \
     prop_bwd_kernel<M, kPropBwdPB><<<grid_for_tiles(N, 16 * kPropBwdPB, kPropBwdBlocks), 256, 0, (hipStream_t)stream>>>(         \
-        feat, plane_stride, LF, F, sel, packed, dsigma, N, dfeat, gpart);                                            \
+        feat, plane_stride, LF, F, sel, packed, dsigma, N, dfeat, gpart, level_absmax);                              \
     PS_CHECK_LAUNCH();                                                                                               \
   }
   PS_PROP_CFGS(X)

@@ -248,10 +248,31 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
   const float* e = ebins + ray * (S + 1);
   // channel-parallel accumulations
   float a_sem = 0.f, a_rgb = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float ws = w[s];
-    if (sem_s != nullptr && lane < C) a_sem += ws * sem_s[(ray * S + s) * C + lane];
-    if (rgb_s != nullptr && lane < 3) a_rgb += ws * rgb_s[(ray * S + s) * 3 + lane];
+  if (sem_s != nullptr || rgb_s != nullptr) {
+    const bool sem_on = sem_s != nullptr && lane < C, rgb_on = rgb_s != nullptr && lane < 3;
+    const float* ps = sem_s + ray * S * C + lane;
+    const float* pr = rgb_s + ray * S * 3 + lane;
+    // 8 sample rows in flight per lane (the rows are independent 256-byte streams; the FMA chain is the only dependency)
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      float v[8], c3[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = sem_on ? ps[(int64_t)(s + k) * C] : 0.0f;
+        c3[k] = rgb_on ? pr[(int64_t)(s + k) * 3] : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float ws = w[s + k];
+        a_sem += ws * v[k];
+        a_rgb += ws * c3[k];
+      }
+    }
+    for (; s < S; ++s) {
+      const float ws = w[s];
+      if (sem_on) a_sem += ws * ps[(int64_t)s * C];
+      if (rgb_on) a_rgb += ws * pr[(int64_t)s * 3];
+    }
   }
   if (sem != nullptr && lane < C) sem[ray * C + lane] = a_sem;
   if (rgb != nullptr && lane < 3) rgb[ray * 3 + lane] = a_rgb;

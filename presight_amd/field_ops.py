@@ -79,8 +79,20 @@ def _workspace(nbytes: int, device) -> Tensor:
     return ws
 
 
+def _binned(N: int) -> bool:
+    return SCATTER_IMPL == "binned" and N * 8 < (1 << 31)
+
+
+def _scatter_ws(g: GridCfg, N: int, device) -> Optional[Tensor]:
+    """workspace of the binned table backward; its first L words receive the per-level max |d(feature)| straight from the
+    field backward kernel (level_absmax argument), which saves the scatter its own pass over d(features)"""
+    if not _binned(N):
+        return None
+    return _workspace(lib().ps_grid_scatter_workspace(g.num_levels, g.features_per_level, g.log2_hashmap_size, N), device)
+
+
 def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape, sink: Optional[Tensor] = None,
-             counts: Optional[Tensor] = None) -> Optional[Tensor]:
+             counts: Optional[Tensor] = None, ws_with_absmax: Optional[Tensor] = None) -> Optional[Tensor]:
     """table gradient; with `sink` (the parameter's pre-allocated .grad, ops.grad_sink) it is ADDED there and None is returned.
     counts: slice record counts from the forward encode of the same points (_encode(count=True))."""
     N = u.shape[0]
@@ -88,10 +100,10 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
     dtable = sink if sink is not None else torch.empty(table_shape, device=u.device, dtype=torch.float32)
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
     with prof.region(f"grid_scatter_L{L}F{F}"):
-        if SCATTER_IMPL == "binned" and N * 8 < (1 << 31):
-            ws = _workspace(lib().ps_grid_scatter_workspace(L, F, l2t, N), u.device)
+        if _binned(N):
+            ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
             check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
-                                               _p(ws), _stream()), "ps_grid_scatter_binned")
+                                               int(ws_with_absmax is not None), _p(ws), _stream()), "ps_grid_scatter_binned")
         else:
             check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _stream()),
                   "ps_grid_scatter")
@@ -145,10 +157,11 @@ class _PropField(torch.autograd.Function):
         assert pf.value == spec.packed and gf.value == spec.g_total
         gpart = torch.empty(npart.value, spec.g_total, device=u.device)
         dfeat = torch.empty_like(feat)
+        ws = _scatter_ws(g, N, u.device)
         with prof.region("prop_field_bwd"):
             check(lib().ps_prop_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
-                                          _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _stream()), "ps_prop_field_bwd")
-        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
+                                          _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _p(ws), _stream()), "ps_prop_field_bwd")
+        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts, ws)
         grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes, ctx.sinks[1])
         mark_touched(ctx.direct)
         return (None, None, dtable, None, None, *flatten_grads(grads))
@@ -266,6 +279,8 @@ def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     gpart = torch.empty(npart.value, spec.g_total, device=dev)
     dfeat = torch.empty_like(feat)
     dapp = torch.zeros_like(app) if app is not None else None
+    # (the per-level |d(feature)| maxima are NOT tracked in this kernel, unlike the proposal backward: at its register
+    #  pressure the 8 extra live values cost more (+0.2 ms) than the separate 0.13 ms absmax pass)
     with prof.region("main_field_bwd"):
         check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                       _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
