@@ -87,3 +87,30 @@ def voxelize(points: Tensor, features: Tensor, colors: Optional[Tensor], voxel: 
         csum = torch.zeros(V, 3, device=points.device, dtype=torch.float64).index_add_(0, inv, colors.double())
         out["colors"] = (csum / hits[:, None]).float()
     return out
+
+
+@torch.no_grad()
+def finalize_priors(vox: dict, origin: Tensor, hit_thr_ratio: float = 0.0) -> dict:
+    """The `extracted_priors.pkl` payload of ns/scripts/extract_priors.py:186-208 from voxelize()'s output: voxels whose hit
+    count exceeds the `hit_thr_ratio` quantile of all hit counts (numpy's linear-interpolation quantile), as numpy arrays
+    {points f32 [V,3], features f16 [V,64], colors f32 [V,3], hits int64 [V], origin f32 [3]} -- the wire format read by
+    occupancy/mmdet3d/datasets/prior_utils/city_prior.py:59-73."""
+    import numpy as np
+
+    hits = vox["hits"].cpu().numpy()
+    keep = hits > np.quantile(hits, hit_thr_ratio)
+    out = {"points": vox["points"].cpu().numpy()[keep].astype(np.float32),
+           "features": vox["features"].cpu().numpy()[keep].astype(np.float16),
+           "hits": hits[keep],
+           "origin": origin.detach().cpu().numpy().astype(np.float32)}
+    if "colors" in vox:
+        out["colors"] = vox["colors"].cpu().numpy()[keep].astype(np.float32)
+    return out
+
+
+def save_priors(path: str, priors: dict) -> None:
+    """pickle.dump of finalize_priors()'s dict (extract_priors.py:199-208)"""
+    import pickle
+
+    with open(path, "wb") as f:
+        pickle.dump(priors, f)

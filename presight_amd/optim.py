@@ -2,7 +2,7 @@
 (ns/engine/optimizers.py:73-170: one Adam per parameter group, lr 1e-2, eps 1e-15, weight_decay 1e-5)."""
 from __future__ import annotations
 
-from typing import Iterable, List
+from typing import Iterable, List, Optional, Sequence
 
 import torch
 
@@ -79,3 +79,34 @@ class HipAdam:
             a.copy_(b)
         for a, b in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
             a.copy_(b)
+
+
+class WarmupMultiStepSchedule:
+    """Learning-rate schedule of the PreSight method configs (ns/engine/my_schedulers.py:50-70 with the arguments of
+    ns/configs/method_configs.py:158-168): torch's ChainedScheduler([LinearLR(start_factor=0.01, total_iters=warmup_steps),
+    MultiStepLR(milestones, gamma=0.33)]) in closed form,
+        lr(t) = lr_init * (0.01 + 0.99 * min(t, warmup) / warmup) * gamma ** #{m in milestones : m <= t},
+    applied to a HipAdam by step(): call once after every optimizer step, like Optimizers.scheduler_step_all."""
+
+    def __init__(self, optimizer: HipAdam, lr_init: Optional[float] = None, max_steps: int = 1000000,
+                 milestones: Sequence[int] = (500000, 750000, 900000), warmup_steps: Optional[int] = None, gamma: float = 0.33,
+                 start_factor: float = 0.01):
+        self.opt = optimizer
+        self.lr_init = optimizer.lr if lr_init is None else lr_init
+        self.milestones = sorted(int(m) for m in milestones)
+        self.warmup = int(warmup_steps) if warmup_steps else 0
+        self.gamma, self.start_factor, self.max_steps = gamma, start_factor, max_steps
+        self.t = 0
+        self.opt.lr = self.lr_at(0)
+
+    def lr_at(self, t: int) -> float:
+        warm = 1.0 if self.warmup <= 0 else self.start_factor + (1.0 - self.start_factor) * min(t, self.warmup) / self.warmup
+        return self.lr_init * warm * self.gamma ** sum(1 for m in self.milestones if m <= t)
+
+    def step(self, step: Optional[int] = None) -> float:
+        self.t = self.t + 1 if step is None else step + 1
+        self.opt.lr = self.lr_at(self.t)
+        return self.opt.lr
+
+    def get_last_lr(self) -> List[float]:
+        return [self.opt.lr]

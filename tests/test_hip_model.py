@@ -161,6 +161,20 @@ def test_voxel_index_and_dense_lattice_query(gold_model):
     assert int(vox["hits"].sum()) == full["points"].shape[0]
     lo = (vox["min_bound"] - 0.2) + vox["index"].double() * 0.4
     assert bool(((vox["points"].double() >= lo - 1e-4) & (vox["points"].double() <= lo + 0.4 + 1e-4)).all())
+    # wire format of extracted_priors.pkl (extract_priors.py:186-208): hit-count quantile filter, dtypes, keys, pickle round trip
+    import pickle
+    import tempfile
+
+    pri = extract.finalize_priors(vox, origin=torch.tensor([1.0, 2.0, 3.0]), hit_thr_ratio=0.25)
+    hits = vox["hits"].cpu().numpy()
+    keep = hits > np.quantile(hits, 0.25)
+    assert set(pri) == {"points", "features", "hits", "origin"} and pri["points"].dtype == np.float32
+    assert pri["features"].dtype == np.float16 and pri["features"].shape == (int(keep.sum()), 64)
+    assert np.array_equal(pri["hits"], hits[keep]) and pri["origin"].dtype == np.float32
+    with tempfile.TemporaryDirectory() as td:
+        extract.save_priors(td + "/extracted_priors.pkl", pri)
+        back = pickle.load(open(td + "/extracted_priors.pkl", "rb"))
+    assert all(np.array_equal(back[k], pri[k]) for k in pri)
 
 
 def test_flat_gradients_and_fused_adam_match_autograd_path(gold_model):

@@ -177,6 +177,30 @@ def test_flat_grads_touched_ranges():
     assert fg.touched_ranges() == [] and float(fg.flat.abs().sum()) == 0.0
 
 
+def test_lr_schedule_matches_torch_chained_scheduler():
+    """WarmupMultiStepSchedule against torch's ChainedScheduler([LinearLR, MultiStepLR]) as built by the reference
+    (ns/engine/my_schedulers.py:50-70), scaled-down step counts"""
+    from torch.optim import lr_scheduler
+
+    from presight_amd.optim import WarmupMultiStepSchedule
+
+    class _Opt:  # stands in for HipAdam: the schedule only touches .lr
+        lr = 1e-2
+
+    max_steps = 400
+    ms, warm = [max_steps // 4, max_steps // 2, max_steps * 3 // 4], max_steps // 10
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.Adam([p], lr=1e-2)
+    ref = lr_scheduler.ChainedScheduler([lr_scheduler.LinearLR(ref_opt, start_factor=0.01, total_iters=warm),
+                                         lr_scheduler.MultiStepLR(ref_opt, milestones=ms, gamma=0.33)])
+    ours = WarmupMultiStepSchedule(_Opt(), max_steps=max_steps, milestones=ms, warmup_steps=warm)
+    for t in range(max_steps):
+        assert abs(ours.opt.lr - ref_opt.param_groups[0]["lr"]) <= 1e-9 * 1e-2 + 1e-15, (t, ours.opt.lr, ref_opt.param_groups[0]["lr"])
+        ref_opt.step()
+        ref.step()
+        ours.step()
+
+
 def test_hip_ops_refuse_cpu_tensors():
     """No CPU fallback: the product path fails loudly when handed CPU tensors."""
     from presight_amd import field_ops, ops
