@@ -146,6 +146,14 @@ int ps_mse_loss(const float* pred, const float* target, int64_t n, int clip_targ
 int ps_sky_bce_loss(const float* acc, const float* sky_mask, int64_t R, float eps, float* partial, float* dacc,
                     void* stream);
 
+/* data feed: collate one batch from a device-resident ImageChunk (ns/data/PreSight/my_dataset.py:28-73): pick int64 [R]
+ * = drawn pixel slots; chunk arrays rgbs [P,3], skies/depths [P] (nullable), features [P,C] (nullable), pixel_indices /
+ * image_indices / video_ids / widths int64 [P]; ray_indices [R,3] = (image, pixel // width, pixel % width) */
+int ps_gather_batch(const int64_t* pick, int64_t R, const float* rgbs, const float* skies, const float* depths,
+                    const float* features, int C, const int64_t* pixel_indices, const int64_t* image_indices,
+                    const int64_t* video_ids, const int64_t* widths, int64_t* ray_indices, float* o_rgb, float* o_sky,
+                    float* o_depth, float* o_feat, int64_t* o_video, void* stream);
+
 /* ---- field level (fused) -------------------------------------------------------------------------
  * A field evaluation is:  ps_field_points -> ps_grid_encode -> ps_{prop,main}_field_fwd, and backward
  * ps_{prop,main}_field_bwd -> ps_grid_scatter.  Features travel as level planes feat[l][n][f]

@@ -135,6 +135,37 @@ __global__ __launch_bounds__(256) void sky_bce_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+
+// ---- data feed: one training batch out of a device-resident pixel chunk ---------------------------
+// ns/data/PreSight/my_dataset.py:52-73 (ImageChunk.__getitem__) + the DataLoader's collate: for every drawn pixel id
+// gather rgb / sky / depth / features / video id and form ray_index = (image, pixel // width, pixel % width).
+// One wavefront per ray: lane = feature channel (C <= 64), so the 256-byte feature row is one coalesced load.
+__global__ __launch_bounds__(256) void gather_batch_kernel(const int64_t* __restrict__ pick, int64_t R, const float* __restrict__ rgbs,
+                                                           const float* __restrict__ skies, const float* __restrict__ depths,
+                                                           const float* __restrict__ features, int C,
+                                                           const int64_t* __restrict__ pixel_indices,
+                                                           const int64_t* __restrict__ image_indices,
+                                                           const int64_t* __restrict__ video_ids, const int64_t* __restrict__ widths,
+                                                           int64_t* __restrict__ ray_indices, float* __restrict__ o_rgb,
+                                                           float* __restrict__ o_sky, float* __restrict__ o_depth,
+                                                           float* __restrict__ o_feat, int64_t* __restrict__ o_video) {
+  const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = ps_lane();
+  const int64_t i = pick[r];
+  if (features != nullptr && lane < C) o_feat[r * C + lane] = features[i * C + lane];
+  if (lane < 3) o_rgb[r * 3 + lane] = rgbs[i * 3 + lane];
+  if (lane == 0) {
+    const int64_t px = pixel_indices[i], w = widths[i];
+    ray_indices[r * 3] = image_indices[i];
+    ray_indices[r * 3 + 1] = px / w;
+    ray_indices[r * 3 + 2] = px % w;
+    if (skies != nullptr) o_sky[r] = skies[i];
+    if (depths != nullptr) o_depth[r] = depths[i];
+    o_video[r] = video_ids[i];
+  }
+}
+
 }  // namespace
 
 extern "C" int ps_embedding_fwd(const int64_t* idx, const float* table, int64_t R, int D, int out_stride, int col0, float* out,
@@ -189,5 +220,17 @@ extern "C" int ps_sky_bce_loss(const float* acc, const float* sky_mask, int64_t 
                                void* stream) {
   PS_REQUIRE(R > 0, "ps_sky_bce_loss: empty input");
   sky_bce_kernel<<<ps_loss_partials(R), 256, 0, (hipStream_t)stream>>>(acc, sky_mask, R, eps, partial, dacc);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_gather_batch(const int64_t* pick, int64_t R, const float* rgbs, const float* skies, const float* depths,
+                               const float* features, int C, const int64_t* pixel_indices, const int64_t* image_indices,
+                               const int64_t* video_ids, const int64_t* widths, int64_t* ray_indices, float* o_rgb, float* o_sky,
+                               float* o_depth, float* o_feat, int64_t* o_video, void* stream) {
+  PS_REQUIRE(C <= 64, "ps_gather_batch: at most 64 feature channels");
+  if (R == 0) return 0;
+  gather_batch_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(pick, R, rgbs, skies, depths, features, C,
+                                                                               pixel_indices, image_indices, video_ids, widths,
+                                                                               ray_indices, o_rgb, o_sky, o_depth, o_feat, o_video);
   PS_CHECK_LAUNCH();
 }

@@ -283,3 +283,25 @@ def test_adam_matches_torch_optim(dev):
         hip.step()
     for a, b in zip(ref_p, hip_p):
         close(b, a.detach(), rtol=2e-5, atol=1e-6)
+
+
+def test_device_data_feed_matches_per_pixel_getitem(dev):
+    """DeviceImageChunk.gather == collating ImageChunk.__getitem__ (ns/data/PreSight/my_dataset.py:52-73) pixel by pixel"""
+    from presight_amd.datafeed import DeviceImageChunk
+
+    g = torch.Generator().manual_seed(4)
+    P, W, H = 5000, 1600, 900
+    chunk = dict(rgbs=torch.rand(P, 3, generator=g), skies=(torch.rand(P, generator=g) < 0.2).float(), depths=torch.rand(P, generator=g) * 80,
+                 features=torch.rand(P, 64, generator=g), pixel_indices=torch.randint(0, W * H, (P,), generator=g),
+                 image_indices=torch.randint(0, 1440, (P,), generator=g), video_ids=torch.randint(0, 6, (P,), generator=g),
+                 widths=torch.full((P,), W))
+    dc = DeviceImageChunk(**{k: v.to(dev) for k, v in chunk.items()})
+    pick = torch.randint(0, P, (777,), generator=g)
+    b = dc.gather(pick.to(dev))
+    ri = torch.stack([chunk["image_indices"][pick], chunk["pixel_indices"][pick] // W, chunk["pixel_indices"][pick] % W], -1)
+    assert torch.equal(b["ray_indices"].cpu(), ri)
+    assert torch.equal(b["rgb"].cpu(), chunk["rgbs"][pick]) and torch.equal(b["features"].cpu(), chunk["features"][pick])
+    assert torch.equal(b["sky"].cpu(), chunk["skies"][pick]) and torch.equal(b["depth"].cpu(), chunk["depths"][pick])
+    assert torch.equal(b["video_id"].cpu(), chunk["video_ids"][pick])
+    s = dc.sample_batch(1000)
+    assert s["ray_indices"].shape == (1000, 3) and int(s["ray_indices"][:, 2].max()) < W and int(s["ray_indices"][:, 1].max()) < H
