@@ -45,6 +45,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it brings its own copy of the HIP runtime, and the library must bind to THAT instance (the one that owns
+    # torch's device context and streams); loaded the other way round the process ends up with two runtimes and every
+    # launch from here fails with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise PresightHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
