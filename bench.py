@@ -189,9 +189,61 @@ def cpu_baseline(seconds_budget=25.0):
     dt = (time.time() - t0) / n
     used = torch.get_num_threads()
     torch.set_num_threads(max_threads)
+    global _PSNR_VS_ORACLE
+    _PSNR_VS_ORACLE = psnr_vs_oracle(O, cfg, scene)
     return dict(value=rays / dt, unit="rays/s", cores=used, kind="port",
                 sample=f"{n} full training steps (fwd + 5 losses + bwd, no optimizer) of {rays} rays, cfg-2 tables, torch-CPU oracle, "
                        f"{used} threads (best of 8/16/32; host has {os.cpu_count()} logical CPUs)")
+
+
+_PSNR_VS_ORACLE = None
+
+
+def psnr_vs_oracle(O, cfg, scene, rays=1024):
+    """"PSNR vs ref" half of BASELINE.json's metric: the HIP model and the CPU oracle render the same rays
+    (eval mode: no jitter, mean appearance code) from the same cfg-2 parameters; PSNR = 10 log10(1 / MSE) of the RGB
+    difference, plus the largest semantics / expected-depth deviations.  Tables are drawn 300x wider than the init so that
+    the rendering is not a constant."""
+    from presight_amd import ops
+    from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
+    from presight_amd.rays import RayBundle
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    P = O.make_params(cfg, seed=5, table_scale=0.3)
+    P["field.fields.0.mlp_base_mlp.layers.1.bias"][0] = -1.0
+    batch = O.make_batch(cfg, scene, rays, step=99)
+    with torch.no_grad():
+        ref = O.model_forward(P, cfg, scene, batch, training=False)
+    m = cfg["main"]
+    conf = NerfactoNuscMSModelConfig(
+        near_plane=cfg["near"], far_plane=cfg["far"], piecewise_sampler_threshold=cfg["thr"], hidden_dim=m["hidden_dim"],
+        hidden_dim_color=m["hidden_dim_color"], num_levels=m["num_levels"], base_res=m["base_res"], max_res=m["max_res"],
+        log2_hashmap_size=m["log2_hashmap_size"], features_per_level=m["features_per_level"], use_lidar_loss=False,
+        proposal_net_args_list=[dict(features_per_level=p["features_per_level"], log2_hashmap_size=p["log2_hashmap_size"],
+                                     num_levels=p["num_levels"], base_res=p["base_res"], max_res=p["max_res"],
+                                     hidden_dim=p["hidden_dim"], use_linear=False) for p in cfg["props"]],
+        implementation="hip")
+    model = NerfactoNuscMSModel(conf, num_train_cameras=cfg["num_cameras"], num_train_videos=cfg["num_videos"], dino_to_rgb=None,
+                                centroids=scene["centroids"], aabbs=scene["aabbs"])
+    sd = dict(model.state_dict())
+    for k, v in P.items():
+        sd[k] = v
+        for alias in (k.replace("mlp_base_grid.", "mlp_base.0.").replace("mlp_base_mlp.", "mlp_base.1."),
+                      k.replace("encoding.hash_table", "mlp_base.0.hash_table")):
+            if alias in sd:
+                sd[alias] = v
+    model.load_state_dict(sd)
+    model.to(dev).eval()
+    ri = batch["ray_indices"].to(dev)
+    o, d, pa, dn = ops.generate_rays(ri, *(scene[k].to(dev) for k in ("c2w", "fx", "fy", "cx", "cy")))
+    with torch.no_grad():
+        out = model(RayBundle(o, d, pa, camera_indices=ri[:, 0:1], metadata={"video_id": batch["video_ids"].to(dev)[:, None]}))
+    mse = float(((out["rgb"].cpu() - ref["rgb"]) ** 2).mean())
+    return {"psnr_db": 10.0 * __import__("math").log10(1.0 / max(mse, 1e-30)), "rays": rays,
+            "rgb_std": float(ref["rgb"].std()),
+            "max_abs_semantics": float((out["semantics"].cpu() - ref["semantics"]).abs().max()),
+            "max_rel_expected_depth": float(((out["expected_depth"].cpu() - ref["expected_depth"]).abs()
+                                             / ref["expected_depth"].abs().clamp_min(1e-6)).max())}
 
 
 def main():
@@ -286,11 +338,12 @@ def main():
             "value_reference_schedule": world * RAYS * n_sched / dt_sched,
             "replicas_max_abs_diff": replica_diff,
             "psnr_vs_random_targets": psnr,
-            "loss": float(sum(loss_dict.values())),
+            "loss": float(sum(v.detach() for v in loss_dict.values())),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
+            line["psnr_vs_oracle"] = _PSNR_VS_ORACLE
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
