@@ -89,13 +89,14 @@ __device__ __forceinline__ float trunc_exp_grad(float raw) { return expf(fminf(f
 // In the D-register layout lane (j, g) already holds the 16 hidden neurons {16*nb + 4*g + r} of point j, so
 //     z_j   = b + sum over the 4 lane groups of  sum_t wz_g[t] * h_g[t]        (16 FMAs + 2 cross-lane adds)
 //     dh[t] = wz_g[t] * dz_j,      dWz_g[t] += h_g[t] * dz_j                   (no cross-lane traffic until the end)
-// wz_g[t] is element (lane 16*g) of the packed forward fragment t of that layer (row 0 of the A operand).
+// wz_g[t] is element (lane 16*g) of the packed forward fragment t of that layer (row 0 of the A operand; fragments are
+// stored [t/4][lane][t%4]).
 template <class M, class W>
 __device__ __forceinline__ void load_scalar_head(const W& pz, float (&wz)[M::HB * 4], float& bz) {
   using LZ = typename M::LZ;
   const unsigned g = (unsigned)ps_lane() >> 4;
 #pragma unroll
-  for (int t = 0; t < M::HB * 4; ++t) wz[t] = pz.elem(LZ::WF_OFF + t * 64, 16u * g);
+  for (int t = 0; t < M::HB * 4; ++t) wz[t] = pz.elem(LZ::WF_OFF + (t >> 2) * 256 + (t & 3), 64u * g);  // fragment (t, lane 16g)
   bz = pz.elem(LZ::BIAS_OFF, 0u);
 }
 

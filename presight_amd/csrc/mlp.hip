@@ -15,21 +15,24 @@ using namespace ps;
 __device__ __forceinline__ void pack_layer(const float* __restrict__ W, const float* __restrict__ b, int out_dim, int in_dim,
                                            const int* __restrict__ colmap, int KS, int NB, float* __restrict__ fw_block,
                                            float* __restrict__ wt_block) {
-  const int IB = (KS + 3) / 4, KSO = NB * 4;
-  const int n_bias = NB * 16, n_wf = NB * KS * 64, n_wt = IB * KSO * 64;
+  const int IB = (KS + 3) / 4;
+  const int n_bias = NB * 16, n_wf = NB * IB * 256, n_wt = IB * NB * 256;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_bias + n_wf + n_wt; i += gridDim.x * blockDim.x) {
     if (i < n_bias) {
       fw_block[i] = (i < out_dim) ? b[i] : 0.0f;
     } else if (i < n_bias + n_wf) {
+      // wf[nb][q][lane][r]: A-operand fragment of k-step t = 4q+r (zero beyond KS)
       const int e = i - n_bias;
-      const int lane = e & 63, t = (e >> 6) % KS, nb = (e >> 6) / KS;
+      const int r = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % IB, nb = (e >> 8) / IB;
+      const int t = 4 * q + r;
       const int o = 16 * nb + (lane & 15);
-      const int col = colmap[t * 4 + (lane >> 4)];
+      const int col = (t < KS) ? colmap[t * 4 + (lane >> 4)] : -1;
       fw_block[i] = (o < out_dim && col >= 0 && col < in_dim) ? W[(size_t)o * in_dim + col] : 0.0f;
     } else {
+      // wtf[ib][q][lane][r]: transposed fragment of k-step t = 4q+r over the outputs
       const int e = i - n_bias - n_wf;
-      const int lane = e & 63, t = (e >> 6) % KSO, ib = (e >> 6) / KSO;
-      const int o = 16 * (t >> 2) + 4 * (lane >> 4) + (t & 3);
+      const int r = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % NB, ib = (e >> 8) / NB;
+      const int o = 16 * q + 4 * (lane >> 4) + r;
       const int row = lane & 15;
       const int tin = 4 * ib + (row & 3);
       const int col = (tin < KS) ? colmap[tin * 4 + (row >> 2)] : -1;
@@ -305,7 +308,7 @@ extern "C" int ps_mlp_sizes(int in_dim, int hidden, int out_dim, int num_layers,
 extern "C" int ps_mlp_pack_layer(const float* W, const float* b, int out_dim, int in_dim, const int* colmap, int KS, int NB,
                                  float* fw_block, float* wt_block, void* stream) {
   const int IB = (KS + 3) / 4;
-  const int total = NB * 16 + NB * KS * 64 + IB * NB * 4 * 64;
+  const int total = NB * 16 + 2 * NB * IB * 256;
   mlp_pack_layer_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(W, b, out_dim, in_dim, colmap, KS, NB, fw_block,
                                                                               wt_block);
   PS_CHECK_LAUNCH();
@@ -330,7 +333,7 @@ extern "C" int ps_mlp_pack_layers(int n_layers, const float* const* W, const flo
   for (int i = 0; i < n_layers; ++i) {
     a.l[i] = LayerDesc{W[i], b[i], colmap[i], fw_block[i], wt_block[i], out_dim[i], in_dim[i], KS[i], NB[i]};
     const int IB = (KS[i] + 3) / 4;
-    total = max(total, NB[i] * 16 + NB[i] * KS[i] * 64 + IB * NB[i] * 4 * 64);
+    total = max(total, NB[i] * 16 + 2 * NB[i] * IB * 256);
   }
   mlp_pack_layers_kernel<<<dim3((total + 255) / 256, n_layers), 256, 0, (hipStream_t)stream>>>(a);
   PS_CHECK_LAUNCH();

@@ -11,12 +11,13 @@
 // one layer are *directly* the B operands of the next one: k-step t = 4*nb + r pairs the neurons
 // {16*nb + 4*g + r : g = 0..3}.  Activations therefore never leave registers between layers; only
 // the (tiny) weights are re-arranged, once per step, by the pack kernel into "fragment order"
-//     wf[nb][t][lane] = W[16*nb + (lane&15)][colmap(t, lane>>4)]
-// so that every MFMA A operand is one coalesced 256-byte wave load.  `colmap(t, g)` is the torch
+//     wf[nb][t/4][lane][t%4] = W[16*nb + (lane&15)][colmap(t, lane>>4)]
+// so that the A operands of FOUR consecutive k-steps are one 16-byte load per lane (one coalesced 1-KiB wave load:
+// ds_read_b128 from LDS, buffer_load_dwordx4 from L2 -- a quarter of the load instructions of a per-k-step layout).  `colmap(t, g)` is the torch
 // input column that group g supplies at k-step t; for chained layers it is 16*(t/4)+4*g+t%4.
 //
 // Backward.  dX^T = W^T dY^T uses the same trick with transposed fragments
-//     wtf[ib][t][lane] = W[16*(t/4) + 4*(lane>>4) + t%4][colmap(4*ib + (lane&3), (lane&15)>>2)]
+//     wtf[ib][t/4][lane][t%4] = W[16*(t/4) + 4*(lane>>4) + t%4][colmap(4*ib + (lane&3), (lane&15)>>2)]
 // and yields dX in exactly the register layout the forward input had.  dW = dY^T H contracts over
 // points, which needs "lane = neuron" operands; both tiles take one trip through a small per-wave
 // LDS scratch (written 4 bytes/lane, read back 16 bytes/lane), and the 16x16 dW tiles are
@@ -35,11 +36,11 @@ struct LayerT {
   static constexpr int NB = NB_;             // 16-neuron output blocks
   static constexpr int IB = (KS_ + 3) / 4;   // 16-row blocks of dX / columns of dW
   static constexpr int KSO = NB_ * 4;        // k-steps over the outputs (backward data)
-  // forward block: bias[NB*16] | wf[NB][KS][64];  transposed block: wtf[IB][KSO][64]  (floats)
+  // forward block: bias[NB*16] | wf[NB][IB][64][4] (k-steps padded to a multiple of 4);  transposed block: wtf[IB][NB][64][4]
   static constexpr int BIAS_OFF = 0;
   static constexpr int WF_OFF = NB_ * 16;
-  static constexpr int FW = WF_OFF + NB_ * KS_ * 64;
-  static constexpr int WT = IB * KSO * 64;
+  static constexpr int FW = WF_OFF + NB_ * IB * 256;
+  static constexpr int WT = IB * NB_ * 256;
   // packed gradient block: dW tiles in MFMA D layout ([tile = ob*IB+ib][lane][r]), then the bias gradient
   static constexpr int GW_OFF = 0;
   static constexpr int GB_OFF = NB_ * IB * 256;
@@ -53,7 +54,7 @@ constexpr int kScratchLd = 20;  // floats per scratch row: 16 points + 4 pad (ke
 // Forward-only kernels keep the packed forward blocks in LDS (ds_read with an immediate offset).
 struct LdsW {
   const float* base;
-  __device__ __forceinline__ float frag(int float_off) const { return base[float_off + ps_lane()]; }
+  __device__ __forceinline__ f32x4 frag4(int float_off) const { return *reinterpret_cast<const f32x4*>(base + float_off + 4 * ps_lane()); }
   __device__ __forceinline__ f32x4 vec4(int float_off) const { return *reinterpret_cast<const f32x4*>(base + float_off); }
   __device__ __forceinline__ float elem(int float_off, unsigned lane_float_off) const { return base[float_off + lane_float_off]; }
   __device__ __forceinline__ LdsW at(int float_off) const { return LdsW{base + float_off}; }
@@ -65,8 +66,13 @@ struct LdsW {
 struct GlobalW {
   __amdgpu_buffer_rsrc_t rsrc;
   int base;  // float offset inside the buffer
-  __device__ __forceinline__ float frag(int float_off) const {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)ps_lane() * 4u, (base + float_off) * 4, 0));
+  __device__ __forceinline__ f32x4 frag4(int float_off) const {
+#if defined(PS_ABLATE) && PS_ABLATE == 9  // timing only: no weight-fragment traffic from L2 (how much of the kernel is its latency?)
+    const float v = (float)((ps_lane() + float_off) & 7) * 0.01f;
+    return (f32x4){v, v, v, v};
+#else
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)ps_lane() * 16u, (base + float_off) * 4, 0));
+#endif
   }
   __device__ __forceinline__ f32x4 vec4(int float_off) const {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0u, (base + float_off) * 4, 0));
@@ -89,12 +95,21 @@ __device__ __forceinline__ GlobalW make_global_w(const float* p, unsigned n_floa
 template <class LT, class W>
 __device__ __forceinline__ void first_frags_fwd(const W& params, float (&a)[LT::KS]) {
 #pragma unroll
-  for (int t = 0; t < LT::KS; ++t) a[t] = params.frag(LT::WF_OFF + t * 64);
+  for (int q = 0; q < LT::IB; ++q) {
+    const f32x4 v = params.frag4(LT::WF_OFF + q * 256);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * q + r < LT::KS) a[4 * q + r] = v[r];
+  }
 }
 template <class LT, class W>
 __device__ __forceinline__ void first_frags_bwd(const W& wt_block, float (&a)[LT::KSO]) {
 #pragma unroll
-  for (int t = 0; t < LT::KSO; ++t) a[t] = wt_block.frag(t * 64);
+  for (int q = 0; q < LT::NB; ++q) {
+    const f32x4 v = wt_block.frag4(q * 256);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[4 * q + r] = v[r];
+  }
 }
 struct NoPrefetch {
   __device__ __forceinline__ void operator()() const {}
@@ -123,7 +138,12 @@ __device__ __forceinline__ void layer_fwd_pf(const W& params, const float (&a_fi
       b4 = params.vec4_lane(LT::BIAS_OFF + 16 * nb, 4u * (unsigned)g);
     if (nb + 1 < LT::NB) {
 #pragma unroll
-      for (int t = 0; t < LT::KS; ++t) a_nxt[t] = params.frag(LT::WF_OFF + ((nb + 1) * LT::KS + t) * 64);
+      for (int q = 0; q < LT::IB; ++q) {
+        const f32x4 v = params.frag4(LT::WF_OFF + ((nb + 1) * LT::IB + q) * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * q + r < LT::KS) a_nxt[4 * q + r] = v[r];
+      }
     } else {
       next();
     }
@@ -197,7 +217,11 @@ __device__ __forceinline__ void layer_bwd_data_pf(const W& wt_block, const float
   for (int ib = 0; ib < LT::IB; ++ib) {
     if (ib + 1 < LT::IB) {
 #pragma unroll
-      for (int t = 0; t < LT::KSO; ++t) a_nxt[t] = wt_block.frag(((ib + 1) * LT::KSO + t) * 64);
+      for (int q = 0; q < LT::NB; ++q) {
+        const f32x4 v = wt_block.frag4(((ib + 1) * LT::NB + q) * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a_nxt[4 * q + r] = v[r];
+      }
     } else {
       next();
     }

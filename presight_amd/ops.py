@@ -99,7 +99,7 @@ class MlpSpec:
         self.ib = [(k + 3) // 4 for k in self.ks]
         self.colmaps = [first_colmap if first_colmap is not None else linear_colmap(self.ks[0], dims[0])]
         self.colmaps += [chain_colmap(self.ks[i], dims[i]) for i in range(1, self.nl)]
-        self.fw = [nb * 16 + nb * ks * 64 for nb, ks in zip(self.nb, self.ks)]
+        self.fw = [nb * 16 + nb * ib * 256 for nb, ib in zip(self.nb, self.ib)]  # k-steps stored in groups of 4 (one 16-B load/lane)
         self.wt = [ib * nb * 4 * 64 for ib, nb in zip(self.ib, self.nb)]
         self.g = [nb * ib * 256 + nb * 16 for nb, ib in zip(self.nb, self.ib)]
         self.fw_off = [sum(self.fw[:i]) for i in range(self.nl)]
