@@ -434,7 +434,11 @@ __global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           dzb[pb][t] += dcin[pb][4 + t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
+#if defined(PS_ABLATE) && PS_ABLATE == 11  // timing only: no d(appearance) atomics
+          if (false) {
+#else
           if (a.dapp != nullptr) {
+#endif
             const int c = 4 * t + g;
             float v = (p < a.N) ? dcin[pb][8 + t] : 0.0f;
             if (block_in_ray) {
@@ -450,7 +454,11 @@ __global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
     // ---- base MLP backward -> d(features)
     float dx[PB][C::Base::L0::IB * 4];
     mlp_backward<typename C::Base, PB, true>(pk_base, scratch, gacc + C::G_BASE, locks + 0, x, h1, hdummy, dzb, dx);
+#if defined(PS_ABLATE) && PS_ABLATE == 10  // timing only: no d(feature) stores
+    asm volatile("" ::"v"(dx[0][0]), "v"(dx[1][0]), "v"(dx[0][7]), "v"(dx[1][7]), "v"(dx[0][3]), "v"(dx[1][4]));
+#else
     store_dfeat<C::Base::KS0, PB>(a.dfeat, a.plane_stride, a.LF, a.F, first, a.N, dx);
+#endif
   }
   __syncthreads();
   float* out = a.gpart + (size_t)blockIdx.x * C::GPACKED;

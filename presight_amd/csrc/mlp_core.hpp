@@ -92,15 +92,29 @@ __device__ __forceinline__ GlobalW make_global_w(const float* p, unsigned n_floa
 // ---- forward -------------------------------------------------------------------------------
 // v[pb][t] is the B-operand array of a 16-point block: for D-chained data t = 4*nb + r.
 // fragments of output block 0 (issued early by the caller so that their latency hides under earlier work)
+// fragments + bias of one output block (what the MFMAs of that block consume)
+template <class LT>
+struct FwdFrags {
+  float a[LT::KS];
+  f32x4 b;  // bias of the lane's 4 neurons (D-register rows 4g..4g+3 of the block)
+};
 template <class LT, class W>
-__device__ __forceinline__ void first_frags_fwd(const W& params, float (&a)[LT::KS]) {
+__device__ __forceinline__ void fetch_fwd(const W& params, int nb, FwdFrags<LT>& f) {
+  if constexpr (std::is_same<W, LdsW>::value)
+    f.b = params.vec4(LT::BIAS_OFF + 16 * nb + 4 * (ps_lane() >> 4));
+  else
+    f.b = params.vec4_lane(LT::BIAS_OFF + 16 * nb, 4u * ((unsigned)ps_lane() >> 4));
 #pragma unroll
   for (int q = 0; q < LT::IB; ++q) {
-    const f32x4 v = params.frag4(LT::WF_OFF + q * 256);
+    const f32x4 v = params.frag4(LT::WF_OFF + (nb * LT::IB + q) * 256);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (4 * q + r < LT::KS) a[4 * q + r] = v[r];
+      if (4 * q + r < LT::KS) f.a[4 * q + r] = v[r];
   }
+}
+template <class LT, class W>
+__device__ __forceinline__ void first_frags_fwd(const W& params, FwdFrags<LT>& f) {
+  fetch_fwd<LT>(params, 0, f);
 }
 template <class LT, class W>
 __device__ __forceinline__ void first_frags_bwd(const W& wt_block, float (&a)[LT::KSO]) {
@@ -115,74 +129,57 @@ struct NoPrefetch {
   __device__ __forceinline__ void operator()() const {}
 };
 
-// `a_first`: fragments of block 0, already requested.  `next()` is invoked before the MFMAs of the LAST block and may
-// issue the first fragment loads of whatever runs next.
+// `first`: fragments + bias of block 0, already requested.  `next()` is invoked before the MFMAs of the LAST block and may
+// issue the first loads of whatever runs next.
 template <class LT, int PB, class W, class Next>
-__device__ __forceinline__ void layer_fwd_pf(const W& params, const float (&a_first)[LT::KS], const float (&vin)[PB][LT::KS],
+__device__ __forceinline__ void layer_fwd_pf(const W& params, const FwdFrags<LT>& first, const float (&vin)[PB][LT::KS],
                                              float (&vout)[PB][LT::NB * 4], const Next& next) {
-  const int lane = ps_lane();
-  const int g = lane >> 4;
-  // Weight fragments are fetched one output block ahead: the loads of block nb+1 are issued (and fenced with a
-  // scheduling barrier) BEFORE the MFMAs of block nb, so their L2/LDS latency hides under 16*PB matrix ops.
-  // (Left to itself hipcc serialises  load -> s_waitcnt vmcnt(0) -> mfma  per k-step: 12x slower, measured.)
-  float a_cur[LT::KS], a_nxt[LT::KS];
-#pragma unroll
-  for (int t = 0; t < LT::KS; ++t) a_cur[t] = a_first[t];
+  // Weight fragments AND the bias are fetched one output block ahead: the loads of block nb+1 are issued (and fenced with
+  // a scheduling barrier) BEFORE the MFMAs of block nb, so their L2/LDS latency hides under 16*PB matrix ops.
+  // (Left to itself hipcc serialises  load -> s_waitcnt vmcnt(0) -> mfma  per k-step: 12x slower, measured; and a bias
+  // fetched at the top of its own block -- it initialises the accumulators -- exposed one L2 round trip per block:
+  // 1.7 ms of the main backward.)
+  FwdFrags<LT> cur = first, nxt;
 #pragma unroll
   for (int nb = 0; nb < LT::NB; ++nb) {
     f32x4 acc[PB];
-    f32x4 b4;
-    if constexpr (std::is_same<W, LdsW>::value)
-      b4 = params.vec4(LT::BIAS_OFF + 16 * nb + 4 * g);
+    if (nb + 1 < LT::NB)
+      fetch_fwd<LT>(params, nb + 1, nxt);
     else
-      b4 = params.vec4_lane(LT::BIAS_OFF + 16 * nb, 4u * (unsigned)g);
-    if (nb + 1 < LT::NB) {
-#pragma unroll
-      for (int q = 0; q < LT::IB; ++q) {
-        const f32x4 v = params.frag4(LT::WF_OFF + ((nb + 1) * LT::IB + q) * 256);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (4 * q + r < LT::KS) a_nxt[4 * q + r] = v[r];
-      }
-    } else {
       next();
-    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PB == 1) {
       // a single accumulator would serialise on the 40-cycle MFMA dependency: split the k-steps over two
       f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[0] = b4;
+      acc[0] = cur.b;
 #pragma unroll
       for (int t = 0; t < LT::KS; ++t) {
         if (t & 1)
-          acc2 = ps_mfma16(a_cur[t], vin[0][t], acc2);
+          acc2 = ps_mfma16(cur.a[t], vin[0][t], acc2);
         else
-          acc[0] = ps_mfma16(a_cur[t], vin[0][t], acc[0]);
+          acc[0] = ps_mfma16(cur.a[t], vin[0][t], acc[0]);
       }
       acc[0] += acc2;
     } else {
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) acc[pb] = b4;
+      for (int pb = 0; pb < PB; ++pb) acc[pb] = cur.b;
 #pragma unroll
       for (int t = 0; t < LT::KS; ++t)
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) acc[pb] = ps_mfma16(a_cur[t], vin[pb][t], acc[pb]);
+        for (int pb = 0; pb < PB; ++pb) acc[pb] = ps_mfma16(cur.a[t], vin[pb][t], acc[pb]);
     }
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) vout[pb][4 * nb + r] = acc[pb][r];
-    if (nb + 1 < LT::NB) {
-#pragma unroll
-      for (int t = 0; t < LT::KS; ++t) a_cur[t] = a_nxt[t];
-    }
+    if (nb + 1 < LT::NB) cur = nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 template <class LT, int PB, class W>
 __device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB][LT::KS], float (&vout)[PB][LT::NB * 4]) {
-  float a0[LT::KS];
+  FwdFrags<LT> a0;
   first_frags_fwd<LT>(params, a0);
   layer_fwd_pf<LT, PB>(params, a0, vin, vout, NoPrefetch());
 }
@@ -472,10 +469,11 @@ __device__ __forceinline__ void mlp_forward(const W& params, const float (&x)[PB
   using L1 = typename M::L1;
   using LZ = typename M::LZ;
   const W p0 = params.at(M::OFF0), p1 = params.at(M::OFF1), pz = params.at(M::OFFZ);
-  float a0[L0::KS], az[LZ::KS];
+  FwdFrags<L0> a0;
+  FwdFrags<LZ> az;
   first_frags_fwd<L0>(p0, a0);
   if constexpr (M::NL == 3) {
-    float a1[L1::KS];
+    FwdFrags<L1> a1;
     layer_fwd_pf<L0, PB>(p0, a0, x, h1, [&]() { first_frags_fwd<L1>(p1, a1); });
     relu_inplace<PB, M::HB * 4>(h1);
     layer_fwd_pf<L1, PB>(p1, a1, h1, h2, [&]() { first_frags_fwd<LZ>(pz, az); });
