@@ -280,20 +280,23 @@ __device__ __forceinline__ void build_colour_input(const MainArgs& a, int64_t fi
   }
 }
 
-template <class C, int PB>
-__global__ __launch_bounds__(256) void main_fwd_kernel(MainArgs a) {
+// NW waves per workgroup share ONE copy of the packed forward weights in LDS (112 KB: one workgroup per CU).  With NW = 8 and
+// PB = 2 a wave needs < 256 registers, so every SIMD holds TWO waves that fill each other's MFMA issue gaps (4 waves x PB = 4
+// ran the matrix pipe at 68 %).
+template <class C, int PB, int NW>
+__global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[C::FW];
   // forward blocks of the three MLPs, contiguous in LDS
-  for (int i = threadIdx.x * 4; i < C::Base::FW; i += 1024)
+  for (int i = threadIdx.x * 4; i < C::Base::FW; i += NW * 256)
     *reinterpret_cast<f32x4*>(lds + C::FW_BASE + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_BASE + i);
-  for (int i = threadIdx.x * 4; i < C::Sem::FW; i += 1024)
+  for (int i = threadIdx.x * 4; i < C::Sem::FW; i += NW * 256)
     *reinterpret_cast<f32x4*>(lds + C::FW_SEM + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_SEM + i);
-  for (int i = threadIdx.x * 4; i < C::Rgb::FW; i += 1024)
+  for (int i = threadIdx.x * 4; i < C::Rgb::FW; i += NW * 256)
     *reinterpret_cast<f32x4*>(lds + C::FW_RGB + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_RGB + i);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
   const int64_t tiles = (a.N + 16 * PB - 1) / (16 * PB);
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < tiles; tile += (int64_t)gridDim.x * NW) {
     const int64_t first = tile * 16 * PB;
     float zb[PB][20];
     {
@@ -465,6 +468,14 @@ __global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
   for (int i = threadIdx.x; i < C::GPACKED; i += 256) out[i] = gacc[i];
 }
 
+int grid_for_tiles_nw(int64_t N, int pts_per_tile, int waves, int max_blocks) {
+  const int64_t tiles = (N + pts_per_tile - 1) / pts_per_tile;
+  int64_t g = (tiles + waves - 1) / waves;
+  if (g > max_blocks) g = max_blocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 int grid_for_tiles(int64_t N, int pts_per_tile, int max_blocks) {
   const int64_t tiles = (N + pts_per_tile - 1) / pts_per_tile;
   int64_t g = (tiles + 3) / 4;
@@ -473,7 +484,7 @@ int grid_for_tiles(int64_t N, int pts_per_tile, int max_blocks) {
   return (int)g;
 }
 
-constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 4, kMainBwdPB = 2;
+constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 8, kMainBwdPB = 2;
 constexpr int kPropBwdBlocks = 512;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
 
 // (L*F, hidden) of the proposal nets
@@ -575,7 +586,7 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
 #define X(lf, h, hc)                                                                                                  \
   if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
-    main_fwd_kernel<C, kMainFwdPB><<<grid_for_tiles(N, 16 * kMainFwdPB, 256), 256, 0, (hipStream_t)stream>>>(a);      \
+    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves><<<grid_for_tiles_nw(N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, (hipStream_t)stream>>>(a); \
     PS_CHECK_LAUNCH();                                                                                                \
   }
   PS_MAIN_CFGS(X)
