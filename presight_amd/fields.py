@@ -14,7 +14,7 @@ from __future__ import annotations
 
 from copy import deepcopy
 from enum import Enum
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -183,19 +183,44 @@ def _route_groups(points: Tensor, centroids: Tensor) -> List[Tuple[int, Tensor]]
     return groups
 
 
+def routed_apply(points: Tensor, centroids: Tensor, fn, extras: Sequence[Tensor] = ()) -> List[Tensor]:
+    """Evaluate the sub-fields on their points with ONE gather in and ONE scatter out instead of a masked gather + masked
+    scatter per sub-field and output (ns/fields/PreSight/ingp_field_ms.py:97-126 does 4*K masked index ops and K host syncs):
+    the points (and any per-point `extras`) are sorted by sub-field once, every sub-field works on a contiguous slice,
+    the outputs are concatenated in sorted order and un-sorted with a single index_copy.
+    fn(k, points_slice, *extras_slices) -> tuple of [n_k, w] tensors."""
+    assign = ops.route(points, centroids)
+    order = torch.argsort(assign, stable=True)
+    counts = torch.bincount(assign, minlength=centroids.shape[0]).tolist()  # the one host sync of the router
+    pts = points[order]
+    ext = [e[order] for e in extras]
+    outs: Optional[List[List[Tensor]]] = None
+    start = 0
+    for k, c in enumerate(counts):
+        if c == 0:
+            continue
+        vals = fn(k, pts[start:start + c], *[e[start:start + c] for e in ext])
+        if outs is None:
+            outs = [[] for _ in vals]
+        for o, v in zip(outs, vals):
+            o.append(v.reshape(c, -1))
+        start += c
+    res = []
+    for o in outs:
+        cat = o[0] if len(o) == 1 else torch.cat(o, dim=0)
+        res.append(torch.empty_like(cat).index_copy_(0, order, cat))  # un-sort: row order[i] <- sorted row i
+    return res
+
+
 class iNGPFieldMS(nn.Module):
     def __init__(self, fields: List[iNGPField], centroids: Tensor) -> None:
         super().__init__()
         self.register_buffer("centroids", deepcopy(centroids))
         self.fields = nn.ModuleList(fields)
 
-    def _routed(self, positions: Tensor, fn, widths: List[int]) -> List[Tensor]:
-        flat = positions.reshape(-1, 3)
-        outs = [torch.zeros(flat.shape[0], w, device=flat.device) for w in widths]
-        for k, idx in _route_groups(flat, self.centroids):
-            vals = fn(self.fields[k], flat[idx], idx)
-            outs = [o.index_copy(0, idx, v.reshape(idx.shape[0], -1)) for o, v in zip(outs, vals)]
-        return outs
+    def _routed(self, positions: Tensor, fn, widths: List[int], extras: Sequence[Tensor] = ()) -> List[Tensor]:
+        """fn(field, positions_slice, *extras_slices) -> tuple of per-point tensors (widths only documents the outputs)"""
+        return routed_apply(positions.reshape(-1, 3), self.centroids, lambda k, pos, *ex: fn(self.fields[k], pos, *ex), extras)
 
     def forward(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor]) -> Dict[FieldHeadNames, Tensor]:
         R, S = ray_samples.ebins.shape[0], ray_samples.num_samples
@@ -204,13 +229,16 @@ class iNGPFieldMS(nn.Module):
             return self.fields[0](ray_samples, appearance_embedding)
         app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
         positions = ops.sample_positions(rb.origins, rb.directions, ray_samples.ebins)
+        # per-POINT view directions / appearance codes travel with the points through the sort (point n of a sub-field's
+        # slice is then "ray n" of that call: S = 1)
+        per_point = lambda t: t[:, None, :].expand(R, S, t.shape[-1]).reshape(R * S, t.shape[-1])  # noqa: E731 (backward = sum over S)
+        extras = [per_point(rb.directions)] + ([per_point(app)] if app is not None else [])
 
-        def run(field: iNGPField, pos, idx):
-            ray = torch.div(idx, S, rounding_mode="floor")
+        def run(field: iNGPField, pos, dirs, *a):
             u, sel = field.points(pos=pos)
-            return field.evaluate(u, sel, rb.directions[ray], None if app is None else app[ray], 1)
+            return field.evaluate(u, sel, dirs, a[0] if a else None, 1)
 
-        sigma, rgb, sem = self._routed(positions, run, [1, 3, 64])
+        sigma, rgb, sem = self._routed(positions, run, [1, 3, 64], extras)
         return {FieldHeadNames.DENSITY: sigma.view(R, S, 1), FieldHeadNames.RGB: rgb.view(R, S, 3),
                 FieldHeadNames.SEMANTICS: sem.view(R, S, -1)}
 
@@ -218,17 +246,17 @@ class iNGPFieldMS(nn.Module):
         if len(self.fields) == 1:
             return self.fields[0].density_fn(positions)
         w = self.fields[0].geo_feat_dim + self.fields[0].semantic_dim
-        d, e = self._routed(positions, lambda f, pos, idx: f.density_fn(pos), [1, w])
+        d, e = self._routed(positions, lambda f, pos: f.density_fn(pos), [1, w])
         return d.view(*positions.shape[:-1], 1), e.view(*positions.shape[:-1], -1)
 
     def density_only(self, positions: Tensor) -> Tensor:
         """density [*bs,1] through the fused kernel (heads skipped); used by get_depth and prior extraction."""
-        def run(f: iNGPField, pos, idx):
+        def run(f: iNGPField, pos):
             u, sel = f.points(pos=pos)
             return (f.evaluate(u, sel, None, None, 1, want_rgb=False, want_sem=False)[0],)
 
         if len(self.fields) == 1:
-            (d,) = run(self.fields[0], positions.reshape(-1, 3), None)
+            (d,) = run(self.fields[0], positions.reshape(-1, 3))
         else:
             (d,) = self._routed(positions, run, [1])
         return d.view(*positions.shape[:-1], 1)
@@ -239,7 +267,7 @@ class iNGPFieldMS(nn.Module):
     def semantic_fn(self, positions: Tensor) -> Tensor:
         if len(self.fields) == 1:
             return self.fields[0].semantic_fn(positions)
-        (s,) = self._routed(positions, lambda f, pos, idx: (f.semantic_fn(pos),), [64])
+        (s,) = self._routed(positions, lambda f, pos: (f.semantic_fn(pos),), [64])
         return s.view(*positions.shape[:-1], -1)
 
 
@@ -300,10 +328,7 @@ class PropNetDensityFieldMS(nn.Module):
     def density_fn(self, positions: Tensor) -> Tensor:
         if len(self.fields) == 1:
             return self.fields[0].density_fn(positions)
-        flat = positions.reshape(-1, 3)
-        out = torch.zeros(flat.shape[0], 1, device=flat.device)
-        for k, idx in _route_groups(flat, self.centroids):
-            out = out.index_copy(0, idx, self.fields[k].density_fn(flat[idx]))
+        (out,) = routed_apply(positions.reshape(-1, 3), self.centroids, lambda k, pos: (self.fields[k].density_fn(pos),))
         return out.view(*positions.shape[:-1], 1)
 
     def density_of_samples(self, ray_samples: RaySamples) -> Tensor:
