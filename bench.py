@@ -120,6 +120,8 @@ class Trainer:
                 seen.add(id(p))
                 uniq.append(p)
         self.grads = FlatGrads(uniq)
+        # K > 1: a sub-field may get samples on one rank only; "received a gradient" must then be agreed across ranks (DDP)
+        self.grads.flags_may_differ_across_ranks = world > 1 and len(model.field.fields) > 1
         if world > 1 and not model.config.use_same_proposal_network:
             # one bucket per optimizer group: the "fields" bucket (main table + MLPs + sky + embeddings, 2/3 of the bytes) is
             # complete before the proposal networks' backward starts and is exchanged underneath it
