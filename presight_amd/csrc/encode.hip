@@ -688,6 +688,27 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   __syncthreads();
   const float inv = 1.0f / scale;
   float* out = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
+  if (accumulate && n * 4 < entries) {
+    // Sparse flush (many sub-fields / few points per table: far fewer records than rows): walk the records once more and let
+    // the first lane that reaches a row take its total out of LDS (64-bit exchange with 0) and add it to the gradient;
+    // rows no record touched are neither read nor written.  Same values as the dense flush below.
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+      const unsigned e = rec_idx[base + i];
+      const unsigned row = e & 0xffffu, t = e >> 16;
+      const unsigned row_c = (t < 30u) ? ((row ^ ((2u << t) - 1u)) & low) : row;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned r = h ? row_c : row;
+        if (h && row_c == row) break;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const long long v = (long long)atomicExch(reinterpret_cast<unsigned long long*>(&acc[r * F + f]), 0ull);
+          if (v != 0) out[r * F + f] += (float)((double)v * (double)inv);
+        }
+      }
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < entries * F; i += 1024) {
     const float v = (float)((double)acc[i] * (double)inv);
     out[i] = accumulate ? out[i] + v : v;
