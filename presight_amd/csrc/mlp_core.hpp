@@ -45,7 +45,10 @@ struct LayerT {
   static constexpr int GW_OFF = 0;
   static constexpr int GB_OFF = NB_ * IB * 256;
   static constexpr int GPACKED = GB_OFF + NB_ * 16;
-  static constexpr int SCRATCH_ROWS = (NB_ + IB) * 16;  // per-wave LDS rows for the dW transposes
+  // per-wave LDS rows for the dW transposes: the two operands are staged one after the other (H first, then dY in groups
+  // of at most 4 output blocks), so the scratch only has to hold the larger of the two
+  static constexpr int OBG = NB_ < 4 ? NB_ : 4;
+  static constexpr int SCRATCH_ROWS = (IB > OBG ? IB : OBG) * 16;
 };
 
 constexpr int kScratchLd = 20;  // floats per scratch row: 16 points + 4 pad (keeps 16-B alignment)
@@ -280,8 +283,6 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
 #endif
   const int lane = ps_lane();
   const int j = lane & 15, g = lane >> 4;
-  float* sy = scratch;                               // dY tile rows [NB*16]
-  float* sh = scratch + LT::NB * 16 * kScratchLd;    // H tile rows  [IB*16]
   f32x4 dw[LT::NB][LT::IB];
 #pragma unroll
   for (int ob = 0; ob < LT::NB; ++ob)
@@ -290,26 +291,33 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     __builtin_amdgcn_sched_barrier(0);
-    // stage: row = neuron (D-row numbering), column = point j
-#pragma unroll
-    for (int t = 0; t < LT::NB * 4; ++t) sy[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = dvout[pb][t];
+    // stage H: row = neuron (D-row numbering), column = point j; then read it back as B fragments (k-step r of this
+    // 16-point block contracts over points {4*g + r})
 #pragma unroll
     for (int t = 0; t < LT::IB * 4; ++t)
-      sh[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = (t < LT::KS) ? vin[pb][t < LT::KS ? t : 0] : 0.0f;
+      scratch[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = (t < LT::KS) ? vin[pb][t < LT::KS ? t : 0] : 0.0f;
     __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; only stop compiler reordering
-    // k-step r of this 16-point block contracts over points {4*g + r}
     f32x4 bfrag[LT::IB];
 #pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(sh + (16 * ib + j) * kScratchLd + 4 * g);
-#pragma unroll
-    for (int ob = 0; ob < LT::NB; ++ob) {
-      const f32x4 afrag = *reinterpret_cast<const f32x4*>(sy + (16 * ob + j) * kScratchLd + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ob][ib]);
-    }
+    for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(scratch + (16 * ib + j) * kScratchLd + 4 * g);
     __builtin_amdgcn_wave_barrier();
+    // stage dY over the same rows, at most OBG output blocks at a time
+#pragma unroll
+    for (int ob0 = 0; ob0 < LT::NB; ob0 += LT::OBG) {
+#pragma unroll
+      for (int t = 4 * ob0; t < 4 * (ob0 + LT::OBG) && t < LT::NB * 4; ++t)
+        scratch[(16 * ((t >> 2) - ob0) + 4 * g + (t & 3)) * kScratchLd + j] = dvout[pb][t];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ob = ob0; ob < ob0 + LT::OBG && ob < LT::NB; ++ob) {
+        const f32x4 afrag = *reinterpret_cast<const f32x4*>(scratch + (16 * (ob - ob0) + j) * kScratchLd + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ob][ib]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 #if defined(PS_ABLATE) && PS_ABLATE == 3
   asm volatile("" ::"v"(dw[0][0][0]));
@@ -382,29 +390,33 @@ __device__ __forceinline__ void layer_bwd_weights_acc(float* __restrict__ scratc
                                                       const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS]) {
   const int lane = ps_lane();
   const int j = lane & 15, g = lane >> 4;
-  float* sy = scratch;
-  float* sh = scratch + LT::NB * 16 * kScratchLd;
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < LT::NB * 4; ++t) sy[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = dvout[pb][t];
-#pragma unroll
     for (int t = 0; t < LT::IB * 4; ++t)
-      sh[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = (t < LT::KS) ? vin[pb][t < LT::KS ? t : 0] : 0.0f;
+      scratch[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = (t < LT::KS) ? vin[pb][t < LT::KS ? t : 0] : 0.0f;
     __builtin_amdgcn_wave_barrier();
     f32x4 bfrag[LT::IB];
 #pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(sh + (16 * ib + j) * kScratchLd + 4 * g);
-#pragma unroll
-    for (int ob = 0; ob < LT::NB; ++ob) {
-      const f32x4 afrag = *reinterpret_cast<const f32x4*>(sy + (16 * ob + j) * kScratchLd + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ob][ib]);
-    }
+    for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(scratch + (16 * ib + j) * kScratchLd + 4 * g);
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ob0 = 0; ob0 < LT::NB; ob0 += LT::OBG) {
+#pragma unroll
+      for (int t = 4 * ob0; t < 4 * (ob0 + LT::OBG) && t < LT::NB * 4; ++t)
+        scratch[(16 * ((t >> 2) - ob0) + 4 * g + (t & 3)) * kScratchLd + j] = dvout[pb][t];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ob = ob0; ob < ob0 + LT::OBG && ob < LT::NB; ++ob) {
+        const f32x4 afrag = *reinterpret_cast<const f32x4*>(scratch + (16 * (ob - ob0) + j) * kScratchLd + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw[ob][ib]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int nb = 0; nb < LT::NB; ++nb)
 #pragma unroll
