@@ -19,6 +19,11 @@
 #include "mlp_core.hpp"
 #include "pointwise_core.hpp"
 
+#ifndef PS_MAIN_BWD_PB
+#define PS_MAIN_BWD_PB 2     // point blocks (of 16) per wave and iteration of the main backward
+#define PS_MAIN_BWD_WAVES 4  // waves per workgroup (they share the LDS weight-gradient accumulators)
+#endif
+
 namespace {
 
 using namespace ps;
@@ -348,13 +353,13 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   }
 }
 
-template <class C, int PB>
-__global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
+template <class C, int PB, int NW>
+__global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
   constexpr int SCR = C::SCR_ROWS * kScratchLd;
-  __shared__ __attribute__((aligned(16))) float lds[C::GPACKED + 4 * SCR + 16];
+  __shared__ __attribute__((aligned(16))) float lds[C::GPACKED + NW * SCR + 16];
   float* gacc = lds;
-  int* locks = reinterpret_cast<int*>(lds + C::GPACKED + 4 * SCR);
-  for (int i = threadIdx.x; i < C::GPACKED; i += 256) gacc[i] = 0.0f;
+  int* locks = reinterpret_cast<int*>(lds + C::GPACKED + NW * SCR);
+  for (int i = threadIdx.x; i < C::GPACKED; i += NW * 64) gacc[i] = 0.0f;
   if (threadIdx.x < 16) locks[threadIdx.x] = 0;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
   const GlobalW pk_base = pk_all.at(C::P_BASE), pk_sem = pk_all.at(C::P_SEM), pk_rgb = pk_all.at(C::P_RGB);
   const int64_t tiles = (a.N + 16 * PB - 1) / (16 * PB);
   // workgroup-uniform trip count (the dW flush contains workgroup barriers); out-of-range tiles are fully masked
-  for (int64_t base = (int64_t)blockIdx.x * 4; base < tiles; base += (int64_t)gridDim.x * 4) {
+  for (int64_t base = (int64_t)blockIdx.x * NW; base < tiles; base += (int64_t)gridDim.x * NW) {
     const int64_t first = (base + wave) * 16 * PB;
     // ---- recompute base
     float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], hdummy[PB][C::Base::HB * 4], zb[PB][20];
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256) void main_bwd_kernel(MainArgs a) {
   }
   __syncthreads();
   float* out = a.gpart + (size_t)blockIdx.x * C::GPACKED;
-  for (int i = threadIdx.x; i < C::GPACKED; i += 256) out[i] = gacc[i];
+  for (int i = threadIdx.x; i < C::GPACKED; i += NW * 64) out[i] = gacc[i];
 }
 
 int grid_for_tiles_nw(int64_t N, int pts_per_tile, int waves, int max_blocks) {
@@ -484,7 +489,7 @@ int grid_for_tiles(int64_t N, int pts_per_tile, int max_blocks) {
   return (int)g;
 }
 
-constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 8, kMainBwdPB = 2;
+constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 8, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
 constexpr int kPropBwdBlocks = 512;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
 
 // (L*F, hidden) of the proposal nets
@@ -558,7 +563,7 @@ extern "C" int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;              \
     *packed_floats = C::PACKED;                                    \
     *grad_floats = C::GPACKED;                                     \
-    *n_parts = grid_for_tiles(N, 16 * kMainBwdPB, 256);            \
+    *n_parts = grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256); \
     if (offsets) {                                                 \
       offsets[0] = C::P_BASE;                                      \
       offsets[1] = C::P_SEM;                                       \
@@ -607,7 +612,7 @@ extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF
 #define X(lf, h, hc)                                                                                                  \
   if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
-    main_bwd_kernel<C, kMainBwdPB><<<grid_for_tiles(N, 16 * kMainBwdPB, 256), 256, 0, (hipStream_t)stream>>>(a);      \
+    main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves><<<grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256), kMainBwdWaves * 64, 0, (hipStream_t)stream>>>(a); \
     PS_CHECK_LAUNCH();                                                                                                \
   }
   PS_MAIN_CFGS(X)

@@ -283,6 +283,75 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
 #endif
   const int lane = ps_lane();
   const int j = lane & 15, g = lane >> 4;
+  if constexpr (PB == 1) {
+    // One point block per wave (kernels that run two waves per SIMD and must fit 256 registers): the dW tiles are computed and
+    // flushed TWO output blocks at a time, so that only 2*IB tiles are live instead of NB*IB.
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < LT::IB * 4; ++t)
+      scratch[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = (t < LT::KS) ? vin[0][t < LT::KS ? t : 0] : 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    f32x4 bfrag[LT::IB];
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(scratch + (16 * ib + j) * kScratchLd + 4 * g);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ob0 = 0; ob0 < LT::NB; ob0 += 2) {
+      constexpr int dummy = 0;
+      (void)dummy;
+#pragma unroll
+      for (int t = 4 * ob0; t < 4 * (ob0 + 2) && t < LT::NB * 4; ++t)
+        scratch[(16 * ((t >> 2) - ob0) + 4 * g + (t & 3)) * kScratchLd + j] = dvout[0][t];
+      __builtin_amdgcn_wave_barrier();
+      f32x4 dw2[2][LT::IB];
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int ib = 0; ib < LT::IB; ++ib) dw2[o][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        if (ob0 + o < LT::NB) {
+          const f32x4 afrag = *reinterpret_cast<const f32x4*>(scratch + (16 * o + j) * kScratchLd + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ib = 0; ib < LT::IB; ++ib) dw2[o][ib] = ps_mfma16(afrag[r], bfrag[ib][r], dw2[o][ib]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      f32x4 db2[2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db2[o][r] = (ob0 + o < LT::NB) ? ps_row16_sum(dvout[0][4 * (ob0 + o < LT::NB ? ob0 + o : 0) + r]) : 0.0f;
+#if !(defined(PS_ABLATE) && PS_ABLATE == 7)
+      if (lane == 0) {
+        while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        if (ob0 + o < LT::NB) {
+#pragma unroll
+          for (int ib = 0; ib < LT::IB; ++ib) {
+            f32x4* dst = reinterpret_cast<f32x4*>(gacc + LT::GW_OFF + (((ob0 + o) * LT::IB + ib) * 64 + lane) * 4);
+            *dst = *dst + dw2[o][ib];
+          }
+          if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gacc[LT::GB_OFF + 16 * (ob0 + o) + 4 * g + r] += db2[o][r];
+          }
+        }
+      }
+#if !(defined(PS_ABLATE) && PS_ABLATE == 7)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicExch(lock, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   f32x4 dw[LT::NB][LT::IB];
 #pragma unroll
   for (int ob = 0; ob < LT::NB; ++ob)
