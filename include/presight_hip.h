@@ -196,7 +196,11 @@ int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t
                         int64_t* grad_floats /*host*/, int* n_parts /*host*/, int64_t* offsets /*host [6]*/);
 int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                       const float* sel, const float* dirs, const float* app, int S, int A, const float* packed, int64_t N,
-                      float* sigma, float* rgb, float* sem, void* stream);
+                      float* sigma, float* rgb, float* sem, float* acts /* nullable: [ceil(N/16)*16, ps_main_field_act_width], register order */,
+                      void* stream);
+/* acts: the hidden activations of the three MLPs, written by the training forward and read by ps_main_field_bwd instead of
+ * recomputing the forward (a third of its matrix ops, half of its weight-fragment traffic; 1.6 KB per point at cfg 2) */
+int ps_main_field_act_width(int LF, int hidden, int hidden_color);
 /* weights == NULL: drgb [N,3] and dsem [N,64] are per-sample gradients.  weights [N] (the compositing weights of
  * RaySamples.get_weights, point n = ray n/S): drgb [R,3] / dsem [R,64] are the gradients of the COMPOSITED per-ray outputs
  * and the kernel forms weights[n] * d[n/S] itself -- the d_rgb_s / d_sem_s outputs of ps_composite_bwd are then not
@@ -204,7 +208,7 @@ int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, in
 int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                       const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
                       const float* dsigma, const float* drgb, const float* dsem, const float* weights /*nullable*/, int64_t N,
-                      float* dfeat, float* dapp, float* gpart, void* stream);
+                      float* dfeat, float* dapp, float* gpart, const float* acts /* nullable: recompute */, void* stream);
 
 /* ---- a18 prior extraction ---------------------------------------------------------------------------
  * voxel index of Open3D's voxel_down_sample_and_trace as called by ns/scripts/extract_priors.py:216-245:

@@ -86,6 +86,43 @@ __device__ __forceinline__ void publish_absmax(const float (&mx)[KS0], int LF, i
   }
 }
 
+// Kept activations, in REGISTER order: for every 16-point block the buffer holds ACT_W/16 "neuron blocks" of [64 lanes][4]
+// floats (1 KiB each) -- exactly the D registers of the block -- so that the forward's stores and the backward's loads are
+// fully coalesced 16-byte-per-lane accesses (a torch-order [N, width] layout made the forward write 64-byte pieces at a
+// 1.6 KB stride and cost it 1.4 ms).  col0 = first neuron column of the activation (multiple of 16), stride = ACT_W.
+template <int NBLK, int PB>
+__device__ __forceinline__ void store_act(float* __restrict__ acts, int stride, int col0, int64_t first, int64_t N,
+                                          const float (&v)[PB][NBLK * 4]) {
+  const int lane = ps_lane();
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int64_t blk = first / 16 + pb;  // 16-point block index
+    if (blk * 16 < N) {
+      float* base = acts + blk * (int64_t)stride * 16 + (int64_t)col0 * 16 + lane * 4;
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb)
+        *reinterpret_cast<f32x4*>(base + nb * 256) = (f32x4){v[pb][4 * nb], v[pb][4 * nb + 1], v[pb][4 * nb + 2], v[pb][4 * nb + 3]};
+    }
+  }
+}
+template <int NBLK, int PB>
+__device__ __forceinline__ void load_act(const float* __restrict__ acts, int stride, int col0, int64_t first, int64_t N,
+                                         float (&v)[PB][NBLK * 4]) {
+  const int lane = ps_lane();
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int64_t blk = first / 16 + pb;
+    const float* base = acts + blk * (int64_t)stride * 16 + (int64_t)col0 * 16 + lane * 4;
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+      f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (blk * 16 < N) t = *reinterpret_cast<const f32x4*>(base + nb * 256);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[pb][4 * nb + r] = t[r];
+    }
+  }
+}
+
 __device__ __forceinline__ float trunc_exp_grad(float raw) { return expf(fminf(fmaxf(raw, -15.0f), 15.0f)); }
 
 // ------------------------------------------------------------------------------------------ proposal field
@@ -245,6 +282,9 @@ struct MainArgs {
   float* dfeat;
   float* dapp;  // [R,A], accumulated with atomics
   float* gpart;
+  // hidden activations of the three MLPs, [N, MainCfg::ACT_W] (training forward writes them, the backward reads them instead
+  // of recomputing the forward: a third of its matrix ops and half of its L2 weight-fragment traffic); null = not kept
+  float* acts;
 };
 
 template <int KS0_, int HB_, int HBC_>
@@ -255,6 +295,9 @@ struct MainCfg {
   static constexpr int P_BASE = 0, P_SEM = Base::PACKED, P_RGB = P_SEM + Sem::PACKED, PACKED = P_RGB + Rgb::PACKED;
   static constexpr int G_BASE = 0, G_SEM = Base::GPACKED, G_RGB = G_SEM + Sem::GPACKED, GPACKED = G_RGB + Rgb::GPACKED;
   static constexpr int FW_BASE = 0, FW_SEM = Base::FW, FW_RGB = FW_SEM + Sem::FW, FW = FW_RGB + Rgb::FW;
+  // columns of the kept activations (D-register order: block nb, lane group g, register r = neuron 16nb + 4g + r)
+  static constexpr int ACT_H1 = 0, ACT_ZB = ACT_H1 + HB_ * 16, ACT_S1 = ACT_ZB + 80, ACT_S2 = ACT_S1 + 64, ACT_C1 = ACT_S2 + 64,
+                       ACT_C2 = ACT_C1 + HBC_ * 16, ACT_CO = ACT_C2 + HBC_ * 16, ACT_W = ACT_CO + 16;
   static constexpr int SCR_ROWS = Base::SCRATCH_ROWS > Sem::SCRATCH_ROWS
                                       ? (Base::SCRATCH_ROWS > Rgb::SCRATCH_ROWS ? Base::SCRATCH_ROWS : Rgb::SCRATCH_ROWS)
                                       : (Sem::SCRATCH_ROWS > Rgb::SCRATCH_ROWS ? Sem::SCRATCH_ROWS : Rgb::SCRATCH_ROWS);
@@ -308,6 +351,10 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], h2[PB][C::Base::HB * 4];
       load_feat<C::Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
       mlp_forward<typename C::Base, PB>(LdsW{lds + C::FW_BASE}, x, h1, h2, zb);
+      if (a.acts != nullptr) {
+        store_act<C::Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
+        store_act<5, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb);
+      }
     }
     if (a.sigma != nullptr && g == 0) {
 #pragma unroll
@@ -323,6 +370,10 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][4 + t];
       mlp_forward<typename C::Sem, PB>(LdsW{lds + C::FW_SEM}, sin_, s1, s2, so);
+      if (a.acts != nullptr) {
+        store_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
+        store_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
+      }
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const int64_t p = first + pb * 16 + j;
@@ -339,6 +390,11 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       int64_t ray_of[PB];
       build_colour_input<PB>(a, first, zb, cin, ray_of);
       mlp_forward<typename C::Rgb, PB>(LdsW{lds + C::FW_RGB}, cin, c1, c2, co);
+      if (a.acts != nullptr) {
+        store_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
+        store_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, c2);
+        store_act<1, PB>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, co);
+      }
       if (g == 0) {
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
@@ -353,7 +409,8 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   }
 }
 
-template <class C, int PB, int NW>
+// STORED: the hidden activations come from the training forward (a.acts) instead of being recomputed
+template <class C, int PB, int NW, bool STORED>
 __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
   constexpr int SCR = C::SCR_ROWS * kScratchLd;
   __shared__ __attribute__((aligned(16))) float lds[C::GPACKED + NW * SCR + 16];
@@ -373,7 +430,12 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
     // ---- recompute base
     float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], hdummy[PB][C::Base::HB * 4], zb[PB][20];
     load_feat<C::Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
-    mlp_forward<typename C::Base, PB>(pk_base, x, h1, hdummy, zb);
+    if constexpr (STORED) {
+      load_act<C::Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
+      load_act<5, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb);
+    } else {
+      mlp_forward<typename C::Base, PB>(pk_base, x, h1, hdummy, zb);
+    }
     float dzb[PB][20];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
@@ -389,7 +451,12 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
       for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][4 + t];
-      mlp_forward<typename C::Sem, PB>(pk_sem, sin_, s1, s2, so);
+      if constexpr (STORED) {
+        load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
+        load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
+      } else {
+        mlp_forward<typename C::Sem, PB>(pk_sem, sin_, s1, s2, so);
+      }
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const int64_t p = first + pb * 16 + j;
@@ -416,7 +483,13 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
       float cin[PB][12], c1[PB][C::Rgb::HB * 4], c2[PB][C::Rgb::HB * 4], co[PB][4];
       int64_t ray_of[PB];
       build_colour_input<PB>(a, first, zb, cin, ray_of);
-      mlp_forward<typename C::Rgb, PB>(pk_rgb, cin, c1, c2, co);
+      if constexpr (STORED) {
+        load_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
+        load_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, c2);
+        load_act<1, PB>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, co);
+      } else {
+        mlp_forward<typename C::Rgb, PB>(pk_rgb, cin, c1, c2, co);
+      }
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const int64_t p = first + pb * 16 + j;
@@ -580,14 +653,24 @@ extern "C" int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t
   return -2;
 }
 
+// floats per point of the kept-activation buffer (ps_main_field_fwd `acts`), 0 if the shape is unsupported
+extern "C" int ps_main_field_act_width(int LF, int hidden, int hidden_color) {
+#define X(lf, h, hc) \
+  if (LF == lf && hidden == h && hidden_color == hc) return MainCfg<(lf + 3) / 4, h / 16, hc / 16>::ACT_W;
+  PS_MAIN_CFGS(X)
+#undef X
+  return 0;
+}
+
 extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                  const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
-                                 int64_t N, float* sigma, float* rgb, float* sem, void* stream) {
+                                 int64_t N, float* sigma, float* rgb, float* sem, float* acts, void* stream) {
   if (N == 0) return 0;
   PS_REQUIRE(A <= 16 && S > 0, "ps_main_field_fwd: appearance dim must be <= 16");
+  PS_REQUIRE(acts == nullptr || (sem != nullptr && rgb != nullptr), "ps_main_field_fwd: activations are kept for full evaluations only");
   MainArgs a{};
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
-  a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem;
+  a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem; a.acts = acts;
 #define X(lf, h, hc)                                                                                                  \
   if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
@@ -603,16 +686,20 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
 extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                  const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
                                  const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t N,
-                                 float* dfeat, float* dapp, float* gpart, void* stream) {
+                                 float* dfeat, float* dapp, float* gpart, const float* acts, void* stream) {
   if (N == 0) return 0;
+  PS_REQUIRE(acts == nullptr || (drgb != nullptr && dsem != nullptr), "ps_main_field_bwd: kept activations need both head gradients");
   PS_REQUIRE(A <= 16 && S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
   MainArgs a{};
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
-  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart;
+  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts);
 #define X(lf, h, hc)                                                                                                  \
   if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
-    main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves><<<grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256), kMainBwdWaves * 64, 0, (hipStream_t)stream>>>(a); \
+    if (acts != nullptr)                                                                                              \
+      main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256), kMainBwdWaves * 64, 0, (hipStream_t)stream>>>(a); \
+    else                                                                                                              \
+      main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256), kMainBwdWaves * 64, 0, (hipStream_t)stream>>>(a); \
     PS_CHECK_LAUNCH();                                                                                                \
   }
   PS_MAIN_CFGS(X)

@@ -66,6 +66,7 @@ def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, count: bool 
 
 _WORKSPACES = {}
 SCATTER_IMPL = "binned"  # "binned" (records + int64 LDS accumulation) or "owner" (LDS slice-owner scan)
+KEEP_ACTIVATIONS = True  # training forward of the main field keeps its hidden activations (1.6 KB/point) for the backward
 
 
 def _workspace(nbytes: int, device) -> Tensor:
@@ -251,22 +252,28 @@ def _main_forward(ctx, table_needs_grad, u, sel, dirs, app, S, table, scalings, 
     sem = torch.empty(N, SEM_DIM, device=dev) if want_sem else None
     dirs = _f32(dirs) if dirs is not None else torch.zeros(1, 3, device=dev)
     app_c = _f32(app) if (app is not None and want_rgb) else None
+    # training forward of the full field: keep the hidden activations for the backward (no recompute there)
+    acts = None
+    if KEEP_ACTIVATIONS and table_needs_grad and want_rgb and want_sem and N > 0:
+        acts = torch.empty((N + 15) // 16 * 16, lib().ps_main_field_act_width(g.out_dim, hidden, hidden_color), device=dev)
     with prof.region("main_field_fwd"):
         check(lib().ps_main_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                       _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb), _p(sem),
-                                      _stream()), "ps_main_field_fwd")
+                                      _p(acts), _stream()), "ps_main_field_fwd")
     ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
                 want_rgb, want_sem)
     ctx.sinks = (grad_sink(table), layer_sinks(layers))
     ctx.direct = direct_params(table, *wb)
-    return (u, sel, dirs, app_c, scalings, feat, packed, counts), (sigma, rgb, sem)
+    return (u, sel, dirs, app_c, scalings, feat, packed, counts, acts), (sigma, rgb, sem)
 
 
 def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     """shared backward: fused MLP backward -> table scatter -> weight-gradient reduction.  weights != None: d_rgb / d_sem are
     per-RAY gradients (see ps_main_field_bwd).  -> (dapp, dtable | None, [dW0, db0, ...] with None for in-place gradients)"""
-    u, sel, dirs, app, scalings, feat, packed, counts = saved
+    u, sel, dirs, app, scalings, feat, packed, counts, acts = saved
     g, hidden, hidden_color, A, S, tshape, shapes, n_base, n_sem, want_rgb, want_sem = ctx.meta
+    if d_rgb is None or d_sem is None:
+        acts = None  # a head without gradient: the recompute kernel skips it
     spec = _main_spec(g.out_dim, hidden, hidden_color, A)
     N = u.shape[0]
     dev = u.device
@@ -284,7 +291,7 @@ def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     with prof.region("main_field_bwd"):
         check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                       _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                      _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _stream()), "ps_main_field_bwd")
+                                      _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _stream()), "ps_main_field_bwd")
     dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
     descs = []
     for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
