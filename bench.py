@@ -29,10 +29,10 @@ RAYS = 65536
 # algorithmic work per training ray at cfg 2: MLP flops fwd = 2*(64*26752 + 192*576)
 MAIN_MAC_PER_SAMPLE = 26752
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32 matrix peak
-# HBM bytes per launch of main_bwd_kernel from the PMC passes of this very command (profiles/r01_pmc_summary_v5.txt, separate
-# --pmc passes): FETCH_SIZE 303 027 KB, doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming reads, + WRITE_SIZE
-# 585 184 KB.  Algorithmic: features in 0.54 GB + d(features) out 0.54 GB + per-sample scalars 0.07 GB.
-MAIN_BWD_HBM_BYTES_PMC = (2 * 303026.8 + 585184.0) * 1024
+# HBM bytes per launch of main_bwd_kernel from the PMC passes of this very command (profiles/r01_pmc_summary_v6.txt, separate
+# --pmc passes): FETCH_SIZE 3 717 794 KB, doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming 16-byte reads, +
+# WRITE_SIZE 585 184 KB.  Algorithmic: kept activations in 7.0 GB + features in 0.54 GB + d(features) out 0.54 GB.
+MAIN_BWD_HBM_BYTES_PMC = (2 * 3717793.5 + 585184.0) * 1024
 
 
 def cfg2():
@@ -334,7 +334,7 @@ def main():
                        "rays_per_gpu": RAYS, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "main_bwd_kernel (fused main-field backward)", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": MAIN_BWD_HBM_BYTES_PMC,
-                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_summary_v5.txt)",
+                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_summary_v6.txt)",
                          "avg_launch_ms": t_bwd, "launches": n_launch},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
             "value_reference_schedule": world * RAYS * n_sched / dt_sched,

@@ -66,7 +66,9 @@ def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, count: bool 
 
 _WORKSPACES = {}
 SCATTER_IMPL = "binned"  # "binned" (records + int64 LDS accumulation) or "owner" (LDS slice-owner scan)
-KEEP_ACTIVATIONS = True  # training forward of the main field keeps its hidden activations (1.6 KB/point) for the backward
+# training forward of the main field keeps its hidden activations (1.6 KB/point) for the backward; PRESIGHT_KEEP_ACTIVATIONS=0
+# (or this flag) switches to recomputing them there (7 GB less memory at cfg 2, same results)
+KEEP_ACTIVATIONS = __import__("os").environ.get("PRESIGHT_KEEP_ACTIVATIONS", "1") != "0"
 
 
 def _workspace(nbytes: int, device) -> Tensor:
