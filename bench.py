@@ -122,7 +122,7 @@ class Trainer:
         self.grads = FlatGrads(uniq)
         # K > 1: a sub-field may get samples on one rank only; "received a gradient" must then be agreed across ranks (DDP)
         self.grads.flags_may_differ_across_ranks = world > 1 and len(model.field.fields) > 1
-        if world > 1 and not model.config.use_same_proposal_network:
+        if world > 1 and not model.config.use_same_proposal_network and os.environ.get("PRESIGHT_NO_OVERLAP") != "1":
             # one bucket per optimizer group: the "fields" bucket (main table + MLPs + sky + embeddings, 2/3 of the bytes) is
             # complete before the proposal networks' backward starts and is exchanged underneath it
             uid = {id(p) for p in uniq}
@@ -249,6 +249,10 @@ def psnr_vs_oracle(O, cfg, scene, rays=1024):
 
 
 def main():
+    if os.environ.get("PRESIGHT_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["PRESIGHT_HANG_DUMP"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
