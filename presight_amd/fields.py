@@ -114,7 +114,7 @@ class iNGPField(nn.Module):
         rb = ray_samples.ray_bundle
         R = ray_samples.ebins.shape[0]
         u, sel = self.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
-        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         g = self.mlp_base_grid
         rgb, acc, depth, expd, sem, w = F.main_field_render(
             u, sel, rb.directions, app, ray_samples.ebins, g.hash_table, g.scalings_on(u.device), _grid_cfg(g),
@@ -158,7 +158,7 @@ class iNGPField(nn.Module):
         rb = ray_samples.ray_bundle
         R, S = ray_samples.ebins.shape[0], ray_samples.num_samples
         u, sel = self.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
-        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         sigma, rgb, sem = self.evaluate(u, sel, rb.directions, app, S)
         return {FieldHeadNames.DENSITY: sigma.view(R, S, 1), FieldHeadNames.RGB: rgb.view(R, S, 3),
                 FieldHeadNames.SEMANTICS: sem.view(R, S, -1)}
@@ -168,6 +168,13 @@ class iNGPField(nn.Module):
         u, sel = self.points(pos=positions.reshape(-1, 3))
         _, _, sem = self.evaluate(u, sel, None, None, 1, want_rgb=False, want_sem=True)
         return sem.view(*positions.shape[:-1], -1)
+
+
+def _per_ray(appearance_embedding: Tensor, R: int) -> Tensor:
+    """[R, A] appearance code of a ray from the reference's per-sample layout [R, S or 1, A] (all S copies are equal).  A pure
+    view when the middle dimension is 1 -- `x[:, 0]` would cost a zero-fill + copy (select_backward) in every backward."""
+    a = appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])
+    return a.reshape(R, a.shape[-1]) if a.shape[1] == 1 else a[:, 0]
 
 
 def _route_groups(points: Tensor, centroids: Tensor) -> List[Tuple[int, Tensor]]:
@@ -227,7 +234,7 @@ class iNGPFieldMS(nn.Module):
         rb = ray_samples.ray_bundle
         if len(self.fields) == 1:
             return self.fields[0](ray_samples, appearance_embedding)
-        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         positions = ops.sample_positions(rb.origins, rb.directions, ray_samples.ebins)
         # per-POINT view directions / appearance codes travel with the points through the sort (point n of a sub-field's
         # slice is then "ray n" of that call: S = 1)
@@ -368,7 +375,7 @@ class SkyField(nn.Module):
 
     def forward(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor]):
         R = ray_samples.ebins.shape[0]
-        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         return self.get_outputs(ray_samples.ray_bundle.directions, app)
 
 
@@ -382,7 +389,7 @@ class SkyFieldMS(nn.Module):
         """routed by ray ORIGIN (ns/fields/PreSight/sky_field_ms.py:97-114)"""
         rb = ray_samples.ray_bundle
         R = rb.origins.shape[0]
-        app = None if appearance_embedding is None else appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])[:, 0]
+        app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         if len(self.fields) == 1:
             return self.fields[0].get_outputs(rb.directions, app)
         outs: Dict[FieldHeadNames, Tensor] = {}

@@ -84,7 +84,7 @@ class _Distortion(torch.autograd.Function):
 def distortion_loss(weights_list: Sequence[Tensor], ray_samples_list) -> Tensor:
     """mip-NeRF 360 distortion of the final level (ns/model_components/losses.py:130-149)."""
     w = weights_list[-1]
-    w = w[..., 0] if w.dim() == 3 else w
+    w = w.reshape(w.shape[0], w.shape[1]) if w.dim() == 3 else w  # a view (x[..., 0] costs a zero-fill + copy in backward)
     return _Distortion.apply(ray_samples_list[-1].sbins, w)
 
 
@@ -113,10 +113,10 @@ def z_anti_aliasing_interlevel_loss(weights_list: Sequence[Tensor], ray_samples_
     is detached, gradients flow to the proposal weights only."""
     c = ray_samples_list[-1].sbins.detach()
     w = weights_list[-1].detach()
-    w = w[..., 0] if w.dim() == 3 else w
+    w = w.reshape(w.shape[0], w.shape[1]) if w.dim() == 3 else w  # a view (x[..., 0] costs a zero-fill + copy in backward)
     total = 0.0
     for i, (rs, wp) in enumerate(zip(ray_samples_list[:-1], weights_list[:-1])):
-        wp = wp[..., 0] if wp.dim() == 3 else wp
+        wp = wp.reshape(wp.shape[0], wp.shape[1]) if wp.dim() == 3 else wp
         total = total + _Interlevel.apply(c, w, rs.sbins, wp, pulse_width[i])
     return total
 
@@ -144,7 +144,7 @@ def line_of_sight_loss(weights: Tensor, termination_depth: Tensor, ray_samples, 
                        upper_bound: float = 75.0, pose_scale_factor: float = 1.0) -> Tensor:
     """URF line-of-sight loss (ns/model_components/PreSight/losses.py:28-65).  Takes the RaySamples (bin edges in scene
     units) + pose_scale_factor instead of the pre-divided `steps` tensor: the midpoints are formed inside the kernel."""
-    w = weights[..., 0] if weights.dim() == 3 else weights
+    w = weights.reshape(weights.shape[0], weights.shape[1]) if weights.dim() == 3 else weights
     sky = None if sky_mask is None else sky_mask.reshape(-1)
     return _LineOfSight.apply(w, ray_samples.ebins, termination_depth.reshape(-1), sky, sigma, upper_bound, pose_scale_factor)
 

@@ -90,5 +90,5 @@ class RaySamples:
 
     def get_weights(self, densities: Tensor) -> Tensor:
         """ns/cameras/rays.py:128-150: densities [R,S,1] -> weights [R,S,1]."""
-        w = ops.weights_from_density(self.ebins, densities[..., 0])
+        w = ops.weights_from_density(self.ebins, densities.reshape(densities.shape[0], densities.shape[1]))
         return w[..., None]

@@ -34,7 +34,7 @@ class NearFarCollider(nn.Module):
 def render_all(weights: Tensor, ray_samples: RaySamples, rgb: Optional[Tensor], semantics: Optional[Tensor], threshold: float = 0.5):
     """One pass over the samples of every ray: -> (rgb [R,3], accumulation [R,1] unclamped, threshold depth [R,1],
     expected depth [R,1] (clipped to the batch-global sample range), semantics [R,C])."""
-    w = weights[..., 0] if weights.dim() == 3 else weights
+    w = weights.reshape(weights.shape[0], weights.shape[1]) if weights.dim() == 3 else weights
     return ops.composite(w, ray_samples.ebins, rgb, semantics, threshold)
 
 

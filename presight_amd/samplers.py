@@ -87,7 +87,7 @@ class PDFSampler(Sampler):
                 jitter = torch.rand((R, 1), device=dev)
         else:
             jitter = None
-        w = weights[..., 0] if weights.dim() == 3 else weights
+        w = weights.reshape(weights.shape[0], weights.shape[1]) if weights.dim() == 3 else weights
         nsb, neb = ops.pdf_resample(w, ray_samples.sbins, num_samples, jitter, anneal, near, far, thr,
                                     pad=self.histogram_padding, eps=eps)
         return RaySamples(ray_bundle, neb, nsb, spacing_to_euclidean_fn=ray_samples.spacing_to_euclidean_fn)
