@@ -35,13 +35,14 @@ def lattice_points(aabb: Tensor, res: int, start: int, count: int, device) -> Te
 def query_priors(model, pts: Tensor) -> Tuple[Tensor, Tensor]:
     """-> (mean density [n], features fp16 [n,64]); pts are in the model's (scaled) frame."""
     dens = [p.density_fn(pts).reshape(-1) for p in model.proposal_networks]
-    dens.append(model.field.density_only(pts).reshape(-1))
+    d_main, sem = model.field.density_and_semantics(pts)  # one pass of the main field for both (the reference makes three)
+    dens.append(d_main.reshape(-1))
     if len(dens) == 3:
         out = torch.empty_like(dens[0])
         check(lib().ps_mean_density(_p(dens[0]), _p(dens[1]), _p(dens[2]), out.numel(), _p(out), _stream()), "ps_mean_density")
     else:
         out = torch.stack(dens, 0).mean(0)
-    feats = model.field.semantic_fn(pts).clip(0.0, 1.0).to(torch.float16)
+    feats = sem.reshape(-1, sem.shape[-1]).clip(0.0, 1.0).to(torch.float16)
     return out, feats
 
 

@@ -268,6 +268,21 @@ class iNGPFieldMS(nn.Module):
             (d,) = self._routed(positions, run, [1])
         return d.view(*positions.shape[:-1], 1)
 
+    def density_and_semantics(self, positions: Tensor) -> Tuple[Tensor, Tensor]:
+        """(density [*bs,1], semantics [*bs,64]) from ONE evaluation of the field.  The reference's prior extraction calls
+        density_fn and semantic_fn separately (ns/scripts/extract_priors.py:133-138) and semantic_fn re-runs density_fn
+        (ingp_field.py:256): the hash encode and the base MLP run three times per point there, once here."""
+        def run(f: iNGPField, pos):
+            u, sel = f.points(pos=pos)
+            d, _, s = f.evaluate(u, sel, None, None, 1, want_rgb=False, want_sem=True)
+            return d, s
+
+        if len(self.fields) == 1:
+            d, s = run(self.fields[0], positions.reshape(-1, 3))
+        else:
+            d, s = self._routed(positions, run, [1, 64])
+        return d.view(*positions.shape[:-1], 1), s.view(*positions.shape[:-1], -1)
+
     def get_density(self, ray_samples: RaySamples):
         return self.density_fn(ray_samples.frustums.get_positions())
 
