@@ -407,11 +407,13 @@ class SkyFieldMS(nn.Module):
         app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         if len(self.fields) == 1:
             return self.fields[0].get_outputs(rb.directions, app)
-        outs: Dict[FieldHeadNames, Tensor] = {}
-        for k, idx in _route_groups(rb.origins, self.centroids):
-            o = self.fields[k].get_outputs(rb.directions[idx], None if app is None else app[idx])
-            for name, v in o.items():
-                if name not in outs:
-                    outs[name] = torch.zeros(R, v.shape[-1], device=v.device)
-                outs[name] = outs[name].index_copy(0, idx, v)
-        return outs
+        names: List[FieldHeadNames] = []
+
+        def run(k, _origins, dirs, *a):
+            o = self.fields[k].get_outputs(dirs, a[0] if a else None)
+            if not names:
+                names.extend(o.keys())
+            return tuple(o[n] for n in names)
+
+        vals = routed_apply(rb.origins, self.centroids, run, [rb.directions] + ([app] if app is not None else []))
+        return dict(zip(names, vals))
