@@ -1,65 +1,121 @@
 """bench.py — training rays/sec of the PreSight NeRF prior-builder hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|extract] [--scaling weak|strong]
 
-One "step" = one full training iteration of NerfactoNuscMSModel on one synthetic nuScenes-shaped ray batch
-(BASELINE.json configs[1]: one Boston-Seaport sub-tile, 16-level hash grid (F=2, T=2^19) + 64-wide MLPs, proposal nets
-L=8 F=1 T=2^20, 65 536 rays, 128/64/64 samples): ray generation -> proposal sampling (2 proposal fields, 2 PDF
-resamplings) -> main field -> compositing -> sky -> 5 losses -> full backward (proposal nets updated every step) ->
-gradient exchange (N > 1) -> Adam.  Inputs are resident in HBM before the timed region.  Weak scaling: every rank
-trains on its own 65 536-ray batch and the gradients are averaged with one RCCL all-reduce per step.
+With --gpus N > 1 and no torchrun environment the script starts its own N worker processes (one per GPU, RCCL) through
+`python -m torch.distributed.run` BEFORE touching the GPU, relays rank 0's JSON line and exits with the workers' code; under
+an external `torchrun` (RANK / WORLD_SIZE set) it is a worker.  A mismatch between --gpus and WORLD_SIZE is an error.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, measured live with HIP
-events on the launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores, rank 0, N == 1 only)."""
+One "step" = one full training iteration of NerfactoNuscMSModel on one synthetic nuScenes-shaped ray batch: ray generation ->
+proposal sampling (2 proposal fields, 2 PDF resamplings) -> main field -> compositing -> sky -> 5 losses -> full backward
+(proposal nets updated every step) -> gradient exchange (N > 1) -> Adam.  Inputs are resident in HBM before the timed region.
+
+  --config cfg2 (default; BASELINE.json configs[1], the configuration the metric is quoted on at N = 1): one Boston-Seaport
+      sub-tile, 16-level hash grid (F=2, T=2^19) + 64-wide MLPs, proposal nets L=8 F=1 T=2^20, 128/64/64 samples.
+  --config cfg3 (BASELINE.json configs[2]): the production tile — K = 16 sub-fields, main tables L=10 F=4 T=2^20 (940 M
+      parameters), nearest-centroid routing; default scaling "strong" (65 536 rays per step over all ranks = 8192 per GPU at
+      N = 8, as ns/data/PreSight/my_datamanager.py:203-212 splits them), sharded gradient exchange.
+  --config extract (BASELINE.json configs[4]): prior extraction of one tile, 512^3 lattice (see presight_amd/extract.py).
+  --scaling weak: every rank trains on its own 65 536-ray batch (default for cfg2); strong: 65 536 // N rays per rank.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, measured live with HIP events on
+the launch stream), `roofline_kernels` (the MFMA-bound and HBM-bound kernels of the step, same measurement), `end_to_end`
+(fraction of the binding end-to-end ceiling of SURVEY.md 8d) and `cpu_baseline` (the CPU oracle timed on the host cores,
+rank 0, N == 1 only)."""
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 RAYS = 65536
-# algorithmic work per training ray at cfg 2: MLP flops fwd = 2*(64*26752 + 192*576)
-MAIN_MAC_PER_SAMPLE = 26752
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32 matrix peak
-# HBM bytes per launch of main_bwd_kernel from the PMC passes of this very command (profiles/r01_pmc_summary_v6.txt, separate
-# --pmc passes): FETCH_SIZE 3 717 794 KB, doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming 16-byte reads, +
-# WRITE_SIZE 585 184 KB.  Algorithmic: kept activations in 7.0 GB + features in 0.54 GB + d(features) out 0.54 GB.
-MAIN_BWD_HBM_BYTES_PMC = (2 * 3717793.5 + 585184.0) * 1024
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+CONFIGS = {
+    # iNGPField constructor defaults = BASELINE cfg 2 (ns/fields/PreSight/ingp_field.py:74-84); proposal nets nerfacto_nusc_ms.py:114-121
+    "cfg2": dict(K=1, model=dict(num_levels=16, features_per_level=2, log2_hashmap_size=19, base_res=16, max_res=2048, hidden_dim=64,
+                                 hidden_dim_color=64),
+                 scaling="weak", exchange="allreduce",
+                 workload="BASELINE cfg 2: one sub-tile, 16-level hash grid (F=2,T=2^19) + 64-wide MLPs, 2 proposal nets (L=8,F=1,T=2^20), "
+                          "128/64/64 samples, fwd+5 losses+bwd+Adam"),
+    # production tile: model defaults L=10,F=4,T=2^20,max 16384 (nerfacto_nusc_ms.py:88-101), num_aabbs=16 (method_configs.py:141)
+    "cfg3": dict(K=16, model=dict(num_levels=10, features_per_level=4, log2_hashmap_size=20, base_res=16, max_res=16384, hidden_dim=64,
+                                  hidden_dim_color=64),
+                 scaling="strong", exchange="sharded",
+                 workload="BASELINE cfg 3: production tile, K=16 sub-fields (L=10,F=4,T=2^20 main tables, 940 M parameters), routed, "
+                          "128/64/64 samples, fwd+5 losses+bwd+Adam"),
+}
 
 
-def cfg2():
-    return dict(near=0.005, far=50.0, thr=5.0, num_cameras=1440, num_videos=6)
+# --------------------------------------------------------------------------------------------------------- launcher
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "extract"], default="cfg2")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
+    ap.add_argument("--exchange", choices=["allreduce", "sharded"], default=None)
+    ap.add_argument("--rays", type=int, default=RAYS, help="rays per step: per GPU (weak) / over all GPUs (strong)")
+    ap.add_argument("--global-depth-clip", action="store_true", help="expected-depth clip bounds over ALL ranks' batches")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args(argv)
 
 
-def build_model(dev, seed):
+def self_launch(args) -> int:
+    """--gpus N > 1 outside torchrun: start N ranks (one per GPU) and relay their output.  Nothing here touches the GPU
+    (torch.cuda.device_count() does not initialise it), so the children are ordinary fresh processes."""
+    import torch
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and os.environ.get("PRESIGHT_SINGLE_DEVICE") != "1":
+        print(f"bench.py: --gpus {args.gpus} but this node has {n_dev} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# --------------------------------------------------------------------------------------------------------- workload
+def build_model(dev, seed, config="cfg2"):
+    import torch
+
     from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
 
     torch.manual_seed(seed)
-    c = cfg2()
-    conf = NerfactoNuscMSModelConfig(
-        near_plane=c["near"], far_plane=c["far"], piecewise_sampler_threshold=c["thr"],
-        # iNGPField constructor defaults = BASELINE cfg 2 (ns/fields/PreSight/ingp_field.py:74-84)
-        num_levels=16, features_per_level=2, log2_hashmap_size=19, base_res=16, max_res=2048, hidden_dim=64, hidden_dim_color=64,
-        implementation="hip", use_lidar_loss=False, proposal_weights_anneal_max_num_iters=10000, proposal_warmup=10000)
-    scene = make_scene(c["num_cameras"], c["num_videos"])
-    model = NerfactoNuscMSModel(conf, num_train_cameras=c["num_cameras"], num_train_videos=c["num_videos"], dino_to_rgb=None,
-                                centroids=scene["centroids"], aabbs=scene["aabbs"])
+    c = CONFIGS[config]
+    conf = NerfactoNuscMSModelConfig(near_plane=0.005, far_plane=50.0, piecewise_sampler_threshold=5.0, implementation="hip",
+                                     use_lidar_loss=False, proposal_weights_anneal_max_num_iters=10000, proposal_warmup=10000, **c["model"])
+    scene = make_scene(1440, 6, K=c["K"])
+    model = NerfactoNuscMSModel(conf, num_train_cameras=1440, num_train_videos=6, dino_to_rgb=None, centroids=scene["centroids"],
+                                aabbs=scene["aabbs"])
     model.to(dev)
     return model, {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
 
 
-def make_scene(num_cameras, num_videos, seed=7):
+def make_scene(num_cameras, num_videos, seed=7, K=1):
     """Synthetic nuScenes-shaped rig: 6 pinhole cameras 1600x900 moving along a polyline at 0.5 m/frame,
-    poses scaled by 0.05 and mean-centred; one sub-field whose AABB is the trajectory quantile box +-15 m."""
+    poses scaled by 0.05 and mean-centred.  K = 1: one sub-field whose AABB is the trajectory quantile box +-15 m;
+    K > 1: K centroids on the polyline, one AABB (+-45 m) around each (the reference clusters the poses with k-means,
+    ns/data/dataparsers/mynuscenes_ms_dataparser.py:231-269)."""
     import math
+
+    import torch
 
     gen = torch.Generator().manual_seed(seed)
     n_frames = num_cameras // 6
@@ -80,15 +136,23 @@ def make_scene(num_cameras, num_videos, seed=7):
     C = c2w.shape[0]
     fx = torch.full((C,), 1266.0) + torch.rand(C, generator=gen)
     ext = 15.0 * scale
-    lo = c2w[:, :, 3].quantile(0.02, dim=0) - ext
-    hi = c2w[:, :, 3].quantile(0.98, dim=0) + ext
-    return dict(c2w=c2w, fx=fx, fy=fx.clone(), cx=torch.full((C,), 800.0), cy=torch.full((C,), 450.0),
-                centroids=c2w[C // 2: C // 2 + 1, :, 3].clone(), aabbs=torch.stack([lo, hi])[None], H=900, W=1600,
-                frames_per_video=max(1, C // num_videos))
+    if K == 1:
+        lo = c2w[:, :, 3].quantile(0.02, dim=0) - ext
+        hi = c2w[:, :, 3].quantile(0.98, dim=0) + ext
+        centroids, aabbs = c2w[C // 2: C // 2 + 1, :, 3].clone(), torch.stack([lo, hi])[None]
+    else:
+        sel = torch.linspace(0, C - 1, K + 2)[1:-1].long()
+        centroids = c2w[sel, :, 3].clone()
+        aabbs = torch.stack([torch.stack([c - 3 * ext, c + 3 * ext]) for c in centroids])
+    return dict(c2w=c2w, fx=fx, fy=fx.clone(), cx=torch.full((C,), 800.0), cy=torch.full((C,), 450.0), centroids=centroids, aabbs=aabbs,
+                H=900, W=1600, frames_per_video=max(1, C // num_videos))
 
 
 def make_batches(scene, dev, n_batches, rank, rays=RAYS):
-    """uniform-random ray indices + random targets, manual_seed(1234 + step) (+rank: each DP rank draws its own rays)"""
+    """uniform-random ray indices + random targets, manual_seed(1234 + step) (+1000*rank: every DP rank draws its own rays,
+    as the reference seeds its workers with seed + rank, ns/scripts/train.py:99)"""
+    import torch
+
     out = []
     C = scene["c2w"].shape[0]
     for step in range(n_batches):
@@ -103,39 +167,56 @@ def make_batches(scene, dev, n_batches, rank, rays=RAYS):
 
 class Trainer:
     """The timed region: what ns/engine/trainer.py:463-505 does per iteration (zero_grad, forward, loss, backward with
-    the reference's fixed loss scale of 2**10, DDP gradient averaging, Adam lr 1e-2 eps 1e-15 wd 1e-5)."""
+    the reference's fixed loss scale of 2**10, DDP gradient averaging, Adam lr 1e-2 eps 1e-15 wd 1e-5).
 
-    def __init__(self, model, scene, world):
-        from presight_amd.dist import FlatGrads
+    exchange = "allreduce": bucketed all-reduce overlapped with backward, Adam over everything on every rank;
+               "sharded":   bucketed reduce-scatter overlapped with backward, Adam on the owned shard, all-gather of the
+                            updated parameters overlapped with the next step's ray generation / proposal sampling."""
+
+    def __init__(self, model, scene, world, exchange="allreduce", global_depth_clip=False):
+        from presight_amd.dist import FlatGrads, global_depth_clip as depth_hook
+        from presight_amd.optim import HipAdam
 
         self.model, self.scene, self.world = model, scene, world
-        groups = model.get_param_groups()  # group-major order: a group that receives no gradient in a step (proposal nets
-        params = [p for k in sorted(groups, reverse=True) for p in groups[k]]  # off-schedule) is one contiguous range to skip
-        params = [p for p in params if p.requires_grad and p.numel() > 0]
-        assert {id(p) for p in params} == {id(p) for p in model.parameters() if p.requires_grad and p.numel() > 0}
-        # the reference registers mlp_base = Sequential(grid, mlp): the same tensors appear twice in parameters() -> dedup
-        seen, uniq = set(), []
-        for p in params:
-            if id(p) not in seen:
-                seen.add(id(p))
-                uniq.append(p)
-        self.grads = FlatGrads(uniq)
+        groups = model.get_param_groups()
+        # bucket-major order, in the order backward COMPLETES the groups: "fields" (main field, sky, embeddings) are finished
+        # before the proposal networks' backward starts, so their exchange runs underneath it; a group that receives no
+        # gradient in a step (proposal nets off-schedule) is one contiguous range to skip
+        order = [k for k in ("fields", "proposal_networks") if k in groups] + sorted(k for k in groups if k not in ("fields", "proposal_networks"))
+        seen, uniq, sizes = set(), [], []
+        for k in order:
+            n0 = len(uniq)
+            for p in groups[k]:  # the reference registers mlp_base = Sequential(grid, mlp): the same tensors appear twice -> dedup
+                if p.requires_grad and p.numel() > 0 and id(p) not in seen:
+                    seen.add(id(p))
+                    uniq.append(p)
+            sizes.append(len(uniq) - n0)
+        assert seen == {id(p) for p in model.parameters() if p.requires_grad and p.numel() > 0}
+        self.group_names = order
+        sharded = exchange == "sharded" and world > 1
+        self.grads = FlatGrads(uniq, bucket_sizes=sizes, shard_world=world if sharded else 1)
         # K > 1: a sub-field may get samples on one rank only; "received a gradient" must then be agreed across ranks (DDP)
         self.grads.flags_may_differ_across_ranks = world > 1 and len(model.field.fields) > 1
         if world > 1 and not model.config.use_same_proposal_network and os.environ.get("PRESIGHT_NO_OVERLAP") != "1":
-            # one bucket per optimizer group: the "fields" bucket (main table + MLPs + sky + embeddings, 2/3 of the bytes) is
-            # complete before the proposal networks' backward starts and is exchanged underneath it
-            uid = {id(p) for p in uniq}
-            self.grads.enable_overlap([[p for p in groups[k] if id(p) in uid] for k in sorted(groups, reverse=True)])
-        from presight_amd.optim import HipAdam
+            buckets, i = [], 0
+            for n in sizes:
+                buckets.append(uniq[i:i + n])
+                i += n
+            self.grads.enable_overlap(buckets, mode="sharded" if sharded else "allreduce")
+            if sharded:
+                model.param_gate = lambda name: self.grads.wait_params(self.group_names.index(name))
+        self.exchange = "sharded" if sharded else "allreduce"
+        if global_depth_clip and world > 1:
+            from presight_amd import ops
 
+            ops.set_depth_clip_hook(depth_hook())
         self.opt = HipAdam(uniq, lr=1e-2, eps=1e-15, weight_decay=1e-5, flat_grads=self.grads)
         self.step_idx = 0
         self.loss_scale = 2.0 ** 10
         self.update_props_every_step = True
 
     def step(self, batch):
-        from presight_amd import ops
+        from presight_amd import ops, prof
         from presight_amd.rays import RayBundle
 
         m, s = self.model, self.scene
@@ -151,51 +232,99 @@ class Trainer:
         loss_dict = m.get_loss_dict(out, batch)
         loss = sum(loss_dict.values())
         (loss * self.loss_scale).backward()
-        self.grads.finish_exchange()
-        self.opt.step()
+        with prof.region("exchange_exposed"):
+            self.grads.finish_exchange()
+        with prof.region("adam"):
+            self.opt.step()
         m.after_train_iteration(self.step_idx)
         self.step_idx += 1
         return loss_dict, out
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The CPU oracle (validated restatement of the reference's torch path) on a bounded sample of the same workload:
-    same field/table sizes, fewer rays.  kind = "port".  torch's CPU ops scale badly past a few dozen threads on this
-    many-core host, so the thread count is the best of a short probe (reported as `cores`)."""
+# --------------------------------------------------------------------------------------------------------- CPU baseline
+def host_cpu_info():
+    """(physical cores, model name) from /proc/cpuinfo"""
+    cores, model = set(), "unknown"
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return (len(cores) or os.cpu_count() or 1), model
+
+
+def cpu_baseline():
+    """SURVEY.md 8d protocol: the CPU oracle (validated restatement of the reference's torch path, kind = "port") runs the
+    SAME step as the GPU side — forward, 5 losses, backward AND torch.optim.Adam (lr 1e-2, eps 1e-15, wd 1e-5) — on a bounded
+    sample of the workload (cfg-2 tables and networks, 2048-ray batches instead of 65 536): 3 warm-up + 10 timed steps,
+    median.  torch's CPU kernels stop scaling long before this host's core count, so the thread count is probed (one
+    512-ray step each at 8/16/32/64/128/#physical threads) and the best one is used and reported."""
+    import statistics
+
+    import torch
+
     from oracle import nerf_oracle as O
 
     cfg = O.default_config()
     scene = O.make_scene(cfg)
     P = O.make_params(cfg, seed=42)
+    for v in P.values():
+        v.requires_grad_(True)
+    opt = torch.optim.Adam(list(P.values()), lr=1e-2, eps=1e-15, weight_decay=1e-5)
     rays = 2048
+    phys, model_name = host_cpu_info()
     max_threads = torch.get_num_threads()
-    O.train_step(P, cfg, scene, O.make_batch(cfg, scene, 256, step=0))  # page in the 64 + 2*32 MiB tables
+
+    def one_step(n_rays, step):
+        opt.zero_grad(set_to_none=True)
+        L, _, g = O.train_step(P, cfg, scene, O.make_batch(cfg, scene, n_rays, step=step))
+        for k, v in P.items():
+            v.grad = g.get(k)
+        opt.step()
+
+    one_step(256, 0)  # page in the 64 + 2*32 MiB tables and the optimizer state
     best_t, best_dt = None, float("inf")
-    for th in (8, 16, 32):
-        if th > max_threads:
-            continue
+    probe = sorted({t for t in (8, 16, 32, 64, 128, phys) if t <= max(phys, max_threads)})
+    probe_log = {}
+    for th in probe:
         torch.set_num_threads(th)
         t0 = time.time()
-        O.train_step(P, cfg, scene, O.make_batch(cfg, scene, 512, step=0))
+        one_step(512, 0)
         dt = time.time() - t0
+        probe_log[th] = round(512 / dt, 1)
         if dt < best_dt:
             best_t, best_dt = th, dt
     torch.set_num_threads(best_t or max_threads)
-    t0 = time.time()
-    O.train_step(P, cfg, scene, O.make_batch(cfg, scene, rays, step=1))
-    first = time.time() - t0
-    n = max(1, min(6, int(seconds_budget / max(first, 1e-3)) - 1))
-    t0 = time.time()
-    for i in range(n):
-        O.train_step(P, cfg, scene, O.make_batch(cfg, scene, rays, step=2 + i))
-    dt = (time.time() - t0) / n
+    for i in range(3):
+        one_step(rays, 1 + i)
+    times = []
+    for i in range(10):
+        t0 = time.time()
+        one_step(rays, 4 + i)
+        times.append(time.time() - t0)
+        if sum(times) > 40.0 and len(times) >= 5:
+            break  # bounded: a slow host must not stretch the default bench run past a few minutes
+    dt = statistics.median(times)
     used = torch.get_num_threads()
     torch.set_num_threads(max_threads)
     global _PSNR_VS_ORACLE
+    for v in P.values():
+        v.requires_grad_(False)
     _PSNR_VS_ORACLE = psnr_vs_oracle(O, cfg, scene)
     return dict(value=rays / dt, unit="rays/s", cores=used, kind="port",
-                sample=f"{n} full training steps (fwd + 5 losses + bwd, no optimizer) of {rays} rays, cfg-2 tables, torch-CPU oracle, "
-                       f"{used} threads (best of 8/16/32; host has {os.cpu_count()} logical CPUs)")
+                sample=f"median of {len(times)} timed steps after 3 warm-up (fwd + 5 losses + bwd + torch.optim.Adam) of {rays} rays, "
+                       f"cfg-2 tables, torch-CPU oracle, {used} threads",
+                host=dict(cpu_model=model_name, physical_cores=phys, logical_cpus=os.cpu_count(), thread_probe_rays_per_s=probe_log))
 
 
 _PSNR_VS_ORACLE = None
@@ -206,6 +335,10 @@ def psnr_vs_oracle(O, cfg, scene, rays=1024):
     (eval mode: no jitter, mean appearance code) from the same cfg-2 parameters; PSNR = 10 log10(1 / MSE) of the RGB
     difference, plus the largest semantics / expected-depth deviations.  Tables are drawn 300x wider than the init so that
     the rendering is not a constant."""
+    import math
+
+    import torch
+
     from presight_amd import ops
     from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
     from presight_amd.rays import RayBundle
@@ -241,77 +374,158 @@ def psnr_vs_oracle(O, cfg, scene, rays=1024):
     with torch.no_grad():
         out = model(RayBundle(o, d, pa, camera_indices=ri[:, 0:1], metadata={"video_id": batch["video_ids"].to(dev)[:, None]}))
     mse = float(((out["rgb"].cpu() - ref["rgb"]) ** 2).mean())
-    return {"psnr_db": 10.0 * __import__("math").log10(1.0 / max(mse, 1e-30)), "rays": rays,
-            "rgb_std": float(ref["rgb"].std()),
+    return {"psnr_db": 10.0 * math.log10(1.0 / max(mse, 1e-30)), "rays": rays, "rgb_std": float(ref["rgb"].std()),
             "max_abs_semantics": float((out["semantics"].cpu() - ref["semantics"]).abs().max()),
             "max_rel_expected_depth": float(((out["expected_depth"].cpu() - ref["expected_depth"]).abs()
                                              / ref["expected_depth"].abs().clamp_min(1e-6)).max())}
 
 
+# --------------------------------------------------------------------------------------------------------- roofline
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/traffic.json, written by
+    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this very command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-byte streaming reads on gfx950).  The entry carries the hash of the kernel
+    sources it was measured on: after the kernels change the figure is stale and None is reported instead."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path))
+        ent = rec["kernels"][kernel_key]
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC record"
+    if rec.get("src_sha16") != kernel_sources_sha():
+        return None, f"stale: {os.path.relpath(path, ROOT)} was measured on other kernel sources"
+    return float(ent["hbm_bytes_per_launch"]), ent.get("source", "profiles/traffic.json")
+
+
+def kernel_sources_sha() -> str:
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "presight_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def roofline_entries(kern, cfg, rays):
+    """per-kernel roofline rows from the HIP-event regions of presight_amd.prof (mean ms per launch over the timed steps).
+    Algorithmic work: MLP flops = 2 x MACs (backward = 2 x forward: dX + dW); hash bytes = one
+    F*4-byte row per corner, 8 corners per (point, level), gathered once forward, read + written once backward."""
+    m = cfg["model"]
+    L, F = m["num_levels"], m["features_per_level"]
+    n_main, n_p0, n_p1 = rays * 64, rays * 128, rays * 64
+    mac_main = (L * F) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3)  # base + semantic head + colour head
+    mac_prop = 8 * 64 + 64
+    rows = []
+
+    def add(name, region, bound, work, unit):
+        if region not in kern:
+            return
+        n, ms = kern[region]
+        if not ms > 0:
+            return
+        peak = FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS
+        ach = work / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
+        rows.append(dict(kernel=name, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_launch_ms=ms, launches=n,
+                         algorithmic=work))
+
+    add("main_bwd_kernel", "main_field_bwd", "mfma", 2 * 2 * mac_main * n_main, "TFLOP/s")
+    add("main_fwd_kernel", "main_field_fwd", "mfma", 2 * mac_main * n_main, "TFLOP/s")
+    add("prop_bwd_kernel (both fields)", "prop_field_bwd", "mfma", 2 * 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s")
+    add("prop_fwd_kernel (both fields)", "prop_field_fwd", "mfma", 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s")
+    add(f"grid_encode main (L{L} F{F})", f"grid_encode_L{L}F{F}", "hbm", n_main * L * 8 * F * 4, "GB/s")
+    add("grid_encode proposal (L8 F1, mean of both)", "grid_encode_L8F1", "hbm", (n_p0 + n_p1) / 2 * 8 * 8 * 4, "GB/s")
+    add(f"table backward main (absmax+bin+accumulate, L{L} F{F})", f"grid_scatter_L{L}F{F}", "hbm", 2 * n_main * L * 8 * F * 4, "GB/s")
+    add("table backward proposal (bin+accumulate, L8 F1, mean of both)", "grid_scatter_L8F1", "hbm", 2 * (n_p0 + n_p1) / 2 * 8 * 8 * 4, "GB/s")
+    return rows
+
+
+# --------------------------------------------------------------------------------------------------------- main
 def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.config == "extract":
+        from presight_amd.extract import bench_main
+
+        sys.exit(bench_main(args))
+
+    import torch
+
     if os.environ.get("PRESIGHT_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
         import faulthandler
 
         faulthandler.dump_traceback_later(float(os.environ["PRESIGHT_HANG_DUMP"]), exit=True)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
 
     from presight_amd import prof
     from presight_amd.dist import init_from_env
 
     rank, local_rank, world = init_from_env("cuda")
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path for the product)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    model, scene = build_model(dev, seed=42)  # same init on every rank (DDP broadcast equivalent)
-    trainer = Trainer(model, scene, world)
-    batches = make_batches(scene, dev, 4, rank)
+    cfg = CONFIGS[args.config]
+    scaling = args.scaling or cfg["scaling"]
+    exchange = args.exchange or cfg["exchange"]
+    rays = args.rays if scaling == "weak" else args.rays // world  # ns/data/PreSight/my_datamanager.py:203-212: R // world
+    model, scene = build_model(dev, seed=42, config=args.config)  # same init on every rank (DDP broadcast equivalent)
+    trainer = Trainer(model, scene, world, exchange=exchange, global_depth_clip=args.global_depth_clip)
+    batches = make_batches(scene, dev, 4, rank, rays=rays)
 
-    for i in range(args.warmup):
-        trainer.step(batches[i % len(batches)])
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
+    def run(n):
+        for i in range(n):
+            out = trainer.step(batches[i % len(batches)])
+        return out
+
+    def timed(n):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run(n)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, out
+
+    run(args.warmup)
+    trainer.grads.stats = {"collectives": 0, "bytes": 0}
     prof.enable(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss_dict, out = trainer.step(batches[i % len(batches)])
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, (loss_dict, out) = timed(args.steps)
     kern = prof.summary()
     prof.enable(False)
+    comm = dict(trainer.grads.stats)
     # secondary figure (NOT `value`): the reference's own steady-state proposal-update schedule after warm-up
     # (ray_samplers.py:586 + nerfacto_nusc_ms.py:300-305: gradients reach the proposal nets every 6th step)
     trainer.update_props_every_step = False
     trainer.step_idx = 50000
     model.proposal_sampler._steps_since_update = 0
     n_sched = 12
-    for i in range(6):
-        trainer.step(batches[i % len(batches)])
+    run(6)
+    dt_sched, _ = timed(n_sched)
+    # secondary figure: the other scaling mode on the same ranks (strong: args.rays over all ranks; weak: args.rays per rank)
+    other = None
     if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(n_sched):
-        trainer.step(batches[i % len(batches)])
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt_sched = time.perf_counter() - t1
+        trainer.update_props_every_step = True
+        o_rays = args.rays // world if scaling == "weak" else args.rays
+        o_batches = make_batches(scene, dev, 2, rank, rays=o_rays)
+        keep, batches = batches, o_batches
+        run(3)
+        dt_o, _ = timed(8)
+        batches = keep
+        other = dict(scaling="strong" if scaling == "weak" else "weak", rays_per_gpu=o_rays, value=world * o_rays * 8 / dt_o,
+                     ms_per_step=dt_o / 8 * 1e3)
     replica_diff = None
     if world > 1:
-        tmax = torch.tensor([dt], device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
         # data-parallel consistency: every rank applied the same averaged gradients, so the replicas must still be identical
+        trainer.grads.wait_params()
         mine = trainer.opt.flat[0]
         ref = mine.clone()
         torch.distributed.broadcast(ref, src=0)
@@ -321,37 +535,54 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = world * RAYS * args.steps / dt
-        N = RAYS * 64
-        # dominant kernel: fused main-field backward.  Algorithmic flops per launch = dX + dW passes of the three MLPs
-        # (2 x forward MACs x 2 flop) for N = 65536*64 samples; the in-kernel forward recompute is NOT counted.
-        n_launch, t_bwd = kern.get("main_field_bwd", (0, float("nan")))
-        flops = 2 * 2 * MAIN_MAC_PER_SAMPLE * N
-        achieved = flops / (t_bwd * 1e-3) / 1e12
+        value = world * rays * args.steps / dt
+        rows = roofline_entries(kern, cfg, rays)
+        dom = rows[0] if rows else None
+        traffic, traffic_src = pmc_traffic("main_bwd_kernel") if (args.config == "cfg2" and rays == RAYS) else (None, "not collected for this shape")
         psnr = float(model.get_metrics_dict(out, batches[(args.steps - 1) % len(batches)])["psnr"].detach())
+        # end-to-end ceilings per training ray: MLP flops (fwd + 2x bwd) against the fp32 matrix peak, hash bytes
+        # (gather fwd, read + write bwd) against HBM; the binding (lower) ceiling is the fp32 MFMA one
+        m = cfg["model"]
+        L, F = m["num_levels"], m["features_per_level"]
+        mac_main = (L * F) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3)
+        flop_ray = 3 * 2 * (64 * mac_main + 192 * 576)
+        byte_ray = 3 * (64 * L * 8 * F * 4 + 192 * 8 * 8 * 4)
+        ceil_mfma, ceil_hbm = FP32_MFMA_PEAK_TFLOPS * 1e12 / flop_ray, HBM_PEAK_GBS * 1e9 / byte_ray
+        per_gpu = value / world
         line = {
             "metric": "training rays/sec (whole node)", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg 2: one sub-tile, 16-level hash grid (F=2,T=2^19) + 64-wide MLPs, 2 proposal nets "
-                                   "(L=8,F=1,T=2^20), 65536 rays/GPU/step, 128/64/64 samples, fwd+5 losses+bwd+Adam",
-                       "rays_per_gpu": RAYS, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "main_bwd_kernel (fused main-field backward)", "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": MAIN_BWD_HBM_BYTES_PMC,
-                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_summary_v6.txt)",
-                         "avg_launch_ms": t_bwd, "launches": n_launch},
+            "config": {"workload": cfg["workload"], "rays_per_gpu": rays, "rays_per_step_global": rays * world, "parallelism": f"dp{world}",
+                       "exchange": trainer.exchange if world > 1 else None},
+            "roofline": None if dom is None else {
+                "bound": "mfma", "kernel": "main_bwd_kernel (fused main-field backward)", "achieved": dom["achieved"], "peak": dom["peak"],
+                "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC)",
+                "traffic_source": traffic_src, "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"]},
+            "roofline_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows],
+            "end_to_end": {"flop_per_ray": flop_ray, "hash_bytes_per_ray": byte_ray, "ceiling_mfma_rays_per_s": ceil_mfma,
+                           "ceiling_hbm_rays_per_s": ceil_hbm, "binding": "mfma" if ceil_mfma < ceil_hbm else "hbm",
+                           "frac_of_binding": per_gpu / min(ceil_mfma, ceil_hbm), "frac_of_mfma": per_gpu / ceil_mfma,
+                           "frac_of_hbm": per_gpu / ceil_hbm},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
-            "value_reference_schedule": world * RAYS * n_sched / dt_sched,
+            "value_reference_schedule": world * rays * n_sched / dt_sched,
+            "other_scaling": other,
+            "comm": None if world == 1 else {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                                             "collectives_per_step": comm["collectives"] / args.steps,
+                                             "bytes_on_link_per_rank_per_step": comm["bytes"] / args.steps,
+                                             "exchange_exposed_ms": kern.get("exchange_exposed", (0, None))[1]},
             "replicas_max_abs_diff": replica_diff,
             "psnr_vs_random_targets": psnr,
             "loss": float(sum(v.detach() for v in loss_dict.values())),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
             line["psnr_vs_oracle"] = _PSNR_VS_ORACLE
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

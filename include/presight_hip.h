@@ -226,6 +226,13 @@ int ps_mean_density(const float* a, const float* b, const float* c, int64_t n, f
  * p, g, m, v: [n] fp32, 16-byte aligned; step counts from 1. */
 int ps_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, void* stream);
+/* The same update over n_ranges disjoint ranges [start[i], start[i]+count[i]) (floats; start multiples of 4) of flat
+ * p / g / m / v buffers, range i at its OWN step count (torch.optim.Adam advances state["step"] per parameter, only when
+ * the parameter has a gradient: ns/engine/optimizers.py:133-140 after zero_grad(set_to_none=True)).  start / count / step
+ * are HOST arrays; the range table travels as a kernel argument (one launch per 32 ranges, no host->device copy). */
+int ps_adam_step_ranges(float* p, const float* g, float* m, float* v, int n_ranges, const int64_t* start /*host*/,
+                        const int64_t* count /*host*/, const int* step /*host*/, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,12 +3,24 @@ torch.distributed's "nccl" backend; "gloo" on CPU for tests).
 
 The reference wraps the model in DDP(find_unused_parameters=True) (ns/pipelines/PreSight/my_pipeline.py:121-124): every
 parameter gradient is averaged over ranks each step.  Here all gradients live in ONE flat fp32 buffer (the parameters'
-.grad tensors are views into it), so the exchange is a single large all-reduce per group with no packing copies:
+.grad tensors are views into it), so the exchange needs no packing copies:
  * xGMI is point-to-point, so few, large messages are what keeps all 7 links busy;
- * "unused parameter" handling is free: a sub-field that saw no sample this step just contributes zeros."""
+ * "unused parameter" handling is free: a sub-field that saw no sample this step just contributes zeros.
+
+Two exchange modes (FlatGrads.enable_overlap(..., mode=)):
+ * "allreduce" — every bucket is averaged with one all-reduce; every rank then runs Adam over everything (cfg 2: 134 MB);
+ * "sharded"   — every bucket is averaged with a REDUCE-SCATTER (rank r receives the r-th of `world` equal shards), Adam runs
+   on the owned shard only (1/world of the optimizer traffic and state: the production tile has 940 M parameters = 26 GB of
+   Adam traffic per step) and the updated parameters return with an ALL-GATHER that is left in flight on the side stream:
+   the next step's ray generation and proposal sampling run underneath it, `wait_params(bucket)` is called right before the
+   first kernel that reads the bucket.  Same bytes on the links as a ring all-reduce.
+
+Collectives are always ISSUED IN THE SAME ORDER on every rank (NCCL / gloo pair collectives by issue order): buckets go out
+strictly in the order they were passed to enable_overlap, whether a bucket is launched from a gradient hook (complete
+during backward) or from finish_exchange (a sub-field without samples on this rank never completes it)."""
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -26,40 +38,97 @@ def _mark_touched(p):
     p._ps_touched = True
 
 
+def _merge(ranges: Sequence[Tuple[int, int]]) -> List[Tuple[int, int]]:
+    out: List[List[int]] = []
+    for a, b in sorted(ranges):
+        if b <= a:
+            continue
+        if out and out[-1][1] >= a:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
+    return [(a, b) for a, b in out]
+
+
+def intersect_ranges(xs: Sequence[Tuple[int, int]], ys: Sequence[Tuple[int, int]]) -> List[Tuple[int, int]]:
+    """intersection of two sorted lists of disjoint half-open ranges"""
+    out, i, j = [], 0, 0
+    while i < len(xs) and j < len(ys):
+        a, b = max(xs[i][0], ys[j][0]), min(xs[i][1], ys[j][1])
+        if a < b:
+            out.append((a, b))
+        if xs[i][1] < ys[j][1]:
+            i += 1
+        else:
+            j += 1
+    return out
+
+
 class FlatGrads:
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_sizes: Optional[Sequence[int]] = None, shard_world: int = 1):
+        """bucket_sizes: number of consecutive parameters per exchange bucket (bucket-major parameter order); with
+        shard_world = W every bucket's range is padded to a multiple of 4*W floats so that it splits into W equal,
+        16-byte-aligned shards (mode "sharded")."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and p.numel() > 0]
         pad = lambda n: (n + 3) // 4 * 4  # noqa: E731  keep every view 16-byte aligned (vectorised optimizer kernels)
-        total = sum(pad(p.numel()) for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        if bucket_sizes is None:
+            bucket_sizes = [len(self.params)]
+        if sum(bucket_sizes) != len(self.params):
+            raise ValueError("FlatGrads: bucket_sizes must cover the parameters exactly")
+        align = 4 * max(1, int(shard_world))
         self.offsets: List[int] = []
-        off = 0
-        for p in self.params:
+        self.bucket_ranges: List[Tuple[int, int]] = []
+        self.bucket_params: List[Tuple[int, int]] = []  # (first parameter index, one past the last)
+        off, i = 0, 0
+        for nb in bucket_sizes:
+            start = off
+            for p in self.params[i:i + nb]:
+                self.offsets.append(off)
+                off += pad(p.numel())
+            off = (off + align - 1) // align * align
+            self.bucket_ranges.append((start, off))
+            self.bucket_params.append((i, i + nb))
+            i += nb
+        self.total = off
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            p.grad = self.flat[o:o + n].view_as(p)
             # opt in to in-place gradient accumulation by the HIP backward kernels (presight_amd.ops.grad_sink): the buffer
             # is zeroed once per step (zero_()), so "+=" from any number of uses of the parameter is the full gradient
             p._ps_direct_grad = True
             p._ps_touched = False
             p.register_post_accumulate_grad_hook(_mark_touched)  # gradients that arrive through autograd's own accumulation
-            self.offsets.append(off)
-            off += pad(n)
-        self.total = total
         self._pad = pad
+        self.shard_world = max(1, int(shard_world))
         self.flags_may_differ_across_ranks = False  # set when routing can leave a sub-field without samples on one rank only
         self._buckets: List[dict] = []
+        self._next_launch = 0
         self._group = None
         self._comm_stream = None
+        self.mode = "allreduce"
+        self._dirty: Optional[List[Tuple[int, int]]] = None  # ranges that may be non-zero (None = unknown -> everything)
+        self._param_events: Dict[int, object] = {}
+        self.stats = {"collectives": 0, "bytes": 0}
 
+    # ------------------------------------------------------------------ per-step bookkeeping
     def zero_(self):
         """Start of a step: gradients to zero, "received a gradient this step" flags cleared (torch's zero_grad(set_to_none=True)
-        + "grad is None -> the optimizer skips the parameter" semantics, without freeing the flat buffer)."""
-        self.flat.zero_()
+        + "grad is None -> the optimizer skips the parameter" semantics, without freeing the flat buffer).  Only the ranges
+        that received a gradient in the previous step (as agreed across ranks: touched_ranges) are written; everything else
+        is still zero (a production tile's 3.5 GiB buffer is mostly untouched when a sub-field gets no samples)."""
+        if self._dirty is None:
+            self.flat.zero_()
+        else:
+            for a, b in self._dirty:
+                self.flat[a:b].zero_()
+        self._dirty = None
         for p in self.params:
             p._ps_touched = False
         for b in self._buckets:
             b["seen"], b["launched"], b["work"] = 0, False, None
+        self._next_launch = 0
 
     def touched(self, group: Optional[dist.ProcessGroup] = None) -> List[bool]:
         flags = [bool(p._ps_touched) for p in self.params]
@@ -69,28 +138,33 @@ class FlatGrads:
             flags = [bool(v) for v in t.tolist()]
         return flags
 
+    def touched_params(self, group: Optional[dist.ProcessGroup] = None) -> List[int]:
+        """indices of the parameters that received a gradient this step (agreed across ranks when routing may differ); also
+        records their ranges as the only part of the buffer the next zero_() has to clear"""
+        flags = self.touched(group)
+        idx = [i for i, t in enumerate(flags) if t]
+        self._dirty = _merge([(self.offsets[i], self.offsets[i] + self._pad(self.params[i].numel())) for i in idx])
+        return idx
+
     def touched_ranges(self, group: Optional[dist.ProcessGroup] = None) -> List[tuple]:
         """[(first float, one-past-last float)] of the flat buffer covering exactly the parameters that received a gradient
-        this step, adjacent parameters merged (all touched -> one range)."""
-        out: List[list] = []
-        for p, off, t in zip(self.params, self.offsets, self.touched(group)):
-            if not t:
-                continue
-            end = off + self._pad(p.numel())
-            if out and out[-1][1] == off:
-                out[-1][1] = end
-            else:
-                out.append([off, end])
-        return [tuple(r) for r in out]
+        this step, adjacent parameters merged (all touched -> one range per bucket-padding-free run)."""
+        self.touched_params(group)
+        return list(self._dirty)
 
     # ------------------------------------------------------------------ overlapped, bucketed exchange
-    def enable_overlap(self, buckets: List[List[torch.nn.Parameter]], group: Optional[dist.ProcessGroup] = None):
+    def enable_overlap(self, buckets: List[List[torch.nn.Parameter]], group: Optional[dist.ProcessGroup] = None,
+                       mode: str = "allreduce"):
         """Exchange the gradient buffer in buckets, each as soon as it is complete, on a side stream, while the backward of the
         remaining parameters is still running (the reference's DDP overlaps its bucketed all-reduce with backward the same
-        way).  A bucket = parameters that are contiguous in the flat buffer (e.g. one optimizer group); it is launched when
-        every one of its parameters has received its gradient of this step; whatever has not been launched by then
-        (parameters that got no gradient) goes out in finish_exchange().  A parameter must receive at most ONE gradient
-        contribution per step (checked: a second one after the launch raises)."""
+        way).  A bucket = parameters that are contiguous in the flat buffer (e.g. one optimizer group); it becomes READY when
+        every one of its parameters has received its gradient of this step.  Buckets are launched strictly in the order of
+        `buckets` (pass them in the order backward completes them): a ready bucket waits for its predecessors, and whatever
+        has not been launched by the end of backward goes out in finish_exchange() — in the same order on every rank, which
+        is what keeps the collectives of ranks whose routing left different sub-fields without samples paired correctly.
+        A parameter must receive at most ONE gradient contribution per step (checked: a second one after the launch raises)."""
+        if mode not in ("allreduce", "sharded"):
+            raise ValueError(mode)
         index = {id(p): i for i, p in enumerate(self.params)}
         self._buckets = []
         for plist in buckets:
@@ -100,11 +174,21 @@ class FlatGrads:
             if ids != list(range(ids[0], ids[-1] + 1)):
                 raise ValueError("FlatGrads.enable_overlap: the parameters of a bucket must be contiguous in the flat buffer")
             a, b = self.offsets[ids[0]], self.offsets[ids[-1]] + self._pad(self.params[ids[-1]].numel())
-            self._buckets.append(dict(range=(a, b), n=len(ids), seen=0, launched=False, work=None))
+            if mode == "sharded":
+                match = [r for r, pr in zip(self.bucket_ranges, self.bucket_params) if pr == (ids[0], ids[-1] + 1)]
+                if not match or (match[0][1] - match[0][0]) % (4 * self.shard_world):
+                    raise ValueError("FlatGrads: sharded exchange needs the buckets declared at construction (bucket_sizes=, "
+                                     "shard_world=) so that their ranges split into equal aligned shards")
+                a, b = match[0]
+            self._buckets.append(dict(range=(a, b), n=len(ids), seen=0, launched=False, work=None, index=len(self._buckets)))
             for i in ids:
                 self.params[i]._ps_bucket = len(self._buckets) - 1
                 self.params[i]._ps_on_touch = self._on_touch
         self._group = group
+        self.mode = mode
+        self._next_launch = 0
+        if mode == "sharded" and self._distributed() and dist.get_world_size(group) != self.shard_world:
+            raise ValueError(f"FlatGrads: built for shard_world={self.shard_world}, process group has {dist.get_world_size(group)} ranks")
         if self.flat.is_cuda:
             self._comm_stream = torch.cuda.Stream(device=self.flat.device)
 
@@ -120,40 +204,115 @@ class FlatGrads:
         if not p._ps_touched:
             b["seen"] += 1
             if b["seen"] == b["n"]:
-                self._launch(b)
+                self._launch_ready()
+
+    def _launch_ready(self):
+        """launch, in bucket order, every bucket whose predecessors have gone out and whose gradients are complete"""
+        while self._next_launch < len(self._buckets):
+            b = self._buckets[self._next_launch]
+            if b["seen"] < b["n"]:
+                return
+            self._launch(b)
+            self._next_launch += 1
+
+    def _rank_world(self):
+        return dist.get_rank(self._group), dist.get_world_size(self._group)
 
     def _launch(self, b):
         b["launched"] = True
         if not self._distributed():
             return
-        world = dist.get_world_size(self._group)
-        seg = self.flat[b["range"][0]:b["range"][1]]
+        rank, world = self._rank_world()
+        a, e = b["range"]
+        seg = self.flat[a:e]
+
+        def issue():
+            seg.div_(world)
+            if self.mode == "sharded":
+                n = (e - a) // world
+                b["work"] = dist.reduce_scatter_tensor(seg[rank * n:(rank + 1) * n], seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+                self.stats["bytes"] += 4 * (e - a) * (world - 1) // world
+            else:
+                b["work"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+                self.stats["bytes"] += 2 * 4 * (e - a) * (world - 1) // world
+            self.stats["collectives"] += 1
+
         if self._comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record()  # everything enqueued so far on the compute stream = the complete gradients of this bucket
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
-                seg.div_(world)
-                b["work"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+                issue()
         else:
-            seg.div_(world)
-            b["work"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+            issue()
 
     def finish_exchange(self):
-        """after backward: launch the buckets that are still local, then make the compute stream wait for all of them"""
+        """after backward: launch the buckets that are still local (in order), then make the compute stream wait for all of them"""
         if not self._buckets:
             return self.all_reduce_mean(self._group)
-        for b in self._buckets:
-            if not b["launched"]:
-                if b["seen"] == 0 and not self.flags_may_differ_across_ranks:
-                    b["launched"] = True  # no parameter of the bucket got a gradient on any rank (schedule-driven): nothing to exchange
-                else:
-                    self._launch(b)
+        for b in self._buckets[self._next_launch:]:
+            if b["seen"] == 0 and not self.flags_may_differ_across_ranks:
+                b["launched"] = True  # no parameter of the bucket got a gradient on any rank (schedule-driven): nothing to exchange
+            else:
+                self._launch(b)
+        self._next_launch = len(self._buckets)
         for b in self._buckets:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
         return None
+
+    # ------------------------------------------------------------------ sharded mode: who owns what, parameters back
+    def owned_ranges(self) -> List[Tuple[int, int]]:
+        """ranges of the flat buffers whose averaged gradient THIS rank holds after finish_exchange() and that its optimizer
+        has to update (everything in "allreduce" mode or without a process group)"""
+        if self.mode != "sharded" or not self._distributed():
+            return [(0, self.total)]
+        rank, world = self._rank_world()
+        out = []
+        for b in self._buckets:
+            a, e = b["range"]
+            n = (e - a) // world
+            out.append((a + rank * n, a + (rank + 1) * n))
+        return _merge(out)
+
+    def gather_params(self, flat_params: Tensor, touched: Optional[Sequence[Tuple[int, int]]] = None):
+        """sharded mode, after the optimizer step: all-gather the updated shards of every bucket that took part in this step's
+        exchange into the (replicated) flat parameter buffer, asynchronously on the side stream; wait_params(i) orders the
+        compute stream behind bucket i's gather."""
+        self._param_events = {}
+        if self.mode != "sharded" or not self._distributed():
+            return
+        rank, world = self._rank_world()
+        ev = None
+        if self._comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+        for b in self._buckets:
+            a, e = b["range"]
+            if touched is not None and not intersect_ranges([(a, e)], touched):
+                continue  # nothing in this bucket was updated on any rank
+            n = (e - a) // world
+            seg = flat_params[a:e]
+            if self._comm_stream is not None:
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ev)
+                    dist.all_gather_into_tensor(seg, seg[rank * n:(rank + 1) * n], group=self._group, async_op=True).wait()
+                    done = torch.cuda.Event()
+                    done.record()
+                self._param_events[b["index"]] = done
+            else:
+                dist.all_gather_into_tensor(seg, seg[rank * n:(rank + 1) * n], group=self._group)
+            self.stats["collectives"] += 1
+            self.stats["bytes"] += 4 * (e - a) * (world - 1) // world
+
+    def wait_params(self, bucket: Optional[int] = None):
+        """compute stream waits (device side, no host sync) until the parameters of `bucket` (all buckets if None) are back"""
+        keys = list(self._param_events) if bucket is None else [bucket]
+        for k in keys:
+            ev = self._param_events.pop(k, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
 
     def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
         """Average the flat gradient buffer over the ranks of `group` (no-op without an initialised process group)."""
@@ -161,7 +320,23 @@ class FlatGrads:
             return None
         world = dist.get_world_size(group)
         self.flat.div_(world)
+        self.stats["collectives"] += 1
+        self.stats["bytes"] += 2 * 4 * self.total * (world - 1) // world
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def global_depth_clip(group: Optional[dist.ProcessGroup] = None):
+    """hook for presight_amd.ops.set_depth_clip_hook: the expected-depth clip bounds become the min / max sample midpoint over
+    the batches of ALL ranks (one 2-float all-reduce per render: MAX over {-min, max})"""
+    def hook(minmax: Tensor):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        t = torch.stack([-minmax[0], minmax[1]])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        minmax[0] = -t[0]
+        minmax[1] = t[1]
+
+    return hook
 
 
 def init_from_env(device_type: str = "cuda") -> tuple:
@@ -175,6 +350,11 @@ def init_from_env(device_type: str = "cuda") -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("PRESIGHT_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        if backend == "gloo":
+            # gloo connects its pairs lazily (inside the first collective) to the address it derives from the HOSTNAME unless
+            # told which interface to use; the container hostname may not resolve (or resolve to an unroutable address), which
+            # shows up as a first all-reduce that never returns.  Single-node runs always go through loopback.
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if os.environ.get("PRESIGHT_SINGLE_DEVICE") == "1":
             local_rank = 0  # functional test of the multi-rank path on a one-GPU box (all ranks share GPU 0, gloo transport)
         if device_type == "cuda" and backend == "nccl":

@@ -347,6 +347,7 @@ class _MainFieldRender(torch.autograd.Function):
         minmax = ops._minmax_init(dev).clone()
         check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), _p(sem_s), R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth),
                                      _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
+        ops._apply_minmax_hook(minmax)
         raw = expd.clone()
         check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
         ctx.save_for_backward(*saved, ebins, sigma, w, rgb_s, sem_s, raw, expd)

@@ -195,6 +195,9 @@ class NerfactoNuscMSModel(nn.Module):
             self.semantic_loss = semantic_loss
         self.step = 0
         self.fused_render = True  # training, one sub-field, <= 64 samples: field + weights + renderers as one autograd node
+        # data-parallel trainers with a sharded optimizer leave the all-gather of the updated parameters in flight and gate
+        # the first use of each optimizer group here: param_gate("proposal_networks" | "fields") (a device-side stream wait)
+        self.param_gate = None
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         groups = {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
@@ -257,7 +260,11 @@ class NerfactoNuscMSModel(nn.Module):
     def get_outputs(self, ray_bundle: RayBundle, jitters: Optional[List[Tensor]] = None):
         """nerfacto_nusc_ms.py:452-546"""
         c = self.config
+        if self.param_gate is not None:
+            self.param_gate("proposal_networks")
         ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns, jitters=jitters)
+        if self.param_gate is not None:
+            self.param_gate("fields")
         app = self._appearance(ray_bundle)
         app3 = None if app is None else app[:, None, :]
         if (self.training and self.fused_render and c.use_semantics and len(self.field.fields) == 1

@@ -392,6 +392,22 @@ def pdf_resample(weights: Tensor, sbins: Tensor, n_new: int, jitter: Optional[Te
 
 
 _MINMAX_INIT = {}
+_MINMAX_HOOK = None
+
+
+def set_depth_clip_hook(fn):
+    """fn(minmax [2] device tensor = {min, max} sample midpoint of this rank's batch) runs between the composite kernel and
+    the clip of the expected depth.  DepthRenderer("expected") clips to the BATCH-global sample range
+    (ns/model_components/renderers.py:377-379); under data parallelism every rank sees its shard only (so does the
+    reference under DDP) -- presight_amd.dist.global_depth_clip() installs a hook that takes the bounds over all ranks, which
+    reproduces the single-process result.  None removes the hook."""
+    global _MINMAX_HOOK
+    _MINMAX_HOOK = fn
+
+
+def _apply_minmax_hook(minmax):
+    if _MINMAX_HOOK is not None:
+        _MINMAX_HOOK(minmax)
 
 
 def _minmax_init(dev):
@@ -418,6 +434,7 @@ class _Composite(torch.autograd.Function):
         minmax = _minmax_init(dev).clone()
         check(lib().ps_composite_fwd(_p(weights), _p(ebins), _p(rgb_s), _p(sem_s), R, S, C, threshold, _p(rgb), _p(acc), _p(depth),
                                      _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
+        _apply_minmax_hook(minmax)
         raw = expd.clone()
         check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
         ctx.save_for_backward(weights, ebins, rgb_s, sem_s, raw, expd)

@@ -4,9 +4,12 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional, Sequence
 
+import ctypes
+
 import torch
 
 from ._lib import check, lib
+from .dist import intersect_ranges
 from .ops import _p, _stream
 
 
@@ -21,7 +24,8 @@ class HipAdam:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("HipAdam: parameters must be contiguous fp32 CUDA tensors")
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.step_count = 0
+        self.step_count = 0  # optimizer steps taken (informational; the bias corrections use the per-parameter counts)
+        self.steps: List[int] = [0] * len(self.params)  # torch's state[p]["step"]
         self.flat = None
         if flat_grads is not None:
             if len(flat_grads.params) != len(self.params) or any(a is not b for a, b in zip(flat_grads.params, self.params)):
@@ -46,24 +50,50 @@ class HipAdam:
 
     @torch.no_grad()
     def step(self):
+        """torch.optim.Adam semantics per PARAMETER: state["step"] (the bias-correction exponent) advances only for parameters
+        that received a gradient this step; the others are skipped entirely (no decay, no moment update), like torch with
+        grad None after zero_grad(set_to_none=True).  Proposal networks (a gradient every ~6th step after warm-up) and
+        sub-fields that saw no sample therefore keep their own, smaller step counts."""
         self.step_count += 1
         s = _stream()
         if self.flat is not None:
-            # parameters without a gradient this step are skipped entirely (no decay, no moment update), like torch.optim
-            # with grad None; the others are updated range by range (all of them -> a single launch)
-            for a, b in self.flat_grads.touched_ranges():
-                ptrs = [t.data_ptr() + 4 * a for t in self.flat]
-                check(lib().ps_adam_step(ptrs[0], ptrs[1], ptrs[2], ptrs[3], b - a, self.lr, self.betas[0], self.betas[1], self.eps,
-                                         self.weight_decay, self.step_count, s), "ps_adam_step")
+            fg = self.flat_grads
+            idx = fg.touched_params()
+            for i in idx:
+                self.steps[i] += 1
+            # adjacent touched parameters with the same step count merge into one range; in sharded data-parallel mode this
+            # rank only updates the shard it owns (presight_amd.dist: reduce-scatter -> Adam on the shard -> all-gather)
+            runs: List[list] = []
+            for i in idx:
+                a, b = fg.offsets[i], fg.offsets[i] + fg._pad(self.params[i].numel())
+                if runs and runs[-1][1] == a and runs[-1][2] == self.steps[i]:
+                    runs[-1][1] = b
+                else:
+                    runs.append([a, b, self.steps[i]])
+            owned = fg.owned_ranges()
+            ranges = []
+            for a, b, st in runs:
+                for x, y in intersect_ranges([(a, b)], owned):
+                    ranges.append((x, y - x, st))
+            if ranges:
+                n = len(ranges)
+                starts = (ctypes.c_int64 * n)(*[r[0] for r in ranges])
+                counts = (ctypes.c_int64 * n)(*[r[1] for r in ranges])
+                steps = (ctypes.c_int * n)(*[r[2] for r in ranges])
+                check(lib().ps_adam_step_ranges(_p(self.flat[0]), _p(self.flat[1]), _p(self.flat[2]), _p(self.flat[3]), n, starts, counts,
+                                                steps, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, s),
+                      "ps_adam_step_ranges")
+            fg.gather_params(self.flat[0], [(a, b) for a, b, _ in runs])  # no-op unless the exchange is sharded
             return
-        for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq):
+        for i, (p, m, v) in enumerate(zip(self.params, self.exp_avg, self.exp_avg_sq)):
             g = p.grad
             if g is None:
                 continue
             if not g.is_contiguous():
                 g = g.contiguous()
+            self.steps[i] += 1
             check(lib().ps_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                     self.weight_decay, self.step_count, s), "ps_adam_step")
+                                     self.weight_decay, self.steps[i], s), "ps_adam_step")
 
     def zero_grad(self):
         for p in self.params:
@@ -71,10 +101,11 @@ class HipAdam:
                 p.grad.zero_()
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
+        return {"step": self.step_count, "steps": list(self.steps), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
 
     def load_state_dict(self, sd):
         self.step_count = sd["step"]
+        self.steps = list(sd.get("steps", [sd["step"]] * len(self.params)))
         for a, b in zip(self.exp_avg, sd["exp_avg"]):
             a.copy_(b)
         for a, b in zip(self.exp_avg_sq, sd["exp_avg_sq"]):

@@ -136,8 +136,10 @@ _WORKER = textwrap.dedent("""
         assert torch.allclose(p.grad, torch.full_like(p, e)), (rank, p.grad, e)
     fg.zero_()
     (params[2] * 2.0).sum().backward()  # bucket 0 gets nothing on any rank -> skipped, bucket 1 exchanged
-    assert [b["launched"] for b in fg._buckets] == [False, True]
+    # buckets go out strictly in order: bucket 1 is complete but waits for bucket 0's turn, which comes in finish_exchange
+    assert [b["launched"] for b in fg._buckets] == [False, False]
     fg.finish_exchange()
+    assert [b["launched"] for b in fg._buckets] == [True, True] and fg._buckets[0]["work"] is None
     assert torch.allclose(params[2].grad, torch.full_like(params[2], 2.0)) and float(params[0].grad.abs().sum()) == 0.0
     from presight_amd.ops import mark_touched
     try:
@@ -145,9 +147,108 @@ _WORKER = textwrap.dedent("""
         raise SystemExit("a second in-place contribution after the launch must raise")
     except RuntimeError as e:
         assert "second gradient" in str(e)
+    # routing left a sub-field without samples on ONE rank only (K > 1): rank 1 never completes bucket 0, rank 0 completes
+    # both during backward (bucket 1 first).  Every rank must still issue the collectives in the same order.
+    fg.flags_may_differ_across_ranks = True
+    fg.zero_()
+    (params[2] * (rank + 1.0)).sum().backward()
+    (params[0] * (rank + 1.0)).sum().backward()
+    if rank == 0:
+        (params[1] * 3.0).sum().backward()
+    assert [b["launched"] for b in fg._buckets] == ([True, True] if rank == 0 else [False, False])
+    fg.finish_exchange()
+    assert torch.allclose(params[0].grad, torch.full_like(params[0], 1.5)), params[0].grad
+    assert torch.allclose(params[1].grad, torch.full_like(params[1], 1.5)), params[1].grad
+    assert torch.allclose(params[2].grad, torch.full_like(params[2], 1.5)), params[2].grad
+    assert fg.touched_params() == [0, 1, 2]  # agreed over ranks
+    fg.zero_()  # only the agreed touched ranges are cleared
+    assert float(fg.flat.abs().sum()) == 0.0
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
 """)
+
+
+_WORKER_SHARDED = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from presight_amd.dist import FlatGrads, init_from_env, intersect_ranges, global_depth_clip
+    rank, local, world = init_from_env("cpu")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2, 2))]
+    fg = FlatGrads(params, bucket_sizes=[2, 1], shard_world=world)
+    assert fg.bucket_ranges == [(0, 24), (24, 32)] and fg.total == 32  # every bucket splits into `world` 16-byte aligned shards
+    fg.enable_overlap([params[0:2], params[2:3]], mode="sharded")
+    # replicated flat parameter buffer (what HipAdam builds) + a plain SGD update on the OWNED shard only
+    flat_p = torch.zeros(fg.total)
+    for p, off in zip(params, fg.offsets):
+        flat_p[off:off + p.numel()] = p.data.reshape(-1)
+        p.data = flat_p[off:off + p.numel()].view_as(p)
+    before = flat_p.clone()
+    for step in range(2):
+        fg.zero_()
+        for i, p in enumerate(params):
+            if step == 1 and i == 2:
+                continue  # second step: bucket 1 gets no gradient on any rank
+            (p * (rank + 1.0) * (i + 1)).sum().backward()
+        fg.finish_exchange()
+        owned = fg.owned_ranges()
+        assert owned == [(12 * rank, 12 * rank + 12), (24 + 4 * rank, 28 + 4 * rank)], owned
+        touched = fg.touched_ranges()
+        for a, b in intersect_ranges(touched, owned):
+            flat_p[a:b] -= 0.1 * fg.flat[a:b]  # the averaged gradient is only guaranteed inside the owned shard
+        fg.gather_params(flat_p, touched)
+        fg.wait_params()
+    # expected: gradient of parameter i averaged over ranks = 1.5 * (i + 1), two steps for i < 2, one for i = 2
+    for i, (p, off) in enumerate(zip(params, fg.offsets)):
+        n = p.numel()
+        steps = 1 if i == 2 else 2
+        assert torch.allclose(flat_p[off:off + n], before[off:off + n] - 0.1 * steps * 1.5 * (i + 1), atol=1e-6), (rank, i)
+    # replicas identical
+    ref = flat_p.clone(); dist.broadcast(ref, src=0)
+    assert torch.equal(ref, flat_p)
+    # expected-depth clip bounds over all ranks
+    mm = torch.tensor([1.0 + rank, 5.0 - rank])
+    global_depth_clip()(mm)
+    assert mm.tolist() == [1.0, 5.0]
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_sharded_exchange_gloo_world2(tmp_path):
+    """reduce-scatter -> update of the owned shard -> all-gather (presight_amd.dist mode "sharded"): bit-equal replicas"""
+    script = tmp_path / "worker_sharded.py"
+    script.write_text(_WORKER_SHARDED.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29733", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
+
+
+def test_bench_launcher_and_arguments():
+    """bench.py --gpus N outside torchrun starts N ranks itself (before touching the GPU) and refuses a node with fewer GPUs;
+    a worker whose WORLD_SIZE disagrees with --gpus fails instead of silently measuring one GPU"""
+    import bench
+
+    a = bench.parse_args(["--gpus", "4", "--steps", "3"])
+    assert a.gpus == 4 and a.steps == 3 and a.config == "cfg2" and a.scaling is None
+    assert bench.CONFIGS["cfg2"]["scaling"] == "weak" and bench.CONFIGS["cfg3"]["scaling"] == "strong"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "this node has 0 GPU" in r.stderr, (r.returncode, r.stderr[-500:])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_range_helpers():
+    from presight_amd.dist import _merge, intersect_ranges
+
+    assert _merge([(8, 12), (0, 4), (4, 8), (20, 24)]) == [(0, 12), (20, 24)]
+    assert intersect_ranges([(0, 10), (20, 30)], [(5, 25)]) == [(5, 10), (20, 25)]
+    assert intersect_ranges([(0, 4)], [(4, 8)]) == []
 
 
 def test_gradient_exchange_gloo_world2(tmp_path):
