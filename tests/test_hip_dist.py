@@ -15,6 +15,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
 def test_adam_intermittent_gradients_match_torch(dev):
     """A parameter without a gradient in a step is skipped AND keeps its own step count (bias corrections), like
     torch.optim.Adam after zero_grad(set_to_none=True): proposal nets off-schedule, sub-fields without samples."""
@@ -118,6 +124,7 @@ def test_trainer_buckets_on_gpu_single_rank(dev):
     # off-schedule step: proposal networks get no gradient -> their bucket is skipped, their Adam step count stays
     tr.update_props_every_step = False
     tr.step_idx = 50000
+    model.proposal_sampler.step_cb(50000)  # past the "first 10 steps always update" rule of ray_samplers.py:586
     model.proposal_sampler._steps_since_update = 0
     tr.step(batches[0])
     n_fields = tr.grads.bucket_params[0][1]
