@@ -210,6 +210,73 @@ int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, in
                       const float* dsigma, const float* drgb, const float* dsem, const float* weights /*nullable*/, int64_t N,
                       float* dfeat, float* dapp, float* gpart, const float* acts /* nullable: recompute */, void* stream);
 
+/* ---- a5 sub-field router: all K sub-fields of a tile in ONE launch per kernel, no host synchronisation ---------------
+ * Reference: iNGPFieldMS / PropNetDensityFieldMS / SkyFieldMS (ns/fields/PreSight/ingp_field_ms.py:97-126,
+ * prop_density_field_ms.py:90-102, sky_field_ms.py:97-114) route with cdist().argmin() and loop over the sub-fields with
+ * boolean masks (4*K masked index ops and K host syncs per call).  Here ps_ms_route sorts the points by sub-field (stable)
+ * into a PADDED layout — every sub-field's group starts on a chunk boundary of ps_ms_chunk() points — described by
+ *   field_start [K+1]  first chunk of every group,  chunk_field [chunks]  sub-field of a chunk (-1 unused),
+ *   perm [slots]       sorted slot -> point index in the caller's order (-1 padding),
+ * and the *_ms entry points below evaluate every group with ITS sub-field's table / AABB / MLP weights.  Their per-point
+ * working arrays (u, sel, feature planes, kept activations, d(features)) are in sorted order (`n_slots` rows); densities,
+ * colours, semantics and their gradients stay in the caller's order (reached through perm). */
+int ps_ms_chunk(void);
+/* out[0] = int32 words of the plan buffer, out[1] / out[2] = word offsets of field_start / chunk_field inside it,
+ * out[3] = slots of the sorted layout (= length of perm), out[4] = chunks */
+int ps_ms_layout(int64_t N, int K, int64_t* out /*host[5]*/);
+/* positions (pos [N,3]) or rays (origins/dirs [R,3], ebins [R,S+1], point n = ray n/S sample n%S); centroids [K,3] */
+int ps_ms_route(const float* pos, const float* origins, const float* dirs, const float* ebins, int S, int64_t N,
+                const float* centroids, int K, int32_t* plan, int32_t* perm, void* stream);
+/* ns/fields/PreSight/ingp_field.py:169-177 per slot with the AABB of the slot's sub-field: aabbs [K,2,3]; u [slots,3], sel [slots] */
+int ps_ms_field_points(const float* pos, const float* origins, const float* dirs, const float* ebins, int S, const float* aabbs,
+                       int contract, int64_t N, int K, const int32_t* plan, const int32_t* perm, float* u, float* sel,
+                       void* stream);
+/* out[perm[i], :] = sorted[i, :] for the occupied slots */
+int ps_ms_unsort(const float* sorted, const int32_t* perm, int64_t n_slots, int width, float* out, void* stream);
+/* hash grid: tables / dtables = DEVICE arrays of K pointers; slice_counts [K, L, slices]; the gradient is ADDED to dtables[k] */
+int ps_grid_encode_ms(const float* u, const float* const* tables, const float* scalings, int L, int F, int log2T, int64_t n_slots,
+                      int64_t plane_stride, float* feat, uint32_t* slice_counts, int K, const int32_t* chunk_field, void* stream);
+int64_t ps_grid_scatter_workspace_ms(int L, int F, int log2T, int64_t n_slots, int K);
+int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t n_slots,
+                              int64_t plane_stride, float* const* dtables, int K, const int32_t* chunk_field,
+                              const uint32_t* slice_counts, int absmax_ready, void* workspace, void* stream);
+/* fused fields: packed = K packed parameter blocks back to back (ps_*_field_sizes packed_floats each); gpart receives
+ * ps_*_field_parts_ms(n_slots, K) partial gradient blocks, reduced per sub-field by ps_mlp_unpack_table_ms */
+int ps_prop_field_parts_ms(int64_t n_slots, int K);
+int ps_main_field_parts_ms(int64_t n_slots, int K);
+int ps_prop_field_fwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel, const float* packed,
+                         int64_t n_slots, float* sigma, const int32_t* perm, const int32_t* field_start, int K, void* stream);
+int ps_prop_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel, const float* packed,
+                         const float* dsigma, int64_t n_slots, float* dfeat, float* gpart, uint32_t* level_absmax /* [K, L] */,
+                         const int32_t* perm, const int32_t* field_start, int K, void* stream);
+int ps_main_field_fwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
+                         const float* dirs, const float* app, int S, int A, const float* packed, int64_t n_slots, float* sigma,
+                         float* rgb, float* sem, float* acts, const int32_t* perm, const int32_t* field_start, int K, void* stream);
+int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
+                         const float* dirs, const float* app, int S, int A, const float* packed, const float* dsigma,
+                         const float* drgb, const float* dsem, const float* weights, int64_t n_slots, float* dfeat, float* dapp,
+                         float* gpart, const float* acts, const int32_t* perm, const int32_t* field_start, int K, void* stream);
+/* fused sky field (ns/fields/PreSight/sky_field.py:95-110): per ray SH4((dir+1)/2) -> semantic head (16 -> 32 -> 32 -> 64) and
+ * [SH | appearance] -> colour head (16+A -> 32 -> 32 -> 3, sigmoid), one kernel per direction; packed = [colour | semantic]
+ * packed stacks (K of them back to back for the routed sky model, perm / field_start from ps_ms_route on the ray ORIGINS,
+ * sky_field_ms.py:97-114; NULL / NULL / 1 for a single field).  rgb / sem / drgb / dsem / dapp are in the caller's ray order;
+ * sem / dsem may be NULL (no semantic head); dapp [R,A] is written (not accumulated). */
+int ps_sky_field_supported(int A, int width, int num_layers, int semantic_dim);
+int ps_sky_field_sizes(int A, int64_t N, int K, int ms, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
+                       int* n_parts /*host*/, int64_t* offsets /*host [4]: packed colour, semantic; gradient colour, semantic*/);
+int ps_sky_field_fwd(const float* dirs, const float* app, int A, const float* packed, int64_t N, float* rgb, float* sem,
+                     const int32_t* perm, const int32_t* field_start, int K, void* stream);
+int ps_sky_field_bwd(const float* dirs, const float* app, int A, const float* packed, const float* drgb, const float* dsem,
+                     int64_t N, float* dapp, float* gpart, const int32_t* perm, const int32_t* field_start, int K, void* stream);
+/* MLP pack / gradient unpack driven by a descriptor TABLE in device memory (one 56-byte record per layer:
+ * {W | partial block, b, colmap, dst0, dst1 : pointers; out_dim, in_dim, KS, NB : int32}, ps_mlp_layer_desc_bytes()).
+ * unpack: record i belongs to sub-field i / layers_per_field; B = workgroups of the backward launch
+ * (ps_*_field_parts_ms / parts_per_block), parts_per_block = 1 (main field) or 4 (proposal field). */
+int ps_mlp_layer_desc_bytes(void);
+int ps_mlp_pack_table(const void* table, int n_layers, int max_elems, void* stream);
+int ps_mlp_unpack_table_ms(const void* table, int n_layers, int layers_per_field, const int32_t* field_start, int K, int B,
+                           int parts_per_block, int64_t part_stride, int max_elems, void* stream);
+
 /* ---- a18 prior extraction ---------------------------------------------------------------------------
  * voxel index of Open3D's voxel_down_sample_and_trace as called by ns/scripts/extract_priors.py:216-245:
  * idx = floor((p - (min_bound - voxel/2)) / voxel), fp64 arithmetic, int64 [n,3] (bit exact); min_bound is a HOST array */

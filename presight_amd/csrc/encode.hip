@@ -17,6 +17,7 @@
 // ns/field_components/encodings.py:343-384 (forward) and its autograd (index_put_ scatter-add).
 #include "common.hpp"
 #include "hashgrid_core.hpp"
+#include "ms_core.hpp"
 #include "pointwise_core.hpp"
 
 namespace {
@@ -124,7 +125,9 @@ template <int F, bool COUNT>
 __global__ __launch_bounds__(256) void grid_encode_pair_kernel(const float* __restrict__ u, const float* __restrict__ table,
                                                                const float* __restrict__ scalings, int L, int log2T, int64_t N,
                                                                int64_t plane_stride, float* __restrict__ feat,
-                                                               unsigned* __restrict__ slice_counts, int log2_slice, int group) {
+                                                               unsigned* __restrict__ slice_counts, int log2_slice, int group,
+                                                               const float* const* __restrict__ tables,
+                                                               const int* __restrict__ chunk_field) {
 #pragma clang fp contract(off)
   __shared__ unsigned cnt[COUNT ? kEncMaxSlices : 1];
   const int64_t chunks = (N + 127) / 128;  // 128 points per pass of a 256-thread workgroup
@@ -134,6 +137,13 @@ __global__ __launch_bounds__(256) void grid_encode_pair_kernel(const float* __re
   xcd_item(groups * L, item, valid);
   if (!valid) return;
   const int level = (int)(item / groups);
+  // multi-sub-field launch (ms_core.hpp): a group of 2048 points is one chunk of the sorted layout and reads ITS sub-field's table
+  if (chunk_field != nullptr) {
+    const int kf = chunk_field[item % groups];
+    if (kf < 0) return;
+    table = tables[kf];
+    if constexpr (COUNT) slice_counts += (int64_t)kf * L * (1 << (log2T - log2_slice));
+  }
   const int n_slices = COUNT ? (1 << (log2T - log2_slice)) : 0;
   if constexpr (COUNT) {
     for (int i = threadIdx.x; i < n_slices; i += 256) cnt[i] = 0u;
@@ -279,19 +289,23 @@ int binned_log2_slice(int F, int log2T);  // defined with the binned backward be
 // number of table slices per level of the binned backward (= length of one level's row in `slice_counts`)
 extern "C" int ps_grid_scatter_slices(int F, int log2T) { return 1 << (log2T - binned_log2_slice(F, log2T)); }
 
-extern "C" int ps_grid_encode(const float* u, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
-                              int64_t plane_stride, float* feat, uint32_t* slice_counts, void* stream) {
+namespace {
+// shared by ps_grid_encode (one table) and ps_grid_encode_ms (K tables, chunk -> sub-field map)
+int grid_encode_impl(const float* u, const float* table, const float* const* tables, const int* chunk_field, int K,
+                     const float* scalings, int L, int F, int log2T, int64_t N, int64_t plane_stride, float* feat,
+                     uint32_t* slice_counts, hipStream_t s) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_encode: features_per_level must be 1, 2 or 4");
-  hipStream_t s = (hipStream_t)stream;
   const int ls = binned_log2_slice(F, log2T);
   if (slice_counts != nullptr) {
     PS_REQUIRE((1 << (log2T - ls)) <= kEncMaxSlices, "ps_grid_encode: too many table slices");
-    hipError_t e = hipMemsetAsync(slice_counts, 0, (size_t)L * (1 << (log2T - ls)) * 4, s);
+    hipError_t e = hipMemsetAsync(slice_counts, 0, (size_t)K * L * (1 << (log2T - ls)) * 4, s);
     if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
   }
   if (N == 0) return 0;
   static const bool paired = getenv("PS_ENCODE_UNPAIRED") == nullptr;
+  PS_REQUIRE(paired || chunk_field == nullptr, "ps_grid_encode_ms: the unpaired debugging kernel has no multi-sub-field mode");
   const int group = paired ? 16 : 8;  // 2048 points of one level per workgroup (also measured faster than 256 without counting)
+  static_assert(16 * 128 == ps::kMsChunk, "a paired encode group is one chunk of the multi-sub-field layout");
   const int64_t chunks = paired ? (N + 127) / 128 : (N + 255) / 256;
   const int64_t groups = (chunks + group - 1) / group;
   const int64_t per = (groups * L + 7) / 8;
@@ -300,9 +314,9 @@ extern "C" int ps_grid_encode(const float* u, const float* table, const float* s
 #define PS_ENCP(FF)                                                                                                          \
   if (F == FF) {                                                                                                            \
     if (slice_counts != nullptr)                                                                                            \
-      grid_encode_pair_kernel<FF, true><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat, slice_counts, ls, group); \
+      grid_encode_pair_kernel<FF, true><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat, slice_counts, ls, group, tables, chunk_field); \
     else                                                                                                                    \
-      grid_encode_pair_kernel<FF, false><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat, nullptr, ls, group);     \
+      grid_encode_pair_kernel<FF, false><<<grid, block, 0, s>>>(u, table, scalings, L, log2T, N, plane_stride, feat, nullptr, ls, group, tables, chunk_field);     \
   }
     PS_ENCP(1) PS_ENCP(2) PS_ENCP(4)
 #undef PS_ENCP
@@ -318,6 +332,21 @@ extern "C" int ps_grid_encode(const float* u, const float* table, const float* s
   PS_ENC(1) PS_ENC(2) PS_ENC(4)
 #undef PS_ENC
   PS_CHECK_LAUNCH();
+}
+}  // namespace
+
+extern "C" int ps_grid_encode(const float* u, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
+                              int64_t plane_stride, float* feat, uint32_t* slice_counts, void* stream) {
+  return grid_encode_impl(u, table, nullptr, nullptr, 1, scalings, L, F, log2T, N, plane_stride, feat, slice_counts, (hipStream_t)stream);
+}
+
+extern "C" int ps_grid_encode_ms(const float* u, const float* const* tables, const float* scalings, int L, int F, int log2T,
+                                 int64_t n_slots, int64_t plane_stride, float* feat, uint32_t* slice_counts, int K,
+                                 const int32_t* chunk_field, void* stream) {
+  PS_REQUIRE(tables != nullptr && chunk_field != nullptr && K >= 1, "ps_grid_encode_ms: need the table pointers and the chunk map");
+  PS_REQUIRE(n_slots % ps::kMsChunk == 0, "ps_grid_encode_ms: the sorted layout is a whole number of chunks");
+  return grid_encode_impl(u, nullptr, tables, chunk_field, K, scalings, L, F, log2T, n_slots, plane_stride, feat, slice_counts,
+                          (hipStream_t)stream);
 }
 
 extern "C" int ps_grid_scatter(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
@@ -394,6 +423,22 @@ __global__ void absmax_kernel(const float* __restrict__ v_all, int64_t n, int64_
   if (ps_lane() == 0 && m > 0.f && isfinite(m)) atomicMax(out_bits, __float_as_uint(m));  // positive floats order like uints
 }
 
+// multi-sub-field variant: one workgroup per (chunk, level), maxima per (sub-field, level)
+__global__ void absmax_ms_kernel(const float* __restrict__ v_all, int F, int64_t plane_stride, int L, const int* __restrict__ chunk_field,
+                                 unsigned* __restrict__ out_all) {
+  const int kf = chunk_field[blockIdx.x];
+  if (kf < 0) return;
+  const float* v = v_all + blockIdx.y * plane_stride + (int64_t)blockIdx.x * ps::kMsChunk * F;
+  float m = 0.f;
+  for (int i = threadIdx.x * 4; i < ps::kMsChunk * F; i += blockDim.x * 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(v + i);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+  if (ps_lane() == 0 && m > 0.f && isfinite(m)) atomicMax(out_all + kf * L + blockIdx.y, __float_as_uint(m));
+}
+
 // scale exponent from the max-|g| bit pattern: 2^e * gmax in [2^35, 2^36)
 __device__ __forceinline__ float fixed_scale(unsigned gmax_bits, int headroom_log2) {
   if (gmax_bits == 0u) return 1.0f;
@@ -409,7 +454,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
                                                           const float* __restrict__ scalings, int L, int log2T,
                                                           int log2_slice, int64_t N, int64_t plane_stride, int64_t n_rec_max,
                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
-                                                          float* __restrict__ rec_val) {
+                                                          float* __restrict__ rec_val, const int* __restrict__ chunk_field) {
   // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record.
   // The staging area holds the common case (4 pair records per point + slack); split pairs can push a workgroup past it
   // (only where a level's resolution exceeds the slice size), those records go straight to their final position.
@@ -429,6 +474,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
   const int level = (int)(blockIdx.x % L);
   const int64_t first = (blockIdx.x / L) * kBinPoints;
 #endif
+  if (chunk_field != nullptr) {  // multi-sub-field launch: (sub-field, level) takes the place of the level in the stream index
+    const int kf = chunk_field[first / ps::kMsChunk];
+    if (kf < 0) return;
+    cursors += (int64_t)kf * L * n_slices;
+  }
   for (int i = threadIdx.x; i < n_slices; i += kBinThreads) cnt[i] = 0u;
   __syncthreads();
   const float s = scalings[level];
@@ -610,16 +660,19 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
                                                           const unsigned* __restrict__ rec_idx,
                                                           const float* __restrict__ rec_val, const unsigned* __restrict__ gmax_bits,
                                                           int L, int log2T, int log2_slice, int64_t n_rec_max, int headroom_log2,
-                                                          int accumulate, float* __restrict__ dtable) {
+                                                          int accumulate, float* __restrict__ dtable, float* const* __restrict__ dtables) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F]
   const int entries = 1 << log2_slice;
   const int n_slices = 1 << (log2T - log2_slice);
-  const int item = blockIdx.x;  // level * n_slices + slice
-  const int level = item / n_slices, sl = item % n_slices;
+  const int item = blockIdx.x;  // (sub-field * L + level) * n_slices + slice
+  const int vlevel = item / n_slices, sl = item % n_slices;
+  const int level = vlevel % L;
+  const int64_t n = cursors[item] - starts[item];  // the write pass advanced the cursor from the stream start to its end
+  if (n == 0 && accumulate) return;  // nothing to add (a sub-field without points: most slices of a multi-sub-field launch)
+  if (dtables != nullptr) dtable = dtables[vlevel / L];
   for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
   __syncthreads();
-  const int64_t n = cursors[item] - starts[item];  // the write pass advanced the cursor from the stream start to its end
-  const float scale = fixed_scale(gmax_bits[level], headroom_log2);
+  const float scale = fixed_scale(gmax_bits[vlevel], headroom_log2);
   const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
   // Every lane takes kChunk CONSECUTIVE records of the stream and merges neighbours that hit the same pair of rows in
   // registers (int64 adds: associative, so merging does not change the result) before touching LDS.  The bin kernel
@@ -729,34 +782,36 @@ int binned_log2_slice(int F, int log2T) {
 
 }  // namespace
 
-// bytes of scratch needed by ps_grid_scatter_binned
-extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N) {
+namespace {
+int64_t binned_workspace(int L, int F, int log2T, int64_t N, int K) {
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
-  const int64_t n_rec_max = binned_rec_capacity(N, L, n_slices);
-  return 4096 + (int64_t)L * n_slices * 4 * 3 + 16 + n_rec_max * 4 * (2 + F) + 256;
+  const int64_t n_rec_max = binned_rec_capacity(N, L, K * n_slices);
+  return 4096 + (int64_t)K * L * n_slices * 4 * 3 + 16 + n_rec_max * 4 * (2 + F) + 256;
 }
 
-extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
-                                      int64_t N, int64_t plane_stride, float* dtable, int accumulate,
-                                      const uint32_t* slice_counts, int absmax_ready, void* workspace, void* stream) {
+// K = 1, chunk_field = null: one table.  Otherwise the multi-sub-field launch of ms_core.hpp: "level" of every stream,
+// cursor and maximum becomes (sub-field, level); N = slots of the sorted layout.
+int scatter_binned_impl(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
+                        int64_t plane_stride, float* dtable, float* const* dtables, int K, const int* chunk_field, int accumulate,
+                        const uint32_t* slice_counts, int absmax_ready, void* workspace, hipStream_t s) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
-  PS_REQUIRE(N * L * 8 + 4096 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
-  hipStream_t s = (hipStream_t)stream;
+  PS_REQUIRE(N * L * 8 + 4096 + 4 * (int64_t)K * L * 256 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
+  PS_REQUIRE(K * L <= 1024, "ps_grid_scatter_binned: at most 1024 (sub-field, level) pairs");
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
   PS_REQUIRE(n_slices <= kMaxSlices, "ps_grid_scatter_binned: too many slices");
-  const int64_t n_rec_max = binned_rec_capacity(N, L, n_slices);
-  const int n_items = L * n_slices;
+  const int64_t n_rec_max = binned_rec_capacity(N, L, K * n_slices);
+  const int n_items = K * L * n_slices;
   PS_REQUIRE(((uintptr_t)workspace & 15) == 0, "ps_grid_scatter_binned: workspace must be 16-byte aligned");
   char* ws = (char*)workspace;
-  unsigned* gmax_bits = (unsigned*)ws;            // [L] (+ padding to 4096)
+  unsigned* gmax_bits = (unsigned*)ws;            // [K*L] (+ padding to 4096)
   unsigned* cursors = (unsigned*)(ws + 4096);     // [n_items]
   unsigned* counts = cursors + n_items;           // [n_items]
   unsigned* starts = counts + n_items;            // [n_items]
   unsigned* rec_idx = starts + ((n_items + 3) & ~3);  // [n_rec_max], 16-byte aligned like every plane behind it
   float* rec_val = (float*)(rec_idx + n_rec_max); // [F+1][n_rec_max] (plane F = ox)
-  // absmax_ready: the first L words of the workspace already hold the per-level max |d(feature)| bits (written by the
+  // absmax_ready: the first K*L words of the workspace already hold the per-level max |d(feature)| bits (written by the
   // field backward kernel that produced dfeat) -> keep them and skip the absmax pass
   hipError_t e = absmax_ready ? hipMemsetAsync(ws + 4096, 0, (int64_t)n_items * 4, s) : hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
   if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
@@ -780,21 +835,48 @@ extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const 
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
     if (N > 0) {                                                                                                          \
-      if (!absmax_ready) absmax_kernel<<<dim3(128, L), 256, 0, s>>>(dfeat, N * FF, plane_stride, gmax_bits);              \
+      if (!absmax_ready) {                                                                                                \
+        if (chunk_field != nullptr)                                                                                       \
+          absmax_ms_kernel<<<dim3((unsigned)(N / ps::kMsChunk), L), 256, 0, s>>>(dfeat, FF, plane_stride, L, chunk_field, gmax_bits); \
+        else                                                                                                              \
+          absmax_kernel<<<dim3(128, L), 256, 0, s>>>(dfeat, N * FF, plane_stride, gmax_bits);                             \
+      }                                                                                                                   \
       if (slice_counts == nullptr)                                                                                        \
         bin_kernel<FF, true><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,          \
-                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val); \
+                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field); \
     }                                                                                                                     \
     stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                           \
     if (N > 0)                                                                                                            \
       bin_kernel<FF, false><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,           \
-                                                                           plane_stride, n_rec_max, cursors, rec_idx, rec_val); \
+                                                                           plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field); \
     accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
-                                                               n_rec_max, headroom, accumulate, dtable);                  \
+                                                               n_rec_max, headroom, accumulate, dtable, dtables);         \
   }
   if (F == 1) PS_LAUNCH_BINNED(1)
   if (F == 2) PS_LAUNCH_BINNED(2)
   if (F == 4) PS_LAUNCH_BINNED(4)
 #undef PS_LAUNCH_BINNED
   PS_CHECK_LAUNCH();
+}
+}  // namespace
+
+// bytes of scratch needed by ps_grid_scatter_binned
+extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N) { return binned_workspace(L, F, log2T, N, 1); }
+extern "C" int64_t ps_grid_scatter_workspace_ms(int L, int F, int log2T, int64_t n_slots, int K) { return binned_workspace(L, F, log2T, n_slots, K); }
+
+extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
+                                      int64_t N, int64_t plane_stride, float* dtable, int accumulate,
+                                      const uint32_t* slice_counts, int absmax_ready, void* workspace, void* stream) {
+  return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, N, plane_stride, dtable, nullptr, 1, nullptr, accumulate, slice_counts,
+                             absmax_ready, workspace, (hipStream_t)stream);
+}
+
+extern "C" int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
+                                         int64_t n_slots, int64_t plane_stride, float* const* dtables, int K,
+                                         const int32_t* chunk_field, const uint32_t* slice_counts, int absmax_ready, void* workspace,
+                                         void* stream) {
+  PS_REQUIRE(dtables != nullptr && chunk_field != nullptr && K >= 1, "ps_grid_scatter_binned_ms: need the gradient pointers and the chunk map");
+  PS_REQUIRE(n_slots % ps::kMsChunk == 0, "ps_grid_scatter_binned_ms: the sorted layout is a whole number of chunks");
+  return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, n_slots, plane_stride, nullptr, dtables, K, chunk_field, /*accumulate=*/1,
+                             slice_counts, absmax_ready, workspace, (hipStream_t)stream);
 }

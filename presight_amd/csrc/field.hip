@@ -17,6 +17,7 @@
 // for ps_grid_scatter.
 #include "common.hpp"
 #include "mlp_core.hpp"
+#include "ms_core.hpp"
 #include "pointwise_core.hpp"
 
 #ifndef PS_MAIN_BWD_PB
@@ -125,6 +126,22 @@ __device__ __forceinline__ void load_act(const float* __restrict__ acts, int str
 
 __device__ __forceinline__ float trunc_exp_grad(float raw) { return expf(fminf(fmaxf(raw, -15.0f), 15.0f)); }
 
+// index of sorted slot p in the CALLER's per-point arrays (densities, colours, semantics, their gradients), -1 = no such point.
+// Single-field launches work in the caller's order; multi-sub-field launches (ms_core.hpp) go through perm.
+template <bool MS>
+__device__ __forceinline__ int64_t orig_index(const int* __restrict__ perm, int64_t p, int64_t N) {
+  if constexpr (MS)
+    return p < N ? (int64_t)perm[p] : (int64_t)-1;
+  else
+    return p < N ? p : (int64_t)-1;
+}
+
+// multi-sub-field launch: which sub-field, which tiles (see ms_core.hpp); single-field: all tiles, strided over the grid
+struct TileRange {
+  int64_t first_pt, end_pt;
+  int j, n;
+};
+
 // ------------------------------------------------------------------------------------------ proposal field
 // The proposal MLP ends in ONE output neuron.  As a 16x16 MFMA tile that layer would be 15/16 padding and, with its
 // data-backward and weight-gradient tiles, 48 of the 88 matrix ops per 16 points; it runs on the vector ALU instead.
@@ -155,12 +172,21 @@ __device__ __forceinline__ void scalar_head_fwd(const float (&wz)[H], float bz, 
   }
 }
 
-template <class M, int PB>
+template <class M, int PB, bool MS>
 __global__ __launch_bounds__(256) void prop_fwd_kernel(const float* __restrict__ feat, int64_t plane_stride, int LF, int F,
                                                        const float* __restrict__ sel, const float* __restrict__ packed,
-                                                       int64_t N, float* __restrict__ sigma) {
+                                                       int64_t N, float* __restrict__ sigma, const int* __restrict__ perm,
+                                                       const int* __restrict__ field_start, int K) {
   static_assert(M::NL == 2 && M::NBO == 1, "proposal MLP: two linear layers, scalar output");
   using L0 = typename M::L0;
+  TileRange tr{0, N, (int)blockIdx.x, (int)gridDim.x};
+  if constexpr (MS) {
+    const MsBlock mb = ms_block(field_start, K, gridDim.x, blockIdx.x);
+    if (mb.k < 0) return;
+    packed += (int64_t)mb.k * M::PACKED;
+    tr = TileRange{mb.first_pt, mb.end_pt, mb.j, mb.n};
+    N = mb.end_pt;
+  }
   __shared__ __attribute__((aligned(16))) float lds[M::FW];
   for (int i = threadIdx.x * 4; i < M::FW; i += 256 * 4)
     *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(packed + i);
@@ -169,9 +195,9 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const float* __restrict__
   const LdsW pw{lds};
   float wz[M::HB * 4], bz;
   load_scalar_head<M>(pw.at(M::OFFZ), wz, bz);
-  const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t first = tile * 16 * PB;
+  for (int64_t tile = (int64_t)tr.j * 4 + wave;; tile += (int64_t)tr.n * 4) {
+    const int64_t first = tr.first_pt + tile * 16 * PB;
+    if (first >= N) break;
     float x[PB][M::KS0], h1[PB][M::HB * 4], z[PB];
     load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
     layer_fwd<L0, PB>(pw.at(M::OFF0), x, h1);
@@ -181,7 +207,8 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const int64_t p = first + pb * 16 + j;
-        if (p < N) sigma[p] = expf(z[pb]) * sel[p];
+        const int64_t op = orig_index<MS>(perm, p, N);
+        if (op >= 0) sigma[op] = expf(z[pb]) * sel[p];
       }
     }
   }
@@ -189,15 +216,25 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const float* __restrict__
 
 // All weight/bias gradients live in registers for the whole kernel (no LDS accumulators, no per-tile flush); every
 // wave writes its own partial block at the end (gpart has 4 blocks per workgroup).
-template <class M, int PB>
+template <class M, int PB, bool MS>
 __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__ feat, int64_t plane_stride, int LF, int F,
                                                        const float* __restrict__ sel, const float* __restrict__ packed,
                                                        const float* __restrict__ dsigma, int64_t N, float* __restrict__ dfeat,
-                                                       float* __restrict__ gpart, unsigned* __restrict__ level_absmax) {
+                                                       float* __restrict__ gpart, unsigned* __restrict__ level_absmax,
+                                                       const int* __restrict__ perm, const int* __restrict__ field_start, int K) {
   static_assert(M::NL == 2 && M::NBO == 1, "proposal MLP: two linear layers, scalar output");
   using L0 = typename M::L0;
   using LZ = typename M::LZ;
   constexpr int H = M::HB * 4;
+  TileRange tr{0, N, (int)blockIdx.x, (int)gridDim.x};
+  if constexpr (MS) {
+    const MsBlock mb = ms_block(field_start, K, gridDim.x, blockIdx.x);
+    if (mb.k < 0) return;
+    packed += (int64_t)mb.k * M::PACKED;
+    if (level_absmax != nullptr) level_absmax += mb.k * (LF / F);
+    tr = TileRange{mb.first_pt, mb.end_pt, mb.j, mb.n};
+    N = mb.end_pt;
+  }
   float mx[M::KS0];
 #pragma unroll
   for (int t = 0; t < M::KS0; ++t) mx[t] = 0.f;
@@ -219,9 +256,9 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int t = 0; t < H; ++t) dwz[t] = 0.f;
-  const int64_t tiles = (N + 16 * PB - 1) / (16 * PB);
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t first = tile * 16 * PB;
+  for (int64_t tile = (int64_t)tr.j * 4 + wave;; tile += (int64_t)tr.n * 4) {
+    const int64_t first = tr.first_pt + tile * 16 * PB;
+    if (first >= N) break;
     float x[PB][M::KS0], h1[PB][H], z[PB], dh[PB][H], dx[PB][L0::IB * 4];
     load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
     layer_fwd<L0, PB>(p0, x, h1);
@@ -230,7 +267,8 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t p = first + pb * 16 + j;
-      const float d = (p < N) ? dsigma[p] * sel[p] * trunc_exp_grad(z[pb]) : 0.0f;  // the same value on the 4 lane groups
+      const int64_t op = orig_index<MS>(perm, p, N);
+      const float d = (op >= 0) ? dsigma[op] * sel[p] * trunc_exp_grad(z[pb]) : 0.0f;  // the same value on the 4 lane groups
       if (g == 0) dbz += d;
 #pragma unroll
       for (int t = 0; t < H; ++t) {
@@ -285,6 +323,12 @@ struct MainArgs {
   // hidden activations of the three MLPs, [N, MainCfg::ACT_W] (training forward writes them, the backward reads them instead
   // of recomputing the forward: a third of its matrix ops and half of its L2 weight-fragment traffic); null = not kept
   float* acts;
+  // multi-sub-field launch (ms_core.hpp): sorted slot -> caller's point index, sub-field groups, packed weights of sub-field k at
+  // packed + k * packed_stride; null / 0 for a single field
+  const int* perm;
+  const int* field_start;
+  int K;
+  int64_t packed_stride;
 };
 
 template <int KS0_, int HB_, int HBC_>
@@ -305,14 +349,20 @@ struct MainCfg {
 
 // colour-head input: k-steps 0-3 SH16 of (d+1)/2, 4-7 base-output block 0 (sigma_raw slot has zero weight),
 // 8-11 appearance embedding
-template <int PB>
+template <int PB, bool MS>
 __device__ __forceinline__ void build_colour_input(const MainArgs& a, int64_t first, const float (&zb)[PB][20],
                                                    float (&cin)[PB][12], int64_t (&ray_of)[PB]) {
   const int lane = ps_lane(), j = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int64_t p = first + pb * 16 + j;
-    const int64_t r = (p < a.N ? p : a.N - 1) / a.S;
+    int64_t r;
+    if constexpr (MS) {
+      const int64_t op = orig_index<true>(a.perm, p, a.N);
+      r = (op >= 0 ? op : 0) / a.S;
+    } else {
+      r = (p < a.N ? p : a.N - 1) / a.S;
+    }
     ray_of[pb] = r;
     float sh[16];
     sh4((a.dirs[r * 3] + 1.0f) / 2.0f, (a.dirs[r * 3 + 1] + 1.0f) / 2.0f, (a.dirs[r * 3 + 2] + 1.0f) / 2.0f, sh);
@@ -331,8 +381,16 @@ __device__ __forceinline__ void build_colour_input(const MainArgs& a, int64_t fi
 // NW waves per workgroup share ONE copy of the packed forward weights in LDS (112 KB: one workgroup per CU).  With NW = 8 and
 // PB = 2 a wave needs < 256 registers, so every SIMD holds TWO waves that fill each other's MFMA issue gaps (4 waves x PB = 4
 // ran the matrix pipe at 68 %).
-template <class C, int PB, int NW>
+template <class C, int PB, int NW, bool MS>
 __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
+  TileRange tr{0, a.N, (int)blockIdx.x, (int)gridDim.x};
+  if constexpr (MS) {
+    const MsBlock mb = ms_block(a.field_start, a.K, gridDim.x, blockIdx.x);
+    if (mb.k < 0) return;
+    a.packed += (int64_t)mb.k * a.packed_stride;
+    tr = TileRange{mb.first_pt, mb.end_pt, mb.j, mb.n};
+    a.N = mb.end_pt;
+  }
   __shared__ __attribute__((aligned(16))) float lds[C::FW];
   // forward blocks of the three MLPs, contiguous in LDS
   for (int i = threadIdx.x * 4; i < C::Base::FW; i += NW * 256)
@@ -343,9 +401,9 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     *reinterpret_cast<f32x4*>(lds + C::FW_RGB + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_RGB + i);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
-  const int64_t tiles = (a.N + 16 * PB - 1) / (16 * PB);
-  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < tiles; tile += (int64_t)gridDim.x * NW) {
-    const int64_t first = tile * 16 * PB;
+  for (int64_t tile = (int64_t)tr.j * NW + wave;; tile += (int64_t)tr.n * NW) {
+    const int64_t first = tr.first_pt + tile * 16 * PB;
+    if (first >= a.N) break;
     float zb[PB][20];
     {
       float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], h2[PB][C::Base::HB * 4];
@@ -360,7 +418,8 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const int64_t p = first + pb * 16 + j;
-        if (p < a.N) a.sigma[p] = expf(zb[pb][0]) * a.sel[p];
+        const int64_t op = orig_index<MS>(a.perm, p, a.N);
+        if (op >= 0) a.sigma[op] = expf(zb[pb][0]) * a.sel[p];
       }
     }
     if (a.sem != nullptr) {
@@ -376,11 +435,11 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       }
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
-        const int64_t p = first + pb * 16 + j;
-        if (p < a.N) {
+        const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
+        if (op >= 0) {
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
-            *reinterpret_cast<f32x4*>(a.sem + p * 64 + 16 * nb + 4 * g) =
+            *reinterpret_cast<f32x4*>(a.sem + op * 64 + 16 * nb + 4 * g) =
                 (f32x4){so[pb][4 * nb], so[pb][4 * nb + 1], so[pb][4 * nb + 2], so[pb][4 * nb + 3]};
         }
       }
@@ -388,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     if (a.rgb != nullptr) {
       float cin[PB][12], c1[PB][C::Rgb::HB * 4], c2[PB][C::Rgb::HB * 4], co[PB][4];
       int64_t ray_of[PB];
-      build_colour_input<PB>(a, first, zb, cin, ray_of);
+      build_colour_input<PB, MS>(a, first, zb, cin, ray_of);
       mlp_forward<typename C::Rgb, PB>(LdsW{lds + C::FW_RGB}, cin, c1, c2, co);
       if (a.acts != nullptr) {
         store_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
@@ -398,10 +457,10 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       if (g == 0) {
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-          const int64_t p = first + pb * 16 + j;
-          if (p < a.N) {
+          const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
+          if (op >= 0) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a.rgb[p * 3 + k] = 1.0f / (1.0f + expf(-co[pb][k]));
+            for (int k = 0; k < 3; ++k) a.rgb[op * 3 + k] = 1.0f / (1.0f + expf(-co[pb][k]));
           }
         }
       }
@@ -410,8 +469,16 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
 }
 
 // STORED: the hidden activations come from the training forward (a.acts) instead of being recomputed
-template <class C, int PB, int NW, bool STORED>
+template <class C, int PB, int NW, bool STORED, bool MS>
 __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
+  TileRange tr{0, a.N, (int)blockIdx.x, (int)gridDim.x};
+  if constexpr (MS) {
+    const MsBlock mb = ms_block(a.field_start, a.K, gridDim.x, blockIdx.x);
+    if (mb.k < 0) return;  // its partial block is never read (ms_field_blocks)
+    a.packed += (int64_t)mb.k * a.packed_stride;
+    tr = TileRange{mb.first_pt, mb.end_pt, mb.j, mb.n};
+    a.N = mb.end_pt;
+  }
   constexpr int SCR = C::SCR_ROWS * kScratchLd;
   __shared__ __attribute__((aligned(16))) float lds[C::GPACKED + NW * SCR + 16];
   float* gacc = lds;
@@ -423,10 +490,9 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
   float* scratch = lds + C::GPACKED + wave * SCR;
   const GlobalW pk_all = make_global_w(a.packed, C::PACKED);
   const GlobalW pk_base = pk_all.at(C::P_BASE), pk_sem = pk_all.at(C::P_SEM), pk_rgb = pk_all.at(C::P_RGB);
-  const int64_t tiles = (a.N + 16 * PB - 1) / (16 * PB);
   // workgroup-uniform trip count (the dW flush contains workgroup barriers); out-of-range tiles are fully masked
-  for (int64_t base = (int64_t)blockIdx.x * NW; base < tiles; base += (int64_t)gridDim.x * NW) {
-    const int64_t first = (base + wave) * 16 * PB;
+  for (int64_t base = (int64_t)tr.j * NW; tr.first_pt + base * 16 * PB < a.N; base += (int64_t)tr.n * NW) {
+    const int64_t first = tr.first_pt + (base + wave) * 16 * PB;
     // ---- recompute base
     float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], hdummy[PB][C::Base::HB * 4], zb[PB][20];
     load_feat<C::Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
@@ -440,9 +506,10 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t p = first + pb * 16 + j;
+      const int64_t op = orig_index<MS>(a.perm, p, a.N);
 #pragma unroll
       for (int t = 0; t < 20; ++t) dzb[pb][t] = 0.0f;
-      if (a.dsigma != nullptr && g == 0 && p < a.N) dzb[pb][0] = a.dsigma[p] * a.sel[p] * trunc_exp_grad(zb[pb][0]);
+      if (a.dsigma != nullptr && g == 0 && op >= 0) dzb[pb][0] = a.dsigma[op] * a.sel[p] * trunc_exp_grad(zb[pb][0]);
     }
     // ---- semantic head
     if (a.dsem != nullptr) {
@@ -459,10 +526,10 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
       }
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
-        const int64_t p = first + pb * 16 + j;
-        const bool in = p < a.N;
-        const float wp = (a.w != nullptr && in) ? a.w[p] : 1.0f;
-        const float* src = a.dsem + ((a.w != nullptr) ? (in ? p / a.S : 0) : p) * 64 + 4 * g;
+        const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
+        const bool in = op >= 0;
+        const float wp = (a.w != nullptr && in) ? a.w[op] : 1.0f;
+        const float* src = a.dsem + (in ? ((a.w != nullptr) ? op / a.S : op) : 0) * 64 + 4 * g;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -482,7 +549,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
     if (a.drgb != nullptr) {
       float cin[PB][12], c1[PB][C::Rgb::HB * 4], c2[PB][C::Rgb::HB * 4], co[PB][4];
       int64_t ray_of[PB];
-      build_colour_input<PB>(a, first, zb, cin, ray_of);
+      build_colour_input<PB, MS>(a, first, zb, cin, ray_of);
       if constexpr (STORED) {
         load_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
         load_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, c2);
@@ -492,13 +559,13 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
       }
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
-        const int64_t p = first + pb * 16 + j;
+        const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float d = 0.0f;
-          if (k < 3 && g == 0 && p < a.N) {
+          if (k < 3 && g == 0 && op >= 0) {
             const float s = 1.0f / (1.0f + expf(-co[pb][k]));
-            const float up = (a.w != nullptr) ? a.w[p] * a.drgb[ray_of[pb] * 3 + k] : a.drgb[p * 3 + k];
+            const float up = (a.w != nullptr) ? a.w[op] * a.drgb[ray_of[pb] * 3 + k] : a.drgb[op * 3 + k];
             d = up * s * (1.0f - s);
           }
           co[pb][k] = d;
@@ -508,10 +575,25 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
       mlp_backward<typename C::Rgb, PB, true>(pk_rgb, scratch, gacc + C::G_RGB, locks + 6, cin, c1, c2, co, dcin);
       // d(appearance) is per RAY: when a 16-point block lies inside one ray (S % 16 == 0) reduce it over the 16 lanes
       // first -> 16x fewer global atomics (67 M -> 4 M per step at cfg 2; MI355X does ~21 G atomics/s)
-      const bool block_in_ray = (a.S % 16) == 0;
+      // (multi-sub-field launches sort the points, so a block may straddle rays or contain padding: there the 16 lanes are
+      //  reduced only when they all carry the same ray)
+      bool block_in_ray = (a.S % 16) == 0;
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const int64_t p = first + pb * 16 + j;
+        bool pt_ok = p < a.N;
+        if constexpr (MS) {
+          const int64_t op = orig_index<true>(a.perm, p, a.N);
+          pt_ok = op >= 0;
+          const int rid = pt_ok ? (int)ray_of[pb] : -1;
+          bool same = true;
+          same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+          same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+          same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x141, 0xF, 0xF, false);  // row_half_mirror
+          same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x140, 0xF, 0xF, false);  // row_mirror
+          const unsigned long long ok = __ballot(same && pt_ok);
+          block_in_ray = ((ok >> (16 * g)) & 0xffffull) == 0xffffull;  // all 16 lanes valid and on one ray
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           dzb[pb][t] += dcin[pb][4 + t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
@@ -521,11 +603,13 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
           if (a.dapp != nullptr) {
 #endif
             const int c = 4 * t + g;
-            float v = (p < a.N) ? dcin[pb][8 + t] : 0.0f;
+            float v = pt_ok ? dcin[pb][8 + t] : 0.0f;
+            float vs = v;
+            if constexpr (MS) vs = ps_row16_sum(v);  // block_in_ray differs per 16-lane row: the DPP reduction runs on all lanes
             if (block_in_ray) {
-              v = ps_row16_sum(v);
-              if (j == 0 && first + pb * 16 < a.N && c < a.A) unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, v);
-            } else if (p < a.N && c < a.A) {
+              if constexpr (!MS) vs = ps_row16_sum(v);
+              if (j == 0 && first + pb * 16 < a.N && c < a.A) unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, vs);
+            } else if (pt_ok && c < a.A) {
               unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, v);
             }
           }
@@ -562,6 +646,15 @@ int grid_for_tiles(int64_t N, int pts_per_tile, int max_blocks) {
   return (int)g;
 }
 
+// multi-sub-field launch: every sub-field needs at least one workgroup (ms_block), the rest is dealt by size
+int ms_grid(int64_t n_slots, int pts_per_tile, int waves, int max_blocks, int K) {
+  const int64_t tiles = (n_slots + pts_per_tile - 1) / pts_per_tile;
+  int64_t g = (tiles + waves - 1) / waves + K;
+  if (g > max_blocks) g = max_blocks;
+  if (g < K) g = K;
+  return (int)g;
+}
+
 constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 8, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
 constexpr int kPropBwdBlocks = 512;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
 
@@ -592,14 +685,19 @@ extern "C" int ps_prop_field_sizes(int LF, int hidden, int64_t N, int64_t* packe
   return -2;
 }
 
-extern "C" int ps_prop_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
-                                 const float* packed, int64_t N, float* sigma, void* stream) {
+namespace {
+int prop_fwd_impl(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel, const float* packed, int64_t N,
+                  float* sigma, const int* perm, const int* field_start, int K, hipStream_t s) {
   if (N == 0) return 0;
 #define X(lf, h)                                                                                                     \
   if (LF == lf && hidden == h) {                                                                                     \
     using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;                                                                  \
-    prop_fwd_kernel<M, kPropFwdPB><<<grid_for_tiles(N, 16 * kPropFwdPB, 1024), 256, 0, (hipStream_t)stream>>>(         \
-        feat, plane_stride, LF, F, sel, packed, N, sigma);                                                           \
+    if (perm != nullptr)                                                                                             \
+      prop_fwd_kernel<M, kPropFwdPB, true><<<ms_grid(N, 16 * kPropFwdPB, 4, 1024, K), 256, 0, s>>>(                    \
+          feat, plane_stride, LF, F, sel, packed, N, sigma, perm, field_start, K);                                   \
+    else                                                                                                             \
+      prop_fwd_kernel<M, kPropFwdPB, false><<<grid_for_tiles(N, 16 * kPropFwdPB, 1024), 256, 0, s>>>(                  \
+          feat, plane_stride, LF, F, sel, packed, N, sigma, nullptr, nullptr, 1);                                    \
     PS_CHECK_LAUNCH();                                                                                               \
   }
   PS_PROP_CFGS(X)
@@ -608,25 +706,62 @@ extern "C" int ps_prop_field_fwd(const float* feat, int64_t plane_stride, int LF
   return -2;
 }
 
-extern "C" int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
-                                 const float* packed, const float* dsigma, int64_t N, float* dfeat, float* gpart,
-                                 uint32_t* level_absmax, void* stream) {
+int prop_bwd_impl(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel, const float* packed,
+                  const float* dsigma, int64_t N, float* dfeat, float* gpart, uint32_t* level_absmax, const int* perm,
+                  const int* field_start, int K, hipStream_t s) {
   if (N == 0) return 0;
   if (level_absmax != nullptr) {
-    hipError_t e = hipMemsetAsync(level_absmax, 0, (size_t)(LF / F) * 4, (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(level_absmax, 0, (size_t)K * (LF / F) * 4, s);
     if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
   }
 #define X(lf, h)                                                                                                     \
   if (LF == lf && hidden == h) {                                                                                     \
     using M = ps::MlpT<(lf + 3) / 4, h / 16, 1, 2>;                                                                  \
-    prop_bwd_kernel<M, kPropBwdPB><<<grid_for_tiles(N, 16 * kPropBwdPB, kPropBwdBlocks), 256, 0, (hipStream_t)stream>>>(         \
-        feat, plane_stride, LF, F, sel, packed, dsigma, N, dfeat, gpart, level_absmax);                              \
+    if (perm != nullptr)                                                                                             \
+      prop_bwd_kernel<M, kPropBwdPB, true><<<ms_grid(N, 16 * kPropBwdPB, 4, kPropBwdBlocks, K), 256, 0, s>>>(          \
+          feat, plane_stride, LF, F, sel, packed, dsigma, N, dfeat, gpart, level_absmax, perm, field_start, K);      \
+    else                                                                                                             \
+      prop_bwd_kernel<M, kPropBwdPB, false><<<grid_for_tiles(N, 16 * kPropBwdPB, kPropBwdBlocks), 256, 0, s>>>(        \
+          feat, plane_stride, LF, F, sel, packed, dsigma, N, dfeat, gpart, level_absmax, nullptr, nullptr, 1);       \
     PS_CHECK_LAUNCH();                                                                                               \
   }
   PS_PROP_CFGS(X)
 #undef X
   ps_set_error("ps_prop_field_bwd: unsupported (L*F, hidden)");
   return -2;
+}
+}  // namespace
+
+extern "C" int ps_prop_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
+                                 const float* packed, int64_t N, float* sigma, void* stream) {
+  return prop_fwd_impl(feat, plane_stride, LF, F, hidden, sel, packed, N, sigma, nullptr, nullptr, 1, (hipStream_t)stream);
+}
+
+extern "C" int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
+                                 const float* packed, const float* dsigma, int64_t N, float* dfeat, float* gpart,
+                                 uint32_t* level_absmax, void* stream) {
+  return prop_bwd_impl(feat, plane_stride, LF, F, hidden, sel, packed, dsigma, N, dfeat, gpart, level_absmax, nullptr, nullptr, 1,
+                       (hipStream_t)stream);
+}
+
+// ---- multi-sub-field launches (ms_core.hpp): n_slots = slots of the sorted layout, packed = K packed blocks back to back,
+// sigma / dsigma in the CALLER's point order (reached through perm), gpart = ps_*_field_parts_ms partial blocks
+extern "C" int ps_prop_field_parts_ms(int64_t n_slots, int K) { return 4 * ms_grid(n_slots, 16 * kPropBwdPB, 4, kPropBwdBlocks, K); }
+extern "C" int ps_main_field_parts_ms(int64_t n_slots, int K) { return ms_grid(n_slots, 16 * kMainBwdPB, kMainBwdWaves, 256, K); }
+
+extern "C" int ps_prop_field_fwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
+                                    const float* packed, int64_t n_slots, float* sigma, const int32_t* perm,
+                                    const int32_t* field_start, int K, void* stream) {
+  PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_prop_field_fwd_ms: need the sorted layout");
+  return prop_fwd_impl(feat, plane_stride, LF, F, hidden, sel, packed, n_slots, sigma, perm, field_start, K, (hipStream_t)stream);
+}
+
+extern "C" int ps_prop_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
+                                    const float* packed, const float* dsigma, int64_t n_slots, float* dfeat, float* gpart,
+                                    uint32_t* level_absmax, const int32_t* perm, const int32_t* field_start, int K, void* stream) {
+  PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_prop_field_bwd_ms: need the sorted layout");
+  return prop_bwd_impl(feat, plane_stride, LF, F, hidden, sel, packed, dsigma, n_slots, dfeat, gpart, level_absmax, perm, field_start, K,
+                       (hipStream_t)stream);
 }
 
 extern "C" int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t* packed_floats,
@@ -662,19 +797,20 @@ extern "C" int ps_main_field_act_width(int LF, int hidden, int hidden_color) {
   return 0;
 }
 
-extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
-                                 const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
-                                 int64_t N, float* sigma, float* rgb, float* sem, float* acts, void* stream) {
-  if (N == 0) return 0;
-  PS_REQUIRE(A <= 16 && S > 0, "ps_main_field_fwd: appearance dim must be <= 16");
-  PS_REQUIRE(acts == nullptr || (sem != nullptr && rgb != nullptr), "ps_main_field_fwd: activations are kept for full evaluations only");
-  MainArgs a{};
-  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
-  a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem; a.acts = acts;
+namespace {
+int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
+  if (a.N == 0) return 0;
+  PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field_fwd: appearance dim must be <= 16");
+  PS_REQUIRE(a.acts == nullptr || (a.sem != nullptr && a.rgb != nullptr), "ps_main_field_fwd: activations are kept for full evaluations only");
 #define X(lf, h, hc)                                                                                                  \
-  if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
+  if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
-    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves><<<grid_for_tiles_nw(N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, (hipStream_t)stream>>>(a); \
+    if (a.perm != nullptr) {                                                                                          \
+      a.packed_stride = C::PACKED;                                                                                    \
+      main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, true><<<ms_grid(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256, a.K), kMainFwdWaves * 64, 0, s>>>(a); \
+    } else {                                                                                                          \
+      main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+    }                                                                                                                 \
     PS_CHECK_LAUNCH();                                                                                                \
   }
   PS_MAIN_CFGS(X)
@@ -683,27 +819,76 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
   return -2;
 }
 
-extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
-                                 const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
-                                 const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t N,
-                                 float* dfeat, float* dapp, float* gpart, const float* acts, void* stream) {
-  if (N == 0) return 0;
-  PS_REQUIRE(acts == nullptr || (drgb != nullptr && dsem != nullptr), "ps_main_field_bwd: kept activations need both head gradients");
-  PS_REQUIRE(A <= 16 && S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
-  MainArgs a{};
-  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
-  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts);
+int main_bwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
+  if (a.N == 0) return 0;
+  PS_REQUIRE(a.acts == nullptr || (a.drgb != nullptr && a.dsem != nullptr), "ps_main_field_bwd: kept activations need both head gradients");
+  PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
 #define X(lf, h, hc)                                                                                                  \
-  if (LF == lf && hidden == h && hidden_color == hc) {                                                                \
+  if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
-    if (acts != nullptr)                                                                                              \
-      main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256), kMainBwdWaves * 64, 0, (hipStream_t)stream>>>(a); \
-    else                                                                                                              \
-      main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256), kMainBwdWaves * 64, 0, (hipStream_t)stream>>>(a); \
+    if (a.perm != nullptr) {                                                                                          \
+      a.packed_stride = C::PACKED;                                                                                    \
+      const int grid = ms_grid(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256, a.K);                                        \
+      if (a.acts != nullptr)                                                                                          \
+        main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, true, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);             \
+      else                                                                                                            \
+        main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, false, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);            \
+    } else {                                                                                                          \
+      const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256);                                   \
+      if (a.acts != nullptr)                                                                                          \
+        main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, true, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);            \
+      else                                                                                                            \
+        main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, false, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);           \
+    }                                                                                                                 \
     PS_CHECK_LAUNCH();                                                                                                \
   }
   PS_MAIN_CFGS(X)
 #undef X
   ps_set_error("ps_main_field_bwd: unsupported (L*F, hidden, hidden_color)");
   return -2;
+}
+}  // namespace
+
+extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                 const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                 int64_t N, float* sigma, float* rgb, float* sem, float* acts, void* stream) {
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem; a.acts = acts; a.K = 1;
+  return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
+}
+
+extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                 const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                 const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t N,
+                                 float* dfeat, float* dapp, float* gpart, const float* acts, void* stream) {
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts); a.K = 1;
+  return main_bwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
+}
+
+// multi-sub-field launches: feat / sel / acts / dfeat in the sorted layout (n_slots), everything else in the caller's order
+extern "C" int ps_main_field_fwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                    const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                    int64_t n_slots, float* sigma, float* rgb, float* sem, float* acts, const int32_t* perm,
+                                    const int32_t* field_start, int K, void* stream) {
+  PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_fwd_ms: need the sorted layout");
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = n_slots; a.sigma = sigma; a.rgb = rgb; a.sem = sem; a.acts = acts; a.perm = perm; a.field_start = field_start; a.K = K;
+  return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
+}
+
+extern "C" int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                    const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                    const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t n_slots,
+                                    float* dfeat, float* dapp, float* gpart, const float* acts, const int32_t* perm,
+                                    const int32_t* field_start, int K, void* stream) {
+  PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_bwd_ms: need the sorted layout");
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = n_slots; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts);
+  a.perm = perm; a.field_start = field_start; a.K = K;
+  return main_bwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
 }

@@ -3,6 +3,7 @@
 // field kernels.  See mlp_core.hpp for the register/fragment layout.
 #include "common.hpp"
 #include "mlp_core.hpp"
+#include "ms_core.hpp"
 
 namespace {
 
@@ -109,6 +110,51 @@ __global__ void mlp_unpack_grad_layer_kernel(const float* __restrict__ gpart, in
 __global__ void mlp_unpack_grad_layers_kernel(LayerBatch a, int n_parts, int64_t part_stride) {
   const LayerDesc& d = a.l[blockIdx.z];
   unpack_layer(d.W, n_parts, part_stride, d.out_dim, d.in_dim, d.colmap, d.KS, d.NB, d.dst0, d.dst1, blockIdx.y, gridDim.y);
+}
+
+// Descriptor TABLE variants for multi-sub-field launches (K x layers descriptors, too many for kernel arguments): the table
+// lives in device memory; it is built once per model by the host (the parameters sit at fixed addresses in the optimizer's
+// flat buffers) and re-used every step.
+__global__ void mlp_pack_table_kernel(const LayerDesc* __restrict__ table) {
+  const LayerDesc d = table[blockIdx.y];
+  pack_layer(d.W, d.b, d.out_dim, d.in_dim, d.colmap, d.KS, d.NB, d.dst0, d.dst1);
+}
+
+// descriptor i belongs to sub-field i / layers_per_field; its partial blocks are those of the workgroups ms_field_blocks deals
+// to that sub-field (parts_per_block partial blocks per workgroup).  blockIdx.y = chunk of kUnpackChunk partials.
+__global__ void mlp_unpack_table_ms_kernel(const LayerDesc* __restrict__ table, int layers_per_field, const int* __restrict__ field_start,
+                                           int K, int B, int parts_per_block, int64_t part_stride) {
+  const LayerDesc d = table[blockIdx.z];
+  const int k = blockIdx.z / layers_per_field;
+  int b0, n;
+  ps::ms_field_blocks(field_start, K, B, k, b0, n);
+  const int lo = b0 * parts_per_block, hi = (b0 + n) * parts_per_block;
+  const int p0 = max(lo, (int)blockIdx.y * kUnpackChunk), p1 = min(hi, ((int)blockIdx.y + 1) * kUnpackChunk);
+  if (p0 >= p1) return;
+  const bool single = (lo / kUnpackChunk) == ((hi - 1) / kUnpackChunk);
+  const int IB = (d.KS + 3) / 4;
+  const int n_w = d.NB * IB * 256, n_b = d.NB * 16;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_w + n_b) return;
+  float* dst = nullptr;
+  if (i < n_w) {
+    const int r = i & 3, lane = (i >> 2) & 63, ib = (i >> 8) % IB, ob = (i >> 8) / IB;  // [tile][lane][r]
+    const int o = 16 * ob + 4 * (lane >> 4) + r;
+    const int row = lane & 15;
+    const int tin = 4 * ib + (row & 3);
+    const int col = (tin < d.KS) ? d.colmap[tin * 4 + (row >> 2)] : -1;
+    if (o < d.out_dim && col >= 0 && col < d.in_dim) dst = d.dst0 + (size_t)o * d.in_dim + col;
+  } else {
+    const int o = i - n_w;
+    if (o < d.out_dim) dst = d.dst1 + o;
+  }
+  if (dst == nullptr) return;
+  float s = 0.f;
+  for (int p = p0; p < p1; ++p) s += d.W[(size_t)p * part_stride + i];
+  if (single)
+    *dst += s;
+  else
+    unsafeAtomicAdd(dst, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -378,4 +424,22 @@ extern "C" int ps_mlp_bwd(const float* x, const float* dy, const float* packed, 
 #undef X
   ps_set_error("ps_mlp_bwd: unsupported MLP shape");
   return -2;
+}
+
+extern "C" int ps_mlp_layer_desc_bytes(void) { return (int)sizeof(LayerDesc); }
+
+extern "C" int ps_mlp_pack_table(const void* table, int n_layers, int max_elems, void* stream) {
+  if (n_layers == 0) return 0;
+  mlp_pack_table_kernel<<<dim3((max_elems + 255) / 256, n_layers), 256, 0, (hipStream_t)stream>>>((const LayerDesc*)table);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_mlp_unpack_table_ms(const void* table, int n_layers, int layers_per_field, const int32_t* field_start, int K, int B,
+                                      int parts_per_block, int64_t part_stride, int max_elems, void* stream) {
+  if (n_layers == 0) return 0;
+  PS_REQUIRE(n_layers == K * layers_per_field, "ps_mlp_unpack_table_ms: one descriptor per (sub-field, layer)");
+  dim3 grid((max_elems + 255) / 256, (B * parts_per_block + kUnpackChunk - 1) / kUnpackChunk, n_layers);
+  mlp_unpack_table_ms_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const LayerDesc*)table, layers_per_field, field_start, K, B,
+                                                                    parts_per_block, part_stride);
+  PS_CHECK_LAUNCH();
 }

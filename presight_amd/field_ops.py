@@ -398,3 +398,495 @@ def main_field(u: Tensor, sel: Tensor, dirs: Optional[Tensor], app: Optional[Ten
     for W, b in list(base) + list(sem) + list(rgb):
         flat += [W, b]
     return _MainField.apply(u, sel, dirs, app, S, table, scalings, g, want_rgb, want_sem, len(base), len(sem), *flat)
+
+
+# ================================================================================================ multi-sub-field ("MS") path
+# All K sub-fields of a tile in ONE launch per kernel (csrc/ms_core.hpp): route + stable sort into the padded chunk layout on
+# the device (no host sync), per-sub-field tables / AABBs / MLP weights selected inside the kernels.  Reference semantics:
+# ns/fields/PreSight/ingp_field_ms.py:97-126, prop_density_field_ms.py:90-102.
+class MsLayout:
+    """Sorted, chunk-padded layout of one routed call (device arrays only)."""
+
+    def __init__(self, centroids: Tensor, pos: Optional[Tensor] = None, origins: Optional[Tensor] = None, dirs: Optional[Tensor] = None,
+                 ebins: Optional[Tensor] = None):
+        c = _f32(centroids)
+        self.K = int(c.shape[0])
+        if pos is not None:
+            pos = _f32(pos).view(-1, 3)
+            self.N, self.S = pos.shape[0], 0
+        else:
+            origins, dirs, ebins = _f32(origins), _f32(dirs), _f32(ebins)
+            self.S = ebins.shape[1] - 1
+            self.N = ebins.shape[0] * self.S
+        self.src = (pos, origins, dirs, ebins)
+        dev = c.device
+        out = (ctypes.c_int64 * 5)()
+        check(lib().ps_ms_layout(self.N, self.K, out), "ps_ms_layout")
+        self.plan = torch.empty(out[0], device=dev, dtype=torch.int32)
+        self.field_start = self.plan.data_ptr() + 4 * out[1]
+        self.chunk_field = self.plan.data_ptr() + 4 * out[2]
+        self.n_slots, self.chunks = int(out[3]), int(out[4])
+        self.perm = torch.empty(self.n_slots, device=dev, dtype=torch.int32)
+        check(lib().ps_ms_route(_p(pos), _p(origins), _p(dirs), _p(ebins), self.S, self.N, _p(c), self.K, _p(self.plan), _p(self.perm),
+                                _stream()), "ps_ms_route")
+
+    def points(self, aabbs: Tensor, contract: bool) -> Tuple[Tensor, Tensor]:
+        """-> (u [slots,3], sel [slots]) with every slot normalised by ITS sub-field's AABB"""
+        pos, origins, dirs, ebins = self.src
+        dev = self.perm.device
+        u = torch.empty(self.n_slots, 3, device=dev)
+        sel = torch.empty(self.n_slots, device=dev)
+        check(lib().ps_ms_field_points(_p(pos), _p(origins), _p(dirs), _p(ebins), self.S, _p(_f32(aabbs)), int(contract), self.N, self.K,
+                                       _p(self.plan), _p(self.perm), _p(u), _p(sel), _stream()), "ps_ms_field_points")
+        return u, sel
+
+
+class _LayerDesc(ctypes.Structure):
+    _fields_ = [("W", ctypes.c_void_p), ("b", ctypes.c_void_p), ("colmap", ctypes.c_void_p), ("dst0", ctypes.c_void_p),
+                ("dst1", ctypes.c_void_p), ("out_dim", ctypes.c_int), ("in_dim", ctypes.c_int), ("KS", ctypes.c_int), ("NB", ctypes.c_int)]
+
+
+def _to_device_bytes(arr, device) -> Tensor:
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+_PTR_CACHE: dict = {}
+
+
+def _ptr_table(tensors: Sequence[Tensor]) -> Tensor:
+    """device array of the tensors' addresses (int64), cached by address tuple (the parameters and their flat-buffer gradients
+    sit at fixed addresses for the life of a trainer)"""
+    key = (str(tensors[0].device), tuple(t.data_ptr() for t in tensors))
+    t = _PTR_CACHE.get(key)
+    if t is None:
+        if len(_PTR_CACHE) > 256:
+            _PTR_CACHE.clear()
+        t = torch.tensor(list(key[1]), dtype=torch.int64, device=tensors[0].device)
+        _PTR_CACHE[key] = t
+    return t
+
+
+class _MsStacks:
+    """K copies of one fused MLP stack (e.g. [base | semantic head | colour head] of the main field): persistent packed-weight
+    and partial-gradient buffers + the device descriptor tables of ps_mlp_pack_table / ps_mlp_unpack_table_ms."""
+
+    _cache: dict = {}
+
+    @classmethod
+    def get(cls, kind, specs, offsets, packed_per_field, g_per_field, layers_per_field: List[List[Tuple[Tensor, Tensor]]], max_parts):
+        key = (kind, tuple(t.data_ptr() for f in layers_per_field for W, b in f for t in (W, b)), max_parts)
+        obj = cls._cache.get(key)
+        if obj is None:
+            if len(cls._cache) > 32:
+                cls._cache.clear()
+            obj = cls(specs, offsets, packed_per_field, g_per_field, layers_per_field, max_parts)
+            cls._cache[key] = obj
+        return obj
+
+    def __init__(self, specs, offsets, packed_per_field, g_per_field, layers_per_field, max_parts):
+        assert ctypes.sizeof(_LayerDesc) == lib().ps_mlp_layer_desc_bytes()
+        self.K = len(layers_per_field)
+        dev = layers_per_field[0][0][0].device
+        self.specs, self.offsets = specs, offsets  # offsets = (p_off list, g_off list) of the stacks inside one field's block
+        self.packed_per_field, self.g_per_field = packed_per_field, g_per_field
+        self.packed = torch.empty(self.K * packed_per_field, device=dev)
+        self.gpart = torch.empty(max_parts, g_per_field, device=dev)
+        self.n_layers = sum(sp.nl for sp in specs)
+        descs = []
+        for k, layers in enumerate(layers_per_field):
+            i = 0
+            for sp, off in zip(specs, offsets[0]):
+                blk = self.packed[k * packed_per_field + off: k * packed_per_field + off + sp.packed]
+                descs += sp.pack_descs(layers[i:i + sp.nl], blk)
+                i += sp.nl
+        self._keep = descs  # the descriptors hold contiguous views of the parameters
+        arr = (_LayerDesc * len(descs))(*[_LayerDesc(_p(d[0]), _p(d[1]), _p(d[4]), d[7], d[8], d[2], d[3], d[5], d[6]) for d in descs])
+        self.pack_table = _to_device_bytes(arr, dev)
+        self.pack_elems = max(d[6] * 16 + 2 * d[6] * ((d[5] + 3) // 4) * 256 for d in descs)
+        self.shapes = [(d[2], d[3]) for d in descs[: self.n_layers]]
+        self._unpack_cache: dict = {}
+
+    def pack(self):
+        check(lib().ps_mlp_pack_table(_p(self.pack_table), self.K * self.n_layers, self.pack_elems, _stream()), "ps_mlp_pack_table")
+
+    def unpack(self, dsts: List[Tuple[Tensor, Tensor]], field_start: int, B: int, parts_per_block: int):
+        """dsts: (dW, db) per (field, layer), accumulated into"""
+        key = tuple(t.data_ptr() for d in dsts for t in d)
+        ent = self._unpack_cache.get(key)
+        if ent is None:
+            if len(self._unpack_cache) > 4:
+                self._unpack_cache.clear()
+            recs = []
+            for k in range(self.K):
+                i = 0
+                for sp, off in zip(self.specs, self.offsets[1]):
+                    for d in sp.unpack_descs(self.gpart, off, self.shapes[i:i + sp.nl]):
+                        dW, db = dsts[k * self.n_layers + i]
+                        recs.append(_LayerDesc(d[0], None, _p(d[3]), _p(dW), _p(db), d[1], d[2], d[4], d[5]))
+                        i += 1
+            arr = (_LayerDesc * len(recs))(*recs)
+            elems = max(r.NB * ((r.KS + 3) // 4) * 256 + r.NB * 16 for r in recs)
+            ent = (_to_device_bytes(arr, self.gpart.device), elems)
+            self._unpack_cache[key] = ent
+        check(lib().ps_mlp_unpack_table_ms(_p(ent[0]), self.K * self.n_layers, self.n_layers, field_start, self.K, B, parts_per_block,
+                                           self.g_per_field, ent[1], _stream()), "ps_mlp_unpack_table_ms")
+
+
+def _ms_encode(lay: MsLayout, u: Tensor, tables: Sequence[Tensor], scalings: Tensor, g: GridCfg, count: bool):
+    feat = torch.empty(g.num_levels, lay.n_slots, g.features_per_level, device=u.device)
+    counts = None
+    if count:
+        counts = torch.empty(lay.K * g.num_levels * lib().ps_grid_scatter_slices(g.features_per_level, g.log2_hashmap_size),
+                             device=u.device, dtype=torch.int32)
+    with prof.region(f"grid_encode_L{g.num_levels}F{g.features_per_level}"):
+        check(lib().ps_grid_encode_ms(_p(u), _p(_ptr_table(tables)), _p(scalings), g.num_levels, g.features_per_level,
+                                      g.log2_hashmap_size, lay.n_slots, lay.n_slots * g.features_per_level, _p(feat), _p(counts), lay.K,
+                                      lay.chunk_field, _stream()), "ps_grid_encode_ms")
+    return feat, counts
+
+
+def _ms_scatter_ws(lay: MsLayout, g: GridCfg, device) -> Tensor:
+    return _workspace(lib().ps_grid_scatter_workspace_ms(g.num_levels, g.features_per_level, g.log2_hashmap_size, lay.n_slots, lay.K),
+                      device)
+
+
+def _ms_scatter(lay: MsLayout, u, dfeat, scalings, g: GridCfg, tables: Sequence[Tensor], counts, ws, absmax_ready: bool):
+    """table gradients of all sub-fields; -> list of returned gradients (None where the gradient went into the parameter's
+    pre-allocated .grad in place)"""
+    sinks = [grad_sink(t) for t in tables]
+    fresh = [None if s is not None else torch.zeros_like(t) for s, t in zip(sinks, tables)]
+    dst = [s if s is not None else f for s, f in zip(sinks, fresh)]
+    L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
+    with prof.region(f"grid_scatter_L{L}F{F}"):
+        check(lib().ps_grid_scatter_binned_ms(_p(u), _p(dfeat), _p(scalings), L, F, l2t, lay.n_slots, lay.n_slots * F, _p(_ptr_table(dst)),
+                                              lay.K, lay.chunk_field, _p(counts), int(absmax_ready), _p(ws), _stream()),
+              "ps_grid_scatter_binned_ms")
+    return fresh
+
+
+def _ms_layer_dsts(layers_flat: Sequence[Tensor]):
+    """(dW, db) destinations per layer: the parameters' in-place gradient sinks, or fresh zero tensors that are returned"""
+    dsts, returned = [], []
+    for i in range(0, len(layers_flat), 2):
+        W, b = layers_flat[i], layers_flat[i + 1]
+        gw, gb = grad_sink(W), grad_sink(b)
+        if gw is not None and gb is not None:
+            dsts.append((gw, gb))
+            returned += [None, None]
+        else:
+            dW, db = torch.zeros_like(W), torch.zeros_like(b)
+            dsts.append((dW, db))
+            returned += [dW, db]
+    return dsts, returned
+
+
+class _PropFieldMS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lay: MsLayout, u, sel, scalings, g: GridCfg, *params):
+        K = lay.K
+        tables = [_f32(t, "hash table") for t in params[:K]]
+        wb = params[K:]
+        per = len(wb) // K  # tensors per sub-field (W, b per layer)
+        layers = [_layers(wb[k * per:(k + 1) * per]) for k in range(K)]
+        hidden = layers[0][0][0].shape[0]
+        spec = _prop_spec(g.out_dim, hidden)
+        dev = u.device
+        train = any(ctx.needs_input_grad[5:5 + K])
+        feat, counts = _ms_encode(lay, u, tables, scalings, g, count=train)
+        st = _MsStacks.get("prop", [spec], ([0], [0]), spec.packed, spec.g_total, layers, lib().ps_prop_field_parts_ms(1 << 40, K))
+        st.pack()
+        sigma = torch.empty(lay.N, device=dev)
+        with prof.region("prop_field_fwd"):
+            check(lib().ps_prop_field_fwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
+                                             _p(st.packed), lay.n_slots, _p(sigma), _p(lay.perm), lay.field_start, K, _stream()),
+                  "ps_prop_field_fwd_ms")
+        ctx.save_for_backward(u, sel, scalings, feat, counts)
+        ctx.meta = (lay, g, hidden, st, tables, wb)
+        ctx.direct = direct_params(*params)
+        return sigma
+
+    @staticmethod
+    def backward(ctx, dsigma):
+        u, sel, scalings, feat, counts = ctx.saved_tensors
+        lay, g, hidden, st, tables, wb = ctx.meta
+        K = lay.K
+        dfeat = torch.empty_like(feat)
+        ws = _ms_scatter_ws(lay, g, u.device)
+        nparts = lib().ps_prop_field_parts_ms(lay.n_slots, K)
+        with prof.region("prop_field_bwd"):
+            check(lib().ps_prop_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
+                                             _p(st.packed), _p(_f32(dsigma)), lay.n_slots, _p(dfeat), _p(st.gpart), _p(ws), _p(lay.perm),
+                                             lay.field_start, K, _stream()), "ps_prop_field_bwd_ms")
+        dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=True)
+        dsts, returned = _ms_layer_dsts(wb)
+        st.unpack(dsts, lay.field_start, nparts // 4, 4)
+        mark_touched(ctx.direct)
+        return (None, None, None, None, None, *dtables, *returned)
+
+
+def ms_prop_field(lay: MsLayout, u: Tensor, sel: Tensor, tables: Sequence[Tensor], scalings: Tensor, g: GridCfg,
+                  layers_per_field: Sequence[Sequence[Tuple[Tensor, Tensor]]]) -> Tensor:
+    """density [N] (caller's point order) of K proposal sub-fields in one launch per kernel"""
+    flat = []
+    for layers in layers_per_field:
+        for W, b in layers:
+            flat += [W, b]
+    return _PropFieldMS.apply(lay, u, sel, scalings, g, *tables, *flat)
+
+
+def _ms_main_forward(ctx, train, lay: MsLayout, u, sel, dirs, app, S, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, params):
+    K = lay.K
+    tables = [_f32(t, "hash table") for t in params[:K]]
+    wb = params[K:]
+    per = len(wb) // K
+    layers = [_layers(wb[k * per:(k + 1) * per]) for k in range(K)]
+    base, rgb_l = layers[0][:n_base], layers[0][n_base + n_sem:]
+    hidden, hidden_color = base[0][0].shape[0], rgb_l[0][0].shape[0]
+    A = rgb_l[0][0].shape[1] - 16 - GEO_DIM
+    if want_rgb and (0 if app is None else app.shape[1]) != A:
+        raise ValueError(f"colour head expects SH16 + geo15 + app{A} inputs, got an appearance embedding of width "
+                         f"{0 if app is None else app.shape[1]}")
+    spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+    dev = u.device
+    feat, counts = _ms_encode(lay, u, tables, scalings, g, count=train)
+    st = _MsStacks.get("main", [spec.base, spec.sem, spec.rgb], (spec.p_off, spec.g_off), spec.packed, spec.g_total, layers,
+                       lib().ps_main_field_parts_ms(1 << 40, K))
+    st.pack()
+    N = lay.N
+    sigma = torch.empty(N, device=dev)
+    rgb = torch.empty(N, 3, device=dev) if want_rgb else None
+    sem = torch.empty(N, SEM_DIM, device=dev) if want_sem else None
+    dirs = _f32(dirs) if dirs is not None else torch.zeros(1, 3, device=dev)
+    app_c = _f32(app) if (app is not None and want_rgb) else None
+    acts = None
+    if KEEP_ACTIVATIONS and train and want_rgb and want_sem and N > 0:
+        acts = torch.empty(lay.n_slots, lib().ps_main_field_act_width(g.out_dim, hidden, hidden_color), device=dev)
+    with prof.region("main_field_fwd"):
+        check(lib().ps_main_field_fwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                         _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(st.packed), lay.n_slots, _p(sigma), _p(rgb), _p(sem),
+                                         _p(acts), _p(lay.perm), lay.field_start, K, _stream()), "ps_main_field_fwd_ms")
+    ctx.meta = (lay, g, hidden, hidden_color, A, S, st, tables, wb, want_rgb, want_sem)
+    ctx.direct = direct_params(*params)
+    return (u, sel, dirs, app_c, scalings, feat, counts, acts), (sigma, rgb, sem)
+
+
+def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
+    u, sel, dirs, app, scalings, feat, counts, acts = saved
+    lay, g, hidden, hidden_color, A, S, st, tables, wb, want_rgb, want_sem = ctx.meta
+    K = lay.K
+    if d_rgb is None or d_sem is None:
+        acts = None
+    dfeat = torch.empty_like(feat)
+    dapp = torch.zeros_like(app) if app is not None else None
+    nparts = lib().ps_main_field_parts_ms(lay.n_slots, K)
+    with prof.region("main_field_bwd"):
+        check(lib().ps_main_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                         _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(st.packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
+                                         _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(lay.perm),
+                                         lay.field_start, K, _stream()), "ps_main_field_bwd_ms")
+    ws = _ms_scatter_ws(lay, g, u.device)
+    dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False)
+    dsts, returned = _ms_layer_dsts(wb)
+    st.unpack(dsts, lay.field_start, nparts, 1)
+    mark_touched(ctx.direct)
+    return dapp, dtables, returned
+
+
+class _MainFieldMS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lay: MsLayout, u, sel, dirs, app, S, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, *params):
+        train = any(ctx.needs_input_grad[12:12 + lay.K])
+        saved, (sigma, rgb, sem) = _ms_main_forward(ctx, train, lay, u, sel, dirs, app, S, scalings, g, want_rgb, want_sem, n_base, n_sem,
+                                                    params)
+        ctx.save_for_backward(*saved)
+        empty = torch.empty(0, device=u.device)
+        return sigma, (rgb if want_rgb else empty), (sem if want_sem else empty)
+
+    @staticmethod
+    def backward(ctx, dsigma, drgb, dsem):
+        want_rgb, want_sem = ctx.meta[-2:]
+        d_sigma = _f32(dsigma) if dsigma is not None else None
+        d_rgb = _f32(drgb) if (want_rgb and drgb is not None) else None
+        d_sem = _f32(dsem) if (want_sem and dsem is not None) else None
+        dapp, dtables, returned = _ms_main_backward(ctx, ctx.saved_tensors, d_sigma, d_rgb, d_sem, None)
+        return (None, None, None, None, dapp, None, None, None, None, None, None, None, *dtables, *returned)
+
+
+class _MainFieldRenderMS(torch.autograd.Function):
+    """_MainFieldRender for K sub-fields: the field kernels write densities / colours / semantics straight into the caller's
+    (ray-major) order through the layout's permutation, so get_weights and the renderers work on them unchanged."""
+
+    @staticmethod
+    def forward(ctx, lay: MsLayout, u, sel, dirs, app, S, ebins, threshold, scalings, g: GridCfg, n_base, n_sem, *params):
+        from . import ops
+
+        train = any(ctx.needs_input_grad[12:12 + lay.K])
+        saved, (sigma, rgb_s, sem_s) = _ms_main_forward(ctx, train, lay, u, sel, dirs, app, S, scalings, g, True, True, n_base, n_sem, params)
+        R = ebins.shape[0]
+        dev = u.device
+        ebins = _f32(ebins)
+        w = torch.empty(R, S, device=dev)
+        check(lib().ps_weights_fwd(_p(ebins), _p(sigma), R, S, _p(w), _stream()), "ps_weights_fwd")
+        rgb, sem = torch.empty(R, 3, device=dev), torch.empty(R, SEM_DIM, device=dev)
+        acc, depth, expd = torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev)
+        minmax = ops._minmax_init(dev).clone()
+        check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), _p(sem_s), R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth),
+                                     _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
+        ops._apply_minmax_hook(minmax)
+        raw = expd.clone()
+        check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
+        ctx.save_for_backward(*saved, ebins, sigma, w, rgb_s, sem_s, raw, expd)
+        ctx.n_field_saved = len(saved)
+        ctx.mark_non_differentiable(depth)
+        return rgb, acc, depth, expd, sem, w
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, _d_depth, d_exp, d_sem, d_w_ext):
+        t = ctx.saved_tensors
+        saved, (ebins, sigma, w, rgb_s, sem_s, raw, expd) = t[:ctx.n_field_saved], t[ctx.n_field_saved:]
+        R, S = w.shape
+        d_rgb = _f32(d_rgb) if d_rgb is not None else None
+        d_sem = _f32(d_sem) if d_sem is not None else None
+        d_acc = _f32(d_acc) if d_acc is not None else None
+        if d_exp is not None:
+            d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
+        dw = torch.empty_like(w)
+        check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s) if d_rgb is not None else None,
+                                     _p(sem_s) if d_sem is not None else None, _p(d_rgb), _p(d_acc), _p(d_sem), _p(d_exp), R, S,
+                                     SEM_DIM, _p(dw), None, None, _stream()), "ps_composite_bwd")
+        if d_w_ext is not None:
+            dw.add_(_f32(d_w_ext))
+        dsig = torch.empty_like(sigma)
+        check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
+        dapp, dtables, returned = _ms_main_backward(ctx, saved, dsig, d_rgb, d_sem, w)
+        return (None, None, None, None, dapp, None, None, None, None, None, None, None, *dtables, *returned)
+
+
+def _ms_params(tables, base, sem, rgb):
+    flat = []
+    for k in range(len(tables)):
+        for W, b in list(base[k]) + list(sem[k]) + list(rgb[k]):
+            flat += [W, b]
+    return flat
+
+
+def ms_main_field(lay: MsLayout, u, sel, dirs, app, S, tables, scalings, g: GridCfg, base, sem, rgb, want_rgb=True, want_sem=True):
+    """-> (density [N], rgb [N,3], semantics [N,64]) in the caller's point order; base/sem/rgb: per sub-field layer lists.
+    Point n belongs to ray n // S (dirs [R,3], app [R,A])."""
+    return _MainFieldMS.apply(lay, u, sel, dirs, app, S, scalings, g, want_rgb, want_sem, len(base[0]), len(sem[0]), *tables,
+                              *_ms_params(tables, base, sem, rgb))
+
+
+def ms_main_field_render(lay: MsLayout, u, sel, dirs, app, ebins, tables, scalings, g: GridCfg, base, sem, rgb, threshold: float = 0.5):
+    """main_field_render for K sub-fields"""
+    S = ebins.shape[1] - 1
+    if S > 64:
+        raise NotImplementedError("ms_main_field_render: at most 64 samples per ray")
+    return _MainFieldRenderMS.apply(lay, u, sel, dirs, app, S, ebins, float(threshold), scalings, g, len(base[0]), len(sem[0]), *tables,
+                                    *_ms_params(tables, base, sem, rgb))
+
+
+# ================================================================================================ fused sky field
+class SkySpec:
+    def __init__(self, A: int):
+        self.A = A
+        self.rgb = MlpSpec([16 + A, 32, 32, 3])
+        self.sem = MlpSpec([16, 32, 32, SEM_DIM])
+        pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        offs = (ctypes.c_int64 * 4)()
+        check(lib().ps_sky_field_sizes(A, 1, 1, 0, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart), offs), "ps_sky_field_sizes")
+        self.p_off, self.g_off = [int(offs[0]), int(offs[1])], [int(offs[2]), int(offs[3])]
+        self.packed, self.g_total = int(pf.value), int(gf.value)
+        assert self.packed == self.rgb.packed + self.sem.packed and self.g_total == self.rgb.g_total + self.sem.g_total
+
+
+_SKY_SPECS: dict = {}
+
+
+def _sky_spec(A: int) -> SkySpec:
+    if A not in _SKY_SPECS:
+        _SKY_SPECS[A] = SkySpec(A)
+    return _SKY_SPECS[A]
+
+
+def sky_supported(app_dim: int, width: int, num_layers: int, semantic_dim: int) -> bool:
+    return bool(lib().ps_sky_field_supported(app_dim, width, num_layers, semantic_dim))
+
+
+class _SkyField(torch.autograd.Function):
+    """colour + semantic head of the sky model for a batch of rays: one kernel per direction; `lay` (an MsLayout over the ray
+    origins) selects the routed K-sub-field variant.  params = per sub-field [rgb W0 b0 W1 b1 W2 b2 | sem W0 ... b2]."""
+
+    @staticmethod
+    def forward(ctx, lay: Optional[MsLayout], dirs, app, *params):
+        K = 1 if lay is None else lay.K
+        dirs = _f32(dirs)
+        R, dev = dirs.shape[0], dirs.device
+        app_c = _f32(app) if app is not None else None
+        A = 0 if app_c is None else app_c.shape[1]
+        spec = _sky_spec(A)
+        per = len(params) // K
+        layers = [_layers(params[k * per:(k + 1) * per]) for k in range(K)]
+        max_parts = ctypes.c_int()
+        pf, gf = ctypes.c_int64(), ctypes.c_int64()
+        check(lib().ps_sky_field_sizes(A, 1 << 40, K, int(lay is not None), ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(max_parts), None),
+              "ps_sky_field_sizes")
+        st = _MsStacks.get("sky", [spec.rgb, spec.sem], (spec.p_off, spec.g_off), spec.packed, spec.g_total, layers, max_parts.value)
+        st.pack()
+        rgb, sem = torch.empty(R, 3, device=dev), torch.empty(R, SEM_DIM, device=dev)
+        N = R if lay is None else lay.n_slots
+        with prof.region("sky_field_fwd"):
+            check(lib().ps_sky_field_fwd(_p(dirs), _p(app_c), A, _p(st.packed), N, _p(rgb), _p(sem), _p(lay.perm) if lay else None,
+                                         lay.field_start if lay else None, K, _stream()), "ps_sky_field_fwd")
+        ctx.save_for_backward(dirs, app_c)
+        ctx.meta = (lay, A, st, params, N)
+        ctx.direct = direct_params(*params)
+        return rgb, sem
+
+    @staticmethod
+    def backward(ctx, drgb, dsem):
+        dirs, app = ctx.saved_tensors
+        lay, A, st, params, N = ctx.meta
+        K = 1 if lay is None else lay.K
+        drgb = _f32(drgb) if drgb is not None else None
+        dsem = _f32(dsem) if dsem is not None else None
+        dapp = torch.empty_like(app) if app is not None else None
+        npart = ctypes.c_int()
+        pf, gf = ctypes.c_int64(), ctypes.c_int64()
+        check(lib().ps_sky_field_sizes(A, N, K, int(lay is not None), ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart), None),
+              "ps_sky_field_sizes")
+        with prof.region("sky_field_bwd"):
+            check(lib().ps_sky_field_bwd(_p(dirs), _p(app), A, _p(st.packed), _p(drgb), _p(dsem), N, _p(dapp), _p(st.gpart),
+                                         _p(lay.perm) if lay else None, lay.field_start if lay else None, K, _stream()), "ps_sky_field_bwd")
+        dsts, returned = _ms_layer_dsts(params)
+        st.unpack(dsts, lay.field_start if lay else _single_field_start(dirs.device, N), npart.value, 1)
+        mark_touched(ctx.direct)
+        return (None, None, dapp, *returned)
+
+
+_SINGLE_FS: dict = {}
+
+
+def _single_field_start(device, N: int) -> int:
+    """field_start of a one-group layout ({0, chunks}) for the table-driven gradient unpack of single-field launches"""
+    chunks = max(1, (N + lib().ps_ms_chunk() - 1) // lib().ps_ms_chunk())
+    key = (str(device), chunks)
+    t = _SINGLE_FS.get(key)
+    if t is None:
+        if len(_SINGLE_FS) > 64:
+            _SINGLE_FS.clear()
+        t = torch.tensor([0, chunks], dtype=torch.int32, device=device)
+        _SINGLE_FS[key] = t
+    return t.data_ptr()
+
+
+def sky_field(dirs: Tensor, app: Optional[Tensor], rgb_layers, sem_layers, lay: Optional[MsLayout] = None):
+    """-> (rgb [R,3], semantics [R,64]).  Single field: rgb_layers / sem_layers are layer lists; routed (lay given): one list
+    per sub-field."""
+    flat = []
+    if lay is None:
+        rgb_layers, sem_layers = [rgb_layers], [sem_layers]
+    for k in range(len(rgb_layers)):
+        for W, b in list(rgb_layers[k]) + list(sem_layers[k]):
+            flat += [W, b]
+    return _SkyField.apply(lay, dirs, app, *flat)

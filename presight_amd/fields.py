@@ -47,6 +47,11 @@ def get_normalized_directions(directions: Tensor) -> Tensor:
     return (directions + 1.0) / 2.0
 
 
+def _same_grid(a: HashEncoding, b: HashEncoding) -> bool:
+    return ((a.num_levels, a.features_per_level, a.log2_hashmap_size) == (b.num_levels, b.features_per_level, b.log2_hashmap_size)
+            and torch.equal(a.scalings, b.scalings))
+
+
 def _grid_cfg(enc: HashEncoding) -> F.GridCfg:
     return F.GridCfg(enc.num_levels, enc.features_per_level, enc.log2_hashmap_size)
 
@@ -229,23 +234,60 @@ class iNGPFieldMS(nn.Module):
         """fn(field, positions_slice, *extras_slices) -> tuple of per-point tensors (widths only documents the outputs)"""
         return routed_apply(positions.reshape(-1, 3), self.centroids, lambda k, pos, *ex: fn(self.fields[k], pos, *ex), extras)
 
+    # -- all K sub-fields in one launch per kernel (field_ops "MS" path, csrc/ms_core.hpp) ----------------------------
+    def _ms(self):
+        """per-sub-field tables / layers / AABBs of the fused MS kernels (the sub-fields of a tile share one configuration)"""
+        f0 = self.fields[0]
+        f0._require_fused()
+        g0 = f0.mlp_base_grid
+        if not getattr(self, "_ms_checked", False):
+            for f in self.fields[1:]:
+                if not _same_grid(f.mlp_base_grid, g0) or not f._fusable:
+                    raise NotImplementedError("presight_amd iNGPFieldMS: the sub-fields of a tile must share one configuration")
+            self._ms_checked = True
+        dev = g0.hash_table.device
+        aabbs = getattr(self, "_aabbs_cache", None)
+        if aabbs is None or aabbs.device != dev:
+            aabbs = torch.stack([f.aabb.float() for f in self.fields]).to(dev).contiguous()
+            self._aabbs_cache = aabbs
+        return dict(aabbs=aabbs, contract=f0.spatial_distortion is not None, tables=[f.mlp_base_grid.hash_table for f in self.fields],
+                    scalings=g0.scalings_on(dev), g=_grid_cfg(g0), base=[f.mlp_base_mlp.layer_params() for f in self.fields],
+                    sem=[f.semantic_head.layer_params() for f in self.fields], rgb=[f.rgb_head.layer_params() for f in self.fields])
+
+    def _ms_points(self, positions: Tensor, want_rgb=False, want_sem=True):
+        m = self._ms()
+        lay = F.MsLayout(self.centroids, pos=positions.reshape(-1, 3))
+        u, sel = lay.points(m["aabbs"], m["contract"])
+        return F.ms_main_field(lay, u, sel, None, None, 1, m["tables"], m["scalings"], m["g"], m["base"], m["sem"], m["rgb"],
+                               want_rgb=want_rgb, want_sem=want_sem)
+
+    def can_render(self, ray_samples: RaySamples) -> bool:
+        return all(f._fusable for f in self.fields) and ray_samples.num_samples <= 64
+
+    def render(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor], threshold: float = 0.5):
+        """iNGPField.render for the routed tile: (rgb, accumulation, threshold depth, expected depth, semantics, weights [R,S,1])"""
+        if len(self.fields) == 1:
+            return self.fields[0].render(ray_samples, appearance_embedding, threshold)
+        rb = ray_samples.ray_bundle
+        R = ray_samples.ebins.shape[0]
+        app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
+        m = self._ms()
+        lay = F.MsLayout(self.centroids, origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        u, sel = lay.points(m["aabbs"], m["contract"])
+        rgb, acc, depth, expd, sem, w = F.ms_main_field_render(lay, u, sel, rb.directions, app, ray_samples.ebins, m["tables"], m["scalings"],
+                                                               m["g"], m["base"], m["sem"], m["rgb"], threshold)
+        return rgb, acc, depth, expd, sem, w[..., None]
+
     def forward(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor]) -> Dict[FieldHeadNames, Tensor]:
         R, S = ray_samples.ebins.shape[0], ray_samples.num_samples
         rb = ray_samples.ray_bundle
         if len(self.fields) == 1:
             return self.fields[0](ray_samples, appearance_embedding)
         app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
-        positions = ops.sample_positions(rb.origins, rb.directions, ray_samples.ebins)
-        # per-POINT view directions / appearance codes travel with the points through the sort (point n of a sub-field's
-        # slice is then "ray n" of that call: S = 1)
-        per_point = lambda t: t[:, None, :].expand(R, S, t.shape[-1]).reshape(R * S, t.shape[-1])  # noqa: E731 (backward = sum over S)
-        extras = [per_point(rb.directions)] + ([per_point(app)] if app is not None else [])
-
-        def run(field: iNGPField, pos, dirs, *a):
-            u, sel = field.points(pos=pos)
-            return field.evaluate(u, sel, dirs, a[0] if a else None, 1)
-
-        sigma, rgb, sem = self._routed(positions, run, [1, 3, 64], extras)
+        m = self._ms()
+        lay = F.MsLayout(self.centroids, origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        u, sel = lay.points(m["aabbs"], m["contract"])
+        sigma, rgb, sem = F.ms_main_field(lay, u, sel, rb.directions, app, S, m["tables"], m["scalings"], m["g"], m["base"], m["sem"], m["rgb"])
         return {FieldHeadNames.DENSITY: sigma.view(R, S, 1), FieldHeadNames.RGB: rgb.view(R, S, 3),
                 FieldHeadNames.SEMANTICS: sem.view(R, S, -1)}
 
@@ -265,7 +307,7 @@ class iNGPFieldMS(nn.Module):
         if len(self.fields) == 1:
             (d,) = run(self.fields[0], positions.reshape(-1, 3))
         else:
-            (d,) = self._routed(positions, run, [1])
+            d = self._ms_points(positions, want_sem=False)[0]
         return d.view(*positions.shape[:-1], 1)
 
     def density_and_semantics(self, positions: Tensor) -> Tuple[Tensor, Tensor]:
@@ -280,7 +322,7 @@ class iNGPFieldMS(nn.Module):
         if len(self.fields) == 1:
             d, s = run(self.fields[0], positions.reshape(-1, 3))
         else:
-            d, s = self._routed(positions, run, [1, 64])
+            d, _, s = self._ms_points(positions)
         return d.view(*positions.shape[:-1], 1), s.view(*positions.shape[:-1], -1)
 
     def get_density(self, ray_samples: RaySamples):
@@ -289,7 +331,7 @@ class iNGPFieldMS(nn.Module):
     def semantic_fn(self, positions: Tensor) -> Tensor:
         if len(self.fields) == 1:
             return self.fields[0].semantic_fn(positions)
-        (s,) = self._routed(positions, lambda f, pos: (f.semantic_fn(pos),), [64])
+        s = self._ms_points(positions)[2]
         return s.view(*positions.shape[:-1], -1)
 
 
@@ -347,16 +389,38 @@ class PropNetDensityFieldMS(nn.Module):
         self.register_buffer("centroids", deepcopy(centroids))
         self.fields = nn.ModuleList(fields)
 
+    def _ms(self):
+        e0 = self.fields[0].encoding
+        if not getattr(self, "_ms_checked", False):
+            for f in self.fields[1:]:
+                if not _same_grid(f.encoding, e0):
+                    raise NotImplementedError("presight_amd PropNetDensityFieldMS: the sub-fields of a tile must share one configuration")
+            self._ms_checked = True
+        dev = e0.hash_table.device
+        aabbs = getattr(self, "_aabbs_cache", None)
+        if aabbs is None or aabbs.device != dev:
+            aabbs = torch.stack([f.aabb.float() for f in self.fields]).to(dev).contiguous()
+            self._aabbs_cache = aabbs
+        return dict(aabbs=aabbs, contract=self.fields[0].spatial_distortion is not None, tables=[f.encoding.hash_table for f in self.fields],
+                    scalings=e0.scalings_on(dev), g=_grid_cfg(e0), layers=[f.mlp_base[1].layer_params() for f in self.fields])
+
+    def _ms_density(self, lay: "F.MsLayout") -> Tensor:
+        """all K sub-fields in one launch per kernel (field_ops "MS" path)"""
+        m = self._ms()
+        u, sel = lay.points(m["aabbs"], m["contract"])
+        return F.ms_prop_field(lay, u, sel, m["tables"], m["scalings"], m["g"], m["layers"])
+
     def density_fn(self, positions: Tensor) -> Tensor:
         if len(self.fields) == 1:
             return self.fields[0].density_fn(positions)
-        (out,) = routed_apply(positions.reshape(-1, 3), self.centroids, lambda k, pos: (self.fields[k].density_fn(pos),))
-        return out.view(*positions.shape[:-1], 1)
+        return self._ms_density(F.MsLayout(self.centroids, pos=positions.reshape(-1, 3))).view(*positions.shape[:-1], 1)
 
     def density_of_samples(self, ray_samples: RaySamples) -> Tensor:
         if len(self.fields) == 1:
             return self.fields[0].density_of_samples(ray_samples)
-        return self.density_fn(ray_samples.frustums.get_positions())
+        rb = ray_samples.ray_bundle
+        lay = F.MsLayout(self.centroids, origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        return self._ms_density(lay).view(ray_samples.ebins.shape[0], ray_samples.num_samples, 1)
 
     def get_density(self, ray_samples: RaySamples):
         return self.density_of_samples(ray_samples), None
@@ -378,8 +442,17 @@ class SkyField(nn.Module):
             self.semantic_head = MLP(in_dim=self.direction_encoding.get_out_dim(), num_layers=mlp_num_layers,
                                      layer_width=mlp_layer_width, out_dim=semantic_dim, activation=nn.ReLU(), out_activation=None)
 
+    def _fused(self, appearance_embedding: Optional[Tensor]) -> bool:
+        A = 0 if appearance_embedding is None else appearance_embedding.shape[-1]
+        r = self.rgb_head
+        return (self.use_semantics and A == self.appearance_embedding_dim and r.layer_width == 32 and r.num_layers == 3
+                and self.semantic_head.out_dim == 64 and F.sky_supported(A, 32, 3, 64))
+
     def get_outputs(self, directions: Tensor, appearance_embedding: Optional[Tensor]):
         """ns/fields/PreSight/sky_field.py:95-110"""
+        if directions.is_cuda and directions.dim() == 2 and self._fused(appearance_embedding):
+            rgb, sem = F.sky_field(directions, appearance_embedding, self.rgb_head.layer_params(), self.semantic_head.layer_params())
+            return {FieldHeadNames.RGB: rgb, FieldHeadNames.SEMANTICS: sem}
         d = self.direction_encoding(get_normalized_directions(directions))
         outputs = {}
         x = torch.cat([d, appearance_embedding], dim=-1) if appearance_embedding is not None else d
@@ -407,6 +480,11 @@ class SkyFieldMS(nn.Module):
         app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         if len(self.fields) == 1:
             return self.fields[0].get_outputs(rb.directions, app)
+        if all(f._fused(app) for f in self.fields):  # all K sub-fields in one launch per direction, routed on the device
+            lay = F.MsLayout(self.centroids, pos=rb.origins)
+            rgb, sem = F.sky_field(rb.directions, app, [f.rgb_head.layer_params() for f in self.fields],
+                                   [f.semantic_head.layer_params() for f in self.fields], lay=lay)
+            return {FieldHeadNames.RGB: rgb, FieldHeadNames.SEMANTICS: sem}
         names: List[FieldHeadNames] = []
 
         def run(k, _origins, dirs, *a):

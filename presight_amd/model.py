@@ -267,10 +267,9 @@ class NerfactoNuscMSModel(nn.Module):
             self.param_gate("fields")
         app = self._appearance(ray_bundle)
         app3 = None if app is None else app[:, None, :]
-        if (self.training and self.fused_render and c.use_semantics and len(self.field.fields) == 1
-                and self.field.fields[0].can_render(ray_samples)):
+        if self.training and self.fused_render and c.use_semantics and self.field.can_render(ray_samples):
             # field + get_weights + renderers in one autograd node (never materialises the per-sample output gradients)
-            rgb, acc_raw, depth, expected_depth, semantics, weights = self.field.fields[0].render(ray_samples, app3)
+            rgb, acc_raw, depth, expected_depth, semantics, weights = self.field.render(ray_samples, app3)
             weights_list.append(weights)
             ray_samples_list.append(ray_samples)
         else:

@@ -65,3 +65,23 @@ def model_fixture_setup(G):
     P = {k[2:]: t(v) for k, v in G.items() if k.startswith("P_")}
     batch = {k[2:]: t(v) for k, v in G.items() if k.startswith("B_")}
     return cfg, scene, P, batch
+
+
+
+def grad_error_stats(named_grads, ref_grads):
+    """Per-tensor max |got - ref| / max|ref| of a set of parameter gradients against the oracle's, as a sorted tensor plus the
+    name of the worst one; tensors whose reference gradient is exactly zero must be exactly zero (asserted) and are counted."""
+    errs, names, n_zero = [], [], 0
+    for name, ref in ref_grads.items():
+        got = named_grads.get(name)
+        got = torch.zeros_like(ref) if got is None else got.detach().cpu()
+        scale = float(ref.abs().max())
+        if scale == 0:
+            assert float(got.abs().max()) == 0, f"{name}: the reference gradient is exactly zero"
+            n_zero += 1
+            continue
+        errs.append(float(((got - ref).abs() / scale).max()))
+        names.append(name)
+    e = torch.tensor(errs)
+    order = torch.argsort(e)
+    return e[order], [names[i] for i in order.tolist()], n_zero
