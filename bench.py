@@ -439,15 +439,131 @@ def roofline_entries(kern, cfg, rays):
     return rows
 
 
+# --------------------------------------------------------------------------------------------------------- extraction bench
+def extract_main(args) -> int:
+    """python bench.py --config extract [--gpus N]: BASELINE configs[4], prior extraction of one tile as a dense 512^3 lattice
+    query (cfg-2 fields): lattice points -> 2 proposal fields + ONE pass of the main field (density + 64-d semantics) -> mean
+    density, clipped fp16 features, density threshold, bit-exact integer voxel index, voxel down-sampling of the kept points.
+    The lattice is split into one contiguous slab per rank; there is no exchange inside the timed region.  One "step" = one
+    pass over the rank's slab.  Prints ONE JSON line."""
+    import torch
+
+    from presight_amd.dist import init_from_env
+    from presight_amd.extract import dense_tile_query, voxelize
+
+    rank, local_rank, world = init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    res = int(os.environ.get("PRESIGHT_EXTRACT_RES", "512"))
+    model, scene = build_model(dev, seed=42, config="cfg2")
+    model.eval()
+    aabb = scene["aabbs"][0]
+    total = res ** 3
+    per = (total + world - 1) // world
+    start, count = rank * per, max(0, min(per, total - rank * per))
+
+    def one_pass():
+        out = dense_tile_query(model, aabb, res=res, chunk=1 << 23, start=start, count=count, density_threshold=1.0)
+        vox = voxelize(out["points"], out["features"], None, voxel=0.4, min_bound=out["min_bound"], points_max=out["points_max"], want_sums=world > 1)
+        return out, vox
+
+    dense_tile_query(model, aabb, res=64)  # warm-up: kernels, allocator
+    for _ in range(max(0, args.warmup - 1)):
+        one_pass()
+    steps = max(1, min(args.steps, 5))
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out, vox = one_pass()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kept, nvox = int(out["points"].shape[0]), int(vox["key"].shape[0])
+    if rank == 0:
+        value = total * steps / dt
+        per_gpu = value / world
+        # SURVEY.md 8d per query point: 1792 B of hash rows (main 16*8*2*4 + 2 proposal nets 8*8*1*4) + 2*(7680+12288) + 2*2*576 FLOP... cfg-2 fields
+        flop_pt, byte_pt = 2 * (16 * 2 * 64 + 64 * 80 + 3 * 64 * 64) + 2 * 2 * 576, 16 * 8 * 2 * 4 + 2 * 8 * 8 * 4 + 64 * 2 + 4
+        line = {"metric": "prior-extraction lattice points/sec (whole node)", "value": value, "unit": "points/s", "n_gpus": world, "steps": steps,
+                "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"BASELINE cfg 5: dense {res}^3 lattice of one tile (cfg-2 fields): 3 field queries + fp16 features + density "
+                                       "threshold + bit-exact voxel index + voxel down-sampling of the kept points", "points_per_gpu": count,
+                           "parallelism": f"slabs{world}"},
+                "roofline": {"bound": "mfma", "kernel": "whole pass (per-point algorithmic work, SURVEY.md 8d)", "achieved": per_gpu * flop_pt / 1e12,
+                             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per_gpu * flop_pt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                             "traffic": None, "hbm_achieved_gbs": per_gpu * byte_pt / 1e9, "hbm_frac": per_gpu * byte_pt / 1e9 / HBM_PEAK_GBS},
+                "kept_points_rank0": kept, "voxels_rank0": nvox}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_query_baseline()
+            line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+def cpu_query_baseline() -> dict:
+    """the CPU oracle's prior query (restatement of extract_priors.py:133-138, kind = "port") on a bounded sample of lattice points"""
+    import statistics
+
+    import torch
+
+    from oracle import nerf_oracle as O
+
+    cfg = O.default_config()
+    scene = O.make_scene(cfg)
+    P = O.make_params(cfg, seed=42)
+    n = 1 << 18
+    g = torch.Generator().manual_seed(0)
+    lo, hi = scene["aabbs"][0][0], scene["aabbs"][0][1]
+    pts = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    phys, model_name = host_cpu_info()
+    maxt = torch.get_num_threads()
+    best, best_dt, probe = None, float("inf"), {}
+    with torch.no_grad():
+        O.prior_query(P, cfg, scene, pts[:4096])
+        for th in sorted({t for t in (8, 16, 32, 64, 128, phys) if t <= max(phys, maxt)}):
+            torch.set_num_threads(th)
+            t0 = time.time()
+            O.prior_query(P, cfg, scene, pts[:65536])
+            d = time.time() - t0
+            probe[th] = round(65536 / d, 1)
+            if d < best_dt:
+                best, best_dt = th, d
+        torch.set_num_threads(best or maxt)
+        times = []
+        for _ in range(5):
+            t0 = time.time()
+            O.prior_query(P, cfg, scene, pts)
+            times.append(time.time() - t0)
+            if sum(times) > 30:
+                break
+    used = torch.get_num_threads()
+    torch.set_num_threads(maxt)
+    return dict(value=n / statistics.median(times), unit="points/s", cores=used, kind="port",
+                sample=f"median of {len(times)} passes over {n} lattice points (2 proposal fields + main field density and semantics, cfg-2 tables), "
+                       f"torch-CPU oracle, {used} threads",
+                host=dict(cpu_model=model_name, physical_cores=phys, logical_cpus=os.cpu_count(), thread_probe_points_per_s=probe))
+
+
 # --------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     if args.config == "extract":
-        from presight_amd.extract import bench_main
-
-        sys.exit(bench_main(args))
+        sys.exit(extract_main(args))
 
     import torch
 

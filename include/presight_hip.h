@@ -69,6 +69,9 @@ int ps_mlp_bwd(const float* x, const float* dy, const float* packed, float* dx, 
 int ps_contract(const float* p, const float* aabb, int64_t M, int contract, float* u, uint8_t* sel, void* stream);
 /* SH degree 4 of (d+1)/2, ns/utils/math.py:27-79 via ns/fields/base_field.py:136-142; out [M,16] */
 int ps_sh4(const float* dirs, int64_t M, float* out, void* stream);
+/* SHEncoding.forward (ns/field_components/encodings.py:711-719): real SH of `levels` (1..4) levels evaluated on x [M,3] AS
+ * GIVEN (the fields pass (d+1)/2); out [M, levels^2] */
+int ps_sh_encode(const float* x, int64_t M, int levels, float* out, void* stream);
 /* argmin_k ||p - c_k||, ns/fields/PreSight/ingp_field_ms.py:97; assign int32 [M] */
 int ps_route(const float* p, int64_t M, const float* centroids, int K, int32_t* assign, void* stream);
 /* o + d*(start+end)/2, ns/cameras/rays.py:49-58; ebins [R,S+1]; pos [R*S,3] */
@@ -287,6 +290,17 @@ int ps_voxel_index(const float* pts, int64_t n, double voxel, const double* min_
 int ps_lattice_points(const float* aabb /*host[6]*/, int res, int64_t start, int64_t count, float* pts, void* stream);
 /* (a + b + c) / 3: mean of proposal-net and main-field densities, extract_priors.py:133-137 */
 int ps_mean_density(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
+
+/* voxel down-sampling of the extracted points (extract_priors.py:151-191, 216-245; Open3D voxel_down_sample_and_trace):
+ * keys[i] = (ix * ny + iy) * nz + iz of the ps_voxel_index triple; after a stable sort of the keys (order [n] = point of
+ * sorted position, starts / counts [V] = run of every voxel) ps_voxel_reduce writes per voxel the mean point (f32), the
+ * mean colour (f32, colors may be NULL) and the mean feature (fp16 members summed in fp64 -> fp16, C <= 64 channels);
+ * sums (nullable) [V, 6 + C] receives the raw fp64 sums {point, colour, feature} for merging partial results of ranks. */
+int ps_voxel_keys(const float* pts, int64_t n, double voxel, const double* min_bound /*host[3]*/, int64_t ny, int64_t nz,
+                  int64_t* keys, void* stream);
+int ps_voxel_reduce(const int64_t* order, const int64_t* starts, const int64_t* counts, int64_t V, const float* pts,
+                    const void* feats_f16, const float* colors, int C, float* o_pts, void* o_feat_f16, float* o_col,
+                    double* sums, void* stream);
 
 /* ---- f1 optimizer: torch.optim.Adam semantics (L2 weight decay added to the gradient, bias-corrected), in place.
  * Reference configuration: ns/configs/method_configs.py:158-168 (lr 1e-2, eps 1e-15, weight_decay 1e-5).

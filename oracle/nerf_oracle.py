@@ -790,3 +790,55 @@ def prior_query(P, cfg, scene, pts: Tensor):
         dens.append(sg)
         density = torch.stack(dens, 0).mean(0)
         return density, sem.clip(0, 1).half()
+
+
+def extract_frame(P, cfg, scene, camera_idx: int, scaling: float, pose_scale_factor: float, max_depth: float = 50.0,
+                  min_depth: float = 0.5, depth_type: str = "depth"):
+    """One iteration of the frame loop of ns/scripts/extract_priors.py:99-145 (no segmentation mask): all pixels of camera
+    `camera_idx` at the rescaled resolution (Cameras.rescale_output_resolution, ns/cameras/cameras.py:953-958: intrinsics * s,
+    size = trunc(size * s) in float32) -> eval depth march (get_depth_for_camera_ray_bundle, one chunk) -> world points ->
+    min_depth < depth < max_depth, -3 < z < 6 -> mean density, clipped fp16 semantics, PCA colours (computed in fp16 like the
+    reference, whose colormap casts its matrices to the features' dtype).
+    -> dict(raw_depth [H*W], sel bool [H*W], world [n,3], dens [n], feats f16 [n,64], colors f16 [n,3])"""
+    s32 = torch.tensor([scaling], dtype=torch.float32)
+    H = int((torch.tensor(int(scene["H"])) * s32).to(torch.int64))
+    W = int((torch.tensor(int(scene["W"])) * s32).to(torch.int64))
+    rows, cols = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    ri = torch.stack([torch.full((H * W,), int(camera_idx)), rows.reshape(-1), cols.reshape(-1)], -1)
+    sc = dict(scene)
+    for k in ("fx", "fy", "cx", "cy"):
+        sc[k] = scene[k] * s32
+    with torch.no_grad():
+        out = model_forward(P, cfg, sc, {"ray_indices": ri, "video_ids": torch.zeros(H * W, dtype=torch.int64)}, training=False)
+        depth = out[depth_type] / pose_scale_factor
+        world = (out["origins"] / pose_scale_factor + out["directions"] * depth).view(-1, 3)
+        depth = depth.flatten()
+        sel = (depth < max_depth) & (depth > min_depth) & (world[:, 2] > -3.0) & (world[:, 2] < 6.0)
+        world = world[sel]
+        res = dict(raw_depth=depth, sel=sel, world=world)
+        if world.shape[0]:
+            dens, feats = prior_query(P, cfg, scene, world * pose_scale_factor)
+            res.update(dens=dens, feats=feats, colors=feature_colormap(feats, scene["dino_to_rgb"]))
+    return res
+
+
+def voxel_downsample(points: Tensor, features: Tensor, colors: Optional[Tensor], voxel: float = 0.4):
+    """ns/scripts/extract_priors.py:160-191 + 216-245: Open3D voxel_down_sample_and_trace (index rule of voxel_index with
+    min_bound = points.min - 1; output point = mean of the members) and the per-voxel traces: colour = fp32 mean of the members,
+    feature = fp64 mean of the fp16 members -> fp16, hits = member count.  Plain python / numpy loops (small cases only).
+    -> dict keyed by the integer voxel triple: (point f64 [3], feature f16 [C], colour f32 [3] | None, hits)."""
+    import numpy as np
+
+    mn = points.min(0).values - 1.0
+    idx = voxel_index(points, voxel, mn).numpy()
+    pts, fe = points.double().numpy(), features.numpy()
+    co = colors.float().numpy() if colors is not None else None
+    groups: Dict[tuple, list] = {}
+    for i, key in enumerate(map(tuple, idx.tolist())):
+        groups.setdefault(key, []).append(i)
+    out = {}
+    for key, members in groups.items():
+        m = np.asarray(members)
+        out[key] = (pts[m].mean(axis=0), fe[m].astype(np.float64).mean(axis=0).astype(np.float16),
+                    None if co is None else co[m].mean(axis=0), len(members))
+    return out

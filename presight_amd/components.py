@@ -23,9 +23,23 @@ from . import ops
 IMPLEMENTATIONS = ("tcnn", "torch", "tcnn+fp32", "hip")
 
 
+_WARNED_TCNN = False
+
+
 def _check_impl(implementation: str):
+    global _WARNED_TCNN
     if implementation not in IMPLEMENTATIONS:
         raise ValueError(f"unknown implementation {implementation!r}")
+    if implementation.startswith("tcnn") and not _WARNED_TCNN:
+        import warnings
+
+        _WARNED_TCNN = True
+        warnings.warn(
+            f"presight_amd: implementation={implementation!r} runs the semantics of nerfstudio's pure-torch path (all levels hashed, "
+            "scale = floor(base * g^l), ceil/floor corners; ns/field_components/encodings.py:324-384) on the HIP kernels.  "
+            "tiny-cuda-nn's grid is a different function of different parameters (dense coarse levels, +0.5 offset, flat params): a "
+            "checkpoint TRAINED with tcnn is not table-compatible; checkpoints of the 'torch' implementation load unchanged.",
+            stacklevel=3)
 
 
 def hash_scalings(num_levels: int, min_res: int, max_res: int) -> Tensor:
@@ -90,11 +104,9 @@ class SHEncoding(nn.Module):
 
     @torch.no_grad()
     def forward(self, in_tensor: Tensor) -> Tensor:
-        """Input is the already shifted direction (d+1)/2 (ns/fields/base_field.py:136-142); the kernel applies the
-        shift itself, so undo it here to keep the operator contract."""
-        flat = in_tensor.reshape(-1, 3) * 2.0 - 1.0
-        out = ops.sh4(flat)[:, : self.levels**2]
-        return out.reshape(*in_tensor.shape[:-1], self.levels**2)
+        """The reference evaluates the harmonics on its input as given (ns/field_components/encodings.py:711-714); the fields
+        hand it the shifted direction (d+1)/2 (ns/fields/base_field.py:136-142)."""
+        return ops.sh_encode(in_tensor.reshape(-1, 3), self.levels).reshape(*in_tensor.shape[:-1], self.levels**2)
 
 
 class MLP(nn.Module):

@@ -3,6 +3,7 @@
 //                      idx = floor((p - (min_bound - voxel/2)) / voxel) per axis, evaluated in fp64 -> int64 (bit exact)
 //   ps_lattice_points: the dense res^3 query lattice over a tile AABB (z fastest), cell centres
 //   ps_mean_density  : mean of the proposal-net and main-field densities (extract_priors.py:133-137)
+#include <hip/hip_fp16.h>
 #include "common.hpp"
 
 namespace {
@@ -59,5 +60,80 @@ extern "C" int ps_lattice_points(const float* aabb /*host[6]: min xyz, max xyz*/
 extern "C" int ps_mean_density(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream) {
   if (n == 0) return 0;
   mean3_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(a, b, c, n, out);
+  PS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Voxel down-sampling of the extracted points (ns/scripts/extract_priors.py:151-191, 216-245): Open3D's
+// voxel_down_sample_and_trace groups the points by integer voxel index and returns, per voxel, the mean point and the member
+// lists; the script then averages the members' colours (fp32) and features (fp16 -> fp64 mean -> fp16) and counts the hits.
+// Here:  ps_voxel_keys      one int64 key per point (x-major linearisation of the bit-exact voxel index of ps_voxel_index),
+//        [caller: stable sort of the keys, run lengths of equal keys]
+//        ps_voxel_reduce    one 64-lane wavefront per voxel walks the run: lane c sums feature channel c of every member in
+//                           fp64 (a member's 64 fp16 channels are one coalesced 128-byte row), lanes 0-2 / 3-5 also carry
+//                           the point / colour sums; means are written in the reference's output types.
+// Members are visited in input order (stable sort), so the fp64 sums are reproducible.
+namespace {
+
+__global__ void voxel_keys_kernel(const float* __restrict__ pts, int64_t n, double voxel, double mx, double my, double mz, int64_t ny,
+                                  int64_t nz, int64_t* __restrict__ keys) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double h = voxel * 0.5;
+  const int64_t ix = (int64_t)floor(((double)pts[i * 3 + 0] - (mx - h)) / voxel);
+  const int64_t iy = (int64_t)floor(((double)pts[i * 3 + 1] - (my - h)) / voxel);
+  const int64_t iz = (int64_t)floor(((double)pts[i * 3 + 2] - (mz - h)) / voxel);
+  keys[i] = (ix * ny + iy) * nz + iz;
+}
+
+// order [n]: point index of sorted position; starts / counts [V]: run of every voxel in the sorted order.
+// sums != null: also write the raw fp64 sums ([V, 3 + 3 + 64]: point, colour, feature) for a later merge of partial results
+__global__ __launch_bounds__(256) void voxel_reduce_kernel(const int64_t* __restrict__ order, const int64_t* __restrict__ starts,
+                                                           const int64_t* __restrict__ counts, int64_t V, const float* __restrict__ pts,
+                                                           const __half* __restrict__ feats, const float* __restrict__ colors, int C,
+                                                           float* __restrict__ o_pts, __half* __restrict__ o_feat,
+                                                           float* __restrict__ o_col, double* __restrict__ sums) {
+  const int64_t v = blockIdx.x * (int64_t)(blockDim.x / 64) + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t s = starts[v], c = counts[v];
+  double fsum = 0.0, psum = 0.0;
+  for (int64_t m = 0; m < c; ++m) {
+    const int64_t p = order[s + m];
+    if (lane < C) fsum += (double)__half2float(feats[p * C + lane]);
+    if (lane < 3) psum += (double)pts[p * 3 + lane];
+    else if (lane < 6 && colors != nullptr) psum += (double)colors[p * 3 + (lane - 3)];
+  }
+  const double inv = 1.0 / (double)c;
+  if (lane < C) o_feat[v * C + lane] = __float2half_rn((float)(fsum * inv));  // fp64 mean -> fp16, like .astype(np.float16)
+  if (lane < 3) o_pts[v * 3 + lane] = (float)(psum * inv);
+  else if (lane < 6 && colors != nullptr) o_col[v * 3 + (lane - 3)] = (float)(psum * inv);
+  if (sums != nullptr) {
+    double* o = sums + v * (6 + C);
+    if (lane < 6) o[lane] = (lane < 3 || colors != nullptr) ? psum : 0.0;
+    if (lane < C) o[6 + lane] = fsum;
+  }
+}
+
+}  // namespace
+
+// keys[i] = (ix * ny + iy) * nz + iz with (ix, iy, iz) = ps_voxel_index(p_i); ny, nz = voxel counts along y / z (any bound >=
+// the largest index + 1); min_bound is a HOST array
+extern "C" int ps_voxel_keys(const float* pts, int64_t n, double voxel, const double* min_bound, int64_t ny, int64_t nz, int64_t* keys,
+                             void* stream) {
+  if (n == 0) return 0;
+  PS_REQUIRE(voxel > 0.0 && ny > 0 && nz > 0, "ps_voxel_keys: voxel size and grid extents must be positive");
+  voxel_keys_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(pts, n, voxel, min_bound[0], min_bound[1], min_bound[2],
+                                                                                 ny, nz, keys);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_voxel_reduce(const int64_t* order, const int64_t* starts, const int64_t* counts, int64_t V, const float* pts,
+                               const void* feats_f16, const float* colors, int C, float* o_pts, void* o_feat_f16, float* o_col,
+                               double* sums, void* stream) {
+  if (V == 0) return 0;
+  PS_REQUIRE(C >= 1 && C <= 64, "ps_voxel_reduce: 1..64 feature channels (one lane each)");
+  voxel_reduce_kernel<<<(unsigned)((V + 3) / 4), 256, 0, (hipStream_t)stream>>>(order, starts, counts, V, pts, (const __half*)feats_f16, colors,
+                                                                                C, o_pts, (__half*)o_feat_f16, o_col, sums);
   PS_CHECK_LAUNCH();
 }

@@ -473,7 +473,7 @@ template <class C, int PB, int NW, bool STORED, bool MS>
 __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
   TileRange tr{0, a.N, (int)blockIdx.x, (int)gridDim.x};
   if constexpr (MS) {
-    const MsBlock mb = ms_block(a.field_start, a.K, gridDim.x, blockIdx.x);
+    const MsBlock mb = ms_block(a.field_start, a.K, gridDim.x, ms_logical_block(blockIdx.x, gridDim.x));
     if (mb.k < 0) return;  // its partial block is never read (ms_field_blocks)
     a.packed += (int64_t)mb.k * a.packed_stride;
     tr = TileRange{mb.first_pt, mb.end_pt, mb.j, mb.n};
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
 #endif
   }
   __syncthreads();
-  float* out = a.gpart + (size_t)blockIdx.x * C::GPACKED;
+  float* out = a.gpart + (size_t)(MS ? ms_logical_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * C::GPACKED;
   for (int i = threadIdx.x; i < C::GPACKED; i += NW * 64) out[i] = gacc[i];
 }
 
@@ -652,7 +652,7 @@ int ms_grid(int64_t n_slots, int pts_per_tile, int waves, int max_blocks, int K)
   int64_t g = (tiles + waves - 1) / waves + K;
   if (g > max_blocks) g = max_blocks;
   if (g < K) g = K;
-  return (int)g;
+  return (int)((g + 7) / 8 * 8);  // ms_logical_block deals the workgroups XCD-major
 }
 
 constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 8, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;

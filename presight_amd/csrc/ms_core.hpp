@@ -44,6 +44,12 @@ __device__ __forceinline__ void ms_field_blocks(const int* __restrict__ field_st
   }
 }
 
+// Hardware workgroup b runs on XCD b % 8 (observed placement, used for speed only): logical block ids are dealt XCD-major, so
+// that the workgroups of ONE sub-field (a contiguous range of logical ids) share an XCD and its L2 keeps that sub-field's
+// weight fragments hot (K = 16 main fields: 3.5 MB of packed weights, more than fits next to the streaming activations when
+// every XCD serves every sub-field).  B must be a multiple of 8.
+__device__ __forceinline__ int ms_logical_block(int b, int B) { return (b & 7) * (B >> 3) + (b >> 3); }
+
 __device__ __forceinline__ MsBlock ms_block(const int* __restrict__ field_start, int K, int B, int b) {
   const int total = field_start[K];
   int nonempty = 0;

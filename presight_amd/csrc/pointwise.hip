@@ -30,6 +30,16 @@ __global__ void sh4_kernel(const float* __restrict__ d, int64_t M, float* __rest
   for (int k = 0; k < 4; ++k) o[k] = (f32x4){sh[4 * k], sh[4 * k + 1], sh[4 * k + 2], sh[4 * k + 3]};
 }
 
+// SH of the input AS GIVEN: SHEncoding.pytorch_fwd evaluates components_from_spherical_harmonics on whatever it is handed
+// (ns/field_components/encodings.py:711-714); the fields hand it (d+1)/2
+__global__ void sh4_raw_kernel(const float* __restrict__ x, int64_t M, int n_out, float* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  float sh[16];
+  ps::sh4(x[i * 3], x[i * 3 + 1], x[i * 3 + 2], sh);
+  for (int k = 0; k < n_out; ++k) out[i * n_out + k] = sh[k];
+}
+
 __global__ void route_kernel(const float* __restrict__ p, int64_t M, const float* __restrict__ centroids, int K,
                              int32_t* __restrict__ assign) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -60,6 +70,13 @@ extern "C" int ps_contract(const float* p, const float* aabb, int64_t M, int con
 extern "C" int ps_sh4(const float* dirs, int64_t M, float* out, void* stream) {
   if (M == 0) return 0;
   sh4_kernel<<<(unsigned)((M + 255) / 256), 256, 0, (hipStream_t)stream>>>(dirs, M, out);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_sh_encode(const float* x, int64_t M, int levels, float* out, void* stream) {
+  if (M == 0) return 0;
+  PS_REQUIRE(levels >= 1 && levels <= 4, "ps_sh_encode: 1..4 spherical-harmonic levels");
+  sh4_raw_kernel<<<(unsigned)((M + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, M, levels * levels, out);
   PS_CHECK_LAUNCH();
 }
 

@@ -312,6 +312,14 @@ def sh4(dirs: Tensor) -> Tensor:
     return out
 
 
+def sh_encode(x: Tensor, levels: int = 4) -> Tensor:
+    """real spherical harmonics of `levels` levels evaluated on x as given -> [M, levels^2]"""
+    x = _f32(x)
+    out = torch.empty(x.shape[0], levels * levels, device=x.device, dtype=torch.float32)
+    check(lib().ps_sh_encode(_p(x), x.shape[0], levels, _p(out), _stream()), "ps_sh_encode")
+    return out
+
+
 def route(p: Tensor, centroids: Tensor) -> Tensor:
     p = _f32(p)
     c = _f32(centroids)

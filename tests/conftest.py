@@ -85,3 +85,33 @@ def grad_error_stats(named_grads, ref_grads):
     e = torch.tensor(errs)
     order = torch.argsort(e)
     return e[order], [names[i] for i in order.tolist()], n_zero
+
+
+def assert_threshold_depth(depth, depth_ref, weights_ref, ebins_ref, threshold: float = 0.5, what: str = "threshold depth"):
+    """DepthRenderer("threshold") is INDEX work (ns/model_components/renderers.py:352-362): the depth is the mid-point of the
+    first sample whose inclusive cumulative weight reaches `threshold`.  It must equal the reference's, except on rays whose
+    reference cumulative weight sits within fp32 summation rounding of the threshold at the decisive sample -- and there the
+    index may move by ONE sample only.  weights_ref [R,S] / ebins_ref [R,S+1]: the reference's (or the oracle's) weights and
+    euclidean bin edges of the same rays."""
+    depth, depth_ref = torch.as_tensor(depth).detach().cpu().reshape(-1), torch.as_tensor(depth_ref).detach().cpu().reshape(-1)
+    w = torch.as_tensor(weights_ref).detach().cpu().float()
+    w = w.reshape(w.shape[0], -1)
+    eb = torch.as_tensor(ebins_ref).detach().cpu().float()
+    R, S = w.shape
+    mids = (eb[:, :-1] + eb[:, 1:]) / 2
+    cs = torch.cumsum(w, -1)
+    ref_idx = torch.clamp(torch.searchsorted(cs, torch.full((R, 1), threshold), side="left"), 0, S - 1)[:, 0]
+    mism = (depth - depth_ref).abs() > 1e-5 * depth_ref.abs().clamp_min(1.0)
+    n_bad = int(mism.sum())
+    if n_bad == 0:
+        return 0
+    rows = torch.nonzero(mism).flatten()
+    got_idx = (mids[rows] - depth[rows, None]).abs().argmin(-1)
+    assert bool(((mids[rows, got_idx] - depth[rows]).abs() <= 1e-4 * depth[rows].abs().clamp_min(1.0)).all()), f"{what}: not a sample mid-point"
+    step = (got_idx - ref_idx[rows]).abs()
+    assert bool((step == 1).all()), f"{what}: index moved by {step.tolist()} samples"
+    lo = torch.minimum(got_idx, ref_idx[rows])  # the sample whose cumulative weight decides between the two indices
+    margin = (cs[rows, lo] - threshold).abs()
+    tol = 16 * S * torch.finfo(torch.float32).eps  # fp32 summation of S weights <= 1
+    assert bool((margin <= tol).all()), f"{what}: {n_bad} rays differ, cumulative weight {margin.max():.2e} away from the threshold (> {tol:.1e})"
+    return n_bad

@@ -468,12 +468,113 @@ def gold_model():
     save("model", **arrs)
 
 
+def gold_losses_real():
+    """interlevel / distortion losses on bins that come out of the reference's REAL sampler chain (piecewise spaced sampler ->
+    PDF -> PDF on a synthetic ray batch), not sorted uniforms: the reference-generated vector the fused loss kernels are held to"""
+    cfg = O.tiny_config()
+    scene = O.make_scene(cfg)
+    R_ = 48
+    batch = O.make_batch(cfg, scene, R_, step=21)
+    thr = 5.0
+    sampler = ns.samplers.SpacedSampler(
+        spacing_fn=lambda x: torch.where(x < thr, x / (2 * thr), 1 - 1 / (2 * x / thr)),
+        spacing_fn_inv=lambda x: torch.where(x < 0.5, x * (2 * thr), thr / (2 - 2 * x)), single_jitter=True)
+    sampler.train()
+    col = ns.colliders.NearFarCollider(near_plane=0.005, far_plane=50.0)
+    col.train()
+    rbc = col(_ray_bundle(scene, batch["ray_indices"]))
+    g = torch.Generator().manual_seed(22)
+
+    def bumpy_sigma(S):
+        # a few surfaces per ray: smooth background + narrow peaks, like a trained field
+        base = torch.rand(R_, S, 1, generator=g) * 0.05
+        centre = torch.randint(4, S - 4, (R_, 1, 1), generator=g).float()
+        idx = torch.arange(S).view(1, S, 1).float()
+        return base + 30.0 * torch.exp(-0.5 * ((idx - centre) / 2.5) ** 2)
+
+    with PatchedRand([torch.rand(R_, 1, generator=g)]):
+        rs0 = sampler(rbc, num_samples=128)
+    w0 = rs0.get_weights(bumpy_sigma(128))
+    pdf = ns.samplers.PDFSampler(include_original=False, single_jitter=True)
+    pdf.train()
+    with PatchedRand([torch.rand(R_, 1, generator=g)]):
+        rs1 = pdf(rbc, rs0, w0, num_samples=64, eps=torch.finfo(torch.float32).eps)
+    w1 = rs1.get_weights(bumpy_sigma(64))
+    with PatchedRand([torch.rand(R_, 1, generator=g)]):
+        rs2 = pdf(rbc, rs1, w1, num_samples=64, eps=torch.finfo(torch.float32).eps)
+    w2 = rs2.get_weights(bumpy_sigma(64))
+    wl = [w.detach().clone().requires_grad_(True) for w in (w0, w1, w2)]
+    rsl = [rs0, rs1, rs2]
+    il = ns.ps_losses.z_anti_anliasing_interlevel_loss(wl, rsl, pulse_width=(0.03, 0.003))
+    g_il = torch.autograd.grad(il, wl[:2], retain_graph=True)
+    dl = ns.losses.distortion_loss(wl, rsl)
+    (g_dl,) = torch.autograd.grad(dl, wl[2])
+    arrs = {}
+    for i, rs in enumerate(rsl):
+        arrs[f"sbins{i}"] = torch.cat([rs.spacing_starts[..., 0], rs.spacing_ends[:, -1:, 0]], -1)
+        arrs[f"w{i}"] = wl[i][..., 0]
+    save("losses_real", interlevel=il, g_interlevel_w0=g_il[0][..., 0], g_interlevel_w1=g_il[1][..., 0], distortion=dl,
+         g_distortion_w2=g_dl[..., 0], **arrs)
+
+
+def gold_extract():
+    """the body of the reference's frame loop (ns/scripts/extract_priors.py:108-145) on the fixture model of gold_model():
+    camera rays at 1/75 resolution -> get_depth_for_camera_ray_bundle -> world points -> depth / height filters -> mean density
+    of the three fields, clipped fp16 semantics, PCA colours"""
+    cfg = O.tiny_config()
+    cfg["num_fields"] = 3
+    for p in [cfg["main"]] + cfg["props"]:
+        p["log2_hashmap_size"] = 9
+    scene = O.make_scene(cfg)
+    P = O.make_params(cfg, seed=5, table_scale=0.3)
+    for k in range(cfg["num_fields"]):
+        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = 1.0  # dense enough for surfaces inside the 0.5..50 m window
+        for i in range(2):
+            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = 1.0
+    model, mod = _build_ref_model(cfg, scene, P)
+    model.eval()
+    cm = __import__("importlib").import_module("nerfstudio.utils.colormaps")
+    pose_scale_factor, max_depth, min_depth = 0.05, 8.6, 5.0  # a window that cuts part of every frame (script defaults: 50 / 0.5)
+    cams = _cameras(scene)
+    cams.rescale_output_resolution(1.0 / 75.0)
+    coords = cams.get_image_coords()
+    arrs = dict(scaling=np.array(1.0 / 75.0), H=np.array(int(cams.height[0])), W=np.array(int(cams.width[0])),
+                pose_scale_factor=np.array(pose_scale_factor), max_depth=np.array(max_depth), min_depth=np.array(min_depth))
+    frames = [0, 5, 11]
+    arrs["frames"] = np.array(frames)
+    with torch.no_grad():
+        for depth_type in ("depth", "expected_depth"):
+            for cam in frames:
+                crb = cams.generate_rays(camera_indices=cam, coords=coords, aabb_box=None)
+                outputs = model.get_depth_for_camera_ray_bundle(crb)
+                depth = outputs[depth_type] / pose_scale_factor
+                world = (crb.origins / pose_scale_factor + crb.directions * depth).view(-1, 3)
+                depth = depth.flatten()
+                sel = (depth < max_depth) & (depth > min_depth) & (world[:, 2] > -3.0) & (world[:, 2] < 6.0)
+                world = world[sel]
+                tag = f"{depth_type}_{cam}"
+                arrs[f"raw_depth_{tag}"] = depth
+                arrs[f"sel_{tag}"] = sel
+                if len(world) == 0:  # extract_priors.py:124-126
+                    continue
+                dl = [p.density_fn(world * pose_scale_factor).squeeze(-1) for p in model.proposal_networks]
+                dl.append(model.field.density_fn(world * pose_scale_factor)[0].squeeze(-1))
+                dens = torch.stack(dl, dim=0).mean(dim=0)
+                feats = model.field.semantic_fn(world * pose_scale_factor).clip(0.0, 1.0).to(torch.float16)
+                colors = cm.apply_feature_colormap(feats, scene["dino_to_rgb"])
+                arrs[f"world_{tag}"] = world
+                arrs[f"dens_{tag}"] = dens
+                arrs[f"feats_{tag}"] = feats
+                arrs[f"colors_{tag}"] = colors
+    save("extract", **arrs)
+
+
 def _with_meta(rb, batch):
     rb.metadata["video_id"] = batch["video_ids"][:, None]
     return rb
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "depth_losses", "model"]
+    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "extract"]
     for w in which:
         globals()["gold_" + w]()

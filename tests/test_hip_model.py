@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import model_fixture_setup, t
+from conftest import assert_threshold_depth, grad_error_stats, model_fixture_setup, t
 
 pytestmark = pytest.mark.gpu
 
@@ -68,9 +68,8 @@ def test_training_step_matches_reference(gold_model):
         close(out["weights_list"][i][..., 0], G[f"T_weights_{i}"], rtol=2e-4, atol=2e-6)
     for k in ["rgb", "accumulation", "expected_depth", "semantics"]:
         close(out[k], G["T_" + k], rtol=2e-4, atol=2e-5)
-    for k in ["depth", "prop_depth_0", "prop_depth_1"]:
-        mism = (out[k].cpu() - t(G["T_" + k])).abs() > 1e-5
-        assert mism.float().mean() <= 0.05, k
+    for k, lvl in (("depth", 2), ("prop_depth_0", 0), ("prop_depth_1", 1)):
+        assert_threshold_depth(out[k], G["T_" + k], G[f"T_weights_{lvl}"], out["ray_samples_list"][lvl].ebins, what=k)
     gt = {"rgb": batch["rgb"].to(dev), "features": batch["features"].to(dev), "sky": batch["sky"].to(dev)}
     ld = model.get_loss_dict(out, gt)
     # the interlevel loss divides fp32 cumsums by very narrow PDF-resampled bins, which amplifies summation-order
@@ -79,22 +78,14 @@ def test_training_step_matches_reference(gold_model):
     for k, v in ld.items():
         close(v, G["TL_" + k], rtol=loose.get(k, 5e-4), atol=1e-7)
     sum(ld.values()).backward()
-    named = dict(model.named_parameters())
-    n = 0
-    for k in G:
-        if not k.startswith("TG_"):
-            continue
-        name = k[3:]
-        ref = t(G[k])
-        got = named[name].grad
-        got = torch.zeros_like(ref) if got is None else got.cpu()
-        scale = float(ref.abs().max())
-        if scale == 0:
-            assert float(got.abs().max()) == 0, name
-        else:
-            torch.testing.assert_close(got / scale, ref / scale, rtol=5e-3, atol=1e-3, msg=lambda m: f"{name}: {m}")
-        n += 1
-    assert n == len(P)
+    g_ref = {k[3:]: t(G[k]) for k in G if k.startswith("TG_")}
+    assert len(g_ref) == len(P)
+    errs, names, n_zero = grad_error_stats({n: p.grad for n, p in model.named_parameters()}, g_ref)
+    q = lambda f: float(errs[min(len(errs) - 1, int(f * len(errs)))])  # noqa: E731
+    print(f"training step vs reference: {len(errs)} parameter gradients (+{n_zero} exactly zero); max |err| / max |ref|: "
+          f"median {q(0.5):.1e}, 90% {q(0.9):.1e}, max {float(errs[-1]):.1e} ({names[-1]})")
+    # achieved on MI355X (round 2): median 1.0e-6, 90 % 9e-6, worst tensor 1.2e-5; the bounds leave ~5x headroom over that
+    assert q(0.5) < 1e-5 and q(0.9) < 5e-5 and float(errs[-1]) < 1e-4, (names[-3:], errs[-3:])
     psnr = float(model.get_metrics_dict(out, gt)["psnr"])
     ref_psnr = float(10 * torch.log10(1.0 / torch.mean((t(G["T_rgb"]) - batch["rgb"]) ** 2)))
     assert abs(psnr - ref_psnr) < 1e-3
@@ -110,17 +101,21 @@ def test_eval_render_depth_and_extraction_queries(gold_model):
         out = model(bundle())
         for k in ["rgb", "accumulation", "expected_depth", "semantics", "dino_rgb"]:
             close(out[k], G["E_" + k], rtol=2e-4, atol=3e-5)
-        assert ((out["depth"].cpu() - t(G["E_depth"])).abs() > 1e-5).float().mean() <= 0.05
+        # the fixture does not hold the eval weights: the oracle (bit-faithful to the reference here, test_oracle_golden.py) supplies them
+        from oracle import nerf_oracle as O
+
+        ref = O.model_forward(P, cfg, scene, batch, training=False, anneal=float(G["T_anneal"]))
+        assert_threshold_depth(out["depth"], G["E_depth"], ref["weights_list"][-1], ref["euclid_list"][-1], what="eval depth")
         dd = model.get_depth_for_camera_ray_bundle(bundle())
-        assert ((dd["depth"].cpu() - t(G["E_get_depth"])).abs() > 1e-5).float().mean() <= 0.05
+        assert_threshold_depth(dd["depth"], G["E_get_depth"], ref["weights_list"][-1], ref["euclid_list"][-1], what="get_depth")
         close(dd["expected_depth"], G["E_get_expected_depth"], rtol=2e-4, atol=3e-5)
         # prior-extraction field queries (ns/scripts/extract_priors.py:133-138)
         pts = t(G["X_pts"]).to(dev)
         dens = [p.density_fn(pts).squeeze(-1) for p in model.proposal_networks]
         dens.append(model.field.density_fn(pts)[0].squeeze(-1))
-        close(torch.stack(dens, 0).mean(0), G["X_density_mean"], rtol=2e-4, atol=1e-6)
+        close(torch.stack(dens, 0).mean(0), G["X_density_mean"], rtol=1e-4, atol=1e-6)  # north_star: prior outputs within 1e-4 rel
         dens[-1] = model.field.density_only(pts).squeeze(-1)  # fused variant of the same query
-        close(torch.stack(dens, 0).mean(0), G["X_density_mean"], rtol=2e-4, atol=1e-6)
+        close(torch.stack(dens, 0).mean(0), G["X_density_mean"], rtol=1e-4, atol=1e-6)
         feats = model.field.semantic_fn(pts).clip(0.0, 1.0).to(torch.float16)
         assert (feats.float().cpu() - t(G["X_feats"]).float()).abs().max() <= 2 ** -10
 
@@ -142,7 +137,7 @@ def test_voxel_index_and_dense_lattice_query(gold_model):
     torch.testing.assert_close(pts.cpu(), ref_pts, rtol=0, atol=1e-6)
     dens, feats = extract.query_priors(model, pts)
     d_ref, f_ref = O.prior_query(P, cfg, scene, pts.cpu())
-    close(dens, d_ref, rtol=2e-4, atol=1e-6)
+    close(dens, d_ref, rtol=1e-4, atol=1e-6)
     assert (feats.float().cpu() - f_ref.float()).abs().max() <= 2 ** -10
     # integer voxel index: bit exact against the oracle's fp64 rule, including negative coordinates
     world = (pts / 0.05).cpu()
@@ -159,7 +154,7 @@ def test_voxel_index_and_dense_lattice_query(gold_model):
     # voxel grouping: hits sum to n, per-voxel mean of points lies inside its voxel
     vox = extract.voxelize(full["points"], full["features"], None, voxel=0.4)
     assert int(vox["hits"].sum()) == full["points"].shape[0]
-    lo = (vox["min_bound"] - 0.2) + vox["index"].double() * 0.4
+    lo = (vox["min_bound"].to(dev) - 0.2) + vox["index"].double() * 0.4
     assert bool(((vox["points"].double() >= lo - 1e-4) & (vox["points"].double() <= lo + 0.4 + 1e-4)).all())
     # wire format of extracted_priors.pkl (extract_priors.py:186-208): hit-count quantile filter, dtypes, keys, pickle round trip
     import pickle

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from conftest import t
+from conftest import assert_threshold_depth
 from oracle import nerf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -206,9 +207,7 @@ def test_weights_pdf_composite(ops, dev, gold_sampling):
         close(acc, G[f"r_{mode}_acc"], rtol=1e-5, atol=1e-6)
         close(expd, G[f"r_{mode}_expdepth"], rtol=1e-5, atol=1e-5)
         close(sem, G[f"r_{mode}_sem"], rtol=1e-5, atol=1e-5)
-        dref = t(G[f"r_{mode}_depth"])
-        mism = (depth.cpu() - dref).abs() > 1e-6
-        assert mism.float().mean() <= 0.05, "threshold depth: more than a borderline fraction of rays differ"
+        assert_threshold_depth(depth, t(G[f"r_{mode}_depth"]), G[f"r_{mode}_w"], eb2, what=f"threshold depth ({mode})")
 
 
 def test_composite_backward_vs_oracle(ops, dev):

@@ -329,3 +329,67 @@ def test_voxel_index_rule():
     ref = np.floor((pts.double().numpy() - (mn.double().numpy() - 0.2)) / 0.4).astype(np.int64)
     assert np.array_equal(idx.numpy(), ref)
     assert (idx >= 0).all()
+
+
+def test_losses_on_real_sampler_bins():
+    """interlevel / distortion losses on bins produced by the reference's own sampler chain (tests/golden/losses_real.npz)"""
+    G = load_golden("losses_real")
+    wl = [t(G[f"w{i}"]).clone().requires_grad_(True) for i in range(3)]
+    bl = [t(G[f"sbins{i}"]) for i in range(3)]
+    il = O.interlevel_loss_zaa(wl, bl, (0.03, 0.003))
+    close(il, G["interlevel"], rtol=1e-4)
+    g = torch.autograd.grad(il, wl[:2], retain_graph=True)
+    for got, key in zip(g, ("g_interlevel_w0", "g_interlevel_w1")):
+        ref = t(G[key])
+        assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), key
+    dl = O.distortion_loss(bl[2], wl[2])
+    close(dl, G["distortion"], rtol=1e-4)
+    close(torch.autograd.grad(dl, wl[2])[0], G["g_distortion_w2"], rtol=1e-4, atol=1e-8)
+
+
+def test_extraction_frame_loop():
+    """the body of the reference's frame loop (ns/scripts/extract_priors.py:108-145) run on the fixture model
+    (tests/golden/extract.npz): raw depths, the depth / height selection, world points, densities, fp16 features, colours"""
+    from conftest import model_fixture_setup
+
+    G = load_golden("extract")
+    cfg, scene, P, _ = model_fixture_setup(load_golden("model"))
+    for k in range(cfg["num_fields"]):  # the extraction fixture's density heads (make_golden.gold_extract)
+        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = 1.0
+        for i in range(2):
+            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = 1.0
+    scene["dino_to_rgb"] = O.make_scene(cfg)["dino_to_rgb"]
+    n_pts = 0
+    for depth_type in ("depth", "expected_depth"):
+        for cam in G["frames"].tolist():
+            tag = f"{depth_type}_{cam}"
+            r = O.extract_frame(P, cfg, scene, cam, float(G["scaling"]), float(G["pose_scale_factor"]), float(G["max_depth"]),
+                                float(G["min_depth"]), depth_type)
+            assert r["raw_depth"].shape[0] == int(G["H"]) * int(G["W"])
+            close(r["raw_depth"], G["raw_depth_" + tag], rtol=2e-5, atol=1e-5)
+            assert torch.equal(r["sel"], t(G["sel_" + tag]))
+            if int(G["sel_" + tag].sum()) == 0:
+                continue
+            close(r["world"], G["world_" + tag], rtol=2e-5, atol=2e-5)
+            close(r["dens"], G["dens_" + tag], rtol=1e-4)
+            assert float((r["feats"].float() - t(G["feats_" + tag]).float()).abs().max()) <= 2 ** -10
+            assert float((r["colors"].float() - t(G["colors_" + tag]).float()).abs().max()) <= 4e-3
+            n_pts += r["world"].shape[0]
+    assert n_pts > 500
+
+
+def test_voxel_downsample_rule():
+    """per-voxel traces of extract_priors.py:166-191 on a hand-made case: two points share a voxel, two sit alone (the point
+    that defines min_bound lies on a voxel boundary in exact arithmetic, so it is kept away from the others)"""
+    pts = torch.tensor([[0.3, 0.3, 0.3], [0.35, 0.32, 0.28], [1.5, 0.3, 0.3], [-0.43, -0.43, -0.43]])
+    feats = torch.tensor([[0.25, 1.0], [0.75, 0.0], [0.5, 0.5], [0.125, 0.125]], dtype=torch.float16)
+    cols = torch.tensor([[0.0, 0.2, 0.4], [1.0, 0.4, 0.0], [0.3, 0.3, 0.3], [0.9, 0.9, 0.9]])
+    vox = O.voxel_downsample(pts, feats, cols, voxel=0.4)
+    assert len(vox) == 3
+    mn = pts.min(0).values - 1.0
+    k01 = tuple(O.voxel_index(pts[:1], 0.4, mn)[0].tolist())
+    assert k01 == (4, 4, 4) and tuple(O.voxel_index(pts[1:2], 0.4, mn)[0].tolist()) == k01
+    p, f, c, h = vox[k01]
+    assert h == 2 and np.allclose(p, [0.325, 0.31, 0.29]) and np.array_equal(f, np.array([0.5, 0.5], dtype=np.float16))
+    assert np.allclose(c, [0.5, 0.3, 0.2])
+    assert vox[(7, 4, 4)][3] == 1
