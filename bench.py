@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", choices=["allreduce", "sharded"], default=None)
     ap.add_argument("--rays", type=int, default=RAYS, help="rays per step: per GPU (weak) / over all GPUs (strong)")
     ap.add_argument("--global-depth-clip", action="store_true", help="expected-depth clip bounds over ALL ranks' batches")
+    ap.add_argument("--fixed-batches", action="store_true", help="recycle 4 pre-made batches instead of the device chunk feed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args(argv)
 
@@ -165,6 +166,21 @@ def make_batches(scene, dev, n_batches, rank, rays=RAYS):
     return out
 
 
+def synthetic_chunk(scene, dev, chunk_index, pixels=1 << 22):
+    """One chunk of the training set as the reference keeps it in memory (ns/data/PreSight/my_dataset.py:28-50: flat per-pixel
+    arrays of the pixels that survived the masks, `chunk_ratio` of every loaded image): uniformly drawn (image, pixel) slots with
+    random targets, generated on the device (the background loader thread of presight_amd.datafeed.ChunkFeed calls this)."""
+    import torch
+
+    g = torch.Generator(device=dev).manual_seed(4321 + chunk_index)
+    C, H, W = scene["c2w"].shape[0], scene["H"], scene["W"]
+    img = torch.randint(0, C, (pixels,), device=dev, generator=g)
+    return dict(rgbs=torch.rand(pixels, 3, device=dev, generator=g), pixel_indices=torch.randint(0, H * W, (pixels,), device=dev, generator=g),
+                image_indices=img, video_ids=torch.clamp(img // scene["frames_per_video"], max=5),
+                widths=torch.full((pixels,), W, device=dev, dtype=torch.int64), skies=(torch.rand(pixels, device=dev, generator=g) < 0.15).float(),
+                depths=None, features=torch.rand(pixels, 64, device=dev, generator=g))
+
+
 class Trainer:
     """The timed region: what ns/engine/trainer.py:463-505 does per iteration (zero_grad, forward, loss, backward with
     the reference's fixed loss scale of 2**10, DDP gradient averaging, Adam lr 1e-2 eps 1e-15 wd 1e-5).
@@ -224,8 +240,8 @@ class Trainer:
         m.before_train_iteration(self.step_idx)
         self.grads.zero_()
         o, d, pa, dn = ops.generate_rays(batch["ray_indices"], s["c2w"], s["fx"], s["fy"], s["cx"], s["cy"])
-        rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1],
-                       metadata={"video_id": batch["video_ids"][:, None], "directions_norm": dn})
+        vid = batch["video_ids"] if "video_ids" in batch else batch["video_id"]  # make_batches / the reference's collated key
+        rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1], metadata={"video_id": vid.view(-1, 1), "directions_norm": dn})
         if self.update_props_every_step:
             m.proposal_sampler._steps_since_update = 1 << 30  # proposal nets receive gradients EVERY step (upper bound of the schedule)
         out = m(rb)
@@ -464,12 +480,18 @@ def extract_main(args) -> int:
     per = (total + world - 1) // world
     start, count = rank * per, max(0, min(per, total - rank * per))
 
+    # the reference keeps points with mean density > 1.0 (extract_priors.py:152), which on a TRAINED tile is the few per cent of
+    # the lattice near surfaces; the synthetic (random-init) fields have no surfaces, so the bench keeps the densest 10 % instead
+    # (threshold = 90th percentile of a 64^3 probe), which gives the voxel down-sampling a realistic amount of work
+    probe = dense_tile_query(model, aabb, res=64, density_threshold=-1.0)  # also the warm-up: kernels, allocator
+    thr = float(torch.quantile(probe["densities"][:: max(1, probe["densities"].numel() // 100000)], 0.9))
+    del probe
+
     def one_pass():
-        out = dense_tile_query(model, aabb, res=res, chunk=1 << 23, start=start, count=count, density_threshold=1.0)
+        out = dense_tile_query(model, aabb, res=res, chunk=1 << 23, start=start, count=count, density_threshold=thr)
         vox = voxelize(out["points"], out["features"], None, voxel=0.4, min_bound=out["min_bound"], points_max=out["points_max"], want_sums=world > 1)
         return out, vox
 
-    dense_tile_query(model, aabb, res=64)  # warm-up: kernels, allocator
     for _ in range(max(0, args.warmup - 1)):
         one_pass()
     steps = max(1, min(args.steps, 5))
@@ -502,7 +524,7 @@ def extract_main(args) -> int:
                 "roofline": {"bound": "mfma", "kernel": "whole pass (per-point algorithmic work, SURVEY.md 8d)", "achieved": per_gpu * flop_pt / 1e12,
                              "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per_gpu * flop_pt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                              "traffic": None, "hbm_achieved_gbs": per_gpu * byte_pt / 1e9, "hbm_frac": per_gpu * byte_pt / 1e9 / HBM_PEAK_GBS},
-                "kept_points_rank0": kept, "voxels_rank0": nvox}
+                "density_threshold": thr, "kept_points_rank0": kept, "voxels_rank0": nvox}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_query_baseline()
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
@@ -588,11 +610,21 @@ def main():
     rays = args.rays if scaling == "weak" else args.rays // world  # ns/data/PreSight/my_datamanager.py:203-212: R // world
     model, scene = build_model(dev, seed=42, config=args.config)  # same init on every rank (DDP broadcast equivalent)
     trainer = Trainer(model, scene, world, exchange=exchange, global_depth_clip=args.global_depth_clip)
-    batches = make_batches(scene, dev, 4, rank, rays=rays)
+    # data: the device-resident chunk feed (one gather launch per batch, next chunk prefetched on a side stream; the reference's
+    # loader semantics: shuffled pass over the chunk, rank r takes every world-th slot) or 4 recycled pre-made batches
+    feed, batches = None, None
+    if args.fixed_batches:
+        batches = make_batches(scene, dev, 4, rank, rays=rays)
+    else:
+        from presight_amd.datafeed import ChunkFeed
+
+        feed = ChunkFeed(lambda i: synthetic_chunk(scene, dev, i), batch_size=rays, device=dev, world=world, rank=rank)
+    last_batch = [None]
 
     def run(n):
         for i in range(n):
-            out = trainer.step(batches[i % len(batches)])
+            last_batch[0] = feed.next_batch() if feed is not None else batches[i % len(batches)]
+            out = trainer.step(last_batch[0])
         return out
 
     def timed(n):
@@ -615,6 +647,7 @@ def main():
     trainer.grads.stats = {"collectives": 0, "bytes": 0}
     prof.enable(True)
     dt, (loss_dict, out) = timed(args.steps)
+    psnr = float(model.get_metrics_dict(out, last_batch[0])["psnr"].detach())
     kern = prof.summary()
     prof.enable(False)
     comm = dict(trainer.grads.stats)
@@ -631,11 +664,11 @@ def main():
     if world > 1:
         trainer.update_props_every_step = True
         o_rays = args.rays // world if scaling == "weak" else args.rays
-        o_batches = make_batches(scene, dev, 2, rank, rays=o_rays)
-        keep, batches = batches, o_batches
+        keep = (feed, batches)
+        feed, batches = None, make_batches(scene, dev, 2, rank, rays=o_rays)
         run(3)
         dt_o, _ = timed(8)
-        batches = keep
+        feed, batches = keep
         other = dict(scaling="strong" if scaling == "weak" else "weak", rays_per_gpu=o_rays, value=world * o_rays * 8 / dt_o,
                      ms_per_step=dt_o / 8 * 1e3)
     replica_diff = None
@@ -655,7 +688,6 @@ def main():
         rows = roofline_entries(kern, cfg, rays)
         dom = rows[0] if rows else None
         traffic, traffic_src = pmc_traffic("main_bwd_kernel") if (args.config == "cfg2" and rays == RAYS) else (None, "not collected for this shape")
-        psnr = float(model.get_metrics_dict(out, batches[(args.steps - 1) % len(batches)])["psnr"].detach())
         # end-to-end ceilings per training ray: MLP flops (fwd + 2x bwd) against the fp32 matrix peak, hash bytes
         # (gather fwd, read + write bwd) against HBM; the binding (lower) ceiling is the fp32 MFMA one
         m = cfg["model"]
@@ -669,6 +701,7 @@ def main():
             "metric": "training rays/sec (whole node)", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "data_feed": "4 recycled batches" if feed is None else f"device chunk feed ({feed.chunks_loaded} chunk(s) of {1 << 22} pixels loaded)",
             "config": {"workload": cfg["workload"], "rays_per_gpu": rays, "rays_per_step_global": rays * world, "parallelism": f"dp{world}",
                        "exchange": trainer.exchange if world > 1 else None},
             "roofline": None if dom is None else {

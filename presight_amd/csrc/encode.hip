@@ -410,17 +410,25 @@ __global__ void absmax_kernel(const float* __restrict__ v_all, int64_t n, int64_
   const float* v = v_all + blockIdx.y * plane_stride;
   unsigned* out_bits = out_all + blockIdx.y;
   float m = 0.f;
+  bool bad = false;  // fmaxf drops NaN operands: non-finite values are tracked separately
   for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
     if (i + 3 < n) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(v + i);
       m = fmaxf(m, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
+      bad |= !isfinite(t.x + t.y + t.z + t.w);
     } else {
-      for (int64_t k = i; k < n; ++k) m = fmaxf(m, fabsf(v[k]));
+      for (int64_t k = i; k < n; ++k) {
+        m = fmaxf(m, fabsf(v[k]));
+        bad |= !isfinite(v[k]);
+      }
     }
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-  if (ps_lane() == 0 && m > 0.f && isfinite(m)) atomicMax(out_bits, __float_as_uint(m));  // positive floats order like uints
+  if (__ballot(bad) != 0ull) m = __builtin_nanf("");
+  // positive floats order like uints; a non-finite gradient publishes the NaN pattern (above every finite value), which makes the
+  // accumulate kernel write NaN into the level's gradient instead of converting inf / NaN to int64 (undefined)
+  if (ps_lane() == 0 && !(m <= 0.f)) atomicMax(out_bits, isfinite(m) ? __float_as_uint(m) : 0x7fc00000u);
 }
 
 // multi-sub-field variant: one workgroup per (chunk, level), maxima per (sub-field, level)
@@ -430,13 +438,16 @@ __global__ void absmax_ms_kernel(const float* __restrict__ v_all, int F, int64_t
   if (kf < 0) return;
   const float* v = v_all + blockIdx.y * plane_stride + (int64_t)blockIdx.x * ps::kMsChunk * F;
   float m = 0.f;
+  bool bad = false;
   for (int i = threadIdx.x * 4; i < ps::kMsChunk * F; i += blockDim.x * 4) {
     const f32x4 t = *reinterpret_cast<const f32x4*>(v + i);
     m = fmaxf(m, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
+    bad |= !isfinite(t.x + t.y + t.z + t.w);
   }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-  if (ps_lane() == 0 && m > 0.f && isfinite(m)) atomicMax(out_all + kf * L + blockIdx.y, __float_as_uint(m));
+  if (__ballot(bad) != 0ull) m = __builtin_nanf("");
+  if (ps_lane() == 0 && !(m <= 0.f)) atomicMax(out_all + kf * L + blockIdx.y, isfinite(m) ? __float_as_uint(m) : 0x7fc00000u);
 }
 
 // scale exponent from the max-|g| bit pattern: 2^e * gmax in [2^35, 2^36)
@@ -672,6 +683,11 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   if (dtables != nullptr) dtable = dtables[vlevel / L];
   for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
   __syncthreads();
+  if (gmax_bits[vlevel] >= 0x7f800000u) {  // a non-finite d(feature) on this level: the gradient is NaN, like torch's index_add of a NaN
+    float* o = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
+    for (int i = threadIdx.x; i < entries * F; i += 1024) o[i] = __builtin_nanf("");
+    return;
+  }
   const float scale = fixed_scale(gmax_bits[vlevel], headroom_log2);
   const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
   // Every lane takes kChunk CONSECUTIVE records of the stream and merges neighbours that hit the same pair of rows in

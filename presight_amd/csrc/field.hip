@@ -70,7 +70,10 @@ __device__ __forceinline__ void track_absmax(const float (&dx)[PB][((KS0 + 3) / 
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-    for (int t = 0; t < KS0; ++t) mx[t] = fmaxf(mx[t], fabsf(dx[pb][t]));
+    for (int t = 0; t < KS0; ++t) {
+      const float a = fabsf(dx[pb][t]);
+      mx[t] = (a == a) ? fmaxf(mx[t], a) : __builtin_inff();  // fmaxf would drop a NaN: keep it visible as "non-finite"
+    }
 }
 template <int KS0>
 __device__ __forceinline__ void publish_absmax(const float (&mx)[KS0], int LF, int F, unsigned* __restrict__ level_absmax) {
@@ -83,7 +86,8 @@ __device__ __forceinline__ void publish_absmax(const float (&mx)[KS0], int LF, i
     m = fmaxf(m, __shfl_xor(m, 2, 64));
     m = fmaxf(m, __shfl_xor(m, 1, 64));
     const int col = 4 * t + g;
-    if (j == 0 && col < LF && m > 0.0f) atomicMax(level_absmax + col / F, __float_as_uint(m));  // non-negative floats order like uints
+    // non-negative floats order like uints; NaN / inf publish the NaN pattern (see absmax_kernel in encode.hip)
+    if (j == 0 && col < LF && !(m <= 0.0f)) atomicMax(level_absmax + col / F, isfinite(m) ? __float_as_uint(m) : 0x7fc00000u);
   }
 }
 

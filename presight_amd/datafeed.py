@@ -61,6 +61,99 @@ class DeviceImageChunk:
         return out
 
     def sample_batch(self, num_rays: int, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
-        """uniform draw with replacement over the chunk's pixels (RandomSampler of the reference's DataLoader)"""
+        """uniform draw WITH replacement over the chunk's pixels (a convenience for tests / synthetic runs; the reference's
+        loader walks a shuffled permutation of the chunk: ChunkFeed / epoch_order below)"""
         pick = torch.randint(0, len(self), (num_rays,), device=self.rgbs.device, generator=generator)
         return self.gather(pick)
+
+
+def epoch_order(num_pixels: int, world: int = 1, rank: int = 0, seed: int = 0, epoch: int = 0, shuffle: bool = True) -> Tensor:
+    """Pixel slots of one pass over a chunk for rank `rank`, in the order the reference's loader yields them
+    (ns/data/PreSight/my_datamanager.py:203-212: DataLoader over the ImageChunk with torch's DistributedSampler —
+    randperm(seed + epoch) on the host, padded by wrapping to a multiple of `world`, rank r takes every world-th slot
+    starting at r).  int64 [ceil(P / world)] host tensor."""
+    import math
+
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(num_pixels, generator=g)
+    else:
+        idx = torch.arange(num_pixels)
+    total = math.ceil(num_pixels / world) * world
+    pad = total - num_pixels
+    if pad > 0:
+        idx = torch.cat([idx, idx[:pad]]) if pad <= num_pixels else torch.cat([idx, idx.repeat(math.ceil(pad / num_pixels))[:pad]])
+    return idx[rank:total:world]
+
+
+class ChunkFeed:
+    """The training data feed of one rank: the reference keeps ONE chunk of pixels in memory, walks it
+    once in shuffled order in batches of train_num_rays_per_batch // world (drop_last), and meanwhile a background executor
+    loads the next chunk (my_datamanager.py:214-236, 257-285; my_dataset.py:165-205).  Here the chunk is resident in HBM and a
+    batch is ONE gather launch; the next chunk is produced by `load_chunk(chunk_index)` on a background thread, uploaded on a
+    side stream (pinned staging + non_blocking copies) and swapped in when the current chunk is exhausted — the training
+    stream only ever waits on an event.
+
+    load_chunk(i) -> dict(rgbs [P,3], pixel_indices, image_indices, video_ids, widths [P], skies / depths / features optional),
+    host or device tensors (the fields of the reference's ImageChunk)."""
+
+    def __init__(self, load_chunk, batch_size: int, device, world: int = 1, rank: int = 0, seed: int = 0, prefetch: bool = True):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.load_chunk, self.batch_size, self.device = load_chunk, int(batch_size), torch.device(device)
+        self.world, self.rank, self.seed = world, rank, seed
+        self.chunk_index = -1
+        self.chunk: Optional[DeviceImageChunk] = None
+        self.order: Optional[Tensor] = None
+        self.pos = 0
+        self.chunks_loaded = 0
+        self._pool = ThreadPoolExecutor(1) if prefetch else None
+        self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._next = None
+        self._start_load(0)
+
+    def _produce(self, i: int):
+        """background thread: build chunk i and upload it on the side stream -> (DeviceImageChunk, order, ready event)"""
+        raw = self.load_chunk(i)
+        with torch.cuda.stream(self._stream):
+            dev = {}
+            for k, v in raw.items():
+                if v is None:
+                    dev[k] = None
+                elif v.is_cuda:
+                    dev[k] = v
+                else:
+                    dev[k] = v.pin_memory().to(self.device, non_blocking=True)
+            order = epoch_order(raw["rgbs"].shape[0], self.world, self.rank, self.seed).pin_memory().to(self.device, non_blocking=True)
+            chunk = DeviceImageChunk(**dev)
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        return chunk, order, ev
+
+    def _start_load(self, i: int):
+        self._next = self._pool.submit(self._produce, i) if self._pool is not None else None
+        self._next_index = i
+
+    def _swap(self):
+        res = self._next.result() if self._next is not None else self._produce(self._next_index)
+        self.chunk, self.order, ev = res
+        torch.cuda.current_stream(self.device).wait_event(ev)  # device-side wait; the host does not block on the upload
+        self.chunk_index = self._next_index
+        self.pos = 0
+        self.chunks_loaded += 1
+        self._start_load(self.chunk_index + 1)
+
+    def next_batch(self) -> Dict[str, Tensor]:
+        """the collated batch the reference's `next(iter_train_image_batch_dataloader)` yields (+ ray_indices), on the device"""
+        while self.chunk is None or self.pos + self.batch_size > self.order.shape[0]:  # drop_last, then the next chunk
+            self._swap()
+            if self.order.shape[0] < self.batch_size:
+                raise RuntimeError(f"ChunkFeed: a chunk of {self.order.shape[0]} pixels per rank cannot fill a batch of {self.batch_size}")
+        pick = self.order[self.pos:self.pos + self.batch_size]
+        self.pos += self.batch_size
+        return self.chunk.gather(pick)
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=False, cancel_futures=True)

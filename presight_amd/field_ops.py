@@ -55,7 +55,7 @@ def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, count: bool 
     N = u.shape[0]
     feat = torch.empty(g.num_levels, N, g.features_per_level, device=u.device)
     counts = None
-    if count and SCATTER_IMPL == "binned" and N * 8 < (1 << 31):
+    if count and _binned(N, g.num_levels):
         counts = torch.empty(g.num_levels * lib().ps_grid_scatter_slices(g.features_per_level, g.log2_hashmap_size), device=u.device,
                              dtype=torch.int32)
     with prof.region(f"grid_encode_L{g.num_levels}F{g.features_per_level}"):
@@ -82,14 +82,16 @@ def _workspace(nbytes: int, device) -> Tensor:
     return ws
 
 
-def _binned(N: int) -> bool:
-    return SCATTER_IMPL == "binned" and N * 8 < (1 << 31)
+def _binned(N: int, L: int = 16) -> bool:
+    """the binned backward addresses its record streams with 32-bit offsets: same bound as ps_grid_scatter_binned's own guard
+    (N * L * 8 records + stream padding < 2^32); beyond it the slice-owner scatter takes over"""
+    return SCATTER_IMPL == "binned" and N * L * 8 + 4096 + 4 * L * 256 < (1 << 32)
 
 
 def _scatter_ws(g: GridCfg, N: int, device) -> Optional[Tensor]:
     """workspace of the binned table backward; its first L words receive the per-level max |d(feature)| straight from the
     field backward kernel (level_absmax argument), which saves the scatter its own pass over d(features)"""
-    if not _binned(N):
+    if not _binned(N, g.num_levels):
         return None
     return _workspace(lib().ps_grid_scatter_workspace(g.num_levels, g.features_per_level, g.log2_hashmap_size, N), device)
 
@@ -103,7 +105,7 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
     dtable = sink if sink is not None else torch.empty(table_shape, device=u.device, dtype=torch.float32)
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
     with prof.region(f"grid_scatter_L{L}F{F}"):
-        if _binned(N):
+        if _binned(N, L):
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
             check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
                                                int(ws_with_absmax is not None), _p(ws), _stream()), "ps_grid_scatter_binned")

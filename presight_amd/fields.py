@@ -217,6 +217,8 @@ def routed_apply(points: Tensor, centroids: Tensor, fn, extras: Sequence[Tensor]
         for o, v in zip(outs, vals):
             o.append(v.reshape(c, -1))
         start += c
+    if outs is None:  # no points at all: probe the output widths with an empty slice of sub-field 0
+        return [v.reshape(0, -1) for v in fn(0, pts[:0], *[e[:0] for e in ext])]
     res = []
     for o in outs:
         cat = o[0] if len(o) == 1 else torch.cat(o, dim=0)

@@ -569,12 +569,43 @@ def gold_extract():
     save("extract", **arrs)
 
 
+def gold_datafeed():
+    """what the reference's loader yields for a chunk: ImageChunk.__getitem__ per pixel slot (ns/data/PreSight/my_dataset.py:52-73)
+    collated by torch's DataLoader, in the order of a DistributedSampler over the chunk (my_datamanager.py:203-212)"""
+    import importlib
+
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+
+    ds = importlib.import_module("nerfstudio.data.PreSight.my_dataset")
+    g = torch.Generator().manual_seed(31)
+    P_ = 1000
+    widths = torch.tensor([1600, 800, 320])[torch.randint(0, 3, (P_,), generator=g)]
+    heights = widths * 9 // 16
+    chunk = ds.ImageChunk(
+        rgbs=torch.rand(P_, 3, generator=g), segs=torch.randint(0, 19, (P_,), generator=g).to(torch.uint8),
+        skies=(torch.rand(P_, generator=g) < 0.2).float(), depths=torch.rand(P_, generator=g) * 60, features=torch.rand(P_, 64, generator=g),
+        pixel_indices=(torch.rand(P_, generator=g) * (widths * heights)).long(), image_indices=torch.randint(0, 240, (P_,), generator=g),
+        video_ids=torch.randint(0, 6, (P_,), generator=g), widths=widths)
+    arrs = dict(rgbs=chunk.rgbs, skies=chunk.skies, depths=chunk.depths, features=chunk.features, pixel_indices=chunk.pixel_indices,
+                image_indices=chunk.image_indices, video_ids=chunk.video_ids, widths=chunk.widths)
+    for world, rank in ((1, 0), (3, 1)):
+        sampler = DistributedSampler(chunk, world, rank)
+        loader = DataLoader(chunk, batch_size=96, sampler=sampler, num_workers=0, drop_last=True)
+        arrs[f"order_w{world}r{rank}"] = torch.tensor(list(iter(sampler)))
+        batches = list(loader)
+        arrs[f"n_batches_w{world}r{rank}"] = np.array(len(batches))
+        for name in ("rgb", "sky", "depth", "features", "video_id", "ray_index"):
+            arrs[f"b_{name}_w{world}r{rank}"] = torch.stack([b[name] for b in batches])
+    save("datafeed", **arrs)
+
+
 def _with_meta(rb, batch):
     rb.metadata["video_id"] = batch["video_ids"][:, None]
     return rb
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "extract"]
+    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "extract", "datafeed"]
     for w in which:
         globals()["gold_" + w]()

@@ -166,3 +166,36 @@ def test_bench_two_ranks_sharded_strong():
     line = _run_bench_two_ranks(["--exchange", "sharded", "--scaling", "strong", "--global-depth-clip"])
     assert line["replicas_max_abs_diff"] == 0.0
     assert line["config"]["rays_per_gpu"] == 2048 and line["config"]["exchange"] == "sharded"
+
+
+def test_chunk_feed_yields_the_reference_loader_batches(dev):
+    """ChunkFeed over a device-resident chunk == the reference's DataLoader(ImageChunk, DistributedSampler) batch for batch
+    (tests/golden/datafeed.npz: ImageChunk.__getitem__ + default collate, generated from the reference), for one rank of one and
+    of three; the next chunk is swapped in when the pass is exhausted (drop_last)"""
+    from conftest import load_golden, t
+    from presight_amd.datafeed import ChunkFeed
+
+    G = load_golden("datafeed")
+    raw = {k: t(G[k]) for k in ("rgbs", "skies", "depths", "features", "pixel_indices", "image_indices", "video_ids", "widths")}
+    calls = []
+
+    def load(i):
+        calls.append(i)
+        return raw  # host tensors: pinned + uploaded on the feed's side stream
+
+    for world, rank in ((1, 0), (3, 1)):
+        calls.clear()
+        feed = ChunkFeed(load, batch_size=96, device=dev, world=world, rank=rank, seed=0)
+        n = int(G[f"n_batches_w{world}r{rank}"])
+        for b in range(n):
+            got = feed.next_batch()
+            for name, key in (("rgb", "rgb"), ("sky", "sky"), ("depth", "depth"), ("features", "features"), ("video_id", "video_id"),
+                              ("ray_index", "ray_indices")):
+                ref = t(G[f"b_{name}_w{world}r{rank}"])[b]
+                assert torch.equal(got[key].cpu().reshape(ref.shape).to(ref.dtype), ref), (world, rank, b, name)
+        assert feed.chunks_loaded == 1
+        first_of_next = feed.next_batch()  # the pass is exhausted (drop_last): chunk 1 takes over, same data -> same first batch
+        assert feed.chunks_loaded == 2 and feed.chunk_index == 1
+        assert torch.equal(first_of_next["rgb"].cpu(), t(G[f"b_rgb_w{world}r{rank}"])[0])
+        feed.close()
+        assert calls[:2] == [0, 1]

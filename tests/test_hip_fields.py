@@ -300,3 +300,22 @@ def test_field_level_empty_and_ragged_inputs(F, dev):
         for a, b in zip(grads, gref):
             s = float(b.abs().max()) + 1e-30
             torch.testing.assert_close(a.cpu() / s, b / s, rtol=1e-3, atol=2e-5)
+
+
+def test_table_gradient_non_finite_input_gives_nan_not_garbage(F, dev):
+    """A NaN / inf in d(features) must surface as NaN in that level's table gradient (torch's index_add would propagate it);
+    the fixed-point scatter used to convert it to int64 (undefined).  Other levels stay finite."""
+    from presight_amd._lib import lib
+
+    g = F.GridCfg(4, 2, 12)
+    gen = torch.Generator().manual_seed(0)
+    N = 5000
+    u = torch.rand(N, 3, generator=gen).to(dev)
+    sc = torch.tensor([16.0, 32.0, 64.0, 128.0], device=dev)
+    for bad in (float("nan"), float("inf")):
+        dfeat = torch.randn(4, N, 2, generator=gen).to(dev)
+        dfeat[2, 123, 1] = bad
+        dt = F._scatter(u, dfeat, sc, g, (4 << 12, 2))
+        per_level = dt.view(4, 1 << 12, 2)
+        assert bool(torch.isnan(per_level[2]).any())
+        assert bool(torch.isfinite(per_level[[0, 1, 3]]).all())

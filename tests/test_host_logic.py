@@ -310,3 +310,16 @@ def test_hip_ops_refuse_cpu_tensors():
         ops.hashgrid_encode(torch.zeros(4, 3), torch.zeros(32, 2), torch.ones(1), 1, 2, 5)
     with pytest.raises(RuntimeError):
         field_ops.field_points(torch.zeros(2, 3), True, pos=torch.zeros(4, 3))
+
+
+def test_epoch_order_is_the_reference_loader_order():
+    """presight_amd.datafeed.epoch_order == iterating torch's DistributedSampler over the reference's ImageChunk
+    (ns/data/PreSight/my_datamanager.py:203-212), captured by tests/golden/make_golden.py::gold_datafeed"""
+    from presight_amd.datafeed import epoch_order
+
+    G = load_golden("datafeed")
+    P = G["rgbs"].shape[0]
+    for world, rank in ((1, 0), (3, 1)):
+        assert torch.equal(epoch_order(P, world, rank, seed=0), torch.from_numpy(G[f"order_w{world}r{rank}"]))
+    # padding by wrap-around keeps every rank's share equal; an unshuffled pass is the identity
+    assert epoch_order(10, 4, 3).shape[0] == 3 and epoch_order(10, 1, 0, shuffle=False).tolist() == list(range(10))
