@@ -389,7 +389,8 @@ extern "C" int ps_grid_scatter(const float* u, const float* dfeat, const float* 
 // |fixed| <= 2^36 and a row receives at most 8N <= 2^26 contributions, so the int64 sums cannot overflow; the
 // resolution is 2^-36 of the largest feature gradient, i.e. finer than the fp32 sums of the reference for anything
 // that matters, and — integer addition being associative — the gradient is bit-reproducible run to run.
-//   phase 0  per-level absmax over d(features)                         (streams N*L*F floats)
+//   phase 0  per-level absmax over d(features): published by the field backward kernel that produced them (proposal
+//            fields) or folded into phase A's write pass, which reads every d(feature) anyway
 //   phase A  bin_kernel x2: count pass (records per (level, slice)) -> exclusive prefix -> write pass: hashes +
 //            weights, LDS counting sort of the workgroup's records by slice, one global cursor reservation per
 //            (workgroup, slice), coalesced record runs to HBM at their exact final position
@@ -404,51 +405,6 @@ constexpr int kBinPointsPerThread = 2;
 constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
 constexpr int kMaxSlices = 256;
 constexpr int kAccBytes = 128 * 1024;
-
-// one maximum per level plane (blockIdx.y = level): levels can differ by orders of magnitude in gradient scale
-__global__ void absmax_kernel(const float* __restrict__ v_all, int64_t n, int64_t plane_stride, unsigned* __restrict__ out_all) {
-  const float* v = v_all + blockIdx.y * plane_stride;
-  unsigned* out_bits = out_all + blockIdx.y;
-  float m = 0.f;
-  bool bad = false;  // fmaxf drops NaN operands: non-finite values are tracked separately
-  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
-    if (i + 3 < n) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(v + i);
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
-      bad |= !isfinite(t.x + t.y + t.z + t.w);
-    } else {
-      for (int64_t k = i; k < n; ++k) {
-        m = fmaxf(m, fabsf(v[k]));
-        bad |= !isfinite(v[k]);
-      }
-    }
-  }
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-  if (__ballot(bad) != 0ull) m = __builtin_nanf("");
-  // positive floats order like uints; a non-finite gradient publishes the NaN pattern (above every finite value), which makes the
-  // accumulate kernel write NaN into the level's gradient instead of converting inf / NaN to int64 (undefined)
-  if (ps_lane() == 0 && !(m <= 0.f)) atomicMax(out_bits, isfinite(m) ? __float_as_uint(m) : 0x7fc00000u);
-}
-
-// multi-sub-field variant: one workgroup per (chunk, level), maxima per (sub-field, level)
-__global__ void absmax_ms_kernel(const float* __restrict__ v_all, int F, int64_t plane_stride, int L, const int* __restrict__ chunk_field,
-                                 unsigned* __restrict__ out_all) {
-  const int kf = chunk_field[blockIdx.x];
-  if (kf < 0) return;
-  const float* v = v_all + blockIdx.y * plane_stride + (int64_t)blockIdx.x * ps::kMsChunk * F;
-  float m = 0.f;
-  bool bad = false;
-  for (int i = threadIdx.x * 4; i < ps::kMsChunk * F; i += blockDim.x * 4) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(v + i);
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
-    bad |= !isfinite(t.x + t.y + t.z + t.w);
-  }
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-  if (__ballot(bad) != 0ull) m = __builtin_nanf("");
-  if (ps_lane() == 0 && !(m <= 0.f)) atomicMax(out_all + kf * L + blockIdx.y, isfinite(m) ? __float_as_uint(m) : 0x7fc00000u);
-}
 
 // scale exponent from the max-|g| bit pattern: 2^e * gmax in [2^35, 2^36)
 __device__ __forceinline__ float fixed_scale(unsigned gmax_bits, int headroom_log2) {
@@ -465,7 +421,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
                                                           const float* __restrict__ scalings, int L, int log2T,
                                                           int log2_slice, int64_t N, int64_t plane_stride, int64_t n_rec_max,
                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
-                                                          float* __restrict__ rec_val, const int* __restrict__ chunk_field) {
+                                                          float* __restrict__ rec_val, const int* __restrict__ chunk_field,
+                                                          unsigned* __restrict__ gmax_track /* nullable: per-level max |dfeat| bits */) {
   // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record.
   // The staging area holds the common case (4 pair records per point + slack); split pairs can push a workgroup past it
   // (only where a level's resolution exceeds the slice size), those records go straight to their final position.
@@ -489,6 +446,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     const int kf = chunk_field[first / ps::kMsChunk];
     if (kf < 0) return;
     cursors += (int64_t)kf * L * n_slices;
+    if (gmax_track != nullptr) gmax_track += kf * L;
   }
   for (int i = threadIdx.x; i < n_slices; i += kBinThreads) cnt[i] = 0u;
   __syncthreads();
@@ -500,6 +458,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
   // as ONE record {row of the floor corner, t, q[F] = w_yz * g[F], ox}; the accumulate kernel expands it.  A pair whose
   // xor reaches the slice bits (probability ~2^-log2_slice) is split into two single-corner records (t = 31).
   constexpr int NP = 4;  // pairs per point-level, in (y,z) corner order: (c,c) (f,c) (c,f) (f,f)
+  float gmax_local = 0.f;  // write pass: max |d(feature)| of this thread's points (the accumulate kernel's fixed-point scale)
   uint32_t r_slice[kBinPointsPerThread][2 * NP], r_pos[kBinPointsPerThread][2 * NP], r_idx[kBinPointsPerThread][2 * NP];
   float r_val[kBinPointsPerThread][2 * NP][F], r_ox[kBinPointsPerThread][2 * NP];
 #pragma unroll
@@ -523,6 +482,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
         g[1] = t.y;
         g[2] = t.z;
         g[3] = t.w;
+      }
+    }
+    if constexpr (!COUNT_ONLY) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float a = fabsf(g[f]);
+        gmax_local = (a == a) ? fmaxf(gmax_local, a) : __builtin_inff();  // a NaN stays visible as "non-finite"
       }
     }
     const uint32_t yc = (uint32_t)c.cy * 2654435761u, yf = (uint32_t)c.fy * 2654435761u;
@@ -566,6 +532,20 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     if ((int)threadIdx.x < n_slices && cnt[threadIdx.x]) atomicAdd(&cursors[level * n_slices + threadIdx.x], cnt[threadIdx.x]);
     return;
   } else {
+    // the level's max |d(feature)| for the accumulate kernel's fixed-point scale: folded into this pass, which reads every
+    // d(feature) anyway (saves the separate absmax pass over the plane).  The atomic is skipped when the published maximum is
+    // already at least as large (a stale read only costs a redundant atomic: the maximum is monotonic; 0.5 M same-address
+    // atomics per launch would serialise in L2 for milliseconds)
+    if (gmax_track != nullptr) {
+      float m = gmax_local;
+#pragma unroll
+      for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+      if (ps_lane() == 0 && !(m <= 0.f)) {
+        const unsigned bits = isfinite(m) ? __float_as_uint(m) : 0x7fc00000u;
+        // (agent-scope load: served by L2 — a plain load would sit in this CU's L1 and never see the other CUs' updates)
+        if (bits > __hip_atomic_load(gmax_track + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gmax_track + level, bits);
+      }
+    }
     // exclusive scan of the bucket sizes by the first wavefront (4 slices per lane + one wave scan, no block barriers)
     if (threadIdx.x < 64) {
       const int b = threadIdx.x * 4;
@@ -851,20 +831,15 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
     if (N > 0) {                                                                                                          \
-      if (!absmax_ready) {                                                                                                \
-        if (chunk_field != nullptr)                                                                                       \
-          absmax_ms_kernel<<<dim3((unsigned)(N / ps::kMsChunk), L), 256, 0, s>>>(dfeat, FF, plane_stride, L, chunk_field, gmax_bits); \
-        else                                                                                                              \
-          absmax_kernel<<<dim3(128, L), 256, 0, s>>>(dfeat, N * FF, plane_stride, gmax_bits);                             \
-      }                                                                                                                   \
       if (slice_counts == nullptr)                                                                                        \
         bin_kernel<FF, true><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,          \
-                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field); \
+                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr); \
     }                                                                                                                     \
     stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                           \
     if (N > 0)                                                                                                            \
       bin_kernel<FF, false><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,           \
-                                                                           plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field); \
+                                                                           plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
+                                                                           absmax_ready ? nullptr : gmax_bits);           \
     accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
                                                                n_rec_max, headroom, accumulate, dtable, dtables);         \
   }

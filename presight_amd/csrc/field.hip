@@ -25,6 +25,20 @@
 #define PS_MAIN_BWD_WAVES 4  // waves per workgroup (they share the LDS weight-gradient accumulators)
 #endif
 
+#if defined(PS_TIMING)
+// profiling build (tools/build_variant.sh timing -DPS_TIMING): shader-clock time of the phases of one main-backward tile, summed
+// over all waves; read back with ps_debug_timing
+__device__ unsigned long long g_ps_timing[16];
+#define PS_TSTAMP(i)                                              \
+  {                                                               \
+    const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+    tacc[i] += now__ - tlast;                                     \
+    tlast = now__;                                                \
+  }
+#else
+#define PS_TSTAMP(i)
+#endif
+
 namespace {
 
 using namespace ps;
@@ -121,7 +135,11 @@ __device__ __forceinline__ void load_act(const float* __restrict__ acts, int str
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb) {
       f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if defined(PS_ABLATE) && PS_ABLATE == 12  // timing only: no activation traffic (how much HBM latency does the backward expose?)
+      t = (f32x4){0.25f, 0.f, 0.5f, 0.f};
+#else
       if (blk * 16 < N) t = *reinterpret_cast<const f32x4*>(base + nb * 256);
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[pb][4 * nb + r] = t[r];
     }
@@ -495,8 +513,12 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
   const GlobalW pk_all = make_global_w(a.packed, C::PACKED);
   const GlobalW pk_base = pk_all.at(C::P_BASE), pk_sem = pk_all.at(C::P_SEM), pk_rgb = pk_all.at(C::P_RGB);
   // workgroup-uniform trip count (the dW flush contains workgroup barriers); out-of-range tiles are fully masked
+#if defined(PS_TIMING)
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
   for (int64_t base = (int64_t)tr.j * NW; tr.first_pt + base * 16 * PB < a.N; base += (int64_t)tr.n * NW) {
     const int64_t first = tr.first_pt + (base + wave) * 16 * PB;
+    PS_TSTAMP(0)
     // ---- recompute base
     float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], hdummy[PB][C::Base::HB * 4], zb[PB][20];
     load_feat<C::Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
@@ -515,6 +537,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
       for (int t = 0; t < 20; ++t) dzb[pb][t] = 0.0f;
       if (a.dsigma != nullptr && g == 0 && op >= 0) dzb[pb][0] = a.dsigma[op] * a.sel[p] * trunc_exp_grad(zb[pb][0]);
     }
+    PS_TSTAMP(1)
     // ---- semantic head
     if (a.dsem != nullptr) {
       float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
@@ -549,6 +572,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) dzb[pb][4 + t] += dsin[pb][t];
     }
+    PS_TSTAMP(2)
     // ---- colour head
     if (a.drgb != nullptr) {
       float cin[PB][12], c1[PB][C::Rgb::HB * 4], c2[PB][C::Rgb::HB * 4], co[PB][4];
@@ -620,6 +644,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
         }
       }
     }
+    PS_TSTAMP(3)
     // ---- base MLP backward -> d(features)
     float dx[PB][C::Base::L0::IB * 4];
     mlp_backward<typename C::Base, PB, true>(pk_base, scratch, gacc + C::G_BASE, locks + 0, x, h1, hdummy, dzb, dx);
@@ -628,7 +653,12 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
 #else
     store_dfeat<C::Base::KS0, PB>(a.dfeat, a.plane_stride, a.LF, a.F, first, a.N, dx);
 #endif
+    PS_TSTAMP(4)
   }
+#if defined(PS_TIMING)
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_ps_timing[i], tacc[i]);
+#endif
   __syncthreads();
   float* out = a.gpart + (size_t)(MS ? ms_logical_block(blockIdx.x, gridDim.x) : (int)blockIdx.x) * C::GPACKED;
   for (int i = threadIdx.x; i < C::GPACKED; i += NW * 64) out[i] = gacc[i];
@@ -896,3 +926,14 @@ extern "C" int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int
   a.perm = perm; a.field_start = field_start; a.K = K;
   return main_bwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
 }
+
+#if defined(PS_TIMING)
+extern "C" int ps_debug_timing(unsigned long long* out /*host[16]*/, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_timing), sizeof(unsigned long long) * 16);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_ps_timing), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif

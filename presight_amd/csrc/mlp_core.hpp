@@ -48,7 +48,10 @@ struct LayerT {
   // per-wave LDS rows for the dW transposes: the two operands are staged one after the other (H first, then dY in groups
   // of at most 4 output blocks), so the scratch only has to hold the larger of the two
   static constexpr int OBG = NB_ < 4 ? NB_ : 4;
-  static constexpr int SCRATCH_ROWS = (IB > OBG ? IB : OBG) * 16;
+  // H lives in rows [0, IB*16), the current dY group in rows [IB*16, (IB+OBG)*16): the pipelined backward (layer_bwd_pipe) stages
+  // the next point block's operands while the current one's fragments are in registers
+  static constexpr int SH_ROW0 = 0, SY_ROW0 = IB * 16;
+  static constexpr int SCRATCH_ROWS = (IB + OBG) * 16;
 };
 
 constexpr int kScratchLd = 20;  // floats per scratch row: 16 points + 4 pad (keeps 16-B alignment)
@@ -368,7 +371,13 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
     __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; only stop compiler reordering
     f32x4 bfrag[LT::IB];
 #pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(scratch + (16 * ib + j) * kScratchLd + 4 * g);
+    for (int ib = 0; ib < LT::IB; ++ib) {
+#if defined(PS_ABLATE) && PS_ABLATE == 13  // timing only: the transposed operands do not come back from LDS (exposed staging latency?)
+      bfrag[ib] = (f32x4){vin[pb][0], vin[pb][1], vin[pb][2], vin[pb][3]};
+#else
+      bfrag[ib] = *reinterpret_cast<const f32x4*>(scratch + (16 * ib + j) * kScratchLd + 4 * g);
+#endif
+    }
     __builtin_amdgcn_wave_barrier();
     // stage dY over the same rows, at most OBG output blocks at a time
 #pragma unroll
@@ -379,7 +388,11 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int ob = ob0; ob < ob0 + LT::OBG && ob < LT::NB; ++ob) {
+#if defined(PS_ABLATE) && PS_ABLATE == 13
+        const f32x4 afrag = (f32x4){dvout[pb][4 * ob], dvout[pb][4 * ob + 1], dvout[pb][4 * ob + 2], dvout[pb][4 * ob + 3]};
+#else
         const f32x4 afrag = *reinterpret_cast<const f32x4*>(scratch + (16 * (ob - ob0) + j) * kScratchLd + 4 * g);
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -450,6 +463,125 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
   if (lane == 0) atomicExch(lock, 0);
 #endif
   __builtin_amdgcn_sched_barrier(0);
+}
+
+// bias-gradient partials + flush of one layer's dW tiles into the workgroup accumulators (see layer_bwd_weights)
+template <class LT, int PB>
+__device__ __forceinline__ void layer_bwd_flush(float* __restrict__ gacc, int* __restrict__ lock, const f32x4 (&dw)[LT::NB][LT::IB],
+                                                const float (&dvout)[PB][LT::NB * 4]) {
+  const int lane = ps_lane();
+  const int j = lane & 15, g = lane >> 4;
+  f32x4 db[LT::NB];
+#pragma unroll
+  for (int nb = 0; nb < LT::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) s += dvout[pb][4 * nb + r];
+      db[nb][r] = ps_row16_sum(s);
+    }
+  if (lane == 0) {
+    while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) {
+      f32x4* dst = reinterpret_cast<f32x4*>(gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 64 + lane) * 4);
+      *dst = *dst + dw[ob][ib];
+    }
+  if (j == 0) {
+#pragma unroll
+    for (int nb = 0; nb < LT::NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gacc[LT::GB_OFF + 16 * nb + 4 * g + r] += db[nb][r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) atomicExch(lock, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Pipelined backward of ONE layer (PB >= 2): data backward FIRST, weight gradient second.
+//   dW = dY^T H needs its operands transposed through the per-wave LDS scratch (write 4 B / lane, read 16 B / lane).  Issued
+//   right where they are consumed, every transpose exposes an LDS round trip to the single wave of its SIMD (measured:
+//   1.3 of the main backward's 6.0 ms).  Here the scratch has separate H / dY regions and
+//     1. the operands of point block 0 are WRITTEN before the dX MFMAs of the layer (dX = W^T dY only needs dY), which hide
+//        the write latency completely,
+//     2. the operands of point block pb+1 are written right after the fragments of block pb have been read back, i.e.
+//        before block pb's dW MFMAs, which hide that latency too;
+//   what stays exposed is one LDS read latency per point block.  `next()` is invoked before the last block's dW MFMAs (the
+//   caller requests the first transposed fragments of the next layer there).
+template <class LT, int PB, bool WANT_DX, class W, class Next>
+__device__ __forceinline__ void layer_bwd_pipe(const W& wt_block, const float (&a_first)[LT::KSO], float* __restrict__ scratch,
+                                               float* __restrict__ gacc, int* __restrict__ lock, const float (&dvout)[PB][LT::NB * 4],
+                                               const float (&vin)[PB][LT::KS], float (&dvin)[PB][LT::IB * 4], const Next& next) {
+  static_assert(PB >= 2, "the pipelined backward works on >= 2 point blocks per wave");
+  const int lane = ps_lane();
+  const int j = lane & 15, g = lane >> 4;
+  float* sh = scratch + LT::SH_ROW0 * kScratchLd;
+  float* sy = scratch + LT::SY_ROW0 * kScratchLd;
+  constexpr int NG = (LT::NB + LT::OBG - 1) / LT::OBG;  // dY groups (2 only for the 80-wide base output)
+  auto write_h = [&](const float (&h)[LT::KS]) {
+#pragma unroll
+    for (int t = 0; t < LT::IB * 4; ++t) sh[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = (t < LT::KS) ? h[t < LT::KS ? t : 0] : 0.0f;
+  };
+  auto write_dy = [&](const float (&dy)[LT::NB * 4], int ob0) {
+#pragma unroll
+    for (int t = 0; t < LT::OBG * 4; ++t)
+      if (4 * ob0 + t < LT::NB * 4) sy[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = dy[(4 * ob0 + t) < LT::NB * 4 ? 4 * ob0 + t : 0];
+  };
+  __builtin_amdgcn_sched_barrier(0);
+  write_h(vin[0]);
+  write_dy(dvout[0], 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (WANT_DX) layer_bwd_data_pf<LT, PB>(wt_block, a_first, dvout, dvin, NoPrefetch());
+  f32x4 dw[LT::NB][LT::IB];
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    f32x4 bfrag[LT::IB];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      const int ob0 = grp * LT::OBG;
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp > 0) write_dy(dvout[pb], ob0);  // (exposed round trip; only the 80-wide layer has a second group)
+      __builtin_amdgcn_wave_barrier();
+      if (grp == 0) {
+#pragma unroll
+        for (int ib = 0; ib < LT::IB; ++ib) bfrag[ib] = *reinterpret_cast<const f32x4*>(sh + (16 * ib + j) * kScratchLd + 4 * g);
+      }
+      f32x4 afrag[LT::OBG];
+#pragma unroll
+      for (int o = 0; o < LT::OBG; ++o)
+        if (ob0 + o < LT::NB) afrag[o] = *reinterpret_cast<const f32x4*>(sy + (16 * o + j) * kScratchLd + 4 * g);
+      __builtin_amdgcn_wave_barrier();
+      if (grp == NG - 1) {
+        // LDS executes a wave's operations in order: these writes land after the reads above
+        if (pb + 1 < PB) {
+          write_h(vin[pb + 1 < PB ? pb + 1 : 0]);
+          write_dy(dvout[pb + 1 < PB ? pb + 1 : 0], 0);
+        } else {
+          next();
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int o = 0; o < LT::OBG; ++o)
+        if (ob0 + o < LT::NB) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ib = 0; ib < LT::IB; ++ib) dw[ob0 + o][ib] = ps_mfma16(afrag[o][r], bfrag[ib][r], dw[ob0 + o][ib]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  layer_bwd_flush<LT, PB>(gacc, lock, dw, dvout);
 }
 
 // Register-resident variant for small MLPs (proposal nets: 2128 gradient words = 52 registers per lane): the dW / db
@@ -581,6 +713,33 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
   using LZ = typename M::LZ;
   const W tz = params.at(M::TOFFZ), t1 = params.at(M::TOFF1), t0 = params.at(M::TOFF0);
   float dh[PB][M::HB * 4];
+#if !defined(PS_BWD_NO_PIPE)
+  if constexpr (PB >= 2) {
+    // pipelined order (layer_bwd_pipe): per layer dX first, then dW; the first transposed fragments of the next layer are
+    // requested before the last dW MFMAs of the current one
+    float az[LZ::KSO];
+    first_frags_bwd<LZ>(tz, az);
+    float a0[L0::KSO];
+    if constexpr (M::NL == 3) {
+      float a1[L1::KSO];
+      layer_bwd_pipe<LZ, PB, true>(tz, az, scratch, gacc + M::GOFFZ, locks + 2, dz, h2, dh, [&]() { first_frags_bwd<L1>(t1, a1); });
+      relu_mask<PB, M::HB * 4>(dh, h2);
+      float dh1[PB][M::HB * 4];
+      layer_bwd_pipe<L1, PB, true>(t1, a1, scratch, gacc + M::GOFF1, locks + 1, dh, h1, dh1, [&]() {
+        if constexpr (WANT_DX) first_frags_bwd<L0>(t0, a0);
+      });
+      relu_mask<PB, M::HB * 4>(dh1, h1);
+      layer_bwd_pipe<L0, PB, WANT_DX>(t0, a0, scratch, gacc + M::GOFF0, locks + 0, dh1, x, dx, NoPrefetch());
+    } else {
+      layer_bwd_pipe<LZ, PB, true>(tz, az, scratch, gacc + M::GOFFZ, locks + 2, dz, h1, dh, [&]() {
+        if constexpr (WANT_DX) first_frags_bwd<L0>(t0, a0);
+      });
+      relu_mask<PB, M::HB * 4>(dh, h1);
+      layer_bwd_pipe<L0, PB, WANT_DX>(t0, a0, scratch, gacc + M::GOFF0, locks + 0, dh, x, dx, NoPrefetch());
+    }
+    return;
+  }
+#endif
   // the first transposed fragments of every data-backward layer are requested before the (long, fragment-free)
   // weight-gradient phase that precedes it
   float az[LZ::KSO];

@@ -1,0 +1,28 @@
+"""phase timing of the main backward (profiling build: tools/build_variant.sh timing -DPS_TIMING; PRESIGHT_HIP_LIB=.../lib_timing.so)"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from presight_amd._lib import lib
+
+dev = torch.device("cuda:0")
+model, scene = bench.build_model(dev, 42)
+tr = bench.Trainer(model, scene, 1)
+b = bench.make_batches(scene, dev, 2, 0)
+for i in range(3):
+    tr.step(b[i % 2])
+torch.cuda.synchronize()
+h = ctypes.CDLL(os.environ["PRESIGHT_HIP_LIB"])
+out = (ctypes.c_ulonglong * 16)()
+h.ps_debug_timing(out, 1)
+n = 4
+for i in range(n):
+    tr.step(b[i % 2])
+torch.cuda.synchronize()
+h.ps_debug_timing(out, 0)
+names = ["loop top / tile select", "loads + prep (x, h1, zb, dzb)", "semantic head backward", "colour head backward", "base backward + d(feature) stores"]
+tot = sum(out[i] for i in range(5))
+tiles = 65536 * 64 / 32
+for i, nm in enumerate(names):
+    print(f"{nm:40s} {out[i] / n / tiles:10.0f} clk/tile   {100 * out[i] / tot:5.1f} %")
+print(f"{'total':40s} {tot / n / tiles:10.0f} clk/tile (s_memtime ticks; 1024 waves x 128 tiles)")
