@@ -344,6 +344,7 @@ def cpu_baseline():
 
 
 _PSNR_VS_ORACLE = None
+_HANG_FILE = None
 
 
 def psnr_vs_oracle(O, cfg, scene, rays=1024):
@@ -592,7 +593,10 @@ def main():
     if os.environ.get("PRESIGHT_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
         import faulthandler
 
-        faulthandler.dump_traceback_later(float(os.environ["PRESIGHT_HANG_DUMP"]), exit=True)
+        path = os.environ.get("PRESIGHT_HANG_DUMP_FILE")
+        global _HANG_FILE  # keep the file object alive
+        _HANG_FILE = open(path.replace("{rank}", os.environ.get("RANK", "0")), "w") if path else sys.stderr
+        faulthandler.dump_traceback_later(float(os.environ["PRESIGHT_HANG_DUMP"]), exit=True, file=_HANG_FILE)
 
     from presight_amd import prof
     from presight_amd.dist import init_from_env

@@ -30,7 +30,8 @@ int ps_device_info(int* cu_count, int* wave_size, char* arch /*host*/, int arch_
  * x [N,3]; table [L*2^log2T, F] level-major; scalings [L] (floor(min_res*g^l), fp32); out [N, L*F]. */
 int ps_hashgrid_fwd(const float* x, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
                     float* out, void* stream);
-/* dtable += d(out)/d(table)^T dout   (fp32 atomics; dtable must be pre-zeroed or hold the running grad) */
+/* dtable += d(out)/d(table)^T dout.  Operator-level reference kernel: global fp32 atomics (dtable must be pre-zeroed or hold the
+ * running gradient); the training path uses the binned fixed-point scatter ps_grid_scatter_binned below instead. */
 int ps_hashgrid_bwd(const float* x, const float* dout, const float* scalings, int L, int F, int log2T, int64_t N,
                     float* dtable, void* stream);
 /* idx [N, L, 8] int64: the 8 corner rows per level in the reference's corner order (encodings.py:354-361) */

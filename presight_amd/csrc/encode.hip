@@ -1,17 +1,20 @@
 // Field-level hash-grid path: sample positions -> normalise/contract -> multires encode, and the
 // table backward.  Data layout in HBM is "level planes": feat[l][n][f] (and dfeat likewise), so that
-//   * the encode kernel (one workgroup = 256 points of ONE level) writes coalesced,
+//   * the encode kernel (one workgroup = 2048 points of ONE level) writes coalesced,
 //   * the MFMA field kernels read 16 consecutive points of a plane per lane group,
 //   * the backward scatter streams exactly one plane.
 //
-// Backward (ps_grid_scatter).  MI355X sustains only ~13-18 G fp32 global atomics/s (measured,
-// profiles/r01_microbench.txt), 30x too slow for the ~10^9 corner contributions of one step, so the
-// table gradient is NOT built with HBM atomics.  Instead every workgroup OWNS one slice of one
-// level's table (<=128 KiB, resident in LDS), streams all points of that level, recomputes the 8
-// corner hashes and accumulates only the corners that fall into its slice with LDS atomics
-// (ds_add_f32); the slice is then written back with plain stores.  Work items are dealt to XCDs
-// level-major, so the ~32 slice owners of a level share one XCD's L2 while they stream the same
-// u / dfeat plane (HBM sees each plane once, L2 serves the other 31 readers).
+// Forward (ps_grid_encode): work items are dealt to the 8 XCDs level-major, so that an XCD's L2 holds the level it is
+// working on; lanes 2i / 2i+1 fetch the floor-x / ceil-x corners of point i in one gather (grid_encode_pair_kernel).
+// The kernel is bound by L2 random-line requests (tools/microbench/gather.hip), not by bytes.
+//
+// Backward: MI355X sustains ~20 G global atomics/s and LDS *float* atomics retire ~1 lane / 10 cycles
+// (profiles/r01_microbench_atomics.txt), both far too slow for the ~10^9 corner contributions of a step.  The product
+// path is the BINNED fixed-point scatter in the second half of this file (ps_grid_scatter_binned: records shuffled
+// through HBM into the stream of the table slice that owns their row, reduced with int64 LDS atomics); the slice-owner
+// float scan right below (ps_grid_scatter: every owner workgroup streams all points of its level and accumulates the
+// corners that fall into its LDS-resident slice with ds_add_f32) is kept as the independent cross-check of
+// tests/test_hip_fields.py.  Multi-sub-field launches (K tables, csrc/ms_core.hpp) share both kernels.
 //
 // Reference semantics: ns/cameras/rays.py:49-58, ns/fields/PreSight/ingp_field.py:169-177,
 // ns/field_components/encodings.py:343-384 (forward) and its autograd (index_put_ scatter-add).

@@ -131,20 +131,33 @@ def test_trainer_buckets_on_gpu_single_rank(dev):
     assert all(s == 3 for s in tr.opt.steps[:n_fields]) and all(s == 2 for s in tr.opt.steps[n_fields:])
 
 
-def _run_bench_two_ranks(extra, timeout=420):
+def _run_bench_two_ranks(extra, timeout=300):
     two_gpus = torch.cuda.device_count() >= 2
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if not two_gpus:  # functional run on a one-GPU box: both ranks share GPU 0, host-staged gloo transport
         env.update(PRESIGHT_SINGLE_DEVICE="1", PRESIGHT_DIST_BACKEND="gloo")
+    # a rank that is still running after 200 s writes every thread's stack to gpurun_out/ and exits: evidence for the rare hang of
+    # the two-processes-on-one-GPU harness (seen twice in ~20 runs, never reproduced in a loop)
+    dump_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(dump_dir, exist_ok=True)
+    dump = os.path.join(dump_dir, "dp2_hang_rank{rank}.txt")
+    for r in (0, 1):
+        if os.path.exists(dump.replace("{rank}", str(r))):
+            os.remove(dump.replace("{rank}", str(r)))
+    env.update(PRESIGHT_HANG_DUMP="200", PRESIGHT_HANG_DUMP_FILE=dump)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rays", "4096",
            "--no-cpu-baseline"] + extra
+    hung = lambda: [r for r in (0, 1) if os.path.exists(dump.replace("{rank}", str(r))) and os.path.getsize(dump.replace("{rank}", str(r))) > 0]  # noqa: E731
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
     except subprocess.TimeoutExpired:
         if two_gpus:
             raise
         pytest.skip("two ranks time-slicing one GPU over gloo did not finish in time (harness limitation, not the RCCL path)")
+    if r.returncode != 0 and hung() and not two_gpus:
+        head = open(dump.replace("{rank}", str(hung()[0]))).read()[:1500]
+        pytest.skip(f"two ranks time-slicing one GPU over gloo hung (stacks kept in gpurun_out/dp2_hang_rank*.txt):\n{head}")
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["comm"]["ranks"] == 2
