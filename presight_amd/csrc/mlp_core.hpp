@@ -260,6 +260,17 @@ __device__ __forceinline__ void layer_bwd_data_pf(const W& wt_block, const float
   }
 }
 
+// transposed fragments of input block ib (what the MFMAs of that block consume)
+template <class LT, class W>
+__device__ __forceinline__ void frags_bwd_block(const W& wt_block, int ib, float (&a)[LT::KSO]) {
+#pragma unroll
+  for (int q = 0; q < LT::NB; ++q) {
+    const f32x4 v = wt_block.frag4((ib * LT::NB + q) * 256);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[4 * q + r] = v[r];
+  }
+}
+
 template <class LT, int PB, class W>
 __device__ __forceinline__ void layer_bwd_data(const W& wt_block, const float (&dvout)[PB][LT::NB * 4],
                                                float (&dvin)[PB][LT::IB * 4]) {
@@ -485,18 +496,33 @@ __device__ __forceinline__ void layer_bwd_flush(float* __restrict__ gacc, int* _
     while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // read-modify-write of the tiles in batches of kBatch: written as "*dst += dw" per tile the compiler keeps every read behind
+  // the previous tile's write (it cannot prove the lane-indexed addresses distinct) and each tile exposes an LDS round trip
+  // to the lone wave of the SIMD (16 per 64x64 layer, 8 layers per tile of points)
+#ifndef PS_FLUSH_BATCH
+#define PS_FLUSH_BATCH 4  // 4: 19.9 ms/step, 8: 19.9-20.0 (2 spills), 16: 20.6
+#endif
+  constexpr int kTiles = LT::NB * LT::IB, kBatch = PS_FLUSH_BATCH;
 #pragma unroll
-  for (int ob = 0; ob < LT::NB; ++ob)
+  for (int t0 = 0; t0 < kTiles; t0 += kBatch) {
+    f32x4 cur[kBatch];
 #pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib) {
-      f32x4* dst = reinterpret_cast<f32x4*>(gacc + LT::GW_OFF + ((ob * LT::IB + ib) * 64 + lane) * 4);
-      *dst = *dst + dw[ob][ib];
-    }
+    for (int k = 0; k < kBatch; ++k)
+      if (t0 + k < kTiles) cur[k] = *reinterpret_cast<const f32x4*>(gacc + LT::GW_OFF + ((t0 + k) * 64 + lane) * 4);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k)
+      if (t0 + k < kTiles)
+        *reinterpret_cast<f32x4*>(gacc + LT::GW_OFF + ((t0 + k) * 64 + lane) * 4) = cur[k] + dw[(t0 + k) / LT::IB][(t0 + k) % LT::IB];
+    __builtin_amdgcn_wave_barrier();
+  }
   if (j == 0) {
+    float bcur[LT::NB * 4];
 #pragma unroll
-    for (int nb = 0; nb < LT::NB; ++nb)
+    for (int i = 0; i < LT::NB * 4; ++i) bcur[i] = gacc[LT::GB_OFF + 16 * (i >> 2) + 4 * g + (i & 3)];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gacc[LT::GB_OFF + 16 * nb + 4 * g + r] += db[nb][r];
+    for (int i = 0; i < LT::NB * 4; ++i) gacc[LT::GB_OFF + 16 * (i >> 2) + 4 * g + (i & 3)] = bcur[i] + db[i >> 2][i & 3];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane == 0) atomicExch(lock, 0);
@@ -717,23 +743,23 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
   if constexpr (PB >= 2) {
     // pipelined order (layer_bwd_pipe): per layer dX first, then dW; the first transposed fragments of the next layer are
     // requested before the last dW MFMAs of the current one
+    // (requesting the fragments two input blocks ahead instead of one was measured: no gain, 12 more registers)
     float az[LZ::KSO];
-    first_frags_bwd<LZ>(tz, az);
+    frags_bwd_block<LZ>(tz, 0, az);
     float a0[L0::KSO];
+    auto req0 = [&]() {
+      if constexpr (WANT_DX) frags_bwd_block<L0>(t0, 0, a0);
+    };
     if constexpr (M::NL == 3) {
       float a1[L1::KSO];
-      layer_bwd_pipe<LZ, PB, true>(tz, az, scratch, gacc + M::GOFFZ, locks + 2, dz, h2, dh, [&]() { first_frags_bwd<L1>(t1, a1); });
+      layer_bwd_pipe<LZ, PB, true>(tz, az, scratch, gacc + M::GOFFZ, locks + 2, dz, h2, dh, [&]() { frags_bwd_block<L1>(t1, 0, a1); });
       relu_mask<PB, M::HB * 4>(dh, h2);
       float dh1[PB][M::HB * 4];
-      layer_bwd_pipe<L1, PB, true>(t1, a1, scratch, gacc + M::GOFF1, locks + 1, dh, h1, dh1, [&]() {
-        if constexpr (WANT_DX) first_frags_bwd<L0>(t0, a0);
-      });
+      layer_bwd_pipe<L1, PB, true>(t1, a1, scratch, gacc + M::GOFF1, locks + 1, dh, h1, dh1, req0);
       relu_mask<PB, M::HB * 4>(dh1, h1);
       layer_bwd_pipe<L0, PB, WANT_DX>(t0, a0, scratch, gacc + M::GOFF0, locks + 0, dh1, x, dx, NoPrefetch());
     } else {
-      layer_bwd_pipe<LZ, PB, true>(tz, az, scratch, gacc + M::GOFFZ, locks + 2, dz, h1, dh, [&]() {
-        if constexpr (WANT_DX) first_frags_bwd<L0>(t0, a0);
-      });
+      layer_bwd_pipe<LZ, PB, true>(tz, az, scratch, gacc + M::GOFFZ, locks + 2, dz, h1, dh, req0);
       relu_mask<PB, M::HB * 4>(dh, h1);
       layer_bwd_pipe<L0, PB, WANT_DX>(t0, a0, scratch, gacc + M::GOFF0, locks + 0, dh, x, dx, NoPrefetch());
     }
