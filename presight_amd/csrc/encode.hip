@@ -578,20 +578,29 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
       const unsigned c = cnt[threadIdx.x];
       gbase[threadIdx.x] = c ? atomicAdd(&cursors[level * n_slices + threadIdx.x], c) : 0u;
     }
-    // stage the records in bucket order
+    // stage the records in bucket order.  The bucket offsets of all 16 record slots are fetched first: written as "read the
+    // offset, store the record" per slot, every slot exposed an LDS round trip (the compiler keeps the read behind the
+    // previous slot's stores)
+    unsigned r_dst[kBinPointsPerThread][8];
 #pragma unroll
     for (int q = 0; q < kBinPointsPerThread; ++q)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        if (r_pos[q][k] != 0xffffffffu) {
-          const unsigned p = off[r_slice[q][k]] + r_pos[q][k];
-          if (p < (unsigned)kRec) {
-            s_idx[p] = r_idx[q][k];
-            s_slice[p] = (unsigned char)r_slice[q][k];
+        const unsigned o = off[r_slice[q][k]];  // unconditional (r_slice is always a valid slice): no branch around the LDS read
+        r_dst[q][k] = (r_pos[q][k] != 0xffffffffu) ? o + r_pos[q][k] : 0xffffffffu;
+      }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int f = 0; f < F; ++f) s_val[f][p] = r_val[q][k][f];
-            s_val[F][p] = r_ox[q][k];
-          }
+    for (int q = 0; q < kBinPointsPerThread; ++q)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned p = r_dst[q][k];
+        if (p < (unsigned)kRec) {
+          s_idx[p] = r_idx[q][k];
+          s_slice[p] = (unsigned char)r_slice[q][k];
+#pragma unroll
+          for (int f = 0; f < F; ++f) s_val[f][p] = r_val[q][k][f];
+          s_val[F][p] = r_ox[q][k];
         }
       }
     __syncthreads();
@@ -611,12 +620,23 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     }
     // coalesced runs to the slice streams
     const unsigned total = min(off[n_slices], (unsigned)kRec);
-    for (unsigned p = threadIdx.x; p < total; p += kBinThreads) {
-      const unsigned sl = s_slice[p];
-      const int64_t dst = (int64_t)gbase[sl] + (p - off[sl]);
-      rec_idx[dst] = s_idx[p];
+    constexpr int kOut = 4;  // records per thread and round: their LDS look-ups (slice -> stream position) are issued together
+    for (unsigned p0 = threadIdx.x; p0 < total; p0 += kBinThreads * kOut) {
+      unsigned sl[kOut];
 #pragma unroll
-      for (int f = 0; f <= F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = s_val[f][p];
+      for (int i = 0; i < kOut; ++i) sl[i] = (p0 + i * kBinThreads < total) ? s_slice[p0 + i * kBinThreads] : 0u;
+      int64_t dst[kOut];
+#pragma unroll
+      for (int i = 0; i < kOut; ++i) dst[i] = (int64_t)gbase[sl[i]] + ((p0 + i * kBinThreads) - off[sl[i]]);
+#pragma unroll
+      for (int i = 0; i < kOut; ++i) {
+        const unsigned p = p0 + i * kBinThreads;
+        if (p < total) {
+          rec_idx[dst[i]] = s_idx[p];
+#pragma unroll
+          for (int f = 0; f <= F; ++f) rec_val[(int64_t)f * n_rec_max + dst[i]] = s_val[f][p];
+        }
+      }
     }
   }
 }
