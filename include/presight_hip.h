@@ -212,7 +212,11 @@ int ps_main_field_act_width(int LF, int hidden, int hidden_color);
 int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                       const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
                       const float* dsigma, const float* drgb, const float* dsem, const float* weights /*nullable*/, int64_t N,
-                      float* dfeat, float* dapp, float* gpart, const float* acts /* nullable: recompute */, void* stream);
+                      float* dfeat, float* dapp, float* gpart, const float* acts /* nullable: recompute */,
+                      float* dzb_scratch /* nullable; with acts: [ceil(N/16)*16, 80] workspace -> the three-kernel backward
+                                            (semantic head, colour head, base MLP: one stack's weight gradients stay in
+                                            registers and its transposed weights in LDS); NULL: one fused kernel */,
+                      void* stream);
 
 /* ---- a5 sub-field router: all K sub-fields of a tile in ONE launch per kernel, no host synchronisation ---------------
  * Reference: iNGPFieldMS / PropNetDensityFieldMS / SkyFieldMS (ns/fields/PreSight/ingp_field_ms.py:97-126,
@@ -259,7 +263,8 @@ int ps_main_field_fwd_ms(const float* feat, int64_t plane_stride, int LF, int F,
 int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
                          const float* dirs, const float* app, int S, int A, const float* packed, const float* dsigma,
                          const float* drgb, const float* dsem, const float* weights, int64_t n_slots, float* dfeat, float* dapp,
-                         float* gpart, const float* acts, const int32_t* perm, const int32_t* field_start, int K, void* stream);
+                         float* gpart, const float* acts, float* dzb_scratch /* as ps_main_field_bwd, [n_slots, 80] */,
+                         const int32_t* perm, const int32_t* field_start, int K, void* stream);
 /* fused sky field (ns/fields/PreSight/sky_field.py:95-110): per ray SH4((dir+1)/2) -> semantic head (16 -> 32 -> 32 -> 64) and
  * [SH | appearance] -> colour head (16+A -> 32 -> 32 -> 3, sigmoid), one kernel per direction; packed = [colour | semantic]
  * packed stacks (K of them back to back for the routed sky model, perm / field_start from ps_ms_route on the ray ORIGINS,

@@ -351,6 +351,9 @@ struct MainArgs {
   const int* field_start;
   int K;
   int64_t packed_stride;
+  // three-kernel backward: d(base-MLP output) [ceil(N/16)*16, 80] in register order, written by main_bwd_sem_kernel /
+  // main_bwd_rgb_kernel and read by main_bwd_base_kernel (null: the single fused kernel)
+  float* dzb;
 };
 
 template <int KS0_, int HB_, int HBC_>
@@ -664,6 +667,219 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
   for (int i = threadIdx.x; i < C::GPACKED; i += NW * 64) out[i] = gacc[i];
 }
 
+// ------------------------------------------------------------------------------------------ main backward as three kernels
+// The fused backward above accumulates the weight gradients of all eight layers in 112 KB of LDS (a read-modify-write of
+// every dW tile per 32 points) and therefore streams the transposed weight fragments (107 KB per 32 points) from L2, where
+// they queue behind the wave's own HBM activation loads (vector memory returns in order): its matrix pipe runs at 50 %.
+// Split by MLP, the weight gradients of ONE stack fit in the registers of a lone wave per SIMD (semantic head 195 + 12 of 512
+// per lane) and its transposed fragments fit in LDS (<= 49 KB):
+//   main_bwd_sem_kernel    kept activations zb[16:80], s1, s2 + d(semantics)   -> dW/db, d(zb[16:80]) -> dzb blocks 1..4
+//   main_bwd_rgb_kernel    zb[0:16], c1, c2, co + d(rgb), d(sigma)             -> dW/db, d(appearance), d(zb[0:16]) -> dzb block 0
+//   main_bwd_base_kernel   features, h1 + dzb                                 -> dW/db, d(features)
+// dzb [ceil(N/16)*16, 80] is a workspace in register order (the price: 640 B per point of extra HBM traffic).  Each kernel
+// reduces its four waves' accumulators through LDS once, at the end, and writes its share of the workgroup's partial block.
+template <bool MS>
+__device__ __forceinline__ bool main_bwd_setup(MainArgs& a, TileRange& tr, int& lb) {
+  tr = TileRange{0, a.N, (int)blockIdx.x, (int)gridDim.x};
+  lb = blockIdx.x;
+  if constexpr (MS) {
+    lb = ms_logical_block(blockIdx.x, gridDim.x);
+    const MsBlock mb = ms_block(a.field_start, a.K, gridDim.x, lb);
+    if (mb.k < 0) return false;  // its partial block is never read (ms_field_blocks)
+    a.packed += (int64_t)mb.k * a.packed_stride;
+    tr = TileRange{mb.first_pt, mb.end_pt, mb.j, mb.n};
+    a.N = mb.end_pt;
+  }
+  return true;
+}
+
+// LDS of a one-stack backward kernel: [max(transposed fragments, gradient block)] [NW per-wave transposes]
+template <class M, int NW>
+struct OneStackLds {
+  static constexpr int WT = M::PACKED - M::FW;
+  static constexpr int HEAD = WT > M::GPACKED ? WT : M::GPACKED;
+  static constexpr int SCR = M::SCRATCH_ROWS * kScratchLd;
+  static constexpr int FLOATS = HEAD + NW * SCR;
+};
+template <class M, int NW>
+__device__ __forceinline__ void load_transposed(float* __restrict__ lds, const float* __restrict__ packed_stack) {
+  for (int i = threadIdx.x * 4; i < OneStackLds<M, NW>::WT; i += NW * 256)
+    *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(packed_stack + M::FW + i);
+  __syncthreads();
+}
+// the waves add their register accumulators into the (now free) head of the LDS, which then goes out as the partial block
+template <class M, int NW>
+__device__ __forceinline__ void reduce_store(float* __restrict__ lds, const MlpAcc<M>& acc, float* __restrict__ out) {
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // every wave is done with the fragments
+#pragma unroll 1
+  for (int w = 0; w < NW; ++w) {
+    if (wave == w) acc.add_to(lds, w == 0);
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < M::GPACKED; i += NW * 64) out[i] = lds[i];
+}
+
+template <class C, int PB, int NW, bool MS>
+__global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
+  using Sem = typename C::Sem;
+  using L = OneStackLds<Sem, NW>;
+  TileRange tr;
+  int lb;
+  if (!main_bwd_setup<MS>(a, tr, lb)) return;
+  __shared__ __attribute__((aligned(16))) float lds[L::FLOATS];
+  load_transposed<Sem, NW>(lds, a.packed + C::P_SEM);
+  const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  float* scratch = lds + L::HEAD + wave * L::SCR;
+  const LdsW pk{lds - Sem::FW};  // mlp_backward addresses the transposed blocks at TOFF* >= FW of the stack's packed block
+  MlpAcc<Sem> acc;
+  acc.zero();
+  for (int64_t tile = (int64_t)tr.j * NW + wave;; tile += (int64_t)tr.n * NW) {
+    const int64_t first = tr.first_pt + tile * 16 * PB;
+    if (first >= a.N) break;
+    float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
+      const bool in = op >= 0;
+      const float wp = (a.w != nullptr && in) ? a.w[op] : 1.0f;
+      const float* src = a.dsem + (in ? ((a.w != nullptr) ? op / a.S : op) : 0) * 64 + 4 * g;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (in) d = *reinterpret_cast<const f32x4*>(src + 16 * nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = d[r] * wp;
+      }
+    }
+    float dsin[PB][16];
+    mlp_backward_acc<Sem, PB, true>(pk, scratch, acc, sin_, s1, s2, so, dsin);
+    store_act<4, PB>(a.dzb, 80, 16, first, a.N, dsin);
+  }
+  reduce_store<Sem, NW>(lds, acc, a.gpart + (size_t)lb * C::GPACKED + C::G_SEM);
+}
+
+template <class C, int PB, int NW, bool MS>
+__global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
+  using Rgb = typename C::Rgb;
+  using L = OneStackLds<Rgb, NW>;
+  TileRange tr;
+  int lb;
+  if (!main_bwd_setup<MS>(a, tr, lb)) return;
+  __shared__ __attribute__((aligned(16))) float lds[L::FLOATS];
+  load_transposed<Rgb, NW>(lds, a.packed + C::P_RGB);
+  const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
+  float* scratch = lds + L::HEAD + wave * L::SCR;
+  const LdsW pk{lds - Rgb::FW};
+  MlpAcc<Rgb> acc;
+  acc.zero();
+  for (int64_t tile = (int64_t)tr.j * NW + wave;; tile += (int64_t)tr.n * NW) {
+    const int64_t first = tr.first_pt + tile * 16 * PB;
+    if (first >= a.N) break;
+    float zb[PB][20];  // build_colour_input reads block 0 only (sigma_raw | geo15)
+    {
+      float zb0[PB][4];
+      load_act<1, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int t = 0; t < 20; ++t) zb[pb][t] = t < 4 ? zb0[pb][t] : 0.0f;
+    }
+    float cin[PB][12], c1[PB][Rgb::HB * 4], c2[PB][Rgb::HB * 4], co[PB][4];
+    int64_t ray_of[PB];
+    build_colour_input<PB, MS>(a, first, zb, cin, ray_of);
+    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
+    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, c2);
+    load_act<1, PB>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, co);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = 0.0f;
+        if (k < 3 && g == 0 && op >= 0) {
+          const float sg = 1.0f / (1.0f + expf(-co[pb][k]));
+          const float up = (a.w != nullptr) ? a.w[op] * a.drgb[ray_of[pb] * 3 + k] : a.drgb[op * 3 + k];
+          d = up * sg * (1.0f - sg);
+        }
+        co[pb][k] = d;
+      }
+    }
+    float dcin[PB][12];
+    mlp_backward_acc<Rgb, PB, true>(pk, scratch, acc, cin, c1, c2, co, dcin);
+    // d(appearance) is per RAY: see main_bwd_kernel
+    float dz0[PB][4];
+    bool block_in_ray = (a.S % 16) == 0;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t p = first + pb * 16 + j;
+      const int64_t op = orig_index<MS>(a.perm, p, a.N);
+      bool pt_ok = p < a.N;
+      if constexpr (MS) {
+        pt_ok = op >= 0;
+        const int rid = pt_ok ? (int)ray_of[pb] : -1;
+        bool same = true;
+        same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+        same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+        same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x141, 0xF, 0xF, false);  // row_half_mirror
+        same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x140, 0xF, 0xF, false);  // row_mirror
+        const unsigned long long ok = __ballot(same && pt_ok);
+        block_in_ray = ((ok >> (16 * g)) & 0xffffull) == 0xffffull;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dz0[pb][t] = dcin[pb][4 + t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
+        if (a.dapp != nullptr) {
+          const int c = 4 * t + g;
+          float v = pt_ok ? dcin[pb][8 + t] : 0.0f;
+          float vs = v;
+          if constexpr (MS) vs = ps_row16_sum(v);
+          if (block_in_ray) {
+            if constexpr (!MS) vs = ps_row16_sum(v);
+            if (j == 0 && first + pb * 16 < a.N && c < a.A) unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, vs);
+          } else if (pt_ok && c < a.A) {
+            unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, v);
+          }
+        }
+      }
+      if (a.dsigma != nullptr && g == 0 && op >= 0) dz0[pb][0] += a.dsigma[op] * a.sel[p] * trunc_exp_grad(zb[pb][0]);
+    }
+    store_act<1, PB>(a.dzb, 80, 0, first, a.N, dz0);
+  }
+  reduce_store<Rgb, NW>(lds, acc, a.gpart + (size_t)lb * C::GPACKED + C::G_RGB);
+}
+
+template <class C, int PB, int NW, bool MS>
+__global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
+  using Base = typename C::Base;
+  using L = OneStackLds<Base, NW>;
+  TileRange tr;
+  int lb;
+  if (!main_bwd_setup<MS>(a, tr, lb)) return;
+  __shared__ __attribute__((aligned(16))) float lds[L::FLOATS];
+  load_transposed<Base, NW>(lds, a.packed + C::P_BASE);
+  const int wave = threadIdx.x >> 6;
+  float* scratch = lds + L::HEAD + wave * L::SCR;
+  const LdsW pk{lds - Base::FW};
+  MlpAcc<Base> acc;
+  acc.zero();
+  for (int64_t tile = (int64_t)tr.j * NW + wave;; tile += (int64_t)tr.n * NW) {
+    const int64_t first = tr.first_pt + tile * 16 * PB;
+    if (first >= a.N) break;
+    float x[PB][Base::KS0], h1[PB][Base::HB * 4], dzb[PB][20];
+    load_feat<Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
+    load_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
+    load_act<5, PB>(a.dzb, 80, 0, first, a.N, dzb);
+    float dx[PB][Base::L0::IB * 4];
+    mlp_backward_acc<Base, PB, true>(pk, scratch, acc, x, h1, h1, dzb, dx);
+    store_dfeat<Base::KS0, PB>(a.dfeat, a.plane_stride, a.LF, a.F, first, a.N, dx);
+  }
+  reduce_store<Base, NW>(lds, acc, a.gpart + (size_t)lb * C::GPACKED + C::G_BASE);
+}
+
 int grid_for_tiles_nw(int64_t N, int pts_per_tile, int waves, int max_blocks) {
   const int64_t tiles = (N + pts_per_tile - 1) / pts_per_tile;
   int64_t g = (tiles + waves - 1) / waves;
@@ -863,13 +1079,21 @@ int main_bwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
     if (a.perm != nullptr) {                                                                                          \
       a.packed_stride = C::PACKED;                                                                                    \
       const int grid = ms_grid(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256, a.K);                                        \
-      if (a.acts != nullptr)                                                                                          \
+      if (a.acts != nullptr && a.dzb != nullptr) {                                                                    \
+        main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);               \
+        main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);               \
+        main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);              \
+      } else if (a.acts != nullptr)                                                                                   \
         main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, true, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);             \
       else                                                                                                            \
         main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, false, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);            \
     } else {                                                                                                          \
       const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256);                                   \
-      if (a.acts != nullptr)                                                                                          \
+      if (a.acts != nullptr && a.dzb != nullptr) {                                                                    \
+        main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);              \
+        main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);              \
+        main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);             \
+      } else if (a.acts != nullptr)                                                                                   \
         main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, true, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);            \
       else                                                                                                            \
         main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, false, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);           \
@@ -895,8 +1119,9 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
 extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                  const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
                                  const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t N,
-                                 float* dfeat, float* dapp, float* gpart, const float* acts, void* stream) {
+                                 float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch, void* stream) {
   MainArgs a{};
+  a.dzb = dzb_scratch;
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
   a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts); a.K = 1;
   return main_bwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
@@ -917,10 +1142,11 @@ extern "C" int ps_main_field_fwd_ms(const float* feat, int64_t plane_stride, int
 extern "C" int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                     const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
                                     const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t n_slots,
-                                    float* dfeat, float* dapp, float* gpart, const float* acts, const int32_t* perm,
-                                    const int32_t* field_start, int K, void* stream) {
+                                    float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch,
+                                    const int32_t* perm, const int32_t* field_start, int K, void* stream) {
   PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_bwd_ms: need the sorted layout");
   MainArgs a{};
+  a.dzb = dzb_scratch;
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
   a.packed = packed; a.N = n_slots; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts);
   a.perm = perm; a.field_start = field_start; a.K = K;

@@ -539,10 +539,14 @@ __device__ __forceinline__ void layer_bwd_flush(float* __restrict__ gacc, int* _
 //        before block pb's dW MFMAs, which hide that latency too;
 //   what stays exposed is one LDS read latency per point block.  `next()` is invoked before the last block's dW MFMAs (the
 //   caller requests the first transposed fragments of the next layer there).
-template <class LT, int PB, bool WANT_DX, class W, class Next>
-__device__ __forceinline__ void layer_bwd_pipe(const W& wt_block, const float (&a_first)[LT::KSO], float* __restrict__ scratch,
-                                               float* __restrict__ gacc, int* __restrict__ lock, const float (&dvout)[PB][LT::NB * 4],
-                                               const float (&vin)[PB][LT::KS], float (&dvin)[PB][LT::IB * 4], const Next& next) {
+//   The dW tiles are ADDED to `dw` (the caller zeroes them per tile of points and flushes, or keeps them over the whole kernel);
+//   WANT_DB: `dbp[ob]` += this lane's share of the bias gradient of output block ob, taken from the transposed dY fragments
+//   (lane (j, g): neuron 16*ob + j summed over the points 4g..4g+3 of every block; reduce over g at the end).
+template <class LT, int PB, bool WANT_DX, bool WANT_DB, class W, class Next>
+__device__ __forceinline__ void layer_bwd_pipe_core(const W& wt_block, const float (&a_first)[LT::KSO], float* __restrict__ scratch,
+                                                    f32x4 (&dw)[LT::NB][LT::IB], float (&dbp)[LT::NB],
+                                                    const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS],
+                                                    float (&dvin)[PB][LT::IB * 4], const Next& next) {
   static_assert(PB >= 2, "the pipelined backward works on >= 2 point blocks per wave");
   const int lane = ps_lane();
   const int j = lane & 15, g = lane >> 4;
@@ -563,11 +567,6 @@ __device__ __forceinline__ void layer_bwd_pipe(const W& wt_block, const float (&
   write_dy(dvout[0], 0);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (WANT_DX) layer_bwd_data_pf<LT, PB>(wt_block, a_first, dvout, dvin, NoPrefetch());
-  f32x4 dw[LT::NB][LT::IB];
-#pragma unroll
-  for (int ob = 0; ob < LT::NB; ++ob)
-#pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     f32x4 bfrag[LT::IB];
@@ -603,12 +602,75 @@ __device__ __forceinline__ void layer_bwd_pipe(const W& wt_block, const float (&
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int ib = 0; ib < LT::IB; ++ib) dw[ob0 + o][ib] = ps_mfma16(afrag[o][r], bfrag[ib][r], dw[ob0 + o][ib]);
+          if constexpr (WANT_DB) dbp[ob0 + o] += (afrag[o][0] + afrag[o][1]) + (afrag[o][2] + afrag[o][3]);
         }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+}
+
+template <class LT, int PB, bool WANT_DX, class W, class Next>
+__device__ __forceinline__ void layer_bwd_pipe(const W& wt_block, const float (&a_first)[LT::KSO], float* __restrict__ scratch,
+                                               float* __restrict__ gacc, int* __restrict__ lock, const float (&dvout)[PB][LT::NB * 4],
+                                               const float (&vin)[PB][LT::KS], float (&dvin)[PB][LT::IB * 4], const Next& next) {
+  f32x4 dw[LT::NB][LT::IB];
+#pragma unroll
+  for (int ob = 0; ob < LT::NB; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dbp[LT::NB];
+  layer_bwd_pipe_core<LT, PB, WANT_DX, false>(wt_block, a_first, scratch, dw, dbp, dvout, vin, dvin, next);
   layer_bwd_flush<LT, PB>(gacc, lock, dw, dvout);
 }
+
+// Wave-resident weight gradients of one layer: a 64 x 64 layer is 64 registers per lane, so a kernel that differentiates ONE
+// MLP (<= 195 accumulator registers of the 512 a lone wave per SIMD owns) keeps every dW tile in registers over all its points
+// -- no flush, no LDS accumulators, no lock -- and the LDS holds the transposed weight fragments instead.
+template <class LT>
+struct LayerAcc {
+  f32x4 dw[LT::NB][LT::IB];
+  float dbp[LT::NB];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int ob = 0; ob < LT::NB; ++ob) {
+      dbp[ob] = 0.0f;
+#pragma unroll
+      for (int ib = 0; ib < LT::IB; ++ib) dw[ob][ib] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // add (or, first: store) this wave's accumulators into an LDS block laid out like the packed gradient block of the layer
+  __device__ __forceinline__ void add_to(float* __restrict__ blk, bool first) const {
+    const int lane = ps_lane(), j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ob = 0; ob < LT::NB; ++ob) {
+#pragma unroll
+      for (int ib = 0; ib < LT::IB; ++ib) {
+        f32x4* dst = reinterpret_cast<f32x4*>(blk + LT::GW_OFF + ((ob * LT::IB + ib) * 64 + lane) * 4);
+        *dst = first ? dw[ob][ib] : *dst + dw[ob][ib];
+      }
+      float v = dbp[ob];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) blk[LT::GB_OFF + 16 * ob + j] = first ? v : blk[LT::GB_OFF + 16 * ob + j] + v;
+    }
+  }
+};
+template <class M>
+struct MlpAcc {
+  LayerAcc<typename M::L0> l0;
+  LayerAcc<typename M::L1> l1;  // unused (and optimised away) when NL == 2
+  LayerAcc<typename M::LZ> lz;
+  __device__ __forceinline__ void zero() {
+    l0.zero();
+    if constexpr (M::NL == 3) l1.zero();
+    lz.zero();
+  }
+  __device__ __forceinline__ void add_to(float* __restrict__ blk, bool first) const {
+    l0.add_to(blk + M::GOFF0, first);
+    if constexpr (M::NL == 3) l1.add_to(blk + M::GOFF1, first);
+    lz.add_to(blk + M::GOFFZ, first);
+  }
+};
 
 // Register-resident variant for small MLPs (proposal nets: 2128 gradient words = 52 registers per lane): the dW / db
 // tiles stay in the caller's registers over ALL tiles of the kernel, so there is no per-tile flush at all.
@@ -792,6 +854,39 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
     if constexpr (WANT_DX) first_frags_bwd<L0>(t0, a0);
     layer_bwd_weights<L0, PB>(scratch, gacc + M::GOFF0, locks + 0, dh, x);
     if constexpr (WANT_DX) layer_bwd_data_pf<L0, PB>(t0, a0, dh, dx, NoPrefetch());
+  }
+}
+
+// mlp_backward with wave-resident weight gradients (MlpAcc): no LDS accumulators, no flush
+template <class M, int PB, bool WANT_DX, class W>
+__device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restrict__ scratch, MlpAcc<M>& acc,
+                                                 const float (&x)[PB][M::KS0], const float (&h1)[PB][M::HB * 4],
+                                                 const float (&h2)[PB][M::HB * 4], const float (&dz)[PB][M::NBO * 4],
+                                                 float (&dx)[PB][M::L0::IB * 4]) {
+  using L0 = typename M::L0;
+  using L1 = typename M::L1;
+  using LZ = typename M::LZ;
+  static_assert(PB >= 2, "pipelined backward only");
+  const W tz = params.at(M::TOFFZ), t1 = params.at(M::TOFF1), t0 = params.at(M::TOFF0);
+  float dh[PB][M::HB * 4];
+  float az[LZ::KSO];
+  frags_bwd_block<LZ>(tz, 0, az);
+  float a0[L0::KSO];
+  auto req0 = [&]() {
+    if constexpr (WANT_DX) frags_bwd_block<L0>(t0, 0, a0);
+  };
+  if constexpr (M::NL == 3) {
+    float a1[L1::KSO];
+    layer_bwd_pipe_core<LZ, PB, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h2, dh, [&]() { frags_bwd_block<L1>(t1, 0, a1); });
+    relu_mask<PB, M::HB * 4>(dh, h2);
+    float dh1[PB][M::HB * 4];
+    layer_bwd_pipe_core<L1, PB, true, true>(t1, a1, scratch, acc.l1.dw, acc.l1.dbp, dh, h1, dh1, req0);
+    relu_mask<PB, M::HB * 4>(dh1, h1);
+    layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh1, x, dx, NoPrefetch());
+  } else {
+    layer_bwd_pipe_core<LZ, PB, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h1, dh, req0);
+    relu_mask<PB, M::HB * 4>(dh, h1);
+    layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh, x, dx, NoPrefetch());
   }
 }
 

@@ -8,6 +8,7 @@ Positions carry no gradient (the reference detaches the sampled bins, ray_sample
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -271,6 +272,13 @@ def _main_forward(ctx, table_needs_grad, u, sel, dirs, app, S, table, scalings, 
     return (u, sel, dirs, app_c, scalings, feat, packed, counts, acts), (sigma, rgb, sem)
 
 
+def _dzb_scratch(n_points: int, dev):
+    """workspace of the three-kernel main backward (ps_main_field_bwd dzb_scratch); PRESIGHT_MAIN_BWD_SPLIT=0 -> the fused kernel"""
+    if os.environ.get("PRESIGHT_MAIN_BWD_SPLIT", "1") == "0":
+        return None
+    return torch.empty((n_points + 15) // 16 * 16, 80, device=dev)
+
+
 def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     """shared backward: fused MLP backward -> table scatter -> weight-gradient reduction.  weights != None: d_rgb / d_sem are
     per-RAY gradients (see ps_main_field_bwd).  -> (dapp, dtable | None, [dW0, db0, ...] with None for in-place gradients)"""
@@ -292,10 +300,11 @@ def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     dapp = torch.zeros_like(app) if app is not None else None
     # (the per-level |d(feature)| maxima are NOT tracked in this kernel, unlike the proposal backward: at its register
     #  pressure the 8 extra live values cost more (+0.2 ms) than the separate 0.13 ms absmax pass)
+    dzb = _dzb_scratch(N, dev) if acts is not None else None
     with prof.region("main_field_bwd"):
         check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                       _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                      _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _stream()), "ps_main_field_bwd")
+                                      _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), _stream()), "ps_main_field_bwd")
     dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
     descs = []
     for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
@@ -681,10 +690,11 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     dfeat = torch.empty_like(feat)
     dapp = torch.zeros_like(app) if app is not None else None
     nparts = lib().ps_main_field_parts_ms(lay.n_slots, K)
+    dzb = _dzb_scratch(lay.n_slots, u.device) if acts is not None else None
     with prof.region("main_field_bwd"):
         check(lib().ps_main_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                          _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(st.packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                         _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(lay.perm),
+                                         _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(dzb), _p(lay.perm),
                                          lay.field_start, K, _stream()), "ps_main_field_bwd_ms")
     ws = _ms_scatter_ws(lay, g, u.device)
     dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False)
