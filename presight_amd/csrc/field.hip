@@ -77,6 +77,47 @@ __device__ __forceinline__ void store_dfeat(float* __restrict__ dfeat, int64_t p
   }
 }
 
+// the same accesses with the per-lane column offsets hoisted out of the tile loop (col / F is a runtime division: 30 vector
+// instructions per element when it sits next to the load)
+template <int KS0>
+struct FeatCols {
+  int64_t off[KS0];  // level * plane_stride + f of column 4t + g, -1: no such column
+  __device__ __forceinline__ void init(int64_t plane_stride, int LF, int F) {
+    const int g = ps_lane() >> 4;
+#pragma unroll
+    for (int t = 0; t < KS0; ++t) {
+      const int col = 4 * t + g;
+      const int level = col / F, f = col - level * F;
+      off[t] = col < LF ? level * plane_stride + f : (int64_t)-1;
+    }
+  }
+};
+template <int KS0, int PB>
+__device__ __forceinline__ void load_feat(const float* __restrict__ feat, const FeatCols<KS0>& fc, int F, int64_t first, int64_t N,
+                                          float (&x)[PB][KS0]) {
+  const int j = ps_lane() & 15;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int64_t p = first + pb * 16 + j;
+    const float* row = feat + p * F;
+#pragma unroll
+    for (int t = 0; t < KS0; ++t) x[pb][t] = (p < N && fc.off[t] >= 0) ? row[fc.off[t]] : 0.0f;
+  }
+}
+template <int KS0, int PB>
+__device__ __forceinline__ void store_dfeat(float* __restrict__ dfeat, const FeatCols<KS0>& fc, int F, int64_t first, int64_t N,
+                                            const float (&dx)[PB][((KS0 + 3) / 4) * 4]) {
+  const int j = ps_lane() & 15;
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb) {
+    const int64_t p = first + pb * 16 + j;
+    float* row = dfeat + p * F;
+#pragma unroll
+    for (int t = 0; t < KS0; ++t)
+      if (p < N && fc.off[t] >= 0) row[fc.off[t]] = dx[pb][t];
+  }
+}
+
 // per-level max |d(feature)| for the fixed-point scale of the binned table backward (encode.hip), kept per lane over all
 // tiles of the kernel and published once per wave: saves that backward a separate pass over d(features)
 template <int KS0, int PB>
@@ -145,6 +186,9 @@ __device__ __forceinline__ void load_act(const float* __restrict__ acts, int str
     }
   }
 }
+
+// ray of point n (n / S): point counts are < 2^31 (checked by the launchers), and a 32-bit division is a fifth of the 64-bit one
+__device__ __forceinline__ int64_t ray_index(int64_t n, int S) { return (int64_t)((uint32_t)n / (uint32_t)S); }
 
 __device__ __forceinline__ float trunc_exp_grad(float raw) { return expf(fminf(fmaxf(raw, -15.0f), 15.0f)); }
 
@@ -384,9 +428,9 @@ __device__ __forceinline__ void build_colour_input(const MainArgs& a, int64_t fi
     int64_t r;
     if constexpr (MS) {
       const int64_t op = orig_index<true>(a.perm, p, a.N);
-      r = (op >= 0 ? op : 0) / a.S;
+      r = ray_index(op >= 0 ? op : 0, a.S);
     } else {
-      r = (p < a.N ? p : a.N - 1) / a.S;
+      r = ray_index(p < a.N ? p : a.N - 1, a.S);
     }
     ray_of[pb] = r;
     float sh[16];
@@ -559,7 +603,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
         const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
         const bool in = op >= 0;
         const float wp = (a.w != nullptr && in) ? a.w[op] : 1.0f;
-        const float* src = a.dsem + (in ? ((a.w != nullptr) ? op / a.S : op) : 0) * 64 + 4 * g;
+        const float* src = a.dsem + (in ? ((a.w != nullptr) ? ray_index(op, a.S) : op) : 0) * 64 + 4 * g;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -734,31 +778,68 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
   const LdsW pk{lds - Sem::FW};  // mlp_backward addresses the transposed blocks at TOFF* >= FW of the stack's packed block
   MlpAcc<Sem> acc;
   acc.zero();
-  for (int64_t tile = (int64_t)tr.j * NW + wave;; tile += (int64_t)tr.n * NW) {
-    const int64_t first = tr.first_pt + tile * 16 * PB;
-    if (first >= a.N) break;
-    float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
+  PsTimer* tm = nullptr;
+#if defined(PS_TIMING)
+  PsTimer tm_;
+  tm_.start();
+  tm = &tm_;
+#endif
+  // A lone wave per SIMD has nobody to hide HBM latency behind (measured: 4.4 k of 35 k cycles per tile waiting for the first
+  // operands).  d(output) -- the only operand the first matrix phase needs -- is gathered one tile AHEAD (34 registers); the
+  // kept activations of the current tile are requested at the top and arrive under that phase (mlp_backward_acc: H_LATE).
+  struct Gather {
+    float w[PB];
+    f32x4 d[PB][4];
+  };
+  auto gather = [&](int64_t first, Gather& v) {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
       const bool in = op >= 0;
-      const float wp = (a.w != nullptr && in) ? a.w[op] : 1.0f;
-      const float* src = a.dsem + (in ? ((a.w != nullptr) ? op / a.S : op) : 0) * 64 + 4 * g;
+      v.w[pb] = (a.w != nullptr && in) ? a.w[op] : 1.0f;
+      const float* src = a.dsem + (in ? ((a.w != nullptr) ? ray_index(op, a.S) : op) : 0) * 64 + 4 * g;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
-        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (in) d = *reinterpret_cast<const f32x4*>(src + 16 * nb);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = d[r] * wp;
+        v.d[pb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (in) v.d[pb][nb] = *reinterpret_cast<const f32x4*>(src + 16 * nb);
       }
     }
+  };
+  const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
+  int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
+  Gather ga;
+  gather(first, ga);
+  for (; first < a.N; first += stride) {
+    PS_STAMP(tm, 0)
+    float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = ga.d[pb][nb][r] * ga.w[pb];
+    gather(first + stride, ga);
+    PS_STAMP(tm, 1)
     float dsin[PB][16];
-    mlp_backward_acc<Sem, PB, true>(pk, scratch, acc, sin_, s1, s2, so, dsin);
+    mlp_backward_acc<Sem, PB, true>(
+        pk, scratch, acc,
+        [&](float (&x)[PB][16]) {
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) x[pb][t] = sin_[pb][t];
+        },
+        s1, s2, so, dsin, tm);
     store_act<4, PB>(a.dzb, 80, 16, first, a.N, dsin);
+    PS_STAMP(tm, 8)
   }
+#if defined(PS_TIMING)
+  if (lane == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_ps_timing[i], tm_.acc[i]);
+#endif
   reduce_store<Sem, NW>(lds, acc, a.gpart + (size_t)lb * C::GPACKED + C::G_SEM);
 }
 
@@ -776,40 +857,88 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
   const LdsW pk{lds - Rgb::FW};
   MlpAcc<Rgb> acc;
   acc.zero();
-  for (int64_t tile = (int64_t)tr.j * NW + wave;; tile += (int64_t)tr.n * NW) {
-    const int64_t first = tr.first_pt + tile * 16 * PB;
-    if (first >= a.N) break;
-    float zb[PB][20];  // build_colour_input reads block 0 only (sigma_raw | geo15)
-    {
-      float zb0[PB][4];
-      load_act<1, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb)
-#pragma unroll
-        for (int t = 0; t < 20; ++t) zb[pb][t] = t < 4 ? zb0[pb][t] : 0.0f;
-    }
-    float cin[PB][12], c1[PB][Rgb::HB * 4], c2[PB][Rgb::HB * 4], co[PB][4];
-    int64_t ray_of[PB];
-    build_colour_input<PB, MS>(a, first, zb, cin, ray_of);
-    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
-    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, c2);
-    load_act<1, PB>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, co);
+  // what the first matrix phase needs -- the pre-sigmoid colour, its upstream gradient and the last hidden layer -- is fetched
+  // one tile AHEAD; everything else is requested at the top of the tile and arrives under the matrix work before its use
+  // (the first layer's input is assembled from the per-ray directions / appearance codes right before that layer)
+  struct Head {
+    float co[PB][4], w[PB], dr[PB][3], c2[PB][Rgb::HB * 4];
+    int64_t ray[PB];
+  };
+  auto fetch_head = [&](int64_t first, Head& h) {
+    load_act<1, PB>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, h.co);
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
-      const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
+      const int64_t p = first + pb * 16 + j;
+      const int64_t op = orig_index<MS>(a.perm, p, a.N);
+      int64_t r;
+      if constexpr (MS)
+        r = ray_index(op >= 0 ? op : 0, a.S);
+      else
+        r = ray_index(p < a.N ? p : a.N - 1, a.S);
+      h.ray[pb] = r;
+      h.w[pb] = 1.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) h.dr[pb][k] = 0.0f;
+      if (g == 0 && op >= 0) {
+        if (a.w != nullptr) h.w[pb] = a.w[op];
+        const float* src = (a.w != nullptr) ? a.drgb + r * 3 : a.drgb + op * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) h.dr[pb][k] = src[k];
+      }
+    }
+    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, h.c2);
+  };
+  const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
+  int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
+  Head hd;
+  fetch_head(first, hd);
+  for (; first < a.N; first += stride) {
+    float c1[PB][Rgb::HB * 4], c2[PB][Rgb::HB * 4], co[PB][4], zb0[PB][4], dirv[PB][3], appv[PB][4];
+    int64_t ray_of[PB];
+    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
+    load_act<1, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);  // sigma_raw | geo15
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t r = hd.ray[pb];
+      ray_of[pb] = r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dirv[pb][k] = a.dirs[r * 3 + k];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * t + g;
+        appv[pb][t] = (a.app != nullptr && c < a.A) ? a.app[r * a.A + c] : 0.0f;
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float d = 0.0f;
-        if (k < 3 && g == 0 && op >= 0) {
-          const float sg = 1.0f / (1.0f + expf(-co[pb][k]));
-          const float up = (a.w != nullptr) ? a.w[op] * a.drgb[ray_of[pb] * 3 + k] : a.drgb[op * 3 + k];
-          d = up * sg * (1.0f - sg);
+        if (k < 3) {
+          const float sg = 1.0f / (1.0f + expf(-hd.co[pb][k]));
+          d = hd.w[pb] * hd.dr[pb][k] * sg * (1.0f - sg);  // dr is zero outside lane group 0 / past the end
         }
         co[pb][k] = d;
       }
+#pragma unroll
+      for (int t = 0; t < Rgb::HB * 4; ++t) c2[pb][t] = hd.c2[pb][t];
     }
+    fetch_head(first + stride, hd);
     float dcin[PB][12];
-    mlp_backward_acc<Rgb, PB, true>(pk, scratch, acc, cin, c1, c2, co, dcin);
+    mlp_backward_acc<Rgb, PB, true, true>(
+        pk, scratch, acc,
+        [&](float (&cin)[PB][12]) {
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) {
+            float sh[16];
+            sh4((dirv[pb][0] + 1.0f) / 2.0f, (dirv[pb][1] + 1.0f) / 2.0f, (dirv[pb][2] + 1.0f) / 2.0f, sh);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float v0 = sh[4 * t], v1 = sh[4 * t + 1], v2 = sh[4 * t + 2], v3 = sh[4 * t + 3];
+              cin[pb][t] = g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
+              cin[pb][4 + t] = zb0[pb][t];
+              cin[pb][8 + t] = appv[pb][t];
+            }
+          }
+        },
+        c1, c2, co, dcin);
     // d(appearance) is per RAY: see main_bwd_kernel
     float dz0[PB][4];
     bool block_in_ray = (a.S % 16) == 0;
@@ -845,7 +974,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
           }
         }
       }
-      if (a.dsigma != nullptr && g == 0 && op >= 0) dz0[pb][0] += a.dsigma[op] * a.sel[p] * trunc_exp_grad(zb[pb][0]);
+      if (a.dsigma != nullptr && g == 0 && op >= 0) dz0[pb][0] += a.dsigma[op] * a.sel[p] * trunc_exp_grad(zb0[pb][0]);
     }
     store_act<1, PB>(a.dzb, 80, 0, first, a.N, dz0);
   }
@@ -866,16 +995,33 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
   const LdsW pk{lds - Base::FW};
   MlpAcc<Base> acc;
   acc.zero();
-  for (int64_t tile = (int64_t)tr.j * NW + wave;; tile += (int64_t)tr.n * NW) {
-    const int64_t first = tr.first_pt + tile * 16 * PB;
-    if (first >= a.N) break;
-    float x[PB][Base::KS0], h1[PB][Base::HB * 4], dzb[PB][20];
-    load_feat<Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
+  FeatCols<Base::KS0> fc;
+  fc.init(a.plane_stride, a.LF, a.F);
+  // d(output) one tile ahead, the rest under the first matrix phase (see main_bwd_sem_kernel)
+  const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
+  int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
+  float dzb_next[PB][20];
+  load_act<5, PB>(a.dzb, 80, 0, first, a.N, dzb_next);
+  for (; first < a.N; first += stride) {
+    float h1[PB][Base::HB * 4], dzb[PB][20], xin[PB][Base::KS0];
     load_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
-    load_act<5, PB>(a.dzb, 80, 0, first, a.N, dzb);
+    load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, xin);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int t = 0; t < 20; ++t) dzb[pb][t] = dzb_next[pb][t];
+    load_act<5, PB>(a.dzb, 80, 0, first + stride, a.N, dzb_next);
     float dx[PB][Base::L0::IB * 4];
-    mlp_backward_acc<Base, PB, true>(pk, scratch, acc, x, h1, h1, dzb, dx);
-    store_dfeat<Base::KS0, PB>(a.dfeat, a.plane_stride, a.LF, a.F, first, a.N, dx);
+    mlp_backward_acc<Base, PB, true>(
+        pk, scratch, acc,
+        [&](float (&x)[PB][Base::KS0]) {
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int t = 0; t < Base::KS0; ++t) x[pb][t] = xin[pb][t];
+        },
+        h1, h1, dzb, dx);
+    store_dfeat<Base::KS0, PB>(a.dfeat, fc, a.F, first, a.N, dx);
   }
   reduce_store<Base, NW>(lds, acc, a.gpart + (size_t)lb * C::GPACKED + C::G_BASE);
 }
@@ -1051,6 +1197,7 @@ namespace {
 int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
   if (a.N == 0) return 0;
   PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field_fwd: appearance dim must be <= 16");
+  PS_REQUIRE(a.N < (int64_t(1) << 31), "ps_main_field_fwd: at most 2^31 - 1 points per call");
   PS_REQUIRE(a.acts == nullptr || (a.sem != nullptr && a.rgb != nullptr), "ps_main_field_fwd: activations are kept for full evaluations only");
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
@@ -1073,6 +1220,7 @@ int main_bwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
   if (a.N == 0) return 0;
   PS_REQUIRE(a.acts == nullptr || (a.drgb != nullptr && a.dsem != nullptr), "ps_main_field_bwd: kept activations need both head gradients");
   PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
+  PS_REQUIRE(a.N < (int64_t(1) << 31), "ps_main_field_bwd: at most 2^31 - 1 points per call");
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \

@@ -54,6 +54,28 @@ struct LayerT {
   static constexpr int SCRATCH_ROWS = (IB + OBG) * 16;
 };
 
+// profiling builds (-DPS_TIMING): shader-clock time per phase, per wave (s_memtime drains the wave's LDS / scalar queue, so the
+// phases are slightly serialised against each other)
+struct PsTimer {
+  unsigned long long acc[16], last;
+  __device__ __forceinline__ void start() {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    last = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void stamp(int i) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    acc[i] += now - last;
+    last = now;
+  }
+};
+#if defined(PS_TIMING)
+#define PS_STAMP(tm, i) \
+  if ((tm) != nullptr) (tm)->stamp(i);
+#else
+#define PS_STAMP(tm, i)
+#endif
+
 constexpr int kScratchLd = 20;  // floats per scratch row: 16 points + 4 pad (keeps 16-B alignment)
 
 // ---- where weight fragments come from --------------------------------------------------------
@@ -542,11 +564,13 @@ __device__ __forceinline__ void layer_bwd_flush(float* __restrict__ gacc, int* _
 //   The dW tiles are ADDED to `dw` (the caller zeroes them per tile of points and flushes, or keeps them over the whole kernel);
 //   WANT_DB: `dbp[ob]` += this lane's share of the bias gradient of output block ob, taken from the transposed dY fragments
 //   (lane (j, g): neuron 16*ob + j summed over the points 4g..4g+3 of every block; reduce over g at the end).
-template <class LT, int PB, bool WANT_DX, bool WANT_DB, class W, class Next>
+//   H_LATE: the layer's input `vin` is still in flight from HBM when the layer starts (the first layer of a backward kernel):
+//   it is staged after the dX MFMAs instead of before them, which exposes one LDS round trip and hides the HBM latency.
+template <class LT, int PB, bool WANT_DX, bool WANT_DB, bool H_LATE = false, class W, class Next>
 __device__ __forceinline__ void layer_bwd_pipe_core(const W& wt_block, const float (&a_first)[LT::KSO], float* __restrict__ scratch,
                                                     f32x4 (&dw)[LT::NB][LT::IB], float (&dbp)[LT::NB],
                                                     const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS],
-                                                    float (&dvin)[PB][LT::IB * 4], const Next& next) {
+                                                    float (&dvin)[PB][LT::IB * 4], const Next& next, PsTimer* tm = nullptr, int slot = 0) {
   static_assert(PB >= 2, "the pipelined backward works on >= 2 point blocks per wave");
   const int lane = ps_lane();
   const int j = lane & 15, g = lane >> 4;
@@ -563,10 +587,15 @@ __device__ __forceinline__ void layer_bwd_pipe_core(const W& wt_block, const flo
       if (4 * ob0 + t < LT::NB * 4) sy[(16 * (t >> 2) + 4 * g + (t & 3)) * kScratchLd + j] = dy[(4 * ob0 + t) < LT::NB * 4 ? 4 * ob0 + t : 0];
   };
   __builtin_amdgcn_sched_barrier(0);
-  write_h(vin[0]);
+  if constexpr (!H_LATE) write_h(vin[0]);
   write_dy(dvout[0], 0);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (WANT_DX) layer_bwd_data_pf<LT, PB>(wt_block, a_first, dvout, dvin, NoPrefetch());
+  if constexpr (H_LATE) {
+    __builtin_amdgcn_sched_barrier(0);
+    write_h(vin[0]);
+  }
+  PS_STAMP(tm, slot)
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     f32x4 bfrag[LT::IB];
@@ -607,6 +636,7 @@ __device__ __forceinline__ void layer_bwd_pipe_core(const W& wt_block, const flo
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  PS_STAMP(tm, slot + 1)
 }
 
 template <class LT, int PB, bool WANT_DX, class W, class Next>
@@ -858,11 +888,15 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
 }
 
 // mlp_backward with wave-resident weight gradients (MlpAcc): no LDS accumulators, no flush
-template <class M, int PB, bool WANT_DX, class W>
-__device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restrict__ scratch, MlpAcc<M>& acc,
-                                                 const float (&x)[PB][M::KS0], const float (&h1)[PB][M::HB * 4],
-                                                 const float (&h2)[PB][M::HB * 4], const float (&dz)[PB][M::NBO * 4],
-                                                 float (&dx)[PB][M::L0::IB * 4]) {
+// mlp_backward with wave-resident weight gradients (MlpAcc): no LDS accumulators, no flush.  The kernel's loads are still in
+// flight when this starts: the last layer's input (h2 / h1) is staged late (H_LATE), and `make_x(x)` produces the first
+// layer's input right before it is needed (the colour head builds it from gathered per-ray data).
+// H1_LATE: the middle layer's input h1 is staged late as well (a narrow last layer gives the loads too little cover).
+template <class M, int PB, bool WANT_DX, bool H1_LATE = false, class W, class MakeX>
+__device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restrict__ scratch, MlpAcc<M>& acc, const MakeX& make_x,
+                                                 const float (&h1)[PB][M::HB * 4], const float (&h2)[PB][M::HB * 4],
+                                                 const float (&dz)[PB][M::NBO * 4], float (&dx)[PB][M::L0::IB * 4],
+                                                 PsTimer* tm = nullptr) {
   using L0 = typename M::L0;
   using L1 = typename M::L1;
   using LZ = typename M::LZ;
@@ -875,18 +909,21 @@ __device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restr
   auto req0 = [&]() {
     if constexpr (WANT_DX) frags_bwd_block<L0>(t0, 0, a0);
   };
+  float x[PB][M::KS0];
   if constexpr (M::NL == 3) {
     float a1[L1::KSO];
-    layer_bwd_pipe_core<LZ, PB, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h2, dh, [&]() { frags_bwd_block<L1>(t1, 0, a1); });
+    layer_bwd_pipe_core<LZ, PB, true, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h2, dh, [&]() { frags_bwd_block<L1>(t1, 0, a1); }, tm, 2);
     relu_mask<PB, M::HB * 4>(dh, h2);
     float dh1[PB][M::HB * 4];
-    layer_bwd_pipe_core<L1, PB, true, true>(t1, a1, scratch, acc.l1.dw, acc.l1.dbp, dh, h1, dh1, req0);
+    layer_bwd_pipe_core<L1, PB, true, true, H1_LATE>(t1, a1, scratch, acc.l1.dw, acc.l1.dbp, dh, h1, dh1, req0, tm, 4);
     relu_mask<PB, M::HB * 4>(dh1, h1);
-    layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh1, x, dx, NoPrefetch());
+    make_x(x);
+    layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh1, x, dx, NoPrefetch(), tm, 6);
   } else {
-    layer_bwd_pipe_core<LZ, PB, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h1, dh, req0);
+    layer_bwd_pipe_core<LZ, PB, true, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h1, dh, req0, tm, 2);
     relu_mask<PB, M::HB * 4>(dh, h1);
-    layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh, x, dx, NoPrefetch());
+    make_x(x);
+    layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh, x, dx, NoPrefetch(), tm, 6);
   }
 }
 

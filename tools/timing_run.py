@@ -20,8 +20,12 @@ for i in range(n):
     tr.step(b[i % 2])
 torch.cuda.synchronize()
 h.ps_debug_timing(out, 0)
-names = ["loop top / tile select", "loads + prep (x, h1, zb, dzb)", "semantic head backward", "colour head backward", "base backward + d(feature) stores"]
-tot = sum(out[i] for i in range(5))
+if os.environ.get("PRESIGHT_MAIN_BWD_SPLIT", "1") == "0":
+    names = ["loop top / tile select", "loads + prep (x, h1, zb, dzb)", "semantic head backward", "colour head backward", "base backward + d(feature) stores"]
+else:  # main_bwd_sem_kernel
+    names = ["loop top", "load issue + d(sem) gather", "LZ: writes + dX (+ operand read-back)", "LZ: dW", "L1: relu + writes + dX", "L1: dW",
+             "L0: relu + writes + dX", "L0: dW", "store d(head input)"]
+tot = sum(out[i] for i in range(len(names)))
 tiles = 65536 * 64 / 32
 for i, nm in enumerate(names):
     print(f"{nm:40s} {out[i] / n / tiles:10.0f} clk/tile   {100 * out[i] / tot:5.1f} %")
