@@ -248,7 +248,49 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
   const float* e = ebins + ray * (S + 1);
   // channel-parallel accumulations
   float a_sem = 0.f, a_rgb = 0.f;
-  if (sem_s != nullptr || rgb_s != nullptr) {
+  const bool vec = (C & 3) == 0;  // 16 lanes x 4 channels cover a row with one 16-byte load per lane: four rows per load instruction
+  if (vec && (sem_s != nullptr || rgb_s != nullptr)) {
+    const int q = lane & 15, g = lane >> 4;
+    if (sem_s != nullptr) {
+      const bool on = 4 * q < C;
+      const float* ps = sem_s + ray * S * C + 4 * q;
+      f32x4 a4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int s0 = 0; s0 < S; s0 += 16) {
+        f32x4 v[4];
+        float ws[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int sr = s0 + 4 * u + g;
+          const bool ok = on && sr < S;
+          v[u] = ok ? *reinterpret_cast<const f32x4*>(ps + (int64_t)sr * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          ws[u] = ok ? w[sr] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4 += v[u] * ws[u];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a4[r] += __shfl_xor(a4[r], 16, 64);
+        a4[r] += __shfl_xor(a4[r], 32, 64);
+      }
+      if (sem != nullptr && g == 0 && on) *reinterpret_cast<f32x4*>(sem + ray * C + 4 * q) = a4;
+    }
+    if (rgb_s != nullptr) {  // lane = sample, three channels each, one wave reduction per channel
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      for (int sr = lane; sr < S; sr += 64) {
+        const float* pr = rgb_s + (ray * S + sr) * 3;
+        const float wv = w[sr];
+        c0 += wv * pr[0];
+        c1 += wv * pr[1];
+        c2 += wv * pr[2];
+      }
+      c0 = ps_wave_sum(c0);
+      c1 = ps_wave_sum(c1);
+      c2 = ps_wave_sum(c2);
+      if (rgb != nullptr && lane < 3) rgb[ray * 3 + lane] = lane == 0 ? c0 : (lane == 1 ? c1 : c2);
+    }
+  } else if (sem_s != nullptr || rgb_s != nullptr) {
     const bool sem_on = sem_s != nullptr && lane < C, rgb_on = rgb_s != nullptr && lane < 3;
     const float* ps = sem_s + ray * S * C + lane;
     const float* pr = rgb_s + ray * S * 3 + lane;
@@ -274,8 +316,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
       if (rgb_on) a_rgb += ws * pr[(int64_t)s * 3];
     }
   }
-  if (sem != nullptr && lane < C) sem[ray * C + lane] = a_sem;
-  if (rgb != nullptr && lane < 3) rgb[ray * 3 + lane] = a_rgb;
+  if (!vec) {
+    if (sem != nullptr && lane < C) sem[ray * C + lane] = a_sem;
+    if (rgb != nullptr && lane < 3) rgb[ray * 3 + lane] = a_rgb;
+  }
   // sample-parallel part
   const int CH = (S + 63) / 64;
   float wl[kMaxCh], st[kMaxCh], local = 0.f, wt = 0.f, smin = 3.4e38f, smax = -3.4e38f;
@@ -395,6 +439,46 @@ __global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __res
   const int lane = ps_lane();
   const float* w = weights + ray * S;
   const float* e = ebins + ray * (S + 1);
+  if ((C & 3) == 0) {
+    // 16 lanes x 4 channels per row, lane group g takes the rows 4u + g: 16 sixteen-byte loads per lane instead of 64 dword
+    // loads, then a recursive halving over the 16 lanes of a row leaves lane (q, g) with the dot product of sample 4q + g
+    const int q = lane & 15, g = lane >> 4;
+    float v[16];
+    const bool on = sem_s != nullptr && d_sem != nullptr && 4 * q < C;
+    const f32x4 gs = on ? *reinterpret_cast<const f32x4*>(d_sem + ray * C + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int sr = 4 * u + g;
+      f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (on && sr < S) x = *reinterpret_cast<const f32x4*>(sem_s + (ray * S + sr) * C + 4 * q);
+      v[u] = (x[0] * gs[0] + x[1] * gs[1]) + (x[2] * gs[2] + x[3] * gs[3]);
+    }
+#define PS_HALVE16(M)                                   \
+  _Pragma("unroll") for (int i = 0; i < M; ++i) {       \
+    const bool up = (q & M) != 0;                       \
+    const float keep = up ? v[i + M] : v[i];            \
+    const float send = up ? v[i] : v[i + M];            \
+    v[i] = keep + __shfl_xor(send, M, 64);              \
+  }
+    PS_HALVE16(8) PS_HALVE16(4) PS_HALVE16(2) PS_HALVE16(1)
+#undef PS_HALVE16
+    const int sr = 4 * q + g;
+    const bool ok = sr < S;
+    float gr = v[0];
+    if (ok && rgb_s != nullptr && d_rgb != nullptr) {
+      const float* pr = rgb_s + (ray * S + sr) * 3;
+      gr += pr[0] * d_rgb[ray * 3] + pr[1] * d_rgb[ray * 3 + 1] + pr[2] * d_rgb[ray * 3 + 2];
+    }
+    const float ws = ok ? w[sr] : 0.0f;
+    const float mid = ok ? (e[sr] + e[sr + 1]) / 2.0f : 0.0f;
+    gr += d_acc ? d_acc[ray] : 0.0f;
+    if (d_exp != nullptr) {
+      const float A = ps_wave_sum(ws * mid), B = ps_wave_sum(ws) + 1e-10f;
+      gr += d_exp[ray] * (mid / B - A / (B * B));
+    }
+    if (ok) d_weights[ray * S + sr] = gr;
+    return;
+  }
   const bool sem_on = sem_s != nullptr && d_sem != nullptr && lane < C;
   const bool rgb_on = rgb_s != nullptr && d_rgb != nullptr && lane < 3;
   const float gsem = sem_on ? d_sem[ray * C + lane] : 0.0f;

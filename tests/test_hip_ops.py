@@ -240,6 +240,28 @@ def test_composite_backward_vs_oracle(ops, dev):
         close(x, y, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("S,C", [(64, 64), (40, 64), (64, 8), (48, 6), (130, 64)])
+def test_composite_weights_only_backward(ops, dev, S, C):
+    """d(weights) alone (the fused render's path: per-sample colour / semantic gradients are formed inside the field backward):
+    16-byte row loads when C % 4 == 0, dword loads otherwise, the general kernel beyond 64 samples"""
+    g = torch.Generator().manual_seed(11)
+    R = 53
+    eb = torch.sort(torch.rand(R, S + 1, generator=g) * 10 + 0.1, dim=-1).values
+    w = torch.rand(R, S, generator=g) / S
+    rgb_s, sem_s = torch.rand(R, S, 3, generator=g), torch.randn(R, S, C, generator=g)
+    cots = [torch.randn(R, 3, generator=g), torch.randn(R, 1, generator=g), torch.randn(R, 1, generator=g), torch.randn(R, C, generator=g)]
+    wr = w.clone().requires_grad_(True)
+    steps = (eb[:, :-1] + eb[:, 1:]) / 2
+    ref_out = [(wr[..., None] * rgb_s).sum(1), wr.sum(-1, keepdim=True), O.expected_depth(wr, steps), (wr[..., None] * sem_s).sum(1)]
+    (gr,) = torch.autograd.grad(sum((o * c).sum() for o, c in zip(ref_out, cots)), wr)
+    wd = w.to(dev).requires_grad_(True)
+    rgb, acc, _, expd, sem = ops.composite(wd, eb.to(dev), rgb_s.to(dev), sem_s.to(dev))
+    for got, want in zip((rgb, acc, expd, sem), ref_out):
+        close(got, want.detach(), rtol=1e-5, atol=1e-5)
+    (gd,) = torch.autograd.grad(sum((o * c.to(dev)).sum() for o, c in zip((rgb, acc, expd, sem), cots)), wd)
+    close(gd, gr, rtol=1e-4, atol=1e-5)
+
+
 def test_weights_large_batch_properties(ops, dev):
     """BASELINE-size batch: size-independent properties instead of a CPU comparison."""
     g = torch.Generator(device=dev).manual_seed(5)
