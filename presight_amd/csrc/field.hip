@@ -807,21 +807,29 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
   };
   const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
   int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
+  // Loads and stores share ONE in-order counter per type on this ISA (vmcnt) and complete out of order with each other: while
+  // a store is outstanding every wait for a load becomes "wait for everything".  The gathered operands are therefore consumed
+  // (and the next gather is issued) at the END of a tile, BEFORE its stores go out; the only waits behind the stores then come
+  // 4 k cycles later, when everything has long arrived.
   Gather ga;
-  gather(first, ga);
-  for (; first < a.N; first += stride) {
-    PS_STAMP(tm, 0)
-    float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
+  float so[PB][16];
+  auto consume = [&]() {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = ga.d[pb][nb][r] * ga.w[pb];
-    gather(first + stride, ga);
+  };
+  gather(first, ga);
+  consume();
+  gather(first + stride, ga);
+  for (; first < a.N; first += stride) {
+    PS_STAMP(tm, 0)
+    float sin_[PB][16], s1[PB][16], s2[PB][16];
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
+    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
     PS_STAMP(tm, 1)
     float dsin[PB][16];
     mlp_backward_acc<Sem, PB, true>(
@@ -833,6 +841,10 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
             for (int t = 0; t < 16; ++t) x[pb][t] = sin_[pb][t];
         },
         s1, s2, so, dsin, tm);
+    __builtin_amdgcn_sched_barrier(0);
+    consume();                            // tile i+1's operands (requested a whole tile ago)
+    gather(first + 2 * stride, ga);
+    __builtin_amdgcn_sched_barrier(0);
     store_act<4, PB>(a.dzb, 80, 16, first, a.N, dsin);
     PS_STAMP(tm, 8)
   }
@@ -890,24 +902,14 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
   };
   const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
   int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
+  // the head is consumed at the END of the previous tile, before that tile's stores and atomics (see main_bwd_sem_kernel)
   Head hd;
-  fetch_head(first, hd);
-  for (; first < a.N; first += stride) {
-    float c1[PB][Rgb::HB * 4], c2[PB][Rgb::HB * 4], co[PB][4], zb0[PB][4], dirv[PB][3], appv[PB][4];
-    int64_t ray_of[PB];
-    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
-    load_act<1, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);  // sigma_raw | geo15
+  float c2[PB][Rgb::HB * 4], co[PB][4];
+  int64_t ray_head[PB];
+  auto consume = [&]() {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
-      const int64_t r = hd.ray[pb];
-      ray_of[pb] = r;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) dirv[pb][k] = a.dirs[r * 3 + k];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int c = 4 * t + g;
-        appv[pb][t] = (a.app != nullptr && c < a.A) ? a.app[r * a.A + c] : 0.0f;
-      }
+      ray_head[pb] = hd.ray[pb];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float d = 0.0f;
@@ -918,9 +920,32 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
         co[pb][k] = d;
       }
 #pragma unroll
-      for (int t = 0; t < Rgb::HB * 4; ++t) c2[pb][t] = hd.c2[pb][t];
+      for (int t = 0; t < Rgb::HB * 4; ++t) {
+        c2[pb][t] = hd.c2[pb][t];
+        asm volatile("" : "+v"(c2[pb][t]));  // a real copy, made HERE
+      }
     }
-    fetch_head(first + stride, hd);
+  };
+  fetch_head(first, hd);
+  consume();
+  fetch_head(first + stride, hd);
+  for (; first < a.N; first += stride) {
+    float c1[PB][Rgb::HB * 4], zb0[PB][4], dirv[PB][3], appv[PB][4];
+    int64_t ray_of[PB];
+    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
+    load_act<1, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);  // sigma_raw | geo15
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t r = ray_head[pb];
+      ray_of[pb] = r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dirv[pb][k] = a.dirs[r * 3 + k];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * t + g;
+        appv[pb][t] = (a.app != nullptr && c < a.A) ? a.app[r * a.A + c] : 0.0f;
+      }
+    }
     float dcin[PB][12];
     mlp_backward_acc<Rgb, PB, true, true>(
         pk, scratch, acc,
@@ -939,6 +964,10 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
           }
         },
         c1, c2, co, dcin);
+    __builtin_amdgcn_sched_barrier(0);
+    consume();
+    fetch_head(first + 2 * stride, hd);
+    __builtin_amdgcn_sched_barrier(0);
     // d(appearance) is per RAY: see main_bwd_kernel
     float dz0[PB][4];
     bool block_in_ray = (a.S % 16) == 0;
@@ -1000,17 +1029,24 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
   // d(output) one tile ahead, the rest under the first matrix phase (see main_bwd_sem_kernel)
   const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
   int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
-  float dzb_next[PB][20];
-  load_act<5, PB>(a.dzb, 80, 0, first, a.N, dzb_next);
-  for (; first < a.N; first += stride) {
-    float h1[PB][Base::HB * 4], dzb[PB][20], xin[PB][Base::KS0];
-    load_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
-    load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, xin);
+  // (consumed at the end of the previous tile, before its stores: see main_bwd_sem_kernel)
+  float dzb_next[PB][20], dzb[PB][20];
+  auto consume = [&]() {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-      for (int t = 0; t < 20; ++t) dzb[pb][t] = dzb_next[pb][t];
-    load_act<5, PB>(a.dzb, 80, 0, first + stride, a.N, dzb_next);
+      for (int t = 0; t < 20; ++t) {
+        dzb[pb][t] = dzb_next[pb][t];
+        asm volatile("" : "+v"(dzb[pb][t]));  // a real copy, made HERE (the wait for the load must not sink below the stores)
+      }
+  };
+  load_act<5, PB>(a.dzb, 80, 0, first, a.N, dzb_next);
+  consume();
+  load_act<5, PB>(a.dzb, 80, 0, first + stride, a.N, dzb_next);
+  for (; first < a.N; first += stride) {
+    float h1[PB][Base::HB * 4], xin[PB][Base::KS0];
+    load_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
+    load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, xin);
     float dx[PB][Base::L0::IB * 4];
     mlp_backward_acc<Base, PB, true>(
         pk, scratch, acc,
@@ -1021,6 +1057,10 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
             for (int t = 0; t < Base::KS0; ++t) x[pb][t] = xin[pb][t];
         },
         h1, h1, dzb, dx);
+    __builtin_amdgcn_sched_barrier(0);
+    consume();
+    load_act<5, PB>(a.dzb, 80, 0, first + 2 * stride, a.N, dzb_next);
+    __builtin_amdgcn_sched_barrier(0);
     store_dfeat<Base::KS0, PB>(a.dfeat, fc, a.F, first, a.N, dx);
   }
   reduce_store<Base, NW>(lds, acc, a.gpart + (size_t)lb * C::GPACKED + C::G_BASE);
