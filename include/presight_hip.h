@@ -145,6 +145,14 @@ int ps_sky_blend_bwd(const float* acc_raw, const float* sky_rgb, const float* sk
  * dpred / dacc the gradient of the MEAN.  MSE: nn.MSELoss (nerfacto_nusc_ms.py:568) and semantic_loss with
  * clip_target=1 (ns/model_components/PreSight/losses.py:117-125); sky BCE: losses.py:106-115 */
 int ps_loss_partials(int64_t n);
+/* the scalar arithmetic around a loss term in one launch each (the reference spends ~6 element-wise launches per term on it:
+ * .mean() / sum()/count, the *_loss_mult scaling of nerfacto_nusc_ms.py:558-645 and their backward nodes):
+ * ps_loss_finish: out[0] = scale * sum(terms[0..n)) / D, D = sum(keep[0..n_keep)) if keep != NULL else denom; inv[0] = scale / D
+ * (nullable).  ps_scale_grad: out[i] = grad[i] * g[0] * (factor ? factor[0] : 1) * host_scale -- g is the device scalar
+ * autograd passes to the loss node, factor the inv[] of ps_loss_finish. */
+int ps_loss_finish(const float* terms, int64_t n, const float* keep, int64_t n_keep, float denom, float scale, float* out,
+                   float* inv, void* stream);
+int ps_scale_grad(const float* grad, int64_t n, const float* g, const float* factor, float host_scale, float* out, void* stream);
 int ps_mse_loss(const float* pred, const float* target, int64_t n, int clip_target, float* partial, float* dpred,
                 void* stream);
 int ps_sky_bce_loss(const float* acc, const float* sky_mask, int64_t R, float eps, float* partial, float* dacc,
@@ -217,6 +225,11 @@ int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, in
                                             (semantic head, colour head, base MLP: one stack's weight gradients stay in
                                             registers and its transposed weights in LDS); NULL: one fused kernel */,
                       void* stream);
+
+/* measurement aid (bench.py times the three kernels of the split backward one by one): which of them later calls with a
+ * dzb_scratch launch -- bit 0 semantic head, bit 1 colour head, bit 2 base MLP; 7 = all (the default).  Returns the previous
+ * mask.  The stages of one backward must still run in this order. */
+int ps_main_field_bwd_stages(int mask);
 
 /* ---- a5 sub-field router: all K sub-fields of a tile in ONE launch per kernel, no host synchronisation ---------------
  * Reference: iNGPFieldMS / PropNetDensityFieldMS / SkyFieldMS (ns/fields/PreSight/ingp_field_ms.py:97-126,

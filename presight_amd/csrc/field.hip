@@ -154,6 +154,10 @@ template <int NBLK, int PB>
 __device__ __forceinline__ void store_act(float* __restrict__ acts, int stride, int col0, int64_t first, int64_t N,
                                           const float (&v)[PB][NBLK * 4]) {
   const int lane = ps_lane();
+#if defined(PS_ABLATE) && PS_ABLATE == 14  // timing only: no activation stores (is the forward bound by its HBM writes?)
+  asm volatile("" ::"v"(v[0][0]), "v"(v[PB - 1][NBLK * 4 - 1]));
+  return;
+#endif
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int64_t blk = first / 16 + pb;  // 16-point block index
@@ -1256,7 +1260,10 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
   return -2;
 }
 
+int g_main_bwd_stages = 7;  // which kernels of the three-kernel backward a call launches (ps_main_field_bwd_stages)
+
 int main_bwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
+  const int st = g_main_bwd_stages;
   if (a.N == 0) return 0;
   PS_REQUIRE(a.acts == nullptr || (a.drgb != nullptr && a.dsem != nullptr), "ps_main_field_bwd: kept activations need both head gradients");
   PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
@@ -1268,9 +1275,9 @@ int main_bwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
       a.packed_stride = C::PACKED;                                                                                    \
       const int grid = ms_grid(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256, a.K);                                        \
       if (a.acts != nullptr && a.dzb != nullptr) {                                                                    \
-        main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);               \
-        main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);               \
-        main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);              \
+        if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
+        if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
+        if (st & 4) main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a); \
       } else if (a.acts != nullptr)                                                                                   \
         main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, true, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);             \
       else                                                                                                            \
@@ -1278,9 +1285,9 @@ int main_bwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
     } else {                                                                                                          \
       const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256);                                   \
       if (a.acts != nullptr && a.dzb != nullptr) {                                                                    \
-        main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);              \
-        main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);              \
-        main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);             \
+        if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
+        if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
+        if (st & 4) main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a); \
       } else if (a.acts != nullptr)                                                                                   \
         main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, true, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);            \
       else                                                                                                            \
@@ -1339,6 +1346,12 @@ extern "C" int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int
   a.packed = packed; a.N = n_slots; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts);
   a.perm = perm; a.field_start = field_start; a.K = K;
   return main_bwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
+}
+
+extern "C" int ps_main_field_bwd_stages(int mask) {
+  const int prev = g_main_bwd_stages;
+  g_main_bwd_stages = mask & 7;
+  return prev;
 }
 
 #if defined(PS_TIMING)

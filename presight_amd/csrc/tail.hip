@@ -203,6 +203,46 @@ extern "C" int ps_sky_blend_bwd(const float* acc_raw, const float* sky_rgb, cons
   PS_CHECK_LAUNCH();
 }
 
+// value of a mean-reduced loss from its terms in ONE launch: out = scale * sum(terms) / D with D = sum(keep) when a validity
+// mask is given (the depth losses average over the qualifying rays only), else `denom`; inv = scale / D is what the backward
+// multiplies the stored per-element gradient with.  One workgroup (n is a ray count or a partial-sum count).
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ terms, int64_t n, const float* __restrict__ keep,
+                                                          int64_t n_keep, float denom, float scale, float* __restrict__ out,
+                                                          float* __restrict__ inv) {
+  __shared__ float red[8];
+  float s = 0.f, k = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += terms[i];
+  for (int64_t i = threadIdx.x; i < n_keep; i += 256) k += keep[i];
+  s = ps_wave_sum(s);
+  k = ps_wave_sum(k);
+  if (ps_lane() == 0) {
+    red[threadIdx.x >> 6] = s;
+    red[4 + (threadIdx.x >> 6)] = k;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float total = (red[0] + red[1]) + (red[2] + red[3]);
+    const float d = keep != nullptr ? (red[4] + red[5]) + (red[6] + red[7]) : denom;
+    out[0] = scale * (total / d);  // d == 0: NaN, like torch.mean of an empty selection
+    if (inv != nullptr) inv[0] = scale / d;
+  }
+}
+
+// out = grad * g[0] * (factor ? factor[0] : 1) * host_scale: the chain rule of a scalar loss in one launch (g is the device
+// scalar autograd hands over)
+__global__ __launch_bounds__(256) void scale_grad_kernel(const float* __restrict__ grad, int64_t n, const float* __restrict__ g,
+                                                         const float* __restrict__ factor, float host_scale, float* __restrict__ out) {
+  const float f = g[0] * (factor != nullptr ? factor[0] : 1.0f) * host_scale;
+  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(grad + i);
+      *reinterpret_cast<f32x4*>(out + i) = v * f;
+    } else {
+      for (int64_t q = i; q < n; ++q) out[q] = grad[q] * f;
+    }
+  }
+}
+
 // number of partial sums ps_mse_loss / ps_sky_bce_loss write for n elements
 extern "C" int ps_loss_partials(int64_t n) {
   const int64_t b = (n + 256 * 8 - 1) / (256 * 8);
@@ -220,6 +260,22 @@ extern "C" int ps_sky_bce_loss(const float* acc, const float* sky_mask, int64_t 
                                void* stream) {
   PS_REQUIRE(R > 0, "ps_sky_bce_loss: empty input");
   sky_bce_kernel<<<ps_loss_partials(R), 256, 0, (hipStream_t)stream>>>(acc, sky_mask, R, eps, partial, dacc);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_loss_finish(const float* terms, int64_t n, const float* keep, int64_t n_keep, float denom, float scale, float* out,
+                              float* inv, void* stream) {
+  PS_REQUIRE(n > 0 && out != nullptr, "ps_loss_finish: no terms");
+  loss_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(terms, n, keep, keep != nullptr ? n_keep : 0, denom, scale, out, inv);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_scale_grad(const float* grad, int64_t n, const float* g, const float* factor, float host_scale, float* out,
+                             void* stream) {
+  if (n == 0) return 0;
+  PS_REQUIRE(g != nullptr, "ps_scale_grad: the upstream gradient is a device scalar");
+  const int64_t b = (n + 1023) / 1024;
+  scale_grad_kernel<<<(unsigned)(b > 2048 ? 2048 : b), 256, 0, (hipStream_t)stream>>>(grad, n, g, factor, host_scale, out);
   PS_CHECK_LAUNCH();
 }
 

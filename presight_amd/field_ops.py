@@ -279,6 +279,21 @@ def _dzb_scratch(n_points: int, dev):
     return torch.empty((n_points + 15) // 16 * 16, 80, device=dev)
 
 
+def _bwd_stages(dzb):
+    """one pass normally; while bench.py's per-kernel timing is on, the three kernels of the split backward are launched by three
+    calls, each inside its own HIP-event region (same kernels, same order, same stream)"""
+    if dzb is None or not prof.enabled():
+        yield
+        return
+    try:
+        for mask, name in ((1, "main_bwd_sem_kernel"), (2, "main_bwd_rgb_kernel"), (4, "main_bwd_base_kernel")):
+            lib().ps_main_field_bwd_stages(mask)
+            with prof.region(name):
+                yield
+    finally:
+        lib().ps_main_field_bwd_stages(7)
+
+
 def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     """shared backward: fused MLP backward -> table scatter -> weight-gradient reduction.  weights != None: d_rgb / d_sem are
     per-RAY gradients (see ps_main_field_bwd).  -> (dapp, dtable | None, [dW0, db0, ...] with None for in-place gradients)"""
@@ -302,9 +317,10 @@ def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     #  pressure the 8 extra live values cost more (+0.2 ms) than the separate 0.13 ms absmax pass)
     dzb = _dzb_scratch(N, dev) if acts is not None else None
     with prof.region("main_field_bwd"):
-        check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                      _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                      _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), _stream()), "ps_main_field_bwd")
+        for _ in _bwd_stages(dzb):
+            check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                          _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
+                                          _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), _stream()), "ps_main_field_bwd")
     dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
     descs = []
     for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
@@ -692,10 +708,11 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     nparts = lib().ps_main_field_parts_ms(lay.n_slots, K)
     dzb = _dzb_scratch(lay.n_slots, u.device) if acts is not None else None
     with prof.region("main_field_bwd"):
-        check(lib().ps_main_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                         _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(st.packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                         _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(dzb), _p(lay.perm),
-                                         lay.field_start, K, _stream()), "ps_main_field_bwd_ms")
+        for _ in _bwd_stages(dzb):
+            check(lib().ps_main_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                             _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(st.packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
+                                             _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(dzb), _p(lay.perm),
+                                             lay.field_start, K, _stream()), "ps_main_field_bwd_ms")
     ws = _ms_scatter_ws(lay, g, u.device)
     dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False)
     dsts, returned = _ms_layer_dsts(wb)

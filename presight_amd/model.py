@@ -308,13 +308,14 @@ class NerfactoNuscMSModel(nn.Module):
         return {"psnr": 10.0 * torch.log10(1.0 / mse)}  # torchmetrics PSNR(data_range=1.0), nerfacto_nusc_ms.py:382,554
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
-        """nerfacto_nusc_ms.py:558-645 (camera-only)"""
+        """nerfacto_nusc_ms.py:558-645 (camera-only); every term is scaled by its *_loss_mult INSIDE the loss launch
+        (losses.py: `scale`), the values equal the reference's mult * loss"""
         c = self.config
         loss_dict = {}
         if RGB in batch:
             loss_dict["rgb_loss"] = self.rgb_loss(batch[RGB][..., :3], outputs["rgb"])
         if c.use_sky_model and SKY in batch:
-            loss_dict["sky_loss"] = c.sky_loss_mult * self.sky_loss(outputs["accumulation"].view(-1, 1), batch[SKY].view(-1, 1))
+            loss_dict["sky_loss"] = self.sky_loss(outputs["accumulation"].view(-1, 1), batch[SKY].view(-1, 1), scale=c.sky_loss_mult)
         if (c.use_monodepth_loss or c.use_lidar_loss) and DEPTH in batch:  # nerfacto_nusc_ms.py:576-629
             rs = outputs["ray_samples_list"][-1]
             scale = self._pose_scale_factor(rs)
@@ -323,18 +324,19 @@ class NerfactoNuscMSModel(nn.Module):
             sky_mask = batch[SKY].view(-1, 1) if mono else None  # the reference reuses the sky branch's mask
             if mono:
                 ed = expected_monodepth_loss(batch[DEPTH], outputs["expected_depth"], sky_mask, upper_bound=ub,
-                                             inverse=c.monodepth_loss_inverse, pose_scale_factor=scale)
+                                             inverse=c.monodepth_loss_inverse, pose_scale_factor=scale, scale=c.expected_depth_loss_mult)
             else:
-                ed = expected_depth_loss(batch[DEPTH], outputs["expected_depth"], upper_bound=ub, pose_scale_factor=scale)
-            loss_dict["expected_depth_loss"] = c.expected_depth_loss_mult * ed
-            loss_dict["line_of_sight_loss"] = self.get_line_of_sight_mult(self.step) * line_of_sight_loss(
+                ed = expected_depth_loss(batch[DEPTH], outputs["expected_depth"], upper_bound=ub, pose_scale_factor=scale,
+                                         scale=c.expected_depth_loss_mult)
+            loss_dict["expected_depth_loss"] = ed
+            loss_dict["line_of_sight_loss"] = line_of_sight_loss(
                 outputs["weights_list"][-1], batch[DEPTH], rs, sigma=self.get_line_of_sight_sigma(self.step), sky_mask=sky_mask,
-                upper_bound=ub, pose_scale_factor=scale)
+                upper_bound=ub, pose_scale_factor=scale, scale=self.get_line_of_sight_mult(self.step))
         if c.use_semantics and FEATURES in batch:
-            loss_dict["semantic_loss"] = c.semantic_loss_mult * self.semantic_loss(pred=outputs["semantics"], target=batch[FEATURES], clip=True)
+            loss_dict["semantic_loss"] = self.semantic_loss(pred=outputs["semantics"], target=batch[FEATURES], clip=True, scale=c.semantic_loss_mult)
         if self.training:
-            loss_dict["interlevel_loss"] = c.interlevel_loss_mult * self.interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"])
-            loss_dict["distortion_loss"] = c.distortion_loss_mult * distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+            loss_dict["interlevel_loss"] = self.interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"], scale=c.interlevel_loss_mult)
+            loss_dict["distortion_loss"] = distortion_loss(outputs["weights_list"], outputs["ray_samples_list"], scale=c.distortion_loss_mult)
         return loss_dict
 
     def get_line_of_sight_sigma(self, step):

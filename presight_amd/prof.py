@@ -18,6 +18,10 @@ def enable(flag: bool = True):
         _events.clear()
 
 
+def enabled() -> bool:
+    return _enabled
+
+
 @contextmanager
 def region(name: str):
     if not _enabled:

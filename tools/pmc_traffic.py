@@ -19,7 +19,8 @@ for line in open(src):
     elif not line.startswith(" ") and not line.startswith("=="):
         cur = line.strip()
 out = {}
-for key, pat in (("main_bwd_kernel", "main_bwd_kernel"), ("main_fwd_kernel", "main_fwd_kernel")):
+for key, pat in (("main_fwd_kernel", "main_fwd_kernel"), ("main_bwd_sem_kernel", "main_bwd_sem_kernel"), ("main_bwd_rgb_kernel", "main_bwd_rgb_kernel"),
+                 ("main_bwd_base_kernel", "main_bwd_base_kernel")):
     for k, d in data.items():
         if pat in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             out[key] = dict(hbm_bytes_per_launch=(2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024, fetch_kb=d["FETCH_SIZE"], write_kb=d["WRITE_SIZE"],
