@@ -29,6 +29,7 @@
 // profiling build (tools/build_variant.sh timing -DPS_TIMING): shader-clock time of the phases of one main-backward tile, summed
 // over all waves; read back with ps_debug_timing
 __device__ unsigned long long g_ps_timing[16];
+__device__ unsigned long long g_ps_timing_fwd[16];
 #define PS_TSTAMP(i)                                              \
   {                                                               \
     const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
@@ -451,11 +452,18 @@ __device__ __forceinline__ void build_colour_input(const MainArgs& a, int64_t fi
   }
 }
 
-// NW waves per workgroup share ONE copy of the packed forward weights in LDS (112 KB: one workgroup per CU).  With NW = 8 and
-// PB = 2 a wave needs < 256 registers, so every SIMD holds TWO waves that fill each other's MFMA issue gaps (4 waves x PB = 4
-// ran the matrix pipe at 68 %).
+// NW = 4 waves per workgroup (one per SIMD, 512 registers each) share ONE copy of the packed forward weights in LDS (112 KB).
+// The training forward writes 1.9 KB per point (kept activations + outputs) and reads 0.2 KB; loads and stores share one
+// in-order counter per type on this ISA and complete out of order with each other, so ANY wait for a load behind an
+// outstanding store waits for that store to reach memory (phase timer, 8 waves x 2 per SIMD: 55 of 92 k cycles per tile and
+// wave spent in such waits).  Hence: every input of a tile (features, selector, per-ray direction / appearance code, the
+// caller's index of the point) is requested one tile AHEAD and copied out ("consumed") between the semantic MLP and its
+// stores -- the only wait of a tile, behind the base stage's stores, which are a whole semantic MLP old by then.
 template <class C, int PB, int NW, bool MS>
 __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
+  using Base = typename C::Base;
+  using Sem = typename C::Sem;
+  using Rgb = typename C::Rgb;
   TileRange tr{0, a.N, (int)blockIdx.x, (int)gridDim.x};
   if constexpr (MS) {
     const MsBlock mb = ms_block(a.field_start, a.K, gridDim.x, blockIdx.x);
@@ -466,79 +474,165 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   }
   __shared__ __attribute__((aligned(16))) float lds[C::FW];
   // forward blocks of the three MLPs, contiguous in LDS
-  for (int i = threadIdx.x * 4; i < C::Base::FW; i += NW * 256)
+  for (int i = threadIdx.x * 4; i < Base::FW; i += NW * 256)
     *reinterpret_cast<f32x4*>(lds + C::FW_BASE + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_BASE + i);
-  for (int i = threadIdx.x * 4; i < C::Sem::FW; i += NW * 256)
+  for (int i = threadIdx.x * 4; i < Sem::FW; i += NW * 256)
     *reinterpret_cast<f32x4*>(lds + C::FW_SEM + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_SEM + i);
-  for (int i = threadIdx.x * 4; i < C::Rgb::FW; i += NW * 256)
+  for (int i = threadIdx.x * 4; i < Rgb::FW; i += NW * 256)
     *reinterpret_cast<f32x4*>(lds + C::FW_RGB + i) = *reinterpret_cast<const f32x4*>(a.packed + C::P_RGB + i);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
-  for (int64_t tile = (int64_t)tr.j * NW + wave;; tile += (int64_t)tr.n * NW) {
-    const int64_t first = tr.first_pt + tile * 16 * PB;
-    if (first >= a.N) break;
-    float zb[PB][20];
+  FeatCols<Base::KS0> fc;
+  fc.init(a.plane_stride, a.LF, a.F);
+  struct In {
+    float x[PB][Base::KS0], sel[PB], dirv[PB][3], appv[PB][4];
+    int op[PB];  // the point's index in the caller's arrays, -1: no such point
+  };
+  auto fetch = [&](int64_t first, In& v) {
+    load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, v.x);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t p = first + pb * 16 + j;
+      const int64_t op = orig_index<MS>(a.perm, p, a.N);
+      v.op[pb] = (int)op;
+      v.sel[pb] = (a.sigma != nullptr && p < a.N) ? a.sel[p] : 0.0f;
+      int64_t r;
+      if constexpr (MS)
+        r = ray_index(op >= 0 ? op : 0, a.S);
+      else
+        r = ray_index(p < a.N ? p : a.N - 1, a.S);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v.dirv[pb][k] = (a.rgb != nullptr && first < a.N) ? a.dirs[r * 3 + k] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * t + g;
+        v.appv[pb][t] = (a.rgb != nullptr && a.app != nullptr && c < a.A && first < a.N) ? a.app[r * a.A + c] : 0.0f;
+      }
+    }
+  };
+  In nxt, cur;
+  auto consume = [&]() {
+    cur = nxt;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {  // real copies, made HERE (the wait for the loads must not sink below later stores)
+#pragma unroll
+      for (int t = 0; t < Base::KS0; ++t) asm volatile("" : "+v"(cur.x[pb][t]));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(cur.appv[pb][t]));
+      asm volatile("" : "+v"(cur.sel[pb]), "+v"(cur.dirv[pb][0]), "+v"(cur.dirv[pb][1]), "+v"(cur.dirv[pb][2]), "+v"(cur.op[pb]));
+    }
+  };
+  PsTimer* tm = nullptr;
+#if defined(PS_TIMING)
+  PsTimer tm_;
+  tm_.start();
+  tm = &tm_;
+#endif
+  const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
+  int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
+  fetch(first, nxt);
+  consume();
+  fetch(first + stride, nxt);
+  for (; first < a.N; first += stride) {
+    PS_STAMP(tm, 0)
+    float zb[PB][20], dirv[PB][3], appv[PB][4];
+    int op_cur[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      op_cur[pb] = cur.op[pb];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dirv[pb][k] = cur.dirv[pb][k];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) appv[pb][t] = cur.appv[pb][t];
+    }
     {
-      float x[PB][C::Base::KS0], h1[PB][C::Base::HB * 4], h2[PB][C::Base::HB * 4];
-      load_feat<C::Base::KS0, PB>(a.feat, a.plane_stride, a.LF, a.F, first, a.N, x);
-      mlp_forward<typename C::Base, PB>(LdsW{lds + C::FW_BASE}, x, h1, h2, zb);
+      float h1[PB][Base::HB * 4], h2[PB][Base::HB * 4];
+      mlp_forward<Base, PB>(LdsW{lds + C::FW_BASE}, cur.x, h1, h2, zb);
+      PS_STAMP(tm, 2)
       if (a.acts != nullptr) {
-        store_act<C::Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
+        store_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
         store_act<5, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb);
       }
     }
     if (a.sigma != nullptr && g == 0) {
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        const int64_t p = first + pb * 16 + j;
-        const int64_t op = orig_index<MS>(a.perm, p, a.N);
-        if (op >= 0) a.sigma[op] = expf(zb[pb][0]) * a.sel[p];
-      }
+      for (int pb = 0; pb < PB; ++pb)
+        if (op_cur[pb] >= 0) a.sigma[op_cur[pb]] = expf(zb[pb][0]) * cur.sel[pb];
     }
+    PS_STAMP(tm, 3)
+    bool consumed = false;
     if (a.sem != nullptr) {
       float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][4 + t];
-      mlp_forward<typename C::Sem, PB>(LdsW{lds + C::FW_SEM}, sin_, s1, s2, so);
+      mlp_forward<Sem, PB>(LdsW{lds + C::FW_SEM}, sin_, s1, s2, so);
+      PS_STAMP(tm, 4)
+      // the next tile's inputs are taken over HERE: the youngest stores in flight are the base stage's, a whole semantic MLP old
+      __builtin_amdgcn_sched_barrier(0);
+      consume();
+      consumed = true;
+      __builtin_amdgcn_sched_barrier(0);
+      PS_STAMP(tm, 6)
       if (a.acts != nullptr) {
         store_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
         store_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
       }
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
-        const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
-        if (op >= 0) {
+        if (op_cur[pb] >= 0) {
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
-            *reinterpret_cast<f32x4*>(a.sem + op * 64 + 16 * nb + 4 * g) =
+            *reinterpret_cast<f32x4*>(a.sem + (int64_t)op_cur[pb] * 64 + 16 * nb + 4 * g) =
                 (f32x4){so[pb][4 * nb], so[pb][4 * nb + 1], so[pb][4 * nb + 2], so[pb][4 * nb + 3]};
         }
       }
     }
+    PS_STAMP(tm, 5)
+    if (!consumed) {  // (no semantic head in this call; uniform)
+      __builtin_amdgcn_sched_barrier(0);
+      consume();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (a.rgb != nullptr) {
-      float cin[PB][12], c1[PB][C::Rgb::HB * 4], c2[PB][C::Rgb::HB * 4], co[PB][4];
-      int64_t ray_of[PB];
-      build_colour_input<PB, MS>(a, first, zb, cin, ray_of);
-      mlp_forward<typename C::Rgb, PB>(LdsW{lds + C::FW_RGB}, cin, c1, c2, co);
+      float cin[PB][12], c1[PB][Rgb::HB * 4], c2[PB][Rgb::HB * 4], co[PB][4];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        float sh[16];
+        sh4((dirv[pb][0] + 1.0f) / 2.0f, (dirv[pb][1] + 1.0f) / 2.0f, (dirv[pb][2] + 1.0f) / 2.0f, sh);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float v0 = sh[4 * t], v1 = sh[4 * t + 1], v2 = sh[4 * t + 2], v3 = sh[4 * t + 3];
+          cin[pb][t] = g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));  // component 4t+g without dynamic register indexing
+          cin[pb][4 + t] = zb[pb][t];
+          cin[pb][8 + t] = appv[pb][t];
+        }
+      }
+      mlp_forward<Rgb, PB>(LdsW{lds + C::FW_RGB}, cin, c1, c2, co);
+      PS_STAMP(tm, 7)
       if (a.acts != nullptr) {
-        store_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
-        store_act<C::Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, c2);
+        store_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
+        store_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, c2);
         store_act<1, PB>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, co);
       }
       if (g == 0) {
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-          const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
-          if (op >= 0) {
+          if (op_cur[pb] >= 0) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a.rgb[op * 3 + k] = 1.0f / (1.0f + expf(-co[pb][k]));
+            for (int k = 0; k < 3; ++k) a.rgb[(int64_t)op_cur[pb] * 3 + k] = 1.0f / (1.0f + expf(-co[pb][k]));
           }
         }
       }
     }
+    fetch(first + 2 * stride, nxt);
+    PS_STAMP(tm, 8)
   }
+#if defined(PS_TIMING)
+  if (lane == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_ps_timing_fwd[i], tm_.acc[i]);
+#endif
 }
 
 // STORED: the hidden activations come from the training forward (a.acts) instead of being recomputed
@@ -1095,7 +1189,7 @@ int ms_grid(int64_t n_slots, int pts_per_tile, int waves, int max_blocks, int K)
   return (int)((g + 7) / 8 * 8);  // ms_logical_block deals the workgroups XCD-major
 }
 
-constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 8, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
+constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 4, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
 constexpr int kPropBwdBlocks = 512;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
 
 // (L*F, hidden) of the proposal nets
@@ -1360,6 +1454,14 @@ extern "C" int ps_debug_timing(unsigned long long* out /*host[16]*/, int reset) 
   if (e == hipSuccess && reset) {
     unsigned long long z[16] = {0};
     e = hipMemcpyToSymbol(HIP_SYMBOL(g_ps_timing), z, sizeof(z));
+  }
+  return (int)e;
+}
+extern "C" int ps_debug_timing_fwd(unsigned long long* out /*host[16]*/, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_timing_fwd), sizeof(unsigned long long) * 16);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_ps_timing_fwd), z, sizeof(z));
   }
   return (int)e;
 }

@@ -15,6 +15,8 @@ torch.cuda.synchronize()
 h = ctypes.CDLL(os.environ["PRESIGHT_HIP_LIB"])
 out = (ctypes.c_ulonglong * 16)()
 h.ps_debug_timing(out, 1)
+outf = (ctypes.c_ulonglong * 16)()
+h.ps_debug_timing_fwd(outf, 1)
 n = 4
 for i in range(n):
     tr.step(b[i % 2])
@@ -30,3 +32,13 @@ tiles = 65536 * 64 / 32
 for i, nm in enumerate(names):
     print(f"{nm:40s} {out[i] / n / tiles:10.0f} clk/tile   {100 * out[i] / tot:5.1f} %")
 print(f"{'total':40s} {tot / n / tiles:10.0f} clk/tile (s_memtime ticks; 1024 waves x 128 tiles)")
+
+h.ps_debug_timing_fwd(outf, 0)
+namesf = ["loop top", "-", "base MLP", "stores h1 zb sigma", "semantic MLP", "stores s1 s2 sem", "consume the next tile's inputs (the wait)",
+          "colour input + MLP", "stores c1 c2 co rgb, fetch"]
+totf = sum(outf[i] for i in range(len(namesf)))
+tiles_per_wave = 65536 * 64 / 32 / 1024
+print("main_fwd_kernel (1024 waves, one per SIMD)")
+for i, nm in enumerate(namesf):
+    print(f"{nm:40s} {outf[i] / n / 1024 / tiles_per_wave:10.0f} clk/tile   {100 * outf[i] / totf:5.1f} %")
+print(f"{'total':40s} {totf / n / 1024 / tiles_per_wave:10.0f} clk/tile")
