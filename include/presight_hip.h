@@ -277,6 +277,9 @@ int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F,
                          const float* dirs, const float* app, int S, int A, const float* packed, const float* dsigma,
                          const float* drgb, const float* dsem, const float* weights, int64_t n_slots, float* dfeat, float* dapp,
                          float* gpart, const float* acts, float* dzb_scratch /* as ps_main_field_bwd, [n_slots, 80] */,
+                         float* dapp_points /* nullable, with dzb_scratch: d(appearance) per point [N, A] in the caller's order,
+                                               WRITTEN; the caller sums it over the samples of a ray and dapp is left untouched
+                                               (the sorted layout would otherwise cost 16 float atomics per point) */,
                          const int32_t* perm, const int32_t* field_start, int K, void* stream);
 /* fused sky field (ns/fields/PreSight/sky_field.py:95-110): per ray SH4((dir+1)/2) -> semantic head (16 -> 32 -> 32 -> 64) and
  * [SH | appearance] -> colour head (16+A -> 32 -> 32 -> 3, sigmoid), one kernel per direction; packed = [colour | semantic]

@@ -403,6 +403,9 @@ struct MainArgs {
   // three-kernel backward: d(base-MLP output) [ceil(N/16)*16, 80] in register order, written by main_bwd_sem_kernel /
   // main_bwd_rgb_kernel and read by main_bwd_base_kernel (null: the single fused kernel)
   float* dzb;
+  // multi-sub-field three-kernel backward: d(appearance) per POINT [N, A] in the caller's order, written (the sorted layout
+  // scatters the samples of a ray over the workgroups: 16 float atomics per point otherwise); the caller sums over the samples
+  float* dapp_pt;
 };
 
 template <int KS0_, int HB_, int HBC_>
@@ -1088,7 +1091,10 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         dz0[pb][t] = dcin[pb][4 + t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
-        if (a.dapp != nullptr) {
+        if (MS && a.dapp_pt != nullptr) {
+          const int c = 4 * t + g;
+          if (pt_ok && c < a.A) a.dapp_pt[op * a.A + c] = dcin[pb][8 + t];
+        } else if (a.dapp != nullptr) {
           const int c = 4 * t + g;
           float v = pt_ok ? dcin[pb][8 + t] : 0.0f;
           float vs = v;
@@ -1431,11 +1437,13 @@ extern "C" int ps_main_field_fwd_ms(const float* feat, int64_t plane_stride, int
 extern "C" int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                     const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
                                     const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t n_slots,
-                                    float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch,
+                                    float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch, float* dapp_points,
                                     const int32_t* perm, const int32_t* field_start, int K, void* stream) {
   PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_bwd_ms: need the sorted layout");
+  PS_REQUIRE(dapp_points == nullptr || (dzb_scratch != nullptr && acts != nullptr), "ps_main_field_bwd_ms: per-point d(appearance) belongs to the three-kernel backward");
   MainArgs a{};
   a.dzb = dzb_scratch;
+  a.dapp_pt = dapp_points;
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
   a.packed = packed; a.N = n_slots; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts);
   a.perm = perm; a.field_start = field_start; a.K = K;

@@ -704,15 +704,20 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     if d_rgb is None or d_sem is None:
         acts = None
     dfeat = torch.empty_like(feat)
-    dapp = torch.zeros_like(app) if app is not None else None
     nparts = lib().ps_main_field_parts_ms(lay.n_slots, K)
     dzb = _dzb_scratch(lay.n_slots, u.device) if acts is not None else None
+    # three-kernel backward: d(appearance) per point, summed over the samples of a ray below (no atomics)
+    per_point = app is not None and dzb is not None and S > 0 and lay.N == app.shape[0] * S
+    dapp_pt = torch.empty(lay.N, A, device=u.device) if per_point else None
+    dapp = None if (app is None or per_point) else torch.zeros_like(app)
     with prof.region("main_field_bwd"):
         for _ in _bwd_stages(dzb):
             check(lib().ps_main_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                              _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(st.packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                             _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(dzb), _p(lay.perm),
+                                             _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(dzb), _p(dapp_pt), _p(lay.perm),
                                              lay.field_start, K, _stream()), "ps_main_field_bwd_ms")
+    if per_point:
+        dapp = dapp_pt.view(app.shape[0], S, A).sum(1)
     ws = _ms_scatter_ws(lay, g, u.device)
     dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False)
     dsts, returned = _ms_layer_dsts(wb)
