@@ -266,22 +266,57 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const float* __restrict__
   const LdsW pw{lds};
   float wz[M::HB * 4], bz;
   load_scalar_head<M>(pw.at(M::OFFZ), wz, bz);
-  for (int64_t tile = (int64_t)tr.j * 4 + wave;; tile += (int64_t)tr.n * 4) {
-    const int64_t first = tr.first_pt + tile * 16 * PB;
-    if (first >= N) break;
-    float x[PB][M::KS0], h1[PB][M::HB * 4], z[PB];
-    load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
-    layer_fwd<L0, PB>(pw.at(M::OFF0), x, h1);
+  // inputs one tile ahead, taken over before the tile's stores (see prop_bwd_kernel / main_fwd_kernel)
+  FeatCols<M::KS0> fc;
+  fc.init(plane_stride, LF, F);
+  struct In {
+    float x[PB][M::KS0], sl[PB];
+    int op[PB];
+  };
+  auto fetch = [&](int64_t first, In& v) {
+    load_feat<M::KS0, PB>(feat, fc, F, first, N, v.x);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t p = first + pb * 16 + j;
+      v.op[pb] = (int)orig_index<MS>(perm, p, N);
+      v.sl[pb] = (p < N) ? sel[p] : 0.0f;
+    }
+  };
+  In cur, nxt;
+  auto consume = [&]() {
+    cur = nxt;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {  // real copies, made HERE
+#pragma unroll
+      for (int t = 0; t < M::KS0; ++t) asm volatile("" : "+v"(cur.x[pb][t]));
+      asm volatile("" : "+v"(cur.op[pb]), "+v"(cur.sl[pb]));
+    }
+  };
+  const int64_t stride = (int64_t)tr.n * 4 * 16 * PB;
+  int64_t first = tr.first_pt + ((int64_t)tr.j * 4 + wave) * 16 * PB;
+  fetch(first, nxt);
+  consume();
+  fetch(first + stride, nxt);
+  for (; first < N; first += stride) {
+    float h1[PB][M::HB * 4], z[PB], out[PB];
+    int op[PB];
+    layer_fwd<L0, PB>(pw.at(M::OFF0), cur.x, h1);
     relu_inplace<PB, M::HB * 4>(h1);
     scalar_head_fwd<PB, M::HB * 4>(wz, bz, h1, z);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      out[pb] = expf(z[pb]) * cur.sl[pb];
+      op[pb] = cur.op[pb];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    consume();
+    __builtin_amdgcn_sched_barrier(0);
     if (g == 0) {
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        const int64_t p = first + pb * 16 + j;
-        const int64_t op = orig_index<MS>(perm, p, N);
-        if (op >= 0) sigma[op] = expf(z[pb]) * sel[p];
-      }
+      for (int pb = 0; pb < PB; ++pb)
+        if (op[pb] >= 0) sigma[op[pb]] = out[pb];
     }
+    fetch(first + 2 * stride, nxt);
   }
 }
 
@@ -310,11 +345,14 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
 #pragma unroll
   for (int t = 0; t < M::KS0; ++t) mx[t] = 0.f;
   constexpr int SCR = L0::SCRATCH_ROWS * kScratchLd;
-  __shared__ __attribute__((aligned(16))) float lds[4 * SCR];
+  __shared__ __attribute__((aligned(16))) float lds[M::PACKED + 4 * SCR];
   const int wave = threadIdx.x >> 6, lane = ps_lane(), j = lane & 15, g = lane >> 4;
-  float* scratch = lds + wave * SCR;
-  const GlobalW gw = make_global_w(packed, M::PACKED);
-  const GlobalW p0 = gw.at(M::OFF0), t0 = gw.at(M::TOFF0);
+  // the packed weights (17 KB) live in LDS: streamed from L2 they queue behind the wave's own HBM loads
+  for (int i = threadIdx.x * 4; i < M::PACKED; i += 1024) *reinterpret_cast<f32x4*>(lds + i) = *reinterpret_cast<const f32x4*>(packed + i);
+  __syncthreads();
+  float* scratch = lds + M::PACKED + wave * SCR;
+  const LdsW gw{lds};
+  const LdsW p0 = gw.at(M::OFF0), t0 = gw.at(M::TOFF0);
   float wz[H], bz;
   load_scalar_head<M>(gw.at(M::OFFZ), wz, bz);
   f32x4 dw0[L0::NB][L0::IB], db0[L0::NB];
@@ -327,19 +365,48 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int t = 0; t < H; ++t) dwz[t] = 0.f;
-  for (int64_t tile = (int64_t)tr.j * 4 + wave;; tile += (int64_t)tr.n * 4) {
-    const int64_t first = tr.first_pt + tile * 16 * PB;
-    if (first >= N) break;
-    float x[PB][M::KS0], h1[PB][H], z[PB], dh[PB][H], dx[PB][L0::IB * 4];
-    load_feat<M::KS0, PB>(feat, plane_stride, LF, F, first, N, x);
+  // The kernel does 30 matrix ops per 16 points: it is all memory latency.  Inputs are requested one tile ahead and taken over
+  // right before the tile's stores go out (loads and stores share one counter: a load waited for behind a store waits for the
+  // store to reach memory, see main_fwd_kernel).
+  FeatCols<M::KS0> fc;
+  fc.init(plane_stride, LF, F);
+  struct In {
+    float x[PB][M::KS0], ds[PB], sl[PB];
+  };
+  auto fetch = [&](int64_t first, In& v) {
+    load_feat<M::KS0, PB>(feat, fc, F, first, N, v.x);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int64_t p = first + pb * 16 + j;
+      const int64_t op = orig_index<MS>(perm, p, N);
+      v.ds[pb] = (op >= 0) ? dsigma[op] : 0.0f;
+      v.sl[pb] = (p < N) ? sel[p] : 0.0f;
+    }
+  };
+  In cur, nxt;
+  auto consume = [&]() {
+    cur = nxt;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {  // real copies, made HERE
+#pragma unroll
+      for (int t = 0; t < M::KS0; ++t) asm volatile("" : "+v"(cur.x[pb][t]));
+      asm volatile("" : "+v"(cur.ds[pb]), "+v"(cur.sl[pb]));
+    }
+  };
+  const int64_t stride = (int64_t)tr.n * 4 * 16 * PB;
+  int64_t first = tr.first_pt + ((int64_t)tr.j * 4 + wave) * 16 * PB;
+  fetch(first, nxt);
+  consume();
+  fetch(first + stride, nxt);
+  for (; first < N; first += stride) {
+    float h1[PB][H], z[PB], dh[PB][H], dx[PB][L0::IB * 4];
+    const float(&x)[PB][M::KS0] = cur.x;
     layer_fwd<L0, PB>(p0, x, h1);
     relu_inplace<PB, H>(h1);
     scalar_head_fwd<PB, H>(wz, bz, h1, z);
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
-      const int64_t p = first + pb * 16 + j;
-      const int64_t op = orig_index<MS>(perm, p, N);
-      const float d = (op >= 0) ? dsigma[op] * sel[p] * trunc_exp_grad(z[pb]) : 0.0f;  // the same value on the 4 lane groups
+      const float d = cur.ds[pb] * cur.sl[pb] * trunc_exp_grad(z[pb]);  // the same value on the 4 lane groups; 0 past the end
       if (g == 0) dbz += d;
 #pragma unroll
       for (int t = 0; t < H; ++t) {
@@ -349,7 +416,11 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
     }
     layer_bwd_weights_acc<L0, PB>(scratch, dw0, db0, dh, x);
     layer_bwd_data<L0, PB>(t0, dh, dx);
-    store_dfeat<M::KS0, PB>(dfeat, plane_stride, LF, F, first, N, dx);
+    __builtin_amdgcn_sched_barrier(0);
+    consume();
+    __builtin_amdgcn_sched_barrier(0);
+    store_dfeat<M::KS0, PB>(dfeat, fc, F, first, N, dx);
+    fetch(first + 2 * stride, nxt);
     track_absmax<M::KS0, PB>(dx, mx);
   }
   if (level_absmax != nullptr) publish_absmax<M::KS0>(mx, LF, F, level_absmax);
