@@ -205,24 +205,38 @@ extern "C" int ps_sky_blend_bwd(const float* acc_raw, const float* sky_rgb, cons
 
 // value of a mean-reduced loss from its terms in ONE launch: out = scale * sum(terms) / D with D = sum(keep) when a validity
 // mask is given (the depth losses average over the qualifying rays only), else `denom`; inv = scale / D is what the backward
-// multiplies the stored per-element gradient with.  One workgroup (n is a ray count or a partial-sum count).
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ terms, int64_t n, const float* __restrict__ keep,
-                                                          int64_t n_keep, float denom, float scale, float* __restrict__ out,
-                                                          float* __restrict__ inv) {
-  __shared__ float red[8];
-  float s = 0.f, k = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += terms[i];
-  for (int64_t i = threadIdx.x; i < n_keep; i += 256) k += keep[i];
+// multiplies the stored per-element gradient with.  One workgroup of 1024 threads (n is a ray count or a partial-sum count:
+// a 65 536-ray batch is 16 independent 16-byte loads per thread, all in flight at once).
+__device__ __forceinline__ float sum_strided(const float* __restrict__ v, int64_t n) {
+  float s = 0.f;
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(v) & 15) == 0 ? n / 4 : 0;
+#pragma unroll 16
+  for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(v)[i];
+    s += (x[0] + x[1]) + (x[2] + x[3]);
+  }
+  for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 1024) s += v[i];
+  return s;
+}
+__global__ __launch_bounds__(1024) void loss_finish_kernel(const float* __restrict__ terms, int64_t n, const float* __restrict__ keep,
+                                                           int64_t n_keep, float denom, float scale, float* __restrict__ out,
+                                                           float* __restrict__ inv) {
+  __shared__ float red[32];
+  float s = sum_strided(terms, n), k = keep != nullptr ? sum_strided(keep, n_keep) : 0.f;
   s = ps_wave_sum(s);
   k = ps_wave_sum(k);
   if (ps_lane() == 0) {
     red[threadIdx.x >> 6] = s;
-    red[4 + (threadIdx.x >> 6)] = k;
+    red[16 + (threadIdx.x >> 6)] = k;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float total = (red[0] + red[1]) + (red[2] + red[3]);
-    const float d = keep != nullptr ? (red[4] + red[5]) + (red[6] + red[7]) : denom;
+    float total = 0.f, kt = 0.f;
+    for (int w = 0; w < 16; ++w) {
+      total += red[w];
+      kt += red[16 + w];
+    }
+    const float d = keep != nullptr ? kt : denom;
     out[0] = scale * (total / d);  // d == 0: NaN, like torch.mean of an empty selection
     if (inv != nullptr) inv[0] = scale / d;
   }
@@ -266,7 +280,7 @@ extern "C" int ps_sky_bce_loss(const float* acc, const float* sky_mask, int64_t 
 extern "C" int ps_loss_finish(const float* terms, int64_t n, const float* keep, int64_t n_keep, float denom, float scale, float* out,
                               float* inv, void* stream) {
   PS_REQUIRE(n > 0 && out != nullptr, "ps_loss_finish: no terms");
-  loss_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(terms, n, keep, keep != nullptr ? n_keep : 0, denom, scale, out, inv);
+  loss_finish_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(terms, n, keep, keep != nullptr ? n_keep : 0, denom, scale, out, inv);
   PS_CHECK_LAUNCH();
 }
 

@@ -7,5 +7,6 @@ mkdir -p gpurun_out; rm -rf /tmp/trace_$TAG
 timeout -k 5 420 rocprofv3 --kernel-trace -d /tmp/trace_$TAG -o trace -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/bench_$TAG.json 2> /tmp/trace_$TAG.err
 echo "rocprofv3 rc=$?"
 python3 tools/rocpd_stats.py $(ls /tmp/trace_$TAG/*.db | head -n 1) 60 > gpurun_out/kernel_stats_$TAG.txt 2>&1
+python3 tools/rocpd_gaps.py $(ls /tmp/trace_$TAG/*.db | head -n 1) 45 > gpurun_out/kernel_gaps_$TAG.txt 2>&1
 head -n 45 gpurun_out/kernel_stats_$TAG.txt | cut -c1-150
 cat gpurun_out/bench_$TAG.json | cut -c1-400
