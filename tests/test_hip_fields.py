@@ -98,9 +98,17 @@ def test_prop_field_golden(F, dev, gold_model):
         close_scaled(gr, G["Ppg_" + n])
 
 
+@pytest.mark.parametrize("backward", ["three kernels", "fused"])
 @pytest.mark.parametrize("which", ["cfg2", "prod"])
-def test_main_field_vs_oracle_ray_batch(F, dev, which):
-    """cfg-2 / production shaped field on a ray batch (positions generated in-kernel from rays + bins)."""
+def test_main_field_vs_oracle_ray_batch(F, dev, which, backward, monkeypatch):
+    """cfg-2 / production shaped field on a ray batch (positions generated in-kernel from rays + bins); the backward as three
+    kernels (one MLP stack each, the training path) and as the single fused kernel"""
+    monkeypatch.setenv("PRESIGHT_MAIN_BWD_SPLIT", "1" if backward == "three kernels" else "0")
+    # Seeded: the appearance codes / cotangents must not depend on what ran before.  (A generator state exists -- found by a
+    # full-suite run -- for which ONE hidden neuron's pre-activation is within rounding of zero at one point: the ReLU mask then
+    # differs between the CPU and the GPU arithmetic and that neuron's row of the weight gradient is off by the point's
+    # contribution, identically for both backward paths.  That is a property of the comparison, not of a kernel.)
+    torch.manual_seed(77)
     cfg = O.default_config()
     if which == "prod":
         cfg["main"].update(num_levels=10, features_per_level=4, log2_hashmap_size=14, max_res=16384)
