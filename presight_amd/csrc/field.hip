@@ -414,8 +414,18 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const float* __restrict__
         dh[pb][t] = h1[pb][t] > 0.0f ? wz[t] * d : 0.0f;
       }
     }
-    layer_bwd_weights_acc<L0, PB>(scratch, dw0, db0, dh, x);
-    layer_bwd_data<L0, PB>(t0, dh, dx);
+    {
+      // dX first (it hides the staging writes of the dW operands), the operands of point block pb+1 staged under the dW MFMAs of pb
+      float a0[L0::KSO], dbp_unused[L0::NB];
+      frags_bwd_block<L0>(t0, 0, a0);
+      layer_bwd_pipe_core<L0, PB, true, false>(t0, a0, scratch, dw0, dbp_unused, dh, x, dx, NoPrefetch());
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int nb = 0; nb < L0::NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) db0[nb][r] += dh[pb][4 * nb + r];  // per-lane partial; reduced over lanes at the end
+    }
     __builtin_amdgcn_sched_barrier(0);
     consume();
     __builtin_amdgcn_sched_barrier(0);
