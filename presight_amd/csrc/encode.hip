@@ -710,18 +710,12 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   const int item = blockIdx.x;  // (sub-field * L + level) * n_slices + slice
   const int vlevel = item / n_slices, sl = item % n_slices;
   const int level = vlevel % L;
-  const int64_t n = cursors[item] - starts[item];  // the write pass advanced the cursor from the stream start to its end
+  const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
+  const int64_t n = cursors[item] - base;  // the write pass advanced the cursor from the stream start to its end
   if (n == 0 && accumulate) return;  // nothing to add (a sub-field without points: most slices of a multi-sub-field launch)
   if (dtables != nullptr) dtable = dtables[vlevel / L];
-  for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
-  __syncthreads();
-  if (gmax_bits[vlevel] >= 0x7f800000u) {  // a non-finite d(feature) on this level: the gradient is NaN, like torch's index_add of a NaN
-    float* o = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
-    for (int i = threadIdx.x; i < entries * F; i += 1024) o[i] = __builtin_nanf("");
-    return;
-  }
-  const float scale = fixed_scale(gmax_bits[vlevel], headroom_log2);
-  const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
+  const unsigned gbits = gmax_bits[vlevel];
+  float* out = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
   // Every lane takes kChunk CONSECUTIVE records of the stream and merges neighbours that hit the same pair of rows in
   // registers (int64 adds: associative, so merging does not change the result) before touching LDS.  The bin kernel
   // emits the records of one wavefront instruction in lane order = consecutive samples of a ray, which share their
@@ -729,10 +723,9 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   // record = {row | t<<16, ox, q[F]}: t < 30 -> pair (rows e and e ^ (2^(t+1)-1), weights 1-ox / ox), t == 30 -> both
   // corners on the same row (exact integer x), t == 31 -> single corner with its weight already applied.
   constexpr int kChunk = 8;
-  const unsigned low = (unsigned)entries - 1u;
-  for (int64_t i0 = (int64_t)threadIdx.x * kChunk; i0 < n; i0 += 1024 * kChunk) {
-    unsigned e[kChunk];
-    float v[F][kChunk], ox[kChunk];
+  unsigned e[kChunk];
+  float v[F][kChunk], ox[kChunk];
+  auto load_batch = [&](int64_t i0) {
 #pragma unroll
     for (int h = 0; h < kChunk; h += 4) {
       const int64_t i = base + i0 + h;
@@ -750,6 +743,30 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
         for (int k = 0; k < 4; ++k) v[f][h + k] = q[k];
       }
     }
+  };
+  // A workgroup owns a whole CU (128 KiB of LDS), so nothing overlaps its own memory latencies: the first batch of records and
+  // -- for the dense read-modify-write flush -- the slice's current gradient are requested BEFORE the accumulators are zeroed
+  // (production shape: ~4 k records per slice, the kernel is a chain of latencies: 3.2 ms for 41 k workgroups)
+  const int64_t first_i0 = (int64_t)threadIdx.x * kChunk;
+  if (first_i0 < n) load_batch(first_i0);
+  const bool dense = !(accumulate && n * 4 < entries);
+  constexpr int kOutPerThread = kAccBytes / 8 / 1024;  // 16 values of the slice per thread
+  float prev[kOutPerThread];
+#pragma unroll
+  for (int k = 0; k < kOutPerThread; ++k) {
+    const int i = threadIdx.x + k * 1024;
+    prev[k] = (dense && accumulate && i < entries * F) ? out[i] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
+  __syncthreads();
+  if (gbits >= 0x7f800000u) {  // a non-finite d(feature) on this level: the gradient is NaN, like torch's index_add of a NaN
+    for (int i = threadIdx.x; i < entries * F; i += 1024) out[i] = __builtin_nanf("");
+    return;
+  }
+  const float scale = fixed_scale(gbits, headroom_log2);
+  const unsigned low = (unsigned)entries - 1u;
+  for (int64_t i0 = first_i0; i0 < n; i0 += 1024 * kChunk) {
+    if (i0 != first_i0) load_batch(i0);
     unsigned p_row = 0xffffffffu, p_rowc = 0xffffffffu;
     long long p_f[F], p_c[F];
 #pragma unroll
@@ -788,8 +805,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   }
   __syncthreads();
   const float inv = 1.0f / scale;
-  float* out = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
-  if (accumulate && n * 4 < entries) {
+  if (!dense) {
     // Sparse flush (many sub-fields / few points per table: far fewer records than rows): walk the records once more and let
     // the first lane that reaches a row take its total out of LDS (64-bit exchange with 0) and add it to the gradient;
     // rows no record touched are neither read nor written.  Same values as the dense flush below.
@@ -810,9 +826,13 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
     }
     return;
   }
-  for (int i = threadIdx.x; i < entries * F; i += 1024) {
-    const float v = (float)((double)acc[i] * (double)inv);
-    out[i] = accumulate ? out[i] + v : v;
+#pragma unroll
+  for (int k = 0; k < kOutPerThread; ++k) {
+    const int i = threadIdx.x + k * 1024;
+    if (i < entries * F) {
+      const float val = (float)((double)acc[i] * (double)inv);
+      out[i] = accumulate ? prev[k] + val : val;
+    }
   }
 }
 
