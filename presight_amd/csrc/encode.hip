@@ -564,20 +564,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     if ((int)threadIdx.x < n_slices && cnt[threadIdx.x]) atomicAdd(&cursors[level * n_slices + threadIdx.x], cnt[threadIdx.x]);
     return;
   } else {
-    // the level's max |d(feature)| for the accumulate kernel's fixed-point scale: folded into this pass, which reads every
-    // d(feature) anyway (saves the separate absmax pass over the plane).  The atomic is skipped when the published maximum is
-    // already at least as large (a stale read only costs a redundant atomic: the maximum is monotonic; 0.5 M same-address
-    // atomics per launch would serialise in L2 for milliseconds)
-    if (gmax_track != nullptr) {
-      float m = gmax_local;
-#pragma unroll
-      for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
-      if (ps_lane() == 0 && !(m <= 0.f)) {
-        const unsigned bits = isfinite(m) ? __float_as_uint(m) : 0x7fc00000u;
-        // (agent-scope load: served by L2 — a plain load would sit in this CU's L1 and never see the other CUs' updates)
-        if (bits > __hip_atomic_load(gmax_track + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gmax_track + level, bits);
-      }
-    }
     // exclusive scan of the bucket sizes by the first wavefront (4 slices per lane + one wave scan, no block barriers)
     if (threadIdx.x < 64) {
       const int b = threadIdx.x * 4;
@@ -603,9 +589,28 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     }
     __syncthreads();
     // one global reservation per (workgroup, slice): absolute position in the record arrays
+    // (the returned position is kept in a register and goes to LDS only AFTER the staging below: the kernel is a chain of
+    //  latencies -- 131 k short workgroups -- and this way the round trip of the reservation overlaps the staging)
+    unsigned my_base = 0u;
     if ((int)threadIdx.x < n_slices) {
       const unsigned c = cnt[threadIdx.x];
-      gbase[threadIdx.x] = c ? atomicAdd(&cursors[level * n_slices + threadIdx.x], c) : 0u;
+      if (c) my_base = atomicAdd(&cursors[level * n_slices + threadIdx.x], c);
+    }
+    // the level's max |d(feature)| for the accumulate kernel's fixed-point scale: folded into this pass, which reads every
+    // d(feature) anyway (saves the separate absmax pass over the plane).  The atomic is skipped when the published maximum is
+    // already at least as large (a stale read only costs a redundant atomic: the maximum is monotonic; 0.5 M same-address
+    // atomics per launch would serialise in L2 for milliseconds).  The published maximum is requested here, next to the
+    // reservations, and looked at after the staging (it used to stand alone between two workgroup barriers).
+    unsigned my_bits = 0u, published = 0xffffffffu;
+    if (gmax_track != nullptr) {
+      float m = gmax_local;
+#pragma unroll
+      for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+      if (ps_lane() == 0 && !(m <= 0.f)) {
+        my_bits = isfinite(m) ? __float_as_uint(m) : 0x7fc00000u;
+        // (agent-scope load: served by L2 — a plain load would sit in this CU's L1 and never see the other CUs' updates)
+        published = __hip_atomic_load(gmax_track + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     // stage the records in bucket order.  The bucket offsets of all 16 record slots are fetched first: written as "read the
     // offset, store the record" per slot, every slot exposed an LDS round trip (the compiler keeps the read behind the
@@ -632,6 +637,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
           s_val[F][p] = r_ox[q][k];
         }
       }
+    if ((int)threadIdx.x < n_slices) gbase[threadIdx.x] = my_base;
+    if (my_bits > published) atomicMax(gmax_track + level, my_bits);  // (published stays 0xffffffff where nothing was requested)
     __syncthreads();
     if (off[n_slices] > (unsigned)kRec) {  // staging area full (workgroup-uniform): the rest goes out uncoalesced
 #pragma unroll
