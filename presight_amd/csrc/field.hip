@@ -30,6 +30,7 @@
 // over all waves; read back with ps_debug_timing
 __device__ unsigned long long g_ps_timing[16];
 __device__ unsigned long long g_ps_timing_fwd[16];
+__device__ unsigned long long g_ps_timing_rgb[16];
 #define PS_TSTAMP(i)                                              \
   {                                                               \
     const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
@@ -1056,6 +1057,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
   // (the first layer's input is assembled from the per-ray directions / appearance codes right before that layer)
   struct Head {
     float co[PB][4], w[PB], dr[PB][3], c2[PB][Rgb::HB * 4];
+    float ds[PB];  // d(sigma) * selector of the point (lane group 0), 0 elsewhere: the density gradient joins d(base output 0)
     int64_t ray[PB];
   };
   auto fetch_head = [&](int64_t first, Head& h) {
@@ -1070,6 +1072,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
       else
         r = ray_index(p < a.N ? p : a.N - 1, a.S);
       h.ray[pb] = r;
+      h.ds[pb] = (a.dsigma != nullptr && g == 0 && op >= 0) ? a.dsigma[op] * a.sel[p] : 0.0f;
       h.w[pb] = 1.0f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) h.dr[pb][k] = 0.0f;
@@ -1086,12 +1089,14 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
   int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
   // the head is consumed at the END of the previous tile, before that tile's stores and atomics (see main_bwd_sem_kernel)
   Head hd;
-  float c2[PB][Rgb::HB * 4], co[PB][4];
+  float c2[PB][Rgb::HB * 4], co[PB][4], ds_head[PB];
   int64_t ray_head[PB];
   auto consume = [&]() {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       ray_head[pb] = hd.ray[pb];
+      ds_head[pb] = hd.ds[pb];
+      asm volatile("" : "+v"(ds_head[pb]));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float d = 0.0f;
@@ -1111,9 +1116,18 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
   fetch_head(first, hd);
   consume();
   fetch_head(first + stride, hd);
+  PsTimer* tm = nullptr;
+#if defined(PS_TIMING)
+  PsTimer tm_;
+  tm_.start();
+  tm = &tm_;
+#endif
   for (; first < a.N; first += stride) {
-    float c1[PB][Rgb::HB * 4], zb0[PB][4], dirv[PB][3], appv[PB][4];
+    PS_STAMP(tm, 0)
+    float c1[PB][Rgb::HB * 4], zb0[PB][4], dirv[PB][3], appv[PB][4], ds_cur[PB];
     int64_t ray_of[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) ds_cur[pb] = ds_head[pb];
     load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
     load_act<1, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);  // sigma_raw | geo15
 #pragma unroll
@@ -1128,6 +1142,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
         appv[pb][t] = (a.app != nullptr && c < a.A) ? a.app[r * a.A + c] : 0.0f;
       }
     }
+    PS_STAMP(tm, 1)
     float dcin[PB][12];
     mlp_backward_acc<Rgb, PB, true, true>(
         pk, scratch, acc,
@@ -1145,11 +1160,12 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
             }
           }
         },
-        c1, c2, co, dcin);
+        c1, c2, co, dcin, tm);
     __builtin_amdgcn_sched_barrier(0);
     consume();
     fetch_head(first + 2 * stride, hd);
     __builtin_amdgcn_sched_barrier(0);
+    PS_STAMP(tm, 8)
     // d(appearance) is per RAY: see main_bwd_kernel
     float dz0[PB][4];
     bool block_in_ray = (a.S % 16) == 0;
@@ -1188,10 +1204,15 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
           }
         }
       }
-      if (a.dsigma != nullptr && g == 0 && op >= 0) dz0[pb][0] += a.dsigma[op] * a.sel[p] * trunc_exp_grad(zb0[pb][0]);
+      dz0[pb][0] += ds_cur[pb] * trunc_exp_grad(zb0[pb][0]);  // (ds is 0 outside lane group 0 / past the end: fetched with the head)
     }
     store_act<1, PB>(a.dzb, 80, 0, first, a.N, dz0);
+    PS_STAMP(tm, 9)
   }
+#if defined(PS_TIMING)
+  if (lane == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_ps_timing_rgb[i], tm_.acc[i]);
+#endif
   reduce_store<Rgb, NW>(lds, acc, a.gpart + (size_t)lb * C::GPACKED + C::G_RGB);
 }
 
@@ -1543,6 +1564,14 @@ extern "C" int ps_debug_timing(unsigned long long* out /*host[16]*/, int reset) 
   if (e == hipSuccess && reset) {
     unsigned long long z[16] = {0};
     e = hipMemcpyToSymbol(HIP_SYMBOL(g_ps_timing), z, sizeof(z));
+  }
+  return (int)e;
+}
+extern "C" int ps_debug_timing_rgb(unsigned long long* out /*host[16]*/, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_timing_rgb), sizeof(unsigned long long) * 16);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_ps_timing_rgb), z, sizeof(z));
   }
   return (int)e;
 }

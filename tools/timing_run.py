@@ -17,6 +17,8 @@ out = (ctypes.c_ulonglong * 16)()
 h.ps_debug_timing(out, 1)
 outf = (ctypes.c_ulonglong * 16)()
 h.ps_debug_timing_fwd(outf, 1)
+outr = (ctypes.c_ulonglong * 16)()
+h.ps_debug_timing_rgb(outr, 1)
 n = 4
 for i in range(n):
     tr.step(b[i % 2])
@@ -42,3 +44,12 @@ print("main_fwd_kernel (1024 waves, one per SIMD)")
 for i, nm in enumerate(namesf):
     print(f"{nm:40s} {outf[i] / n / 1024 / tiles_per_wave:10.0f} clk/tile   {100 * outf[i] / totf:5.1f} %")
 print(f"{'total':40s} {totf / n / 1024 / tiles_per_wave:10.0f} clk/tile")
+
+h.ps_debug_timing_rgb(outr, 0)
+namesr = ["loop top", "issue loads c1 zb0 dirs app", "LZ (64->16): dX", "LZ: stage c2 + dW", "L1: relu + dX", "L1: stage c1 + dW",
+          "L0: build colour input + dX", "L0: dW", "consume head, fetch next head", "d(appearance) sums + atomics, d(sigma), store"]
+totr = sum(outr[i] for i in range(len(namesr)))
+print("main_bwd_rgb_kernel (1024 waves x 128 tiles)")
+for i, nm in enumerate(namesr):
+    print(f"{nm:48s} {outr[i] / n / tiles:10.0f} clk/tile   {100 * outr[i] / totr:5.1f} %")
+print(f"{'total':48s} {totr / n / tiles:10.0f} clk/tile")
