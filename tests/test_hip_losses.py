@@ -172,3 +172,28 @@ def test_model_depth_supervised_step():
     sum(ld.values()).backward()
     gt = model.field.fields[0].mlp_base_grid.hash_table.grad
     assert gt is not None and bool(torch.isfinite(gt).all()) and float(gt.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("n", [1, 3, 1000, 65537])
+def test_loss_finish_and_scale_grad(n):
+    """the one-launch scalar arithmetic around a loss term (ps_loss_finish / ps_scale_grad) against torch: plain mean with a
+    multiplier, mean over a validity mask (also the empty mask: NaN like torch.mean of nothing), unaligned inputs, chain rule"""
+    from presight_amd.losses import _chain, _finish
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(n)
+    buf = torch.randn(n + 1, device=dev, generator=g)
+    for terms in (buf[:n], buf[1:]):  # 16-byte aligned and not
+        val, _ = _finish(terms, 7.0, 0.25)
+        torch.testing.assert_close(val, 0.25 * terms.double().sum().float() / 7.0, rtol=2e-5, atol=1e-6)
+        keep = (torch.rand(n, device=dev, generator=g) > 0.5).float()
+        val, inv = _finish(terms, 0.0, 3.0, keep=keep, want_inv=True)
+        if float(keep.sum()) > 0:
+            torch.testing.assert_close(val, 3.0 * terms.double().sum().float() / keep.sum(), rtol=2e-5, atol=1e-6)
+            torch.testing.assert_close(inv.reshape(()), 3.0 / keep.sum(), rtol=1e-6, atol=0)
+    val, _ = _finish(buf[:n], 0.0, 1.0, keep=torch.zeros(n, device=dev), want_inv=True)
+    assert torch.isnan(val)
+    up = torch.tensor(1.5, device=dev)
+    fac = torch.tensor([0.125], device=dev)
+    torch.testing.assert_close(_chain(buf[:n].contiguous(), up, 2.0), buf[:n] * 3.0, rtol=1e-6, atol=0)
+    torch.testing.assert_close(_chain(buf[1:].contiguous(), up, 2.0, fac), buf[1:] * 0.375, rtol=1e-6, atol=0)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the two-kernel main backward: parity tests with the split on, then the bench with the split off / on
+# A/B of the three-kernel main backward (PRESIGHT_MAIN_BWD_SPLIT=0: the single fused kernel): parity tests with the split on, then the bench with the split off / on
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_hip_fields.py tests/test_hip_model.py tests/test_hip_ms.py -q -x 2>&1 | tail -5
 for sp in 0 1 1; do
