@@ -245,14 +245,15 @@ __global__ __launch_bounds__(1024) void loss_finish_kernel(const float* __restri
 // out = grad * g[0] * (factor ? factor[0] : 1) * host_scale: the chain rule of a scalar loss in one launch (g is the device
 // scalar autograd hands over)
 __global__ __launch_bounds__(256) void scale_grad_kernel(const float* __restrict__ grad, int64_t n, const float* __restrict__ g,
-                                                         const float* __restrict__ factor, float host_scale, float* __restrict__ out) {
+                                                         const float* __restrict__ factor, float host_scale, float* __restrict__ out,
+                                                         int vec /* both arrays 16-byte aligned */) {
   const float f = g[0] * (factor != nullptr ? factor[0] : 1.0f) * host_scale;
   for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
-    if (i + 4 <= n) {
+    if (vec && i + 4 <= n) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(grad + i);
       *reinterpret_cast<f32x4*>(out + i) = v * f;
     } else {
-      for (int64_t q = i; q < n; ++q) out[q] = grad[q] * f;
+      for (int64_t q = i; q < n && q < i + 4; ++q) out[q] = grad[q] * f;
     }
   }
 }
@@ -289,7 +290,8 @@ extern "C" int ps_scale_grad(const float* grad, int64_t n, const float* g, const
   if (n == 0) return 0;
   PS_REQUIRE(g != nullptr, "ps_scale_grad: the upstream gradient is a device scalar");
   const int64_t b = (n + 1023) / 1024;
-  scale_grad_kernel<<<(unsigned)(b > 2048 ? 2048 : b), 256, 0, (hipStream_t)stream>>>(grad, n, g, factor, host_scale, out);
+  const int vec = (((uintptr_t)grad | (uintptr_t)out) & 15) == 0;
+  scale_grad_kernel<<<(unsigned)(b > 2048 ? 2048 : b), 256, 0, (hipStream_t)stream>>>(grad, n, g, factor, host_scale, out, vec);
   PS_CHECK_LAUNCH();
 }
 
