@@ -163,9 +163,12 @@ def test_production_shape_k16_training_step_matches_oracle(dev):
     assert len(errs) > 100 and q(0.5) < 1e-4 and q(0.9) < 1e-3 and float(errs[-1]) < 1e-2, (names[-3:], errs[-3:])
 
 
-def test_ms_fields_equal_the_per_field_kernels(dev):
+@pytest.mark.parametrize("backward", ["three kernels", "fused"])
+def test_ms_fields_equal_the_per_field_kernels(dev, backward, monkeypatch):
     """Same arithmetic per point in both paths: densities / colours / semantics are bit-identical; table gradients too (int64
-    fixed-point accumulation with per-(sub-field, level) scales); MLP weight gradients agree to summation order."""
+    fixed-point accumulation with per-(sub-field, level) scales); MLP weight gradients agree to summation order.  Both forms of
+    the main backward (one kernel per MLP stack = the training path, and the single fused kernel)."""
+    monkeypatch.setenv("PRESIGHT_MAIN_BWD_SPLIT", "1" if backward == "three kernels" else "0")
     from presight_amd import field_ops as F
     from presight_amd.fields import iNGPField, PropNetDensityField, iNGPFieldMS, PropNetDensityFieldMS, routed_apply
     from presight_amd.components import SceneContraction
