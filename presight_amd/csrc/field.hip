@@ -1297,8 +1297,14 @@ int ms_grid(int64_t n_slots, int pts_per_tile, int waves, int max_blocks, int K)
   return (int)((g + 7) / 8 * 8);  // ms_logical_block deals the workgroups XCD-major
 }
 
-constexpr int kPropFwdPB = 4, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 4, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
-constexpr int kPropBwdBlocks = 512;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
+#ifndef PS_PROP_FWD_PB
+#define PS_PROP_FWD_PB 2  // (4: 134 us per launch, 2: 123 us)
+#endif
+#ifndef PS_PROP_BWD_BLOCKS
+#define PS_PROP_BWD_BLOCKS 512
+#endif
+constexpr int kPropFwdPB = PS_PROP_FWD_PB, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 4, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
+constexpr int kPropBwdBlocks = PS_PROP_BWD_BLOCKS;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
 
 // (L*F, hidden) of the proposal nets
 #define PS_PROP_CFGS(X) \
