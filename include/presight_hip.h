@@ -187,7 +187,8 @@ int ps_grid_scatter(const float* u, const float* dfeat, const float* scalings, i
 /* Fast path of the same gradient (used by the fused fields): every corner contribution is computed once, binned
  * through `workspace` (ps_grid_scatter_workspace bytes, caller-allocated device memory) into the record stream of the
  * table slice that owns its row, and reduced with fixed-point int64 LDS atomics -> bit-reproducible;
- * accumulate=0 overwrites dtable, 1 adds to it. */
+ * accumulate=0 overwrites dtable, 1 adds to it, 2 adds to a dtable the caller guarantees to be all zero (first contribution
+ * of a step into a zeroed gradient buffer: written without reading; slices without records are left untouched). */
 int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N);
 int ps_grid_scatter_binned(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                            int64_t plane_stride, float* dtable, int accumulate, const uint32_t* slice_counts /*nullable*/,
@@ -260,7 +261,10 @@ int ps_grid_encode_ms(const float* u, const float* const* tables, const float* s
 int64_t ps_grid_scatter_workspace_ms(int L, int F, int log2T, int64_t n_slots, int K);
 int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t n_slots,
                               int64_t plane_stride, float* const* dtables, int K, const int32_t* chunk_field,
-                              const uint32_t* slice_counts, int absmax_ready, void* workspace, void* stream);
+                              const uint32_t* slice_counts, int absmax_ready, void* workspace,
+                              int dst_is_zero /* the caller guarantees dtables[*] hold zeros (first contribution of the step): the
+                                                 flush then writes instead of read-modify-writing; slices without records stay untouched */,
+                              void* stream);
 /* fused fields: packed = K packed parameter blocks back to back (ps_*_field_sizes packed_floats each); gpart receives
  * ps_*_field_parts_ms(n_slots, K) partial gradient blocks, reduced per sub-field by ps_mlp_unpack_table_ms */
 int ps_prop_field_parts_ms(int64_t n_slots, int K);

@@ -762,7 +762,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
 #pragma unroll
   for (int k = 0; k < kOutPerThread; ++k) {
     const int i = threadIdx.x + k * 1024;
-    prev[k] = (dense && accumulate && i < entries * F) ? out[i] : 0.0f;
+    prev[k] = (dense && accumulate == 1 && i < entries * F) ? out[i] : 0.0f;  // (accumulate == 2: the destination is known to be zero)
   }
   for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
   __syncthreads();
@@ -827,7 +827,10 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
 #pragma unroll
         for (int f = 0; f < F; ++f) {
           const long long v = (long long)atomicExch(reinterpret_cast<unsigned long long*>(&acc[r * F + f]), 0ull);
-          if (v != 0) out[r * F + f] += (float)((double)v * (double)inv);
+          if (v != 0) {
+            const float val = (float)((double)v * (double)inv);
+            out[r * F + f] = accumulate == 1 ? out[r * F + f] + val : val;
+          }
         }
       }
     }
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
     const int i = threadIdx.x + k * 1024;
     if (i < entries * F) {
       const float val = (float)((double)acc[i] * (double)inv);
-      out[i] = accumulate ? prev[k] + val : val;
+      out[i] = accumulate == 1 ? prev[k] + val : val;
     }
   }
 }
@@ -944,9 +947,9 @@ extern "C" int ps_grid_scatter_binned(const float* u, const float* dfeat, const 
 extern "C" int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
                                          int64_t n_slots, int64_t plane_stride, float* const* dtables, int K,
                                          const int32_t* chunk_field, const uint32_t* slice_counts, int absmax_ready, void* workspace,
-                                         void* stream) {
+                                         int dst_is_zero, void* stream) {
   PS_REQUIRE(dtables != nullptr && chunk_field != nullptr && K >= 1, "ps_grid_scatter_binned_ms: need the gradient pointers and the chunk map");
   PS_REQUIRE(n_slots % ps::kMsChunk == 0, "ps_grid_scatter_binned_ms: the sorted layout is a whole number of chunks");
-  return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, n_slots, plane_stride, nullptr, dtables, K, chunk_field, /*accumulate=*/1,
+  return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, n_slots, plane_stride, nullptr, dtables, K, chunk_field, /*accumulate=*/dst_is_zero ? 2 : 1,
                              slice_counts, absmax_ready, workspace, (hipStream_t)stream);
 }

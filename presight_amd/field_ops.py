@@ -97,12 +97,20 @@ def _scatter_ws(g: GridCfg, N: int, device) -> Optional[Tensor]:
     return _workspace(lib().ps_grid_scatter_workspace(g.num_levels, g.features_per_level, g.log2_hashmap_size, N), device)
 
 
+def _sink_is_zero(param: Optional[Tensor]) -> bool:
+    """True when `param`'s in-place gradient sink is known to hold zeros: its owner (presight_amd.dist.FlatGrads) cleared it
+    at the start of the step (zero_ resets `_ps_touched`) and nothing has been written to it since"""
+    return param is not None and getattr(param, "_ps_touched", True) is False
+
+
 def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape, sink: Optional[Tensor] = None,
-             counts: Optional[Tensor] = None, ws_with_absmax: Optional[Tensor] = None) -> Optional[Tensor]:
+             counts: Optional[Tensor] = None, ws_with_absmax: Optional[Tensor] = None, sink_owner: Optional[Tensor] = None) -> Optional[Tensor]:
     """table gradient; with `sink` (the parameter's pre-allocated .grad, ops.grad_sink) it is ADDED there and None is returned.
     counts: slice record counts from the forward encode of the same points (_encode(count=True))."""
     N = u.shape[0]
     acc = int(sink is not None)
+    if acc and _binned(N, g.num_levels) and _sink_is_zero(sink_owner):
+        acc = 2  # first contribution of the step into the zeroed flat gradient buffer: written, not read-modify-written
     dtable = sink if sink is not None else torch.empty(table_shape, device=u.device, dtype=torch.float32)
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
     with prof.region(f"grid_scatter_L{L}F{F}"):
@@ -148,6 +156,7 @@ class _PropField(torch.autograd.Function):
         ctx.save_for_backward(u, sel, scalings, feat, packed, counts)
         ctx.meta = (g, hidden, tuple(table.shape), [tuple(W.shape) for W, _ in layers])
         ctx.sinks = (grad_sink(table), layer_sinks(layers))
+        ctx.table_ref = table
         ctx.direct = direct_params(table, *wb)
         return sigma
 
@@ -167,7 +176,7 @@ class _PropField(torch.autograd.Function):
         with prof.region("prop_field_bwd"):
             check(lib().ps_prop_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
                                           _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _p(ws), _stream()), "ps_prop_field_bwd")
-        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts, ws)
+        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts, ws, sink_owner=ctx.table_ref)
         grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes, ctx.sinks[1])
         mark_touched(ctx.direct)
         return (None, None, dtable, None, None, *flatten_grads(grads))
@@ -268,6 +277,7 @@ def _main_forward(ctx, table_needs_grad, u, sel, dirs, app, S, table, scalings, 
     ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
                 want_rgb, want_sem)
     ctx.sinks = (grad_sink(table), layer_sinks(layers))
+    ctx.table_ref = table
     ctx.direct = direct_params(table, *wb)
     return (u, sel, dirs, app_c, scalings, feat, packed, counts, acts), (sigma, rgb, sem)
 
@@ -321,7 +331,7 @@ def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
             check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                           _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
                                           _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), _stream()), "ps_main_field_bwd")
-    dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts)
+    dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts, sink_owner=ctx.table_ref)
     descs = []
     for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
                         (spec.rgb, spec.g_off[2], shapes[n_base + n_sem:])):
@@ -583,10 +593,11 @@ def _ms_scatter(lay: MsLayout, u, dfeat, scalings, g: GridCfg, tables: Sequence[
     sinks = [grad_sink(t) for t in tables]
     fresh = [None if s is not None else torch.zeros_like(t) for s, t in zip(sinks, tables)]
     dst = [s if s is not None else f for s, f in zip(sinks, fresh)]
+    zero_dst = all(s is None or _sink_is_zero(t) for s, t in zip(sinks, tables))  # fresh zeros / untouched, cleared sinks
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
     with prof.region(f"grid_scatter_L{L}F{F}"):
         check(lib().ps_grid_scatter_binned_ms(_p(u), _p(dfeat), _p(scalings), L, F, l2t, lay.n_slots, lay.n_slots * F, _p(_ptr_table(dst)),
-                                              lay.K, lay.chunk_field, _p(counts), int(absmax_ready), _p(ws), _stream()),
+                                              lay.K, lay.chunk_field, _p(counts), int(absmax_ready), _p(ws), int(zero_dst), _stream()),
               "ps_grid_scatter_binned_ms")
     return fresh
 
