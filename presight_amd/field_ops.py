@@ -292,7 +292,7 @@ def _dzb_scratch(n_points: int, dev):
 def _bwd_stages(dzb):
     """one pass normally; while bench.py's per-kernel timing is on, the three kernels of the split backward are launched by three
     calls, each inside its own HIP-event region (same kernels, same order, same stream)"""
-    if dzb is None or not prof.enabled():
+    if dzb is None or not prof.enabled("main_bwd_sem_kernel"):
         yield
         return
     try:

@@ -8,23 +8,27 @@ from contextlib import contextmanager
 import torch
 
 _enabled = False
+_only = None  # None: every region; else the set of region names that are timed
 _events = defaultdict(list)
 
 
-def enable(flag: bool = True):
-    global _enabled
+def enable(flag: bool = True, only=None):
+    """only: time just these regions (an event pair costs the stream a few microseconds: bench.py times the dominant kernels
+    inside its timed steps and everything else in a separate pass)"""
+    global _enabled, _only
     _enabled = flag
+    _only = None if only is None else set(only)
     if flag:
         _events.clear()
 
 
-def enabled() -> bool:
-    return _enabled
+def enabled(name: str = None) -> bool:
+    return _enabled and (name is None or _only is None or name in _only)
 
 
 @contextmanager
 def region(name: str):
-    if not _enabled:
+    if not enabled(name):
         yield
         return
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
