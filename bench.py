@@ -181,86 +181,14 @@ def synthetic_chunk(scene, dev, chunk_index, pixels=1 << 22):
                 depths=None, features=torch.rand(pixels, 64, device=dev, generator=g))
 
 
-class Trainer:
-    """The timed region: what ns/engine/trainer.py:463-505 does per iteration (zero_grad, forward, loss, backward with
-    the reference's fixed loss scale of 2**10, DDP gradient averaging, Adam lr 1e-2 eps 1e-15 wd 1e-5).
+def Trainer(model, scene, world, exchange="allreduce", global_depth_clip=False):
+    """presight_amd.trainer.Trainer (the timed region) with the bench's setting: proposal networks receive gradients EVERY step
+    (the upper bound of the reference's update schedule; its steady state is reported as `value_reference_schedule`)"""
+    from presight_amd.trainer import Trainer as _Trainer
 
-    exchange = "allreduce": bucketed all-reduce overlapped with backward, Adam over everything on every rank;
-               "sharded":   bucketed reduce-scatter overlapped with backward, Adam on the owned shard, all-gather of the
-                            updated parameters overlapped with the next step's ray generation / proposal sampling."""
-
-    def __init__(self, model, scene, world, exchange="allreduce", global_depth_clip=False):
-        from presight_amd.dist import FlatGrads, global_depth_clip as depth_hook
-        from presight_amd.optim import HipAdam
-
-        self.model, self.scene, self.world = model, scene, world
-        groups = model.get_param_groups()
-        # bucket-major order, in the order backward COMPLETES the groups: "fields" (main field, sky, embeddings) are finished
-        # before the proposal networks' backward starts, so their exchange runs underneath it; a group that receives no
-        # gradient in a step (proposal nets off-schedule) is one contiguous range to skip
-        order = [k for k in ("fields", "proposal_networks") if k in groups] + sorted(k for k in groups if k not in ("fields", "proposal_networks"))
-        seen, uniq, sizes = set(), [], []
-        for k in order:
-            n0 = len(uniq)
-            for p in groups[k]:  # the reference registers mlp_base = Sequential(grid, mlp): the same tensors appear twice -> dedup
-                if p.requires_grad and p.numel() > 0 and id(p) not in seen:
-                    seen.add(id(p))
-                    uniq.append(p)
-            sizes.append(len(uniq) - n0)
-        assert seen == {id(p) for p in model.parameters() if p.requires_grad and p.numel() > 0}
-        self.group_names = order
-        sharded = exchange == "sharded" and world > 1
-        self.grads = FlatGrads(uniq, bucket_sizes=sizes, shard_world=world if sharded else 1)
-        # K > 1: a sub-field may get samples on one rank only; "received a gradient" must then be agreed across ranks (DDP)
-        self.grads.flags_may_differ_across_ranks = world > 1 and len(model.field.fields) > 1
-        if world > 1 and not model.config.use_same_proposal_network and os.environ.get("PRESIGHT_NO_OVERLAP") != "1":
-            buckets, i = [], 0
-            for n in sizes:
-                buckets.append(uniq[i:i + n])
-                i += n
-            self.grads.enable_overlap(buckets, mode="sharded" if sharded else "allreduce")
-            if sharded:
-                model.param_gate = lambda name: self.grads.wait_params(self.group_names.index(name))
-        self.exchange = "sharded" if sharded else "allreduce"
-        if global_depth_clip and world > 1:
-            from presight_amd import ops
-
-            ops.set_depth_clip_hook(depth_hook())
-        self.opt = HipAdam(uniq, lr=1e-2, eps=1e-15, weight_decay=1e-5, flat_grads=self.grads)
-        self.step_idx = 0
-        self.loss_scale = 2.0 ** 10
-        self._seed = None
-        self.update_props_every_step = True
-
-    def step(self, batch):
-        import torch
-
-        from presight_amd import ops, prof
-        from presight_amd.rays import RayBundle
-
-        m, s = self.model, self.scene
-        m.train()
-        m.before_train_iteration(self.step_idx)
-        self.grads.zero_()
-        o, d, pa, dn = ops.generate_rays(batch["ray_indices"], s["c2w"], s["fx"], s["fy"], s["cx"], s["cy"])
-        vid = batch["video_ids"] if "video_ids" in batch else batch["video_id"]  # make_batches / the reference's collated key
-        rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1], metadata={"video_id": vid.view(-1, 1), "directions_norm": dn})
-        if self.update_props_every_step:
-            m.proposal_sampler._steps_since_update = 1 << 30  # proposal nets receive gradients EVERY step (upper bound of the schedule)
-        out = m(rb)
-        loss_dict = m.get_loss_dict(out, batch)
-        # one concat + one reduction instead of a chain of scalar adds; the loss scale enters as the seed of the backward pass
-        loss = torch.stack(list(loss_dict.values())).sum()
-        if self._seed is None:
-            self._seed = torch.full((), self.loss_scale, device=loss.device)
-        loss.backward(gradient=self._seed)
-        with prof.region("exchange_exposed"):
-            self.grads.finish_exchange()
-        with prof.region("adam"):
-            self.opt.step()
-        m.after_train_iteration(self.step_idx)
-        self.step_idx += 1
-        return loss_dict, out
+    t = _Trainer(model, scene, world, exchange=exchange, global_depth_clip=global_depth_clip)
+    t.update_props_every_step = True
+    return t
 
 
 # --------------------------------------------------------------------------------------------------------- CPU baseline

@@ -225,12 +225,11 @@ int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, in
                       float* dzb_scratch /* nullable; with acts: [ceil(N/16)*16, 80] workspace -> the three-kernel backward
                                             (semantic head, colour head, base MLP: one stack's weight gradients stay in
                                             registers and its transposed weights in LDS); NULL: one fused kernel */,
+                      int stages /* three-kernel backward: which kernels THIS call launches -- bit 0 semantic head, bit 1 colour
+                                    head, bit 2 base MLP; 7 = all.  A measurement aid (bench.py times the kernels one by one from
+                                    three calls); the stages of one backward must run in this order */,
                       void* stream);
 
-/* measurement aid (bench.py times the three kernels of the split backward one by one): which of them later calls with a
- * dzb_scratch launch -- bit 0 semantic head, bit 1 colour head, bit 2 base MLP; 7 = all (the default).  Returns the previous
- * mask.  The stages of one backward must still run in this order. */
-int ps_main_field_bwd_stages(int mask);
 
 /* ---- a5 sub-field router: all K sub-fields of a tile in ONE launch per kernel, no host synchronisation ---------------
  * Reference: iNGPFieldMS / PropNetDensityFieldMS / SkyFieldMS (ns/fields/PreSight/ingp_field_ms.py:97-126,
@@ -284,7 +283,7 @@ int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F,
                          float* dapp_points /* nullable, with dzb_scratch: d(appearance) per point [N, A] in the caller's order,
                                                WRITTEN; the caller sums it over the samples of a ray and dapp is left untouched
                                                (the sorted layout would otherwise cost 16 float atomics per point) */,
-                         const int32_t* perm, const int32_t* field_start, int K, void* stream);
+                         const int32_t* perm, const int32_t* field_start, int K, int stages /* as ps_main_field_bwd */, void* stream);
 /* fused sky field (ns/fields/PreSight/sky_field.py:95-110): per ray SH4((dir+1)/2) -> semantic head (16 -> 32 -> 32 -> 64) and
  * [SH | appearance] -> colour head (16+A -> 32 -> 32 -> 3, sigmoid), one kernel per direction; packed = [colour | semantic]
  * packed stacks (K of them back to back for the routed sky model, perm / field_start from ps_ms_route on the ray ORIGINS,
@@ -330,16 +329,26 @@ int ps_voxel_reduce(const int64_t* order, const int64_t* starts, const int64_t* 
 
 /* ---- f1 optimizer: torch.optim.Adam semantics (L2 weight decay added to the gradient, bias-corrected), in place.
  * Reference configuration: ns/configs/method_configs.py:158-168 (lr 1e-2, eps 1e-15, weight_decay 1e-5).
- * p, g, m, v: [n] fp32, 16-byte aligned; step counts from 1. */
+ * p, g, m, v: [n] fp32, 16-byte aligned; step counts from 1.  grad_scale multiplies g before the weight decay is added
+ * (1 / loss scale: GradScaler.step unscales before the optimizer runs, ns/engine/optimizers.py:118-131, trainer.py:470-505). */
 int ps_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int step, void* stream);
-/* The same update over n_ranges disjoint ranges [start[i], start[i]+count[i]) (floats; start multiples of 4) of flat
- * p / g / m / v buffers, range i at its OWN step count (torch.optim.Adam advances state["step"] per parameter, only when
- * the parameter has a gradient: ns/engine/optimizers.py:133-140 after zero_grad(set_to_none=True)).  start / count / step
- * are HOST arrays; the range table travels as a kernel argument (one launch per 32 ranges, no host->device copy). */
+                 float weight_decay, int step, float grad_scale, void* stream);
+/* The same update over n_ranges disjoint, non-empty ranges [start[i], start[i]+count[i]) (floats; start multiples of 4) of
+ * flat p / g / m / v buffers, range i at its OWN step count (torch.optim.Adam advances state["step"] per parameter, only when
+ * the parameter has a gradient: ns/engine/optimizers.py:133-140 after zero_grad(set_to_none=True)).  start / count / step /
+ * group are HOST arrays; the range table travels as a kernel argument (one launch per 32 ranges, no host->device copy).
+ * group (nullable) / group[i] >= 0: whether range i received a gradient this step is decided ON THE DEVICE --
+ * group_flags[group[i]] != 0 (device int32 [n_groups], set by ps_ms_mark_groups for the routed sub-fields that received
+ * samples: ingp_field_ms.py:97-126 never calls an empty sub-field, so its gradients stay None and Adam skips it); its step
+ * count lives in group_steps[group[i]] (device int32) and is advanced after the update.  A range whose flag is 0 is left
+ * untouched: parameters, both moments and the step count keep their bits. */
 int ps_adam_step_ranges(float* p, const float* g, float* m, float* v, int n_ranges, const int64_t* start /*host*/,
-                        const int64_t* count /*host*/, const int* step /*host*/, float lr, float beta1, float beta2,
-                        float eps, float weight_decay, void* stream);
+                        const int64_t* count /*host*/, const int* step /*host*/, const int* group /*host, nullable*/,
+                        const int32_t* group_flags /*device, nullable*/, int32_t* group_steps /*device, nullable*/, int n_groups,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+/* flags[group_of_field[k]] = 1 for every sub-field k of a routed layout (field_start [K+1] from ps_ms_route) that received
+ * points; group_of_field [K] device int32, < 0 = no group.  Called by the routed backward nodes; no host synchronisation. */
+int ps_ms_mark_groups(const int32_t* field_start, int K, const int32_t* group_of_field, int32_t* flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ _ALIASES = {
     "nerfstudio.model_components.losses": "presight_amd.losses",
     "nerfstudio.model_components.PreSight.losses": "presight_amd.losses",
     "nerfstudio.models.PreSight.nerfacto_nusc_ms": "presight_amd.model",
+    "nerfstudio.engine.callbacks": "presight_amd.callbacks",
 }
 
 

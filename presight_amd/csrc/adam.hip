@@ -6,7 +6,7 @@
 namespace {
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                            int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gs) {
   const int64_t i0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
   if (i0 >= n) return;
   if (i0 + 3 < n) {
@@ -14,7 +14,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     f32x4 M = *reinterpret_cast<f32x4*>(m + i0), V = *reinterpret_cast<f32x4*>(v + i0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gk = G[k] + wd * P[k];
+      const float gk = G[k] * gs + wd * P[k];
       M[k] = b1 * M[k] + (1.0f - b1) * gk;
       V[k] = b2 * V[k] + (1.0f - b2) * gk * gk;
       const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
@@ -25,7 +25,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     *reinterpret_cast<f32x4*>(v + i0) = V;
   } else {
     for (int64_t i = i0; i < n; ++i) {
-      const float gk = g[i] + wd * p[i];
+      const float gk = g[i] * gs + wd * p[i];
       m[i] = b1 * m[i] + (1.0f - b1) * gk;
       v[i] = b2 * v[i] + (1.0f - b2) * gk * gk;
       const float denom = sqrtf(v[i]) / bc2_sqrt + eps;
@@ -38,22 +38,38 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // corrections (torch.optim.Adam keeps state["step"] per parameter and advances it only when that parameter has a gradient:
 // ns/engine/optimizers.py:133-140 with zero_grad(set_to_none=True), ns/engine/trainer.py:470).  The table travels as a
 // kernel argument, so there is no host->device copy; a block finds its range by a linear search over the block prefix.
+//
+// Device-decided ranges.  Whether a routed sub-field received samples this step is only known on the device (the router
+// never synchronises with the host, csrc/route.hip).  Such a range carries a GROUP id >= 0: flags[group] != 0 means "received
+// a gradient this step" and steps[group] is its torch-style step count, both in device memory.  A range whose flag is 0 is
+// skipped entirely -- no moment decay, no weight-decay-only update, no step-count advance -- exactly like torch.optim.Adam on
+// a parameter whose .grad is None (the reference's sub-field loop never calls an empty sub-field, ingp_field_ms.py:97-126,
+// and DDP(find_unused_parameters=True) leaves its gradients None).  The step counts of the flagged groups are advanced by
+// adam_commit_kernel AFTER all update launches of the step (stream order: no block reads a count that is being written).
 constexpr int kMaxRanges = 32;
 constexpr int kRangeBlockElems = 256 * 4 * 4;  // elements per workgroup: 256 threads x 4 vectors of 4
 struct AdamRanges {
   int n;
   int64_t start[kMaxRanges], count[kMaxRanges];
   unsigned blk0[kMaxRanges + 1];
-  float bc1[kMaxRanges], bc2_sqrt[kMaxRanges];
+  float bc1[kMaxRanges], bc2_sqrt[kMaxRanges];  // host-decided ranges (group < 0)
+  int group[kMaxRanges];
 };
 
 __global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, AdamRanges R, float lr, float b1, float b2, float eps,
-                                                          float wd) {
+                                                          float wd, float gs, const int* __restrict__ flags, const int* __restrict__ steps) {
   int r = 0;
   while (r + 1 < R.n && blockIdx.x >= R.blk0[r + 1]) ++r;
   const int64_t base = R.start[r], n = R.count[r];
-  const float bc1 = R.bc1[r], bc2_sqrt = R.bc2_sqrt[r];
+  float bc1 = R.bc1[r], bc2_sqrt = R.bc2_sqrt[r];
+  const int grp = R.group[r];
+  if (grp >= 0) {  // workgroup-uniform
+    if (flags[grp] == 0) return;
+    const double st = (double)(steps[grp] + 1);
+    bc1 = (float)(1.0 - pow((double)b1, st));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+  }
   const int64_t first = (int64_t)(blockIdx.x - R.blk0[r]) * kRangeBlockElems;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -68,7 +84,7 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p,
       f32x4 M = *reinterpret_cast<f32x4*>(mm), V = *reinterpret_cast<f32x4*>(vv);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float gk = G[k] + wd * P[k];
+        const float gk = G[k] * gs + wd * P[k];
         M[k] = b1 * M[k] + (1.0f - b1) * gk;
         V[k] = b2 * V[k] + (1.0f - b2) * gk * gk;
         const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p,
       *reinterpret_cast<f32x4*>(vv) = V;
     } else {
       for (int64_t i = 0; i0 + i < n; ++i) {
-        const float gk = gg[i] + wd * pp[i];
+        const float gk = gg[i] * gs + wd * pp[i];
         mm[i] = b1 * mm[i] + (1.0f - b1) * gk;
         vv[i] = b2 * vv[i] + (1.0f - b2) * gk * gk;
         const float denom = sqrtf(vv[i]) / bc2_sqrt + eps;
@@ -89,11 +105,18 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p,
   }
 }
 
+__global__ void adam_commit_kernel(const int* __restrict__ flags, int* __restrict__ steps, int n_groups) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_groups && flags[i] != 0) steps[i] += 1;
+}
+
 }  // namespace
 
-// step >= 1; bias corrections bc1 = 1 - b1^step, bc2 = 1 - b2^step are evaluated on the host in double precision
+// step >= 1; bias corrections bc1 = 1 - b1^step, bc2 = 1 - b2^step are evaluated on the host in double precision.
+// grad_scale multiplies the gradient before the weight decay is added (1 / loss scale: the reference's GradScaler.step unscales
+// the gradients before the optimizer sees them, ns/engine/optimizers.py:118-131).
 extern "C" int ps_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                            float eps, float weight_decay, int step, void* stream) {
+                            float eps, float weight_decay, int step, float grad_scale, void* stream) {
   if (n == 0) return 0;
   PS_REQUIRE(step >= 1, "ps_adam_step: step counts from 1");
   PS_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
@@ -101,38 +124,65 @@ extern "C" int ps_adam_step(float* p, const float* g, float* m, float* v, int64_
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const int64_t threads = (n + 3) / 4;
   adam_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps,
-                                                                                 weight_decay, (float)bc1, (float)sqrt(bc2));
+                                                                                 weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
   PS_CHECK_LAUNCH();
 }
 
-// n_ranges disjoint ranges [start[i], start[i]+count[i]) (floats, start a multiple of 4) of the flat buffers, range i at
-// its own step count step[i] >= 1; start / count / step are HOST arrays.  ceil(n_ranges / 32) launches.
+// n_ranges disjoint, non-empty ranges [start[i], start[i]+count[i]) (floats, start a multiple of 4) of the flat buffers;
+// start / count / step / group are HOST arrays.  group == NULL or group[i] < 0: range i is updated at the host-side step count
+// step[i] >= 1.  group[i] >= 0: the device decides (see adam_ranges_kernel) from group_flags[group[i]] / group_steps[group[i]]
+// (device int32 arrays of n_groups entries); after the last launch the step counts of the flagged groups are advanced by one.
+// ceil(n_ranges / 32) launches (+ 1 when groups are given).
 extern "C" int ps_adam_step_ranges(float* p, const float* g, float* m, float* v, int n_ranges, const int64_t* start,
-                                   const int64_t* count, const int* step, float lr, float beta1, float beta2, float eps,
-                                   float weight_decay, void* stream) {
+                                   const int64_t* count, const int* step, const int* group, const int32_t* group_flags,
+                                   int32_t* group_steps, int n_groups, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, float grad_scale, void* stream) {
   PS_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "ps_adam_step_ranges: buffers must be 16-byte aligned");
+  for (int i = 0; i < n_ranges; ++i) {
+    PS_REQUIRE(count[i] > 0, "ps_adam_step_ranges: empty range");
+    PS_REQUIRE((start[i] & 3) == 0, "ps_adam_step_ranges: range starts must be multiples of 4 floats");
+    const int grp = group != nullptr ? group[i] : -1;
+    PS_REQUIRE(grp >= 0 || step[i] >= 1, "ps_adam_step_ranges: step counts from 1");
+    PS_REQUIRE(grp < n_groups && (grp < 0 || (group_flags != nullptr && group_steps != nullptr)), "ps_adam_step_ranges: bad group id");
+  }
   for (int r0 = 0; r0 < n_ranges; r0 += kMaxRanges) {
     AdamRanges R;
     R.n = 0;
     unsigned blocks = 0;
-    for (int i = r0; i < n_ranges && R.n < kMaxRanges; ++i) {
-      if (count[i] <= 0) continue;
-      PS_REQUIRE(step[i] >= 1, "ps_adam_step_ranges: step counts from 1");
-      PS_REQUIRE((start[i] & 3) == 0, "ps_adam_step_ranges: range starts must be multiples of 4 floats");
-      const double bc1 = 1.0 - pow((double)beta1, (double)step[i]), bc2 = 1.0 - pow((double)beta2, (double)step[i]);
+    for (int i = r0; i < n_ranges && i < r0 + kMaxRanges; ++i) {
+      const int grp = group != nullptr ? group[i] : -1;
+      const double st = grp < 0 ? (double)step[i] : 1.0;
       R.start[R.n] = start[i];
       R.count[R.n] = count[i];
       R.blk0[R.n] = blocks;
-      R.bc1[R.n] = (float)bc1;
-      R.bc2_sqrt[R.n] = (float)sqrt(bc2);
+      R.bc1[R.n] = (float)(1.0 - pow((double)beta1, st));
+      R.bc2_sqrt[R.n] = (float)sqrt(1.0 - pow((double)beta2, st));
+      R.group[R.n] = grp;
       blocks += (unsigned)((count[i] + kRangeBlockElems - 1) / kRangeBlockElems);
       ++R.n;
     }
-    if (R.n == 0) continue;
     R.blk0[R.n] = blocks;
-    adam_ranges_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, R, lr, beta1, beta2, eps, weight_decay);
+    adam_ranges_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, R, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                                                                group_flags, group_steps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
   }
-  return 0;
+  if (group != nullptr && n_groups > 0 && group_flags != nullptr)
+    adam_commit_kernel<<<(unsigned)((n_groups + 255) / 256), 256, 0, (hipStream_t)stream>>>(group_flags, group_steps, n_groups);
+  PS_CHECK_LAUNCH();
+}
+
+// flags[group_of_field[k]] = 1 for every sub-field k of the routed layout (ps_ms_route's field_start) that received points;
+// group_of_field[k] < 0: sub-field k has no device-decided group.  One tiny launch, no host synchronisation.
+namespace {
+__global__ void ms_mark_groups_kernel(const int* __restrict__ field_start, int K, const int* __restrict__ group_of_field,
+                                      int* __restrict__ flags) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K && field_start[k + 1] > field_start[k] && group_of_field[k] >= 0) flags[group_of_field[k]] = 1;
+}
+}  // namespace
+extern "C" int ps_ms_mark_groups(const int32_t* field_start, int K, const int32_t* group_of_field, int32_t* flags, void* stream) {
+  PS_REQUIRE(field_start != nullptr && group_of_field != nullptr && flags != nullptr && K >= 1, "ps_ms_mark_groups: null argument");
+  ms_mark_groups_kernel<<<(unsigned)((K + 63) / 64), 64, 0, (hipStream_t)stream>>>(field_start, K, group_of_field, flags);
+  PS_CHECK_LAUNCH();
 }

@@ -465,15 +465,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
   __shared__ unsigned char s_slice[kRec];
   const int n_slices = 1 << (log2T - log2_slice);
   const int64_t chunks = (N + kBinPoints - 1) / kBinPoints;
-#if defined(PS_BIN_LEVEL_MAJOR)
-  const int level = (int)(blockIdx.x / chunks);
-  const int64_t first = (blockIdx.x % chunks) * kBinPoints;
-#else
   // chunk-major: the workgroups in flight spread over all L levels, so their stream reservations (returning global atomics
   // on the 2 cache lines of a level's cursors) contend 1/L as much, and the L reads of a chunk's points hit in L2
   const int level = (int)(blockIdx.x % L);
   const int64_t first = (blockIdx.x / L) * kBinPoints;
-#endif
   if (chunk_field != nullptr) {  // multi-sub-field launch: (sub-field, level) takes the place of the level in the stream index
     const int kf = chunk_field[first / ps::kMsChunk];
     if (kf < 0) return;

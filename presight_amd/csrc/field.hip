@@ -156,10 +156,6 @@ template <int NBLK, int PB>
 __device__ __forceinline__ void store_act(float* __restrict__ acts, int stride, int col0, int64_t first, int64_t N,
                                           const float (&v)[PB][NBLK * 4]) {
   const int lane = ps_lane();
-#if defined(PS_ABLATE) && PS_ABLATE == 14  // timing only: no activation stores (is the forward bound by its HBM writes?)
-  asm volatile("" ::"v"(v[0][0]), "v"(v[PB - 1][NBLK * 4 - 1]));
-  return;
-#endif
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
     const int64_t blk = first / 16 + pb;  // 16-point block index
@@ -182,11 +178,7 @@ __device__ __forceinline__ void load_act(const float* __restrict__ acts, int str
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb) {
       f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if defined(PS_ABLATE) && PS_ABLATE == 12  // timing only: no activation traffic (how much HBM latency does the backward expose?)
-      t = (f32x4){0.25f, 0.f, 0.5f, 0.f};
-#else
       if (blk * 16 < N) t = *reinterpret_cast<const f32x4*>(base + nb * 256);
-#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[pb][4 * nb + r] = t[r];
     }
@@ -855,11 +847,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           dzb[pb][t] += dcin[pb][4 + t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
-#if defined(PS_ABLATE) && PS_ABLATE == 11  // timing only: no d(appearance) atomics
-          if (false) {
-#else
           if (a.dapp != nullptr) {
-#endif
             const int c = 4 * t + g;
             float v = pt_ok ? dcin[pb][8 + t] : 0.0f;
             float vs = v;
@@ -878,11 +866,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_kernel(MainArgs a) {
     // ---- base MLP backward -> d(features)
     float dx[PB][C::Base::L0::IB * 4];
     mlp_backward<typename C::Base, PB, true>(pk_base, scratch, gacc + C::G_BASE, locks + 0, x, h1, hdummy, dzb, dx);
-#if defined(PS_ABLATE) && PS_ABLATE == 10  // timing only: no d(feature) stores
-    asm volatile("" ::"v"(dx[0][0]), "v"(dx[1][0]), "v"(dx[0][7]), "v"(dx[1][7]), "v"(dx[0][3]), "v"(dx[1][4]));
-#else
     store_dfeat<C::Base::KS0, PB>(a.dfeat, a.plane_stride, a.LF, a.F, first, a.N, dx);
-#endif
     PS_TSTAMP(4)
   }
 #if defined(PS_TIMING)
@@ -1468,10 +1452,9 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
   return -2;
 }
 
-int g_main_bwd_stages = 7;  // which kernels of the three-kernel backward a call launches (ps_main_field_bwd_stages)
-
-int main_bwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
-  const int st = g_main_bwd_stages;
+// stages: which kernels of the three-kernel backward this call launches (bit 0 semantic head, 1 colour head, 2 base MLP)
+int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStream_t s) {
+  const int st = stages & 7;
   if (a.N == 0) return 0;
   PS_REQUIRE(a.acts == nullptr || (a.drgb != nullptr && a.dsem != nullptr), "ps_main_field_bwd: kept activations need both head gradients");
   PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
@@ -1522,12 +1505,12 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
 extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                  const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
                                  const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t N,
-                                 float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch, void* stream) {
+                                 float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch, int stages, void* stream) {
   MainArgs a{};
   a.dzb = dzb_scratch;
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
   a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts); a.K = 1;
-  return main_bwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
+  return main_bwd_impl(a, hidden, hidden_color, stages, (hipStream_t)stream);
 }
 
 // multi-sub-field launches: feat / sel / acts / dfeat in the sorted layout (n_slots), everything else in the caller's order
@@ -1546,7 +1529,7 @@ extern "C" int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int
                                     const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
                                     const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t n_slots,
                                     float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch, float* dapp_points,
-                                    const int32_t* perm, const int32_t* field_start, int K, void* stream) {
+                                    const int32_t* perm, const int32_t* field_start, int K, int stages, void* stream) {
   PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_bwd_ms: need the sorted layout");
   PS_REQUIRE(dapp_points == nullptr || (dzb_scratch != nullptr && acts != nullptr), "ps_main_field_bwd_ms: per-point d(appearance) belongs to the three-kernel backward");
   MainArgs a{};
@@ -1555,13 +1538,7 @@ extern "C" int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
   a.packed = packed; a.N = n_slots; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts);
   a.perm = perm; a.field_start = field_start; a.K = K;
-  return main_bwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
-}
-
-extern "C" int ps_main_field_bwd_stages(int mask) {
-  const int prev = g_main_bwd_stages;
-  g_main_bwd_stages = mask & 7;
-  return prev;
+  return main_bwd_impl(a, hidden, hidden_color, stages, (hipStream_t)stream);
 }
 
 #if defined(PS_TIMING)

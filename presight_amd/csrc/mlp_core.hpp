@@ -95,12 +95,7 @@ struct GlobalW {
   __amdgpu_buffer_rsrc_t rsrc;
   int base;  // float offset inside the buffer
   __device__ __forceinline__ f32x4 frag4(int float_off) const {
-#if defined(PS_ABLATE) && PS_ABLATE == 9  // timing only: no weight-fragment traffic from L2 (how much of the kernel is its latency?)
-    const float v = (float)((ps_lane() + float_off) & 7) * 0.01f;
-    return (f32x4){v, v, v, v};
-#else
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)ps_lane() * 16u, (base + float_off) * 4, 0));
-#endif
   }
   __device__ __forceinline__ f32x4 vec4(int float_off) const {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0u, (base + float_off) * 4, 0));
@@ -314,9 +309,6 @@ __device__ __forceinline__ float ps_sel4(const f32x4& v, int r) {
 template <class LT, int PB>
 __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, float* __restrict__ gacc, int* __restrict__ lock,
                                                   const float (&dvout)[PB][LT::NB * 4], const float (&vin)[PB][LT::KS]) {
-#if defined(PS_ABLATE) && PS_ABLATE == 4
-  return;
-#endif
   const int lane = ps_lane();
   const int j = lane & 15, g = lane >> 4;
   if constexpr (PB == 1) {
@@ -360,12 +352,10 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
       for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int r = 0; r < 4; ++r) db2[o][r] = (ob0 + o < LT::NB) ? ps_row16_sum(dvout[0][4 * (ob0 + o < LT::NB ? ob0 + o : 0) + r]) : 0.0f;
-#if !(defined(PS_ABLATE) && PS_ABLATE == 7)
       if (lane == 0) {
         while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
 #pragma unroll
       for (int o = 0; o < 2; ++o) {
         if (ob0 + o < LT::NB) {
@@ -380,10 +370,8 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
           }
         }
       }
-#if !(defined(PS_ABLATE) && PS_ABLATE == 7)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) atomicExch(lock, 0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     return;
@@ -405,11 +393,7 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
     f32x4 bfrag[LT::IB];
 #pragma unroll
     for (int ib = 0; ib < LT::IB; ++ib) {
-#if defined(PS_ABLATE) && PS_ABLATE == 13  // timing only: the transposed operands do not come back from LDS (exposed staging latency?)
-      bfrag[ib] = (f32x4){vin[pb][0], vin[pb][1], vin[pb][2], vin[pb][3]};
-#else
       bfrag[ib] = *reinterpret_cast<const f32x4*>(scratch + (16 * ib + j) * kScratchLd + 4 * g);
-#endif
     }
     __builtin_amdgcn_wave_barrier();
     // stage dY over the same rows, at most OBG output blocks at a time
@@ -421,11 +405,7 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int ob = ob0; ob < ob0 + LT::OBG && ob < LT::NB; ++ob) {
-#if defined(PS_ABLATE) && PS_ABLATE == 13
-        const f32x4 afrag = (f32x4){dvout[pb][4 * ob], dvout[pb][4 * ob + 1], dvout[pb][4 * ob + 2], dvout[pb][4 * ob + 3]};
-#else
         const f32x4 afrag = *reinterpret_cast<const f32x4*>(scratch + (16 * (ob - ob0) + j) * kScratchLd + 4 * g);
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -434,10 +414,6 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
       __builtin_amdgcn_wave_barrier();
     }
   }
-#if defined(PS_ABLATE) && PS_ABLATE == 3
-  asm volatile("" ::"v"(dw[0][0][0]));
-  return;
-#endif
   // bias gradient partials: sum over the wave's points, reduced over the 16 lanes of a row
   f32x4 db[LT::NB];
 #pragma unroll
@@ -447,36 +423,17 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
       float s = 0.f;
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) s += dvout[pb][4 * nb + r];
-#if defined(PS_ABLATE) && PS_ABLATE == 2
-      db[nb][r] = s;
-#else
       db[nb][r] = ps_row16_sum(s);
-#endif
     }
-#if defined(PS_ABLATE) && PS_ABLATE == 1
-  asm volatile("" ::"v"(dw[0][0][0]), "v"(db[0][0]));
-  return;
-#endif
-#if defined(PS_ABLATE) && PS_ABLATE == 8  // all dW / db values stay live (no dead-code elimination), only the LDS flush is skipped
-#pragma unroll
-  for (int ob = 0; ob < LT::NB; ++ob) {
-#pragma unroll
-    for (int ib = 0; ib < LT::IB; ++ib) asm volatile("" ::"v"(dw[ob][ib][0]), "v"(dw[ob][ib][1]), "v"(dw[ob][ib][2]), "v"(dw[ob][ib][3]));
-    asm volatile("" ::"v"(db[ob][0]), "v"(db[ob][1]), "v"(db[ob][2]), "v"(db[ob][3]));
-  }
-  return;
-#endif
   // Flush into the workgroup accumulators WITHOUT LDS float atomics (ds_add_f32 retires ~1 lane per 10 cycles on
   // gfx950, measured 20x slower than integer LDS atomics or plain LDS traffic): the wave takes this layer's LDS
   // spin lock (integer compare-and-swap, fast), does plain read-modify-writes and releases.  The four waves of a
   // workgroup drift apart after the first collision, so the lock is almost always free; there is no workgroup
   // barrier on this path.
-#if !(defined(PS_ABLATE) && PS_ABLATE == 7)  // 7: racy, timing only -- what do the lock and its contention cost?
   if (lane == 0) {
     while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
   // accumulator layout [tile][lane][4]: one 16-byte LDS read + write per 16x16 tile and lane
 #pragma unroll
   for (int ob = 0; ob < LT::NB; ++ob)
@@ -491,10 +448,8 @@ __device__ __forceinline__ void layer_bwd_weights(float* __restrict__ scratch, f
 #pragma unroll
       for (int r = 0; r < 4; ++r) gacc[LT::GB_OFF + 16 * nb + 4 * g + r] += db[nb][r];
   }
-#if !(defined(PS_ABLATE) && PS_ABLATE == 7)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane == 0) atomicExch(lock, 0);
-#endif
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -831,7 +786,6 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
   using LZ = typename M::LZ;
   const W tz = params.at(M::TOFFZ), t1 = params.at(M::TOFF1), t0 = params.at(M::TOFF0);
   float dh[PB][M::HB * 4];
-#if !defined(PS_BWD_NO_PIPE)
   if constexpr (PB >= 2) {
     // pipelined order (layer_bwd_pipe): per layer dX first, then dW; the first transposed fragments of the next layer are
     // requested before the last dW MFMAs of the current one
@@ -857,7 +811,6 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
     }
     return;
   }
-#endif
   // the first transposed fragments of every data-backward layer are requested before the (long, fragment-free)
   // weight-gradient phase that precedes it
   float az[LZ::KSO];

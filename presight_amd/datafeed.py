@@ -137,8 +137,23 @@ class ChunkFeed:
 
     def _swap(self):
         res = self._next.result() if self._next is not None else self._produce(self._next_index)
+        old_chunk, old_order = self.chunk, self.order
         self.chunk, self.order, ev = res
-        torch.cuda.current_stream(self.device).wait_event(ev)  # device-side wait; the host does not block on the upload
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)  # device-side wait; the host does not block on the upload
+        # The chunk tensors were allocated on the side stream but are read by gather kernels on the training stream, and the
+        # host runs ahead of the GPU: without this the caching allocator would hand the OLD chunk's blocks (freed right here)
+        # back to the side stream, and the next upload could overwrite them while a gather of the old chunk is still queued.
+        # record_stream keeps a block from being reused until the work enqueued on `cur` so far has finished.
+        for obj in (old_chunk, self.chunk):
+            if obj is not None:
+                for name in ("rgbs", "pixel_indices", "image_indices", "video_ids", "widths", "skies", "depths", "features"):
+                    t = getattr(obj, name)
+                    if t is not None and t.is_cuda:
+                        t.record_stream(cur)
+        for t in (old_order, self.order):
+            if t is not None and t.is_cuda:
+                t.record_stream(cur)
         self.chunk_index = self._next_index
         self.pos = 0
         self.chunks_loaded += 1

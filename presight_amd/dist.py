@@ -111,6 +111,37 @@ class FlatGrads:
         self._dirty: Optional[List[Tuple[int, int]]] = None  # ranges that may be non-zero (None = unknown -> everything)
         self._param_events: Dict[int, object] = {}
         self.stats = {"collectives": 0, "bytes": 0}
+        # device-decided "received a gradient this step" groups (define_groups): routed sub-fields
+        self.group_flags: Optional[Tensor] = None   # int32 [n_groups], 1 = the group's sub-field received samples this step
+        self.group_steps: Optional[Tensor] = None   # int32 [n_groups], torch.optim.Adam's state["step"] of the group
+        self.n_groups = 0
+
+    def define_groups(self, groups: Sequence[Sequence[torch.nn.Parameter]]):
+        """Parameters whose "received a gradient this step" is only known ON THE DEVICE: the sub-fields of a routed tile (the
+        router never synchronises with the host, so the host cannot know which sub-fields got samples).  groups[i] = the
+        parameters of one sub-field of one routed module; they receive gradients together.  The routed backward nodes raise
+        group_flags[i] on the device (ps_ms_mark_groups), the optimizer kernel skips a group whose flag is down (parameters,
+        moments and step count untouched, like torch.optim.Adam with grad None: the reference never calls an empty sub-field,
+        ns/fields/PreSight/ingp_field_ms.py:97-126) and keeps the groups' step counts on the device.  Under data parallelism
+        the flags are MAX-reduced over the ranks in finish_exchange (DDP: used on ANY rank -> averaged gradient everywhere),
+        which also makes the host-side flags rank-independent (no flag all-reduce, no host sync)."""
+        index = {id(p): i for i, p in enumerate(self.params)}
+        n = 0
+        for plist in groups:
+            plist = [p for p in plist if id(p) in index]
+            if not plist:
+                continue
+            for p in plist:
+                if getattr(p, "_ps_group", None) is not None:
+                    raise ValueError("FlatGrads.define_groups: a parameter belongs to two groups")
+                p._ps_group = n
+                p._ps_group_owner = self
+            n += 1
+        self.n_groups = n
+        dev = self.flat.device
+        self.group_flags = torch.zeros(max(n, 1), device=dev, dtype=torch.int32)
+        self.group_steps = torch.zeros(max(n, 1), device=dev, dtype=torch.int32)
+        self.flags_may_differ_across_ranks = False
 
     # ------------------------------------------------------------------ per-step bookkeeping
     def zero_(self):
@@ -124,6 +155,8 @@ class FlatGrads:
             for a, b in self._dirty:
                 self.flat[a:b].zero_()
         self._dirty = None
+        if self.n_groups:
+            self.group_flags.zero_()
         for p in self.params:
             p._ps_touched = False
         for b in self._buckets:
@@ -248,6 +281,8 @@ class FlatGrads:
 
     def finish_exchange(self):
         """after backward: launch the buckets that are still local (in order), then make the compute stream wait for all of them"""
+        if self.n_groups and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
+            dist.all_reduce(self.group_flags, op=dist.ReduceOp.MAX, group=self._group)  # device tensor, stream-ordered: no host sync
         if not self._buckets:
             return self.all_reduce_mean(self._group)
         for b in self._buckets[self._next_launch:]:
@@ -305,6 +340,19 @@ class FlatGrads:
                 dist.all_gather_into_tensor(seg, seg[rank * n:(rank + 1) * n], group=self._group)
             self.stats["collectives"] += 1
             self.stats["bytes"] += 4 * (e - a) * (world - 1) // world
+
+    def gather_flat(self, flat: Tensor):
+        """sharded mode: all-gather the owned shards of `flat` (same layout as the gradient buffer: optimizer moments) so that
+        every rank holds all of it; synchronous, a no-op otherwise.  A collective: every rank must call it."""
+        if self.mode != "sharded" or not self._distributed():
+            return
+        self.wait_params()
+        rank, world = self._rank_world()
+        for b in self._buckets:
+            a, e = b["range"]
+            n = (e - a) // world
+            seg = flat[a:e]
+            dist.all_gather_into_tensor(seg, seg[rank * n:(rank + 1) * n].clone(), group=self._group)
 
     def wait_params(self, bucket: Optional[int] = None):
         """compute stream waits (device side, no host sync) until the parameters of `bucket` (all buckets if None) are back"""

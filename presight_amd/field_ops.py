@@ -290,18 +290,14 @@ def _dzb_scratch(n_points: int, dev):
 
 
 def _bwd_stages(dzb):
-    """one pass normally; while bench.py's per-kernel timing is on, the three kernels of the split backward are launched by three
-    calls, each inside its own HIP-event region (same kernels, same order, same stream)"""
+    """stage masks of ps_main_field_bwd: one call normally; while bench.py's per-kernel timing is on, the three kernels of the
+    split backward are launched by three calls, each inside its own HIP-event region (same kernels, same order, same stream)"""
     if dzb is None or not prof.enabled("main_bwd_sem_kernel"):
-        yield
+        yield 7
         return
-    try:
-        for mask, name in ((1, "main_bwd_sem_kernel"), (2, "main_bwd_rgb_kernel"), (4, "main_bwd_base_kernel")):
-            lib().ps_main_field_bwd_stages(mask)
-            with prof.region(name):
-                yield
-    finally:
-        lib().ps_main_field_bwd_stages(7)
+    for mask, name in ((1, "main_bwd_sem_kernel"), (2, "main_bwd_rgb_kernel"), (4, "main_bwd_base_kernel")):
+        with prof.region(name):
+            yield mask
 
 
 def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
@@ -327,10 +323,10 @@ def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     #  pressure the 8 extra live values cost more (+0.2 ms) than the separate 0.13 ms absmax pass)
     dzb = _dzb_scratch(N, dev) if acts is not None else None
     with prof.region("main_field_bwd"):
-        for _ in _bwd_stages(dzb):
+        for stages in _bwd_stages(dzb):
             check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                           _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                          _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), _stream()), "ps_main_field_bwd")
+                                          _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), stages, _stream()), "ps_main_field_bwd")
     dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts, sink_owner=ctx.table_ref)
     descs = []
     for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
@@ -476,6 +472,28 @@ class MsLayout:
         check(lib().ps_ms_field_points(_p(pos), _p(origins), _p(dirs), _p(ebins), self.S, _p(_f32(aabbs)), int(contract), self.N, self.K,
                                        _p(self.plan), _p(self.perm), _p(u), _p(sel), _stream()), "ps_ms_field_points")
         return u, sel
+
+
+_GROUP_TABLES: dict = {}
+
+
+def mark_groups(lay: "MsLayout", reps: Sequence[Tensor]):
+    """raise, ON THE DEVICE, the "received a gradient this step" flag of every sub-field of the routed layout that got points
+    (presight_amd.dist.FlatGrads.define_groups / ps_ms_mark_groups); reps[k] = any parameter of sub-field k.  The optimizer
+    kernel skips the sub-fields whose flag stays down, as torch.optim.Adam skips the parameters the reference's sub-field loop
+    never touched (ns/fields/PreSight/ingp_field_ms.py:97-126)."""
+    owner = getattr(reps[0], "_ps_group_owner", None)
+    if owner is None:
+        return
+    gids = tuple(-1 if getattr(p, "_ps_group", None) is None else p._ps_group for p in reps)
+    key = (str(reps[0].device), id(owner), gids)
+    tbl = _GROUP_TABLES.get(key)
+    if tbl is None:
+        if len(_GROUP_TABLES) > 64:
+            _GROUP_TABLES.clear()
+        tbl = torch.tensor(gids, dtype=torch.int32, device=reps[0].device)
+        _GROUP_TABLES[key] = tbl
+    check(lib().ps_ms_mark_groups(lay.field_start, lay.K, _p(tbl), _p(owner.group_flags), _stream()), "ps_ms_mark_groups")
 
 
 class _LayerDesc(ctypes.Structure):
@@ -658,7 +676,8 @@ class _PropFieldMS(torch.autograd.Function):
         dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=True)
         dsts, returned = _ms_layer_dsts(wb)
         st.unpack(dsts, lay.field_start, nparts // 4, 4)
-        mark_touched(ctx.direct)
+        mark_touched(ctx.direct, groups_on_device=True)
+        mark_groups(lay, tables)
         return (None, None, None, None, None, *dtables, *returned)
 
 
@@ -722,18 +741,19 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     dapp_pt = torch.empty(lay.N, A, device=u.device) if per_point else None
     dapp = None if (app is None or per_point) else torch.zeros_like(app)
     with prof.region("main_field_bwd"):
-        for _ in _bwd_stages(dzb):
+        for stages in _bwd_stages(dzb):
             check(lib().ps_main_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                              _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(st.packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
                                              _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(dzb), _p(dapp_pt), _p(lay.perm),
-                                             lay.field_start, K, _stream()), "ps_main_field_bwd_ms")
+                                             lay.field_start, K, stages, _stream()), "ps_main_field_bwd_ms")
     if per_point:
         dapp = dapp_pt.view(app.shape[0], S, A).sum(1)
     ws = _ms_scatter_ws(lay, g, u.device)
     dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False)
     dsts, returned = _ms_layer_dsts(wb)
     st.unpack(dsts, lay.field_start, nparts, 1)
-    mark_touched(ctx.direct)
+    mark_touched(ctx.direct, groups_on_device=True)
+    mark_groups(lay, tables)
     return dapp, dtables, returned
 
 
@@ -905,7 +925,10 @@ class _SkyField(torch.autograd.Function):
                                          _p(lay.perm) if lay else None, lay.field_start if lay else None, K, _stream()), "ps_sky_field_bwd")
         dsts, returned = _ms_layer_dsts(params)
         st.unpack(dsts, lay.field_start if lay else _single_field_start(dirs.device, N), npart.value, 1)
-        mark_touched(ctx.direct)
+        mark_touched(ctx.direct, groups_on_device=lay is not None)
+        if lay is not None:
+            per = len(params) // K
+            mark_groups(lay, [params[k * per] for k in range(K)])
         return (None, None, dapp, *returned)
 
 

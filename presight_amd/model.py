@@ -16,6 +16,7 @@ from torch import Tensor, nn
 from torch.nn import Parameter
 
 from . import ops
+from .callbacks import TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation  # noqa: F401
 from .components import Embedding, SceneContraction
 from .fields import (FieldHeadNames, PropNetDensityField, PropNetDensityFieldMS, SkyField, SkyFieldMS, iNGPField,
                      iNGPFieldMS)
@@ -172,7 +173,11 @@ class NerfactoNuscMSModel(nn.Module):
 
         if c.proposal_initial_sampler != "piecewise":
             raise NotImplementedError("presight_amd: only the piecewise initial sampler (PreSight default) is built")
-        initial_sampler = SpacedSampler(piecewise_threshold=c.piecewise_sampler_threshold, single_jitter=c.use_single_jitter)
+        thr = c.piecewise_sampler_threshold  # the reference's exact construction (nerfacto_nusc_ms.py:311-316)
+        initial_sampler = SpacedSampler(
+            spacing_fn=lambda x: torch.where(x < thr, x / (2 * thr), 1 - 1 / (2 * x / thr)),
+            spacing_fn_inv=lambda x: torch.where(x < 0.5, x * (2 * thr), thr / (2 - 2 * x)),
+            single_jitter=c.use_single_jitter)
         self.proposal_sampler = ProposalNetworkSampler(
             num_nerf_samples_per_ray=c.num_nerf_samples_per_ray, num_proposal_samples_per_ray=c.num_proposal_samples_per_ray,
             num_proposal_network_iterations=c.num_proposal_iterations, single_jitter=c.use_single_jitter,
@@ -216,13 +221,19 @@ class NerfactoNuscMSModel(nn.Module):
         b = self.config.proposal_weights_anneal_slope
         return float(b * x / ((b - 1) * x + 1))
 
-    def before_train_iteration(self, step: int):
-        self.step = step
+    def get_training_callbacks(self, training_callback_attributes=None) -> List[TrainingCallback]:
+        """nerfacto_nusc_ms.py:417-450: the proposal-weight anneal before every iteration, the sampler's step counter after it"""
+        callbacks = []
         if self.config.use_proposal_weight_anneal:
-            self.proposal_sampler.set_anneal(self.anneal_for_step(step))
+            def set_anneal(step):
+                self.step = step
+                self.proposal_sampler.set_anneal(self.anneal_for_step(step))
 
-    def after_train_iteration(self, step: int):
-        self.proposal_sampler.step_cb(step)
+            callbacks.append(TrainingCallback(where_to_run=[TrainingCallbackLocation.BEFORE_TRAIN_ITERATION], update_every_num_iters=1,
+                                              func=set_anneal))
+            callbacks.append(TrainingCallback(where_to_run=[TrainingCallbackLocation.AFTER_TRAIN_ITERATION], update_every_num_iters=1,
+                                              func=self.proposal_sampler.step_cb))
+        return callbacks
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, ray_bundle: RayBundle, jitters: Optional[List[Tensor]] = None):
@@ -306,6 +317,21 @@ class NerfactoNuscMSModel(nn.Module):
     def get_metrics_dict(self, outputs, batch):
         mse = torch.mean((outputs["rgb"] - batch["rgb"][..., :3]) ** 2)
         return {"psnr": 10.0 * torch.log10(1.0 / mse)}  # torchmetrics PSNR(data_range=1.0), nerfacto_nusc_ms.py:382,554
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
+        """nerfacto_nusc_ms.py:647-686: (metrics, images) of one rendered evaluation image.  PSNR as torchmetrics computes it
+        (data_range = 1.0); ssim / lpips are third-party networks of the reference's logging and are not part of this path."""
+        gt_rgb = self.renderer_rgb.blend_background(batch["rgb"].to(outputs["rgb"].device))
+        predicted_rgb = outputs["rgb"]
+        acc = apply_colormap(outputs["accumulation"])
+        depth = apply_depth_colormap(outputs["depth"], accumulation=outputs["accumulation"])
+        images_dict = {"img": torch.cat([gt_rgb, predicted_rgb], dim=1), "accumulation": acc, "depth": depth}
+        mse = torch.mean((gt_rgb - predicted_rgb) ** 2)
+        metrics_dict = {"psnr": float(10.0 * torch.log10(1.0 / mse))}
+        for i in range(self.config.num_proposal_iterations):
+            key = f"prop_depth_{i}"
+            images_dict[key] = apply_depth_colormap(outputs[key], accumulation=outputs["accumulation"])
+        return metrics_dict, images_dict
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
         """nerfacto_nusc_ms.py:558-645 (camera-only); every term is scaled by its *_loss_mult INSIDE the loss launch
@@ -399,6 +425,35 @@ class NerfactoNuscMSModel(nn.Module):
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle):
         return self._chunked(camera_ray_bundle, lambda rb: self.forward(ray_bundle=rb))
+
+
+def apply_colormap(image: Tensor, eps: float = 1e-9) -> Tensor:
+    """ns/utils/colormaps.py:46-115 for the cases the model uses: 3 channels pass through, 1 float channel goes through the
+    "turbo" map (the reference looks it up in matplotlib's 256-entry table; this is the published polynomial fit of the same
+    map -- a visualisation, not a compared quantity)."""
+    if image.shape[-1] == 3:
+        return image
+    x = torch.clip(torch.nan_to_num(image[..., 0], 0.0), 0.0, 1.0)
+    v4 = torch.stack([torch.ones_like(x), x, x * x, x * x * x], -1)
+    v2 = torch.stack([x ** 4, x ** 5], -1)
+    r4 = v4.new_tensor([0.13572138, 4.61539260, -42.66032258, 132.13108234])
+    g4 = v4.new_tensor([0.09140261, 2.19418839, 4.84296658, -14.18503333])
+    b4 = v4.new_tensor([0.10667330, 12.64194608, -60.58204836, 110.36276771])
+    r2, g2, b2 = v2.new_tensor([-152.94239396, 59.28637943]), v2.new_tensor([4.27729857, 2.82956604]), v2.new_tensor([-89.90310912, 27.34824973])
+    rgb = torch.stack([v4 @ r4 + v2 @ r2, v4 @ g4 + v2 @ g2, v4 @ b4 + v2 @ b2], -1)
+    return torch.clip(rgb, 0.0, 1.0)
+
+
+def apply_depth_colormap(depth: Tensor, accumulation: Optional[Tensor] = None, near_plane: Optional[float] = None,
+                         far_plane: Optional[float] = None) -> Tensor:
+    """ns/utils/colormaps.py:117-149"""
+    near_plane = near_plane or float(torch.min(depth))
+    far_plane = far_plane or float(torch.max(depth))
+    depth = torch.clip((depth - near_plane) / (far_plane - near_plane + 1e-10), 0, 1)
+    colored = apply_colormap(depth)
+    if accumulation is not None:
+        colored = colored * accumulation + (1 - accumulation)
+    return colored
 
 
 def apply_feature_colormap(image: Tensor, dino_to_rgb: dict) -> Tensor:

@@ -181,13 +181,21 @@ def direct_params(*tensors) -> list:
     return [t for t in tensors if t is not None and grad_sink(t) is not None]
 
 
-def mark_touched(params):
-    """tell the owner of the flat gradient buffer that these parameters received a gradient this step"""
+def mark_touched(params, groups_on_device: bool = False):
+    """tell the owner of the flat gradient buffer that these parameters received a gradient this step.  Parameters of a
+    device-decided group (FlatGrads.define_groups: routed sub-fields) additionally need their group flag raised on the device:
+    the routed backward nodes do that themselves from the layout (groups_on_device=True, field_ops.mark_groups); any other
+    node that reaches such a parameter (a sub-field called directly) raises it here."""
+    raised = set()
     for t in params:
         cb = getattr(t, "_ps_on_touch", None)  # bucketed gradient exchange: FlatGrads.enable_overlap
         if cb is not None:
             cb(t)
         t._ps_touched = True
+        gid = getattr(t, "_ps_group", None)
+        if gid is not None and not groups_on_device and (id(t._ps_group_owner), gid) not in raised:
+            raised.add((id(t._ps_group_owner), gid))
+            t._ps_group_owner.group_flags[gid:gid + 1].fill_(1)
 
 
 def unpack_layers(descs: list, n_parts: int, part_stride: int, device, sinks=None) -> list:

@@ -15,8 +15,11 @@ from .ops import _p, _stream
 
 class HipAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-15,
-                 weight_decay: float = 1e-5, flat_grads=None):
-        """flat_grads: a presight_amd.dist.FlatGrads over exactly `params` -> parameters and both moments are moved into
+                 weight_decay: float = 1e-5, flat_grads=None, grad_scale: float = 1.0):
+        """grad_scale: factor applied to every gradient inside the kernel before the weight decay is added -- 1 / loss_scale
+        when the backward pass was seeded with a loss scale (the reference's GradScaler.step unscales first,
+        ns/engine/optimizers.py:118-131).
+        flat_grads: a presight_amd.dist.FlatGrads over exactly `params` -> parameters and both moments are moved into
         flat buffers of the same layout (every parameter's storage is re-pointed to a view of the flat buffer, values
         kept) and the whole update is ONE kernel launch over the flat range instead of one per tensor."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and p.numel() > 0]
@@ -24,6 +27,7 @@ class HipAdam:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("HipAdam: parameters must be contiguous fp32 CUDA tensors")
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.grad_scale = float(grad_scale)
         self.step_count = 0  # optimizer steps taken (informational; the bias corrections use the per-parameter counts)
         self.steps: List[int] = [0] * len(self.params)  # torch's state[p]["step"]
         self.flat = None
@@ -59,29 +63,34 @@ class HipAdam:
         if self.flat is not None:
             fg = self.flat_grads
             idx = fg.touched_params()
-            for i in idx:
-                self.steps[i] += 1
-            # adjacent touched parameters with the same step count merge into one range; in sharded data-parallel mode this
-            # rank only updates the shard it owns (presight_amd.dist: reduce-scatter -> Adam on the shard -> all-gather)
+            gid = [getattr(self.params[i], "_ps_group", None) if fg.n_groups else None for i in idx]
+            for i, gr in zip(idx, gid):
+                if gr is None:
+                    self.steps[i] += 1  # (the step counts of device-decided groups live on the device: fg.group_steps)
+            # adjacent touched parameters of the same group / with the same host step count merge into one range; in sharded
+            # data-parallel mode this rank only updates the shard it owns (reduce-scatter -> Adam on the shard -> all-gather)
             runs: List[list] = []
-            for i in idx:
+            for i, gr in zip(idx, gid):
                 a, b = fg.offsets[i], fg.offsets[i] + fg._pad(self.params[i].numel())
-                if runs and runs[-1][1] == a and runs[-1][2] == self.steps[i]:
+                key = ("g", gr) if gr is not None else ("s", self.steps[i])
+                if runs and runs[-1][1] == a and runs[-1][2] == key:
                     runs[-1][1] = b
                 else:
-                    runs.append([a, b, self.steps[i]])
+                    runs.append([a, b, key])
             owned = fg.owned_ranges()
             ranges = []
-            for a, b, st in runs:
+            for a, b, key in runs:
                 for x, y in intersect_ranges([(a, b)], owned):
-                    ranges.append((x, y - x, st))
+                    ranges.append((x, y - x, key))
             if ranges:
                 n = len(ranges)
                 starts = (ctypes.c_int64 * n)(*[r[0] for r in ranges])
                 counts = (ctypes.c_int64 * n)(*[r[1] for r in ranges])
-                steps = (ctypes.c_int * n)(*[r[2] for r in ranges])
+                steps = (ctypes.c_int * n)(*[(r[2][1] if r[2][0] == "s" else 0) for r in ranges])
+                groups = (ctypes.c_int * n)(*[(r[2][1] if r[2][0] == "g" else -1) for r in ranges])
                 check(lib().ps_adam_step_ranges(_p(self.flat[0]), _p(self.flat[1]), _p(self.flat[2]), _p(self.flat[3]), n, starts, counts,
-                                                steps, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, s),
+                                                steps, groups, _p(fg.group_flags), _p(fg.group_steps), fg.n_groups, self.lr,
+                                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.grad_scale, s),
                       "ps_adam_step_ranges")
             fg.gather_params(self.flat[0], [(a, b) for a, b, _ in runs])  # no-op unless the exchange is sharded
             return
@@ -93,19 +102,46 @@ class HipAdam:
                 g = g.contiguous()
             self.steps[i] += 1
             check(lib().ps_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                     self.weight_decay, self.steps[i], s), "ps_adam_step")
+                                     self.weight_decay, self.steps[i], self.grad_scale, s), "ps_adam_step")
 
     def zero_grad(self):
         for p in self.params:
             if p.grad is not None:
                 p.grad.zero_()
 
+    def param_steps(self) -> List[int]:
+        """torch's state[p]["step"] per parameter; the counts of device-decided groups (FlatGrads.define_groups) are read back
+        from the device (one synchronising copy: checkpointing / tests only)"""
+        out = list(self.steps)
+        fg = getattr(self, "flat_grads", None)
+        if fg is not None and fg.n_groups:
+            dev = fg.group_steps.tolist()
+            for i, p in enumerate(self.params):
+                gr = getattr(p, "_ps_group", None)
+                if gr is not None:
+                    out[i] = dev[gr]
+        return out
+
     def state_dict(self):
-        return {"step": self.step_count, "steps": list(self.steps), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
+        """Checkpoint payload.  With a sharded gradient exchange every rank's moments are valid on its OWNED shard only: they
+        are all-gathered here (a collective: call it on every rank), so that any rank's state_dict is complete."""
+        fg = getattr(self, "flat_grads", None)
+        if fg is not None and self.flat is not None:
+            fg.gather_flat(self.flat[2])
+            fg.gather_flat(self.flat[3])
+        return {"step": self.step_count, "steps": self.param_steps(), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
 
     def load_state_dict(self, sd):
         self.step_count = sd["step"]
         self.steps = list(sd.get("steps", [sd["step"]] * len(self.params)))
+        fg = getattr(self, "flat_grads", None)
+        if fg is not None and fg.n_groups:
+            host = fg.group_steps.tolist()
+            for i, p in enumerate(self.params):
+                gr = getattr(p, "_ps_group", None)
+                if gr is not None:
+                    host[gr] = self.steps[i]
+            fg.group_steps.copy_(torch.tensor(host, dtype=torch.int32))
         for a, b in zip(self.exp_avg, sd["exp_avg"]):
             a.copy_(b)
         for a, b in zip(self.exp_avg_sq, sd["exp_avg_sq"]):

@@ -1,8 +1,9 @@
 """Samplers of the PreSight model on the HIP kernels (same names / arguments / call protocol as
 ns/model_components/ray_samplers.py: SpacedSampler :53-128, PDFSampler :251-372, ProposalNetworkSampler :523-614).
 
-The piecewise spacing of ns/models/PreSight/nerfacto_nusc_ms.py:312-317 is built into the kernels; it is selected
-with `piecewise_threshold` instead of a pair of python lambdas (a python callable cannot run inside a HIP kernel)."""
+The piecewise spacing of ns/models/PreSight/nerfacto_nusc_ms.py:312-317 is built into the kernels (a python callable
+cannot run inside a HIP kernel): SpacedSampler keeps the reference's constructor (two spacing lambdas), recovers the threshold
+from them by probing and REJECTS callables that are not that piecewise spacing."""
 from __future__ import annotations
 
 from typing import Callable, List, Optional, Tuple
@@ -32,17 +33,55 @@ def _near_far(ray_bundle: RayBundle) -> Tuple[float, float]:
     return nf
 
 
-class SpacedSampler(Sampler):
-    """Piecewise spaced sampler: s(t) = t/(2 thr) for t < thr, 1 - thr/(2 t) otherwise."""
+def piecewise_threshold_of(spacing_fn: Callable, spacing_fn_inv: Optional[Callable] = None) -> float:
+    """Recover `thr` from the pair of callables the reference hands to SpacedSampler
+    (ns/models/PreSight/nerfacto_nusc_ms.py:311-316):  s(t) = t / (2 thr) for t < thr, 1 - thr / (2 t) otherwise, with inverse
+    x < .5 ? 2 thr x : thr / (2 - 2x).  A python callable cannot run inside a HIP kernel, so the kernels implement exactly this
+    family; the callables are probed on the host, and anything that is not a member of the family is REJECTED (never ignored)."""
+    probe = torch.tensor([1e-4, 1e-3], dtype=torch.float64)
+    s = torch.as_tensor(spacing_fn(probe), dtype=torch.float64)
+    if not bool(torch.all(s > 0)):
+        raise NotImplementedError("presight_amd SpacedSampler: spacing_fn is not the piecewise spacing of nerfacto_nusc_ms.py:312-317")
+    thr = float((probe / (2.0 * s)).mean())
+    t = torch.tensor([0.05, 0.3, 0.999, 1.0, 1.5, 4.0, 40.0, 1000.0], dtype=torch.float64) * thr
+    want = torch.where(t < thr, t / (2 * thr), 1 - thr / (2 * t))
+    got = torch.as_tensor(spacing_fn(t.to(torch.float32)), dtype=torch.float64)
+    if not torch.allclose(got, want, rtol=1e-5, atol=1e-6):
+        raise NotImplementedError(f"presight_amd SpacedSampler: spacing_fn is not t/(2 thr) | 1 - thr/(2 t) (thr probed as {thr:g}); "
+                                  "only the piecewise spacing of nerfacto_nusc_ms.py:312-317 runs in the kernels")
+    if spacing_fn_inv is not None:
+        x = torch.tensor([0.01, 0.25, 0.499, 0.5, 0.75, 0.99], dtype=torch.float32)
+        want_inv = torch.where(x < 0.5, x * (2 * thr), thr / (2 - 2 * x)).to(torch.float64)
+        got_inv = torch.as_tensor(spacing_fn_inv(x), dtype=torch.float64)
+        if not torch.allclose(got_inv, want_inv, rtol=1e-5, atol=1e-6):
+            raise NotImplementedError("presight_amd SpacedSampler: spacing_fn_inv is not the inverse of the piecewise spacing")
+    return float(round(thr, 6)) if abs(round(thr, 6) - thr) < 1e-7 * max(1.0, thr) else thr
 
-    def __init__(self, piecewise_threshold: float = 1.0, num_samples: Optional[int] = None, train_stratified=True,
-                 single_jitter=False, spacing_fn: Optional[Callable] = None, spacing_fn_inv: Optional[Callable] = None) -> None:
+
+class SpacedSampler(Sampler):
+    """Piecewise spaced sampler: s(t) = t/(2 thr) for t < thr, 1 - thr/(2 t) otherwise.  Constructed like the reference
+    (ns/model_components/ray_samplers.py:53-76: spacing_fn, spacing_fn_inv, num_samples, train_stratified, single_jitter) --
+    the threshold is then recovered from the callables (piecewise_threshold_of) -- or directly with `piecewise_threshold`."""
+
+    def __init__(self, spacing_fn: Optional[Callable] = None, spacing_fn_inv: Optional[Callable] = None, num_samples: Optional[int] = None,
+                 train_stratified=True, single_jitter=False, piecewise_threshold: Optional[float] = None) -> None:
         super().__init__(num_samples=num_samples)
         if not single_jitter:
             raise NotImplementedError("presight_amd SpacedSampler: PreSight uses single_jitter=True")
         self.train_stratified = train_stratified
         self.single_jitter = single_jitter
-        self.thr = float(piecewise_threshold)
+        if spacing_fn is not None:
+            thr = piecewise_threshold_of(spacing_fn, spacing_fn_inv)
+            if piecewise_threshold is not None and abs(thr - float(piecewise_threshold)) > 1e-6 * max(1.0, thr):
+                raise ValueError(f"SpacedSampler: spacing_fn has threshold {thr:g}, piecewise_threshold={piecewise_threshold:g}")
+        elif spacing_fn_inv is not None:
+            raise ValueError("SpacedSampler: spacing_fn_inv without spacing_fn")
+        elif piecewise_threshold is None:
+            raise ValueError("SpacedSampler: pass spacing_fn / spacing_fn_inv (reference signature) or piecewise_threshold")
+        else:
+            thr = float(piecewise_threshold)
+        self.thr = thr
+        self.spacing_fn, self.spacing_fn_inv = spacing_fn, spacing_fn_inv
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, num_samples: Optional[int] = None,
                              jitter: Optional[Tensor] = None) -> RaySamples:

@@ -68,14 +68,95 @@ def test_adam_ranges_launch_equals_single_range_launches(dev):
     s = torch.cuda.current_stream().cuda_stream
     for st, cnt, step in ranges:
         check(lib().ps_adam_step(a[0].data_ptr() + 4 * st, g.data_ptr() + 4 * st, a[1].data_ptr() + 4 * st, a[2].data_ptr() + 4 * st, cnt,
-                                 1e-2, 0.9, 0.999, 1e-15, 1e-5, step, s), "ps_adam_step")
+                                 1e-2, 0.9, 0.999, 1e-15, 1e-5, step, 1.0, s), "ps_adam_step")
     k = len(ranges)
     check(lib().ps_adam_step_ranges(b[0].data_ptr(), g.data_ptr(), b[1].data_ptr(), b[2].data_ptr(), k,
                                     (ctypes.c_int64 * k)(*[r[0] for r in ranges]), (ctypes.c_int64 * k)(*[r[1] for r in ranges]),
-                                    (ctypes.c_int * k)(*[r[2] for r in ranges]), 1e-2, 0.9, 0.999, 1e-15, 1e-5, s), "ps_adam_step_ranges")
+                                    (ctypes.c_int * k)(*[r[2] for r in ranges]), None, None, None, 0, 1e-2, 0.9, 0.999, 1e-15, 1e-5, 1.0, s),
+          "ps_adam_step_ranges")
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert not torch.equal(a[0], p0)
+
+
+def test_adam_unscales_the_loss_scale_like_gradscaler(dev):
+    """The backward pass is seeded with the loss scale 2**10; GradScaler.step unscales the gradients BEFORE Adam adds the
+    weight decay (ns/engine/optimizers.py:118-131).  grad_scale = 1/1024 inside the kernel == torch.optim.Adam on g / 1024
+    (with eps = 1e-15 Adam itself is scale invariant, the weight decay is not)."""
+    from presight_amd.dist import FlatGrads
+    from presight_amd.optim import HipAdam
+
+    torch.manual_seed(3)
+    ref_p = [torch.nn.Parameter(torch.randn(300, 4) * 3), torch.nn.Parameter(torch.randn(77))]
+    hip_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-2, eps=1e-15, weight_decay=1e-2)  # a large decay makes a wrong order of operations visible
+    fg = FlatGrads(hip_p)
+    opt = HipAdam(hip_p, lr=1e-2, eps=1e-15, weight_decay=1e-2, flat_grads=fg, grad_scale=1.0 / 1024)
+    wrong = [p.detach().clone() for p in ref_p]
+    for it in range(4):
+        fg.zero_()
+        for a, b in zip(ref_p, hip_p):
+            g = torch.randn_like(a) * 1e-3
+            a.grad = g.clone()
+            b.grad.copy_((g * 1024).to(dev))
+            b._ps_touched = True
+        ref.step()
+        opt.step()
+    for a, b, w in zip(hip_p, ref_p, wrong):
+        torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=3e-6, atol=3e-7)
+    # the single-tensor entry point takes the same factor
+    solo = HipAdam([torch.nn.Parameter(wrong[0].clone().to(dev))], lr=1e-2, eps=1e-15, weight_decay=1e-2, grad_scale=0.5)
+    chk = torch.optim.Adam([torch.nn.Parameter(wrong[0].clone())], lr=1e-2, eps=1e-15, weight_decay=1e-2)
+    g = torch.randn_like(wrong[0])
+    solo.params[0].grad = (2 * g).to(dev)
+    chk.param_groups[0]["params"][0].grad = g.clone()
+    solo.step()
+    chk.step()
+    torch.testing.assert_close(solo.params[0].detach().cpu(), chk.param_groups[0]["params"][0].detach(), rtol=3e-6, atol=3e-7)
+
+
+def test_adam_skips_groups_whose_device_flag_is_down(dev):
+    """Device-decided groups (FlatGrads.define_groups): a group whose flag is 0 keeps parameters, both moments and its step
+    count BIT-identical; flagged groups advance their own device-side step counts and match torch.optim.Adam."""
+    from presight_amd.dist import FlatGrads
+    from presight_amd.optim import HipAdam
+
+    torch.manual_seed(4)
+    shapes = [(64, 2), (33,), (128, 4), (7, 7), (50,)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    hip_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-2, eps=1e-15, weight_decay=1e-5)
+    fg = FlatGrads(hip_p)
+    fg.define_groups([[hip_p[0], hip_p[1]], [hip_p[2], hip_p[3]]])  # two "sub-fields"; parameter 4 is host-decided
+    opt = HipAdam(hip_p, lr=1e-2, eps=1e-15, weight_decay=1e-5, flat_grads=fg)
+    gen = torch.Generator().manual_seed(5)
+    live = [[0, 1], [1], [], [0], [0, 1], [1]]  # which groups received samples in each step
+    for step, groups in enumerate(live):
+        ref.zero_grad(set_to_none=True)
+        fg.zero_()
+        snap = [(p.detach().clone(), m.clone(), v.clone()) for p, m, v in zip(hip_p, opt.exp_avg, opt.exp_avg_sq)]
+        for i in range(5):
+            gid = {0: 0, 1: 0, 2: 1, 3: 1}.get(i)
+            hip_p[i]._ps_touched = True  # the routed nodes mark every sub-field on the host; the device flag decides
+            if gid is None or gid in groups:
+                g = torch.randn(*shapes[i], generator=gen)
+                ref_p[i].grad = g.clone()
+                hip_p[i].grad.copy_(g.to(dev))
+        for gid in groups:
+            fg.group_flags[gid] = 1
+        ref.step()
+        opt.step()
+        for i in range(4):
+            if {0: 0, 1: 0, 2: 1, 3: 1}[i] not in groups:
+                assert torch.equal(hip_p[i].detach(), snap[i][0]) and torch.equal(opt.exp_avg[i], snap[i][1]) and torch.equal(opt.exp_avg_sq[i], snap[i][2])
+    assert opt.param_steps() == [3, 3, 4, 4, 6] and opt.state_dict()["steps"] == [3, 3, 4, 4, 6]
+    for a, b in zip(hip_p, ref_p):
+        torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=2e-6, atol=2e-7)
+    # checkpoint round trip of the device-side step counts
+    sd = opt.state_dict()
+    fg.group_steps.zero_()
+    opt.load_state_dict(sd)
+    assert opt.param_steps() == [3, 3, 4, 4, 6]
 
 
 def _tiny_model(dev, K=1):

@@ -158,7 +158,11 @@ def test_model_depth_supervised_step():
                    metadata={"video_id": batch["video_ids"][:, None], "directions_norm": dn,
                              "pose_scale_factor": torch.full((256, 1), 0.05, device=dev)})
     model.train()
-    model.before_train_iteration(6000)
+    from presight_amd.callbacks import TrainingCallbackLocation
+
+    for cb in model.get_training_callbacks():
+        cb.run_callback_at_location(6000, TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+    assert model.step == 6000
     out = model(rb)
     ld = model.get_loss_dict(out, batch)
     assert {"expected_depth_loss", "line_of_sight_loss"} <= set(ld)

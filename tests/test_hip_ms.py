@@ -289,6 +289,31 @@ def test_full_size_k16_step_properties(dev):
     for p, t_ in zip(tr.grads.params, touched):
         if not t_:
             assert float(p.grad.abs().max()) == 0.0
+    # Sub-fields without samples: the router decides on the device which of the K sub-fields received points; their group flag
+    # stays down and the optimizer kernel leaves parameters, both moments and the step count BIT-identical (the reference never
+    # calls an empty sub-field, ingp_field_ms.py:97-126, so torch.optim.Adam sees grad None).  Rays of ONE camera only reach a
+    # few of the 16 sub-fields.
+    one_cam = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    one_cam["ray_indices"][:, 0] = 0
+    one_cam["video_ids"][:] = 0
+    for _ in range(2):
+        tr.step(batch)  # every group that can be reached gets moments first
+    before = [(p.detach().clone(), m.clone(), v.clone()) for p, m, v in zip(tr.opt.params, tr.opt.exp_avg, tr.opt.exp_avg_sq)]
+    steps_before = tr.opt.param_steps()
+    tr.step(one_cam)
+    flags = tr.grads.group_flags.tolist()
+    steps_after = tr.opt.param_steps()
+    assert tr.grads.n_groups == 16 * 4 and 0 < sum(flags) < len(flags)
+    n_skipped = 0
+    for i, p in enumerate(tr.opt.params):
+        gid = getattr(p, "_ps_group", None)
+        if gid is not None and flags[gid] == 0:
+            n_skipped += 1
+            assert steps_after[i] == steps_before[i]
+            assert torch.equal(p.detach(), before[i][0]) and torch.equal(tr.opt.exp_avg[i], before[i][1]) and torch.equal(tr.opt.exp_avg_sq[i], before[i][2])
+        elif gid is not None:
+            assert steps_after[i] == steps_before[i] + 1 and not torch.equal(p.detach(), before[i][0])
+    assert n_skipped > 0
 
 
 def test_fused_sky_field_equals_operator_level_path(dev):

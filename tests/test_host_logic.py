@@ -98,6 +98,90 @@ def test_anneal_and_update_schedule_match_reference_formulas():
     assert s.update_sched(0) == 1 and s.update_sched(500) == 2.5 and s.update_sched(5000) == 5
 
 
+def test_spaced_sampler_takes_the_reference_callables():
+    """ns/models/PreSight/nerfacto_nusc_ms.py:311-316 constructs SpacedSampler(spacing_fn=..., spacing_fn_inv=..., single_jitter=...):
+    the threshold is recovered from the callables; a spacing that the kernels do not implement is rejected, never ignored."""
+    from presight_amd.samplers import SpacedSampler, piecewise_threshold_of
+
+    for thr in (1.0, 5.0, 2.5):
+        s = SpacedSampler(spacing_fn=lambda x: torch.where(x < thr, x / (2 * thr), 1 - 1 / (2 * x / thr)),
+                          spacing_fn_inv=lambda x: torch.where(x < 0.5, x * (2 * thr), thr / (2 - 2 * x)), single_jitter=True)
+        assert s.thr == thr
+    assert SpacedSampler(piecewise_threshold=5.0, single_jitter=True).thr == 5.0
+    with pytest.raises(NotImplementedError):
+        SpacedSampler(spacing_fn=lambda x: x, spacing_fn_inv=lambda x: x, single_jitter=True)  # UniformSampler's spacing
+    with pytest.raises(NotImplementedError):
+        SpacedSampler(spacing_fn=lambda x: torch.log(1 + x), spacing_fn_inv=lambda x: torch.exp(x) - 1, single_jitter=True)
+    with pytest.raises(NotImplementedError):  # right spacing, wrong inverse
+        SpacedSampler(spacing_fn=lambda x: torch.where(x < 5.0, x / 10.0, 1 - 1 / (2 * x / 5.0)), spacing_fn_inv=lambda x: x * 10.0,
+                      single_jitter=True)
+    with pytest.raises(ValueError):
+        SpacedSampler(spacing_fn=lambda x: torch.where(x < 5.0, x / 10.0, 1 - 1 / (2 * x / 5.0)), single_jitter=True, piecewise_threshold=1.0)
+    with pytest.raises(ValueError):
+        SpacedSampler(single_jitter=True)
+    assert piecewise_threshold_of(lambda x: torch.where(x < 0.7, x / 1.4, 1 - 0.7 / (2 * x))) == 0.7
+
+
+def test_model_through_the_reference_call_sequence():
+    """What the reference's pipeline / trainer do with a model (ns/pipelines/PreSight/my_pipeline.py:107-118, ns/engine/
+    trainer.py:154-160,252-267): config.setup(**kwargs) -> get_param_groups -> get_training_callbacks(attributes) -> callbacks
+    run before / after every iteration -> get_image_metrics_and_images on a rendered image.  YAML round trip included."""
+    import numpy as np
+
+    from presight_amd import compat
+
+    compat.install()
+    from nerfstudio.engine.callbacks import TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation
+    from nerfstudio.models.PreSight.nerfacto_nusc_ms import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
+
+    conf = NerfactoNuscMSModelConfig(use_lidar_loss=False, num_levels=2, features_per_level=2, log2_hashmap_size=4, max_res=64,
+                                     hidden_dim=32, hidden_dim_color=32, proposal_weights_anneal_max_num_iters=1000,
+                                     piecewise_sampler_threshold=5.0,
+                                     proposal_net_args_list=[dict(features_per_level=1, log2_hashmap_size=4, num_levels=2,
+                                                                  base_res=16, max_res=32, hidden_dim=32, use_linear=False)])
+    conf = yaml.load(yaml.dump(conf), Loader=yaml.Loader)  # what ns-train writes to config.yml and eval_setup reads back
+    assert isinstance(conf, NerfactoNuscMSModelConfig) and conf.piecewise_sampler_threshold == 5.0
+    model = conf.setup(scene_box=None, num_train_data=-1, num_train_cameras=2, num_train_videos=1, dino_to_rgb=None,
+                       centroids=torch.zeros(1, 3), aabbs=torch.tensor([[[-1.0, -1, -1], [1, 1, 1]]]))
+    assert isinstance(model, NerfactoNuscMSModel)
+    assert model.proposal_sampler.initial_sampler.thr == 5.0  # recovered from the two lambdas of nerfacto_nusc_ms.py:311-316
+    assert set(model.get_param_groups()) == {"proposal_networks", "fields"}
+    cbs = model.get_training_callbacks(TrainingCallbackAttributes(optimizers=None, grad_scaler=None, pipeline=None))
+    assert len(cbs) == 2 and all(isinstance(c, TrainingCallback) for c in cbs)
+    assert cbs[0].where_to_run == [TrainingCallbackLocation.BEFORE_TRAIN_ITERATION]
+    assert cbs[1].where_to_run == [TrainingCallbackLocation.AFTER_TRAIN_ITERATION]
+    for step in (0, 1, 2, 250):
+        for cb in cbs:
+            cb.run_callback_at_location(step, TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        x = np.clip(step / 1000, 0, 1)
+        assert model.step == step and abs(model.proposal_sampler._anneal - 10 * x / (9 * x + 1)) < 1e-12
+        before = model.proposal_sampler._steps_since_update
+        for cb in cbs:
+            cb.run_callback_at_location(step, TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+        assert model.proposal_sampler._step == step and model.proposal_sampler._steps_since_update == before + 1
+    conf2 = NerfactoNuscMSModelConfig(use_lidar_loss=False, use_proposal_weight_anneal=False, num_levels=2, features_per_level=2,
+                                      log2_hashmap_size=4, max_res=64, hidden_dim=32, hidden_dim_color=32,
+                                      proposal_net_args_list=conf.proposal_net_args_list)
+    m2 = conf2.setup(num_train_cameras=2, num_train_videos=1, dino_to_rgb=None, centroids=torch.zeros(1, 3),
+                     aabbs=torch.tensor([[[-1.0, -1, -1], [1, 1, 1]]]))
+    assert m2.get_training_callbacks(None) == []  # nerfacto_nusc_ms.py:421: both callbacks hang on use_proposal_weight_anneal
+    with pytest.raises(AssertionError):
+        TrainingCallback([TrainingCallbackLocation.AFTER_TRAIN], func=lambda s: None)  # callbacks.py:79-81: needs a `step` argument
+    # evaluation image -> metrics + images (nerfacto_nusc_ms.py:647-686)
+    H, W = 6, 8
+    g = torch.Generator().manual_seed(0)
+    outputs = {"rgb": torch.rand(H, W, 3, generator=g), "accumulation": torch.rand(H, W, 1, generator=g), "depth": torch.rand(H, W, 1, generator=g) * 9,
+               "prop_depth_0": torch.rand(H, W, 1, generator=g), "prop_depth_1": torch.rand(H, W, 1, generator=g)}
+    batch = {"rgb": torch.rand(H, W, 3, generator=g)}
+    metrics, images = model.get_image_metrics_and_images(outputs, batch)
+    mse = float(((outputs["rgb"] - batch["rgb"]) ** 2).mean())
+    assert abs(metrics["psnr"] - 10 * np.log10(1 / mse)) < 1e-4
+    assert images["img"].shape == (H, 2 * W, 3) and torch.equal(images["img"][:, :W], batch["rgb"]) and torch.equal(images["img"][:, W:], outputs["rgb"])
+    assert set(images) == {"img", "accumulation", "depth", "prop_depth_0", "prop_depth_1"}
+    for k in ("accumulation", "depth", "prop_depth_0"):
+        assert images[k].shape == (H, W, 3) and float(images[k].min()) >= 0 and float(images[k].max()) <= 1
+
+
 _WORKER = textwrap.dedent("""
     import os, sys, torch, torch.distributed as dist
     sys.path.insert(0, {root!r})
