@@ -53,6 +53,17 @@ CONFIGS = {
                  scaling="strong", exchange="sharded",
                  workload="BASELINE cfg 3: production tile, K=16 sub-fields (L=10,F=4,T=2^20 main tables, 940 M parameters), routed, "
                           "128/64/64 samples, fwd+5 losses+bwd+Adam"),
+    # BASELINE cfg 4: static + dynamic dual field.  The reference has no dynamic field: the model is the one
+    # defined by oracle/dual_oracle.py -- static branch = the cfg-2 field, dynamic branch = 4-D hash grid (L=8, F=4, T=2^19,
+    # resolutions 16..512 on x, y, z, t) + 64-wide flow MLP + the same MLP stack, temporal aggregation over 3 warped positions
+    "cfg4": dict(K=1, model=dict(num_levels=16, features_per_level=2, log2_hashmap_size=19, base_res=16, max_res=2048, hidden_dim=64,
+                                 hidden_dim_color=64),
+                 dynamic=dict(dynamic_num_levels=8, dynamic_features_per_level=4, dynamic_log2_hashmap_size=19, dynamic_base_res=16,
+                              dynamic_max_res=512, dynamic_hidden_dim=64, dynamic_hidden_dim_color=64, flow_hidden_dim=64),
+                 scaling="weak", exchange="allreduce",
+                 workload="BASELINE cfg 4: static (cfg-2 field) + dynamic (4-D hash grid L=8,F=4,T=2^19 + flow MLP 32-64-64-6 + MLP stack, "
+                          "3-position temporal aggregation) dual field, density-weighted blend, 2 static proposal nets, 128/64/64 samples, "
+                          "fwd+6 losses+bwd+Adam"),
 }
 
 
@@ -62,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "extract"], default="cfg2")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "extract"], default="cfg2")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
     ap.add_argument("--exchange", choices=["allreduce", "sharded"], default=None)
     ap.add_argument("--rays", type=int, default=RAYS, help="rays per step: per GPU (weak) / over all GPUs (strong)")
@@ -100,11 +111,17 @@ def build_model(dev, seed, config="cfg2"):
 
     torch.manual_seed(seed)
     c = CONFIGS[config]
-    conf = NerfactoNuscMSModelConfig(near_plane=0.005, far_plane=50.0, piecewise_sampler_threshold=5.0, implementation="hip",
-                                     use_lidar_loss=False, proposal_weights_anneal_max_num_iters=10000, proposal_warmup=10000, **c["model"])
+    common = dict(near_plane=0.005, far_plane=50.0, piecewise_sampler_threshold=5.0, implementation="hip", use_lidar_loss=False,
+                  proposal_weights_anneal_max_num_iters=10000, proposal_warmup=10000, **c["model"])
     scene = make_scene(1440, 6, K=c["K"])
-    model = NerfactoNuscMSModel(conf, num_train_cameras=1440, num_train_videos=6, dino_to_rgb=None, centroids=scene["centroids"],
-                                aabbs=scene["aabbs"])
+    if "dynamic" in c:
+        from presight_amd.dynamic import NerfactoNuscDualModel, NerfactoNuscDualModelConfig
+
+        conf = NerfactoNuscDualModelConfig(time_step=1.0 / (1440 // 6 - 1), **common, **c["dynamic"])
+        cls = NerfactoNuscDualModel
+    else:
+        conf, cls = NerfactoNuscMSModelConfig(**common), NerfactoNuscMSModel
+    model = cls(conf, num_train_cameras=1440, num_train_videos=6, dino_to_rgb=None, centroids=scene["centroids"], aabbs=scene["aabbs"])
     model.to(dev)
     return model, {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
 
@@ -145,8 +162,10 @@ def make_scene(num_cameras, num_videos, seed=7, K=1):
         sel = torch.linspace(0, C - 1, K + 2)[1:-1].long()
         centroids = c2w[sel, :, 3].clone()
         aabbs = torch.stack([torch.stack([c - 3 * ext, c + 3 * ext]) for c in centroids])
+    # normalised timestamp of every camera (frame-major, 6 cameras per frame): what the dual field of cfg 4 reads as ray time
+    cam_times = (torch.arange(C) // 6).float() / float(max(1, n_frames - 1))
     return dict(c2w=c2w, fx=fx, fy=fx.clone(), cx=torch.full((C,), 800.0), cy=torch.full((C,), 450.0), centroids=centroids, aabbs=aabbs,
-                H=900, W=1600, frames_per_video=max(1, C // num_videos))
+                H=900, W=1600, frames_per_video=max(1, C // num_videos), cam_times=cam_times)
 
 
 def make_batches(scene, dev, n_batches, rank, rays=RAYS):
@@ -161,6 +180,7 @@ def make_batches(scene, dev, n_batches, rank, rays=RAYS):
         idx = torch.stack([torch.randint(0, C, (rays,), generator=g), torch.randint(0, scene["H"], (rays,), generator=g),
                            torch.randint(0, scene["W"], (rays,), generator=g)], -1)
         out.append(dict(ray_indices=idx.to(dev), video_ids=torch.clamp(idx[:, 0] // scene["frames_per_video"], max=5).to(dev),
+                        times=scene["cam_times"].cpu()[idx[:, 0]].to(dev),
                         rgb=torch.rand(rays, 3, generator=g).to(dev), features=torch.rand(rays, 64, generator=g).to(dev),
                         sky=(torch.rand(rays, generator=g) < 0.15).float().to(dev)))
     return out
@@ -649,6 +669,12 @@ def main():
         mac_main = (L * F) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3)
         flop_ray = 3 * 2 * (64 * mac_main + 192 * 576)
         byte_ray = 3 * (64 * L * 8 * F * 4 + 192 * 8 * 8 * 4)
+        if "dynamic" in cfg:  # cfg 4: the dynamic branch's MLP stack + flow MLP, 3 position sets x 16 corners of its 4-D grid
+            dy = cfg["dynamic"]
+            Ld, Fd = dy["dynamic_num_levels"], dy["dynamic_features_per_level"]
+            mac_dyn = (Ld * Fd) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3) + (Ld * Fd * 64 + 64 * 64 + 64 * 6)
+            flop_ray += 3 * 2 * 64 * mac_dyn
+            byte_ray += 3 * 64 * (3 * Ld * 16 * Fd * 4)
         ceil_mfma, ceil_hbm = FP32_MFMA_PEAK_TFLOPS * 1e12 / flop_ray, HBM_PEAK_GBS * 1e9 / byte_ray
         per_gpu = value / world
         line = {

@@ -350,6 +350,47 @@ int ps_adam_step_ranges(float* p, const float* g, float* m, float* v, int n_rang
  * points; group_of_field [K] device int32, < 0 = no group.  Called by the routed backward nodes; no host synchronisation. */
 int ps_ms_mark_groups(const int32_t* field_start, int K, const int32_t* group_of_field, int32_t* flags, void* stream);
 
+/* ---- BASELINE cfg 4: dynamic branch of the dual (static + dynamic) field -- csrc/dynamic.hip.  The reference has no dynamic /
+ * flow field ("no counterpart"); these entry points implement the model DEFINED by
+ * oracle/dual_oracle.py, whose conventions are those of the static stack (ns/fields/PreSight/ingp_field.py:168-267 for the MLP
+ * stack and trunc_exp * selector, ns/field_components/encodings.py:324-384 for the hash grid, extended by a time axis with
+ * Instant-NGP's fourth prime 3674653429).  A maintainer would bind them from a new field class next to iNGPField. */
+/* x4[n] = (u[n], times[n / S]): the static field's normalised positions u [N,3] + the rays' normalised timestamps [N / S] */
+int ps_dyn_points(const float* u, const float* times, int S, int64_t N, float* x4 /*[N,4]*/, void* stream);
+/* 4-D multiresolution hash grid on level planes feat[l][n][f].  e0 == NULL: feat = H4(x), x [N,4].
+ * e0 != NULL (temporal aggregation): x [2N,4] = forward-warped then backward-warped positions, feat = (e0 + H4(x[n]) + H4(x[N+n])) / 3 */
+int ps_grid4_encode(const float* x, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
+                    int64_t plane_stride, const float* e0 /*nullable*/, float* feat, void* stream);
+/* dx[m][0..3) = g_scale * sum_l scalings[l] * <dfeat[l][m mod period], d H4[l] / d x_a> for the spatial axes (the hash grid is
+ * multilinear inside a cell; exactly integer coordinates have zero derivative, like autograd through ceil / floor).
+ * x [M,4], M <= 2 * period when period > 0 (two position sets share one gradient plane), dx [M,3]. */
+int ps_grid4_input_grad(const float* x, const float* dfeat, const float* table, const float* scalings, int L, int F, int log2T,
+                        int64_t M, int64_t period, int64_t plane_stride, float g_scale, float* dx, void* stream);
+/* table gradient of the 4-D grid: the binned fixed-point scatter of ps_grid_scatter_binned with 8 x-pair records per (point,
+ * level); dtable (+)= out_scale * scatter(dfeat); accumulate as ps_grid_scatter_binned; workspace of ps_grid4_scatter_workspace */
+int64_t ps_grid4_scatter_workspace(int L, int F, int log2T, int64_t M);
+int ps_grid4_scatter_binned(const float* x, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t M,
+                            int64_t period, int64_t plane_stride, float out_scale, float* dtable, int accumulate, void* workspace,
+                            void* stream);
+/* flow MLP Linear(L*F, H) ReLU Linear(H, H) ReLU Linear(H, 6) on the fp32 matrix cores; packed as ps_mlp_pack_layers packs a
+ * 3-layer stack (ps_flow_sizes: packed / gradient block sizes, partial blocks ps_flow_bwd writes).
+ * fwd: xw [2N,4] <- (u + s*flow[0:3], t + dt) for n < N, (u + s*flow[3:6], t - dt) for N + n (x4 [N,4] = (u, t)).
+ * bwd: dxw [2N,3] = gradient w.r.t. the warped positions (ps_grid4_input_grad); de0 = dagg / 3 + d(e0 via the flow MLP). */
+int ps_flow_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/, int* n_parts /*host*/);
+int ps_flow_fwd(const float* e0, int64_t plane_stride, int LF, int F, int hidden, const float* packed, const float* x4, int64_t N,
+                float flow_scale, float dt, float* xw, void* stream);
+int ps_flow_bwd(const float* e0, int64_t plane_stride, int LF, int F, int hidden, const float* packed, const float* dxw,
+                const float* dagg, int64_t N, float flow_scale, float* de0, float* gpart, void* stream);
+/* density-weighted blend of the two branches per sample: sigma = ss + sd, wd = sd / max(sigma, 1e-6), c = cs + wd (cd - cs) for
+ * the colour [N,3] and the semantics [N,C] (C a multiple of 4).  bwd: any of dsigma / drgb / dsem may be NULL (no gradient);
+ * extra_dsigma_d (nullable) is added to d(sigma_d): gradients that reach the dynamic density directly (its regulariser). */
+int ps_blend_fwd(const float* sigma_s, const float* rgb_s, const float* sem_s, const float* sigma_d, const float* rgb_d,
+                 const float* sem_d, int64_t N, int C, float* sigma, float* rgb, float* sem, void* stream);
+int ps_blend_bwd(const float* sigma_s, const float* rgb_s, const float* sem_s, const float* sigma_d, const float* rgb_d,
+                 const float* sem_d, const float* dsigma, const float* drgb, const float* dsem, int64_t N, int C,
+                 const float* extra_dsigma_d, float* dsigma_s, float* drgb_s, float* dsem_s, float* dsigma_d, float* drgb_d,
+                 float* dsem_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -639,10 +639,14 @@ def _routed(fn_per_field, assign: Tensor, K: int, outs_dims: Sequence[int]):
 # --------------------------------------------------------------------------------------
 # a14 + a17  whole-model forward (training or eval), losses, one training step
 # --------------------------------------------------------------------------------------
-def model_forward(P, cfg, scene, batch, training: bool = True, anneal: float = 1.0, prop_requires_grad: bool = True):
+def model_forward(P, cfg, scene, batch, training: bool = True, anneal: float = 1.0, prop_requires_grad: bool = True,
+                  main_override=None):
     """NerfactoNuscMSModel.forward (collider + get_outputs).
     ns/models/base_model.py:131-142, ns/models/PreSight/nerfacto_nusc_ms.py:452-546,
-    ns/model_components/ray_samplers.py:572-614."""
+    ns/model_components/ray_samplers.py:572-614.
+    main_override(static_eval, pos [R*S,3], dir_s, app_s, R, S) -> (sigma, rgb_s, sem_s, extras): hook used by
+    oracle/dual_oracle.py (BASELINE cfg 4) to put a second field next to the static one; `static_eval()` evaluates the
+    reference's field exactly as below."""
     K = cfg["num_fields"]
     cent, aabbs = scene["centroids"], scene["aabbs"]
     o, d, _, _ = generate_rays(batch["ray_indices"], scene["c2w"], scene["fx"], scene["fy"], scene["cx"], scene["cy"])
@@ -694,7 +698,11 @@ def model_forward(P, cfg, scene, batch, training: bool = True, anneal: float = 1
         rgb, sem = main_heads(P, cfg, k, dir_s[msk], emb, app_s[msk])
         return sg, rgb, sem
 
-    sigma, rgb_s, sem_s = _routed(main_eval, assign, K, [1, 3, 64])
+    extras = {}
+    if main_override is None:
+        sigma, rgb_s, sem_s = _routed(main_eval, assign, K, [1, 3, 64])
+    else:
+        sigma, rgb_s, sem_s, extras = main_override(lambda: _routed(main_eval, assign, K, [1, 3, 64]), pos, dir_s, app_s, R, Sm)
     w = weights_from_density(deltas, sigma.view(R, Sm))
     weights_list.append(w)
     bins_list.append(bins)
@@ -715,6 +723,7 @@ def model_forward(P, cfg, scene, batch, training: bool = True, anneal: float = 1
         pass  # RGBRenderer eval-mode nan_to_num/clamp acts on the pre-sky rgb only (renderers.py:221-228)
     out = dict(rgb=rgb, accumulation=acc, depth=depth, expected_depth=exp_depth, semantics=sem,
                weights_list=weights_list, bins_list=bins_list, euclid_list=eu_list, origins=o, directions=d)
+    out.update(extras)
     for i in range(len(S) - 1):
         st = (eu_list[i][:, :-1] + eu_list[i][:, 1:]) / 2
         out[f"prop_depth_{i}"] = threshold_depth(weights_list[i], st)

@@ -19,46 +19,16 @@
 // Reference semantics: ns/cameras/rays.py:49-58, ns/fields/PreSight/ingp_field.py:169-177,
 // ns/field_components/encodings.py:343-384 (forward) and its autograd (index_put_ scatter-add).
 #include "common.hpp"
+#include "encode_core.hpp"
 #include "hashgrid_core.hpp"
 #include "ms_core.hpp"
 #include "pointwise_core.hpp"
 
 namespace {
 
-__device__ __forceinline__ void xcd_item(int64_t n_items, int64_t& item, bool& valid) {
-  const int64_t b = blockIdx.x;
-  const int64_t per = (n_items + 7) / 8;
-  const int64_t x = b & 7, i = b >> 3;
-  item = x * per + i;
-  valid = (i < per) && (item < n_items);
-}
-
-// Work distribution of the encode.  A workgroup takes one group of points of ONE level; hardware workgroup b runs on XCD
-// b % 8, and an XCD should work on one level at a time so that its 4 MiB L2 keeps that level's table.  Dealing the levels
-// to the XCDs in order (levels 2x, 2x+1 on XCD x) leaves the XCDs with the coarse levels idle for half of the kernel: a coarse
-// level's gathers hit in L1 / L2, a hashed fine level's do not (measured with the gathers of the fine levels removed: the
-// 4 coarsest of 16 levels finish in 0.54 of the kernel's 1.36 ms).  So every level is cut into P parts (L * P a multiple of
-// 16) and the (level, part) blocks are dealt in MIRRORED level order 0, L-1, 1, L-2, ...: every XCD gets as many coarse as
-// fine blocks, still one level at a time.  Grids of few levels (L <= 8: one or two levels per XCD) are cut four times finer,
-// which evens out what the mirroring leaves (measured, proposal grid L8 F1 T2^20: 0.95 -> 0.74 -> 0.67 ms per launch; the
-// 16-level main grid is best with the coarse cut: 1.36 -> 0.96 ms, 0.97 with the finer one).
-inline int enc_parts(int L) {
-  int low = L & -L;  // gcd(L, 16)
-  if (low > 16) low = 16;
-  return (L <= 8 ? 4 : 1) * 16 / low;
-}
-__device__ __forceinline__ void enc_item(int64_t groups, int L, int P, int& level, int64_t& group, bool& valid) {
-  const int64_t gp = (groups + P - 1) / P;  // groups per block
-  const int B = L * P / 8;                  // blocks per XCD (even)
-  const int64_t b = blockIdx.x;
-  const int x = (int)(b & 7);
-  const int64_t i = b >> 3;
-  const int q = x * B + (int)(i / gp);      // block in the dealt sequence
-  const int part = q / L, r = q % L;
-  level = (r & 1) ? L - 1 - (r >> 1) : (r >> 1);
-  group = (int64_t)part * gp + i % gp;
-  valid = i < (int64_t)B * gp && group < groups;
-}
+using ps::enc_item;
+using ps::enc_parts;
+using ps::xcd_item;
 
 // u[n] = contract(normalise(position n)), sel[n] in {0,1}.  Positions are either given (pos != null)
 // or generated from rays: point n = ray n/S, sample n%S.
@@ -433,8 +403,8 @@ extern "C" int ps_grid_scatter(const float* u, const float* dfeat, const float* 
 namespace {
 
 constexpr int kBinThreads = 256;
-constexpr int kBinPointsPerThread = 2;
-constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
+constexpr int bin_points_per_thread(int D) { return D == 4 ? 1 : 2; }
+constexpr int bin_points(int D) { return kBinThreads * bin_points_per_thread(D); }  // points per workgroup
 constexpr int kMaxSlices = 256;
 constexpr int kAccBytes = 128 * 1024;
 
@@ -448,17 +418,24 @@ __device__ __forceinline__ float fixed_scale(unsigned gmax_bits, int headroom_lo
 // COUNT_ONLY = true : pass 1, per-(level, slice) record counts (cursors[] += bucket sizes)
 // COUNT_ONLY = false: pass 2, cursors[] hold the exclusive prefix (stream start) of every (level, slice) and are
 //                     advanced by the reservations; records are written at their exact final position.
-template <int F, bool COUNT_ONLY>
+// D = 3: u [N,3].  D = 4 (dynamic.hip, the (x,y,z,t) grid of the dynamic field): u [N,4], 8 x-pairs per (point, level) -- the
+// (y,z) combinations at the ceil-t corner, then at the floor-t corner -- and half as many points per workgroup.
+// period > 0: point n >= period takes the d(feature) row n - period (two position sets sharing one gradient plane).
+template <int F, bool COUNT_ONLY, int D = 3>
 __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restrict__ u, const float* __restrict__ dfeat,
                                                           const float* __restrict__ scalings, int L, int log2T,
                                                           int log2_slice, int64_t N, int64_t plane_stride, int64_t n_rec_max,
                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
                                                           float* __restrict__ rec_val, const int* __restrict__ chunk_field,
-                                                          unsigned* __restrict__ gmax_track /* nullable: per-level max |dfeat| bits */) {
+                                                          unsigned* __restrict__ gmax_track /* nullable: per-level max |dfeat| bits */,
+                                                          int64_t period) {
+  constexpr int kBinPointsPerThread = bin_points_per_thread(D);
+  constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
+  constexpr int NP = D == 4 ? 8 : 4;  // x-pairs per (point, level)
   // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record.
   // The staging area holds the common case (4 pair records per point + slack); split pairs can push a workgroup past it
   // (only where a level's resolution exceeds the slice size), those records go straight to their final position.
-  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * 4 + kBinPoints / 4;
+  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * NP + kBinPoints * NP / 16;
   __shared__ unsigned cnt[kMaxSlices], off[kMaxSlices + 1], gbase[kMaxSlices];
   __shared__ unsigned s_idx[kRec];
   __shared__ float s_val[F + 1][kRec];  // plane F holds ox
@@ -484,7 +461,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
   // hashes that differ by cx^fx = 2^(t+1)-1 (low bits only), so they almost always live in the same slice: they travel
   // as ONE record {row of the floor corner, t, q[F] = w_yz * g[F], ox}; the accumulate kernel expands it.  A pair whose
   // xor reaches the slice bits (probability ~2^-log2_slice) is split into two single-corner records (t = 31).
-  constexpr int NP = 4;  // pairs per point-level, in (y,z) corner order: (c,c) (f,c) (c,f) (f,f)
+  // pairs per point-level, in (y,z) corner order: (c,c) (f,c) (c,f) (f,f) [D = 4: at ceil t, then the same four at floor t]
   float gmax_local = 0.f;  // write pass: max |d(feature)| of this thread's points (the accumulate kernel's fixed-point scale)
   uint32_t r_slice[kBinPointsPerThread][2 * NP], r_pos[kBinPointsPerThread][2 * NP], r_idx[kBinPointsPerThread][2 * NP];
   float r_val[kBinPointsPerThread][2 * NP][F], r_ox[kBinPointsPerThread][2 * NP];
@@ -495,16 +472,17 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     float g[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) g[f] = 0.f;
-    ps::Cell c = ps::make_cell(ok ? u[n * 3] : 0.f, ok ? u[n * 3 + 1] : 0.f, ok ? u[n * 3 + 2] : 0.f, s);
+    ps::Cell c = ps::make_cell(ok ? u[n * D] : 0.f, ok ? u[n * D + 1] : 0.f, ok ? u[n * D + 2] : 0.f, s);
+    const int64_t ng = (period > 0 && n >= period) ? n - period : n;
     if (ok) {
-      if constexpr (F == 1) g[0] = g_plane[n];
+      if constexpr (F == 1) g[0] = g_plane[ng];
       if constexpr (F == 2) {
-        const f32x2 t = *reinterpret_cast<const f32x2*>(g_plane + n * 2);
+        const f32x2 t = *reinterpret_cast<const f32x2*>(g_plane + ng * 2);
         g[0] = t.x;
         g[1] = t.y;
       }
       if constexpr (F == 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(g_plane + n * 4);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(g_plane + ng * 4);
         g[0] = t.x;
         g[1] = t.y;
         g[2] = t.z;
@@ -520,9 +498,32 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     }
     const uint32_t yc = (uint32_t)c.cy * 2654435761u, yf = (uint32_t)c.fy * 2654435761u;
     const uint32_t zc = (uint32_t)c.cz * 805459861u, zf = (uint32_t)c.fz * 805459861u;
-    const uint32_t hyz[NP] = {yc ^ zc, yf ^ zc, yc ^ zf, yf ^ zf};
-    const float oy = c.oy, oz = c.oz, uy = 1.0f - oy, uz = 1.0f - oz;
-    const float wyz[NP] = {oy * oz, uy * oz, oy * uz, uy * uz};
+    uint32_t hyz[NP];
+    float wyz[NP];
+    {
+      const float oy = c.oy, oz = c.oz, uy = 1.0f - oy, uz = 1.0f - oz;
+      const uint32_t h4[4] = {yc ^ zc, yf ^ zc, yc ^ zf, yf ^ zf};
+      const float w4[4] = {oy * oz, uy * oz, oy * uz, uy * uz};
+      if constexpr (D == 4) {
+#pragma clang fp contract(off)
+        const float st = (ok ? u[n * D + 3] : 0.f) * s;
+        const float flt = floorf(st), ot = st - flt;
+        const uint32_t tc = (uint32_t)(int)ceilf(st) * 3674653429u, tf = (uint32_t)(int)flt * 3674653429u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hyz[k] = h4[k] ^ tc;
+          hyz[4 + k] = h4[k] ^ tf;
+          wyz[k] = w4[k] * ot;
+          wyz[4 + k] = w4[k] * (1.0f - ot);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hyz[k] = h4[k];
+          wyz[k] = w4[k];
+        }
+      }
+    }
     const uint32_t xdiff = ((uint32_t)c.cx ^ (uint32_t)c.fx) & mask;  // 0 (exact integer) or 2^(t+1)-1
     const bool together = (xdiff >> log2_slice) == 0u;
     const uint32_t tcode = xdiff == 0u ? 30u : (uint32_t)(31 - __clz((int)xdiff));  // t (xdiff = 2^(t+1)-1), 30 = same row
@@ -610,11 +611,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     // stage the records in bucket order.  The bucket offsets of all 16 record slots are fetched first: written as "read the
     // offset, store the record" per slot, every slot exposed an LDS round trip (the compiler keeps the read behind the
     // previous slot's stores)
-    unsigned r_dst[kBinPointsPerThread][8];
+    unsigned r_dst[kBinPointsPerThread][2 * NP];
 #pragma unroll
     for (int q = 0; q < kBinPointsPerThread; ++q)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 2 * NP; ++k) {
         const unsigned o = off[r_slice[q][k]];  // unconditional (r_slice is always a valid slice): no branch around the LDS read
         r_dst[q][k] = (r_pos[q][k] != 0xffffffffu) ? o + r_pos[q][k] : 0xffffffffu;
       }
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
 #pragma unroll
     for (int q = 0; q < kBinPointsPerThread; ++q)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 2 * NP; ++k) {
         const unsigned p = r_dst[q][k];
         if (p < (unsigned)kRec) {
           s_idx[p] = r_idx[q][k];
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
 #pragma unroll
       for (int q = 0; q < kBinPointsPerThread; ++q)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 2 * NP; ++k) {
           if (r_pos[q][k] != 0xffffffffu && off[r_slice[q][k]] + r_pos[q][k] >= (unsigned)kRec) {
             const int64_t dst = (int64_t)gbase[r_slice[q][k]] + r_pos[q][k];
             rec_idx[dst] = r_idx[q][k];
@@ -705,7 +706,8 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
                                                           const unsigned* __restrict__ rec_idx,
                                                           const float* __restrict__ rec_val, const unsigned* __restrict__ gmax_bits,
                                                           int L, int log2T, int log2_slice, int64_t n_rec_max, int headroom_log2,
-                                                          int accumulate, float* __restrict__ dtable, float* const* __restrict__ dtables) {
+                                                          int accumulate, float* __restrict__ dtable, float* const* __restrict__ dtables,
+                                                          float out_scale /* the gradient is multiplied by this (1: exactly the plain result) */) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F]
   const int entries = 1 << log2_slice;
   const int n_slices = 1 << (log2T - log2_slice);
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
         for (int f = 0; f < F; ++f) {
           const long long v = (long long)atomicExch(reinterpret_cast<unsigned long long*>(&acc[r * F + f]), 0ull);
           if (v != 0) {
-            const float val = (float)((double)v * (double)inv);
+            const float val = (float)((double)v * (double)inv * (double)out_scale);
             out[r * F + f] = accumulate == 1 ? out[r * F + f] + val : val;
           }
         }
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   for (int k = 0; k < kOutPerThread; ++k) {
     const int i = threadIdx.x + k * 1024;
     if (i < entries * F) {
-      const float val = (float)((double)acc[i] * (double)inv);
+      const float val = (float)((double)acc[i] * (double)inv * (double)out_scale);
       out[i] = accumulate == 1 ? prev[k] + val : val;
     }
   }
@@ -843,7 +845,9 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
 
 // records the streams can hold: 8 per (point, level) worst case + every stream start rounded up to 4 records + the
 // vector-load overshoot of the last chunk; a multiple of 4 so that all planes stay 16-byte aligned
-int64_t binned_rec_capacity(int64_t N, int L, int n_slices) { return ((N * L * 8 + 4 * (int64_t)L * n_slices + 64) + 3) & ~(int64_t)3; }
+int64_t binned_rec_capacity(int64_t N, int L, int n_slices, int D = 3) {
+  return ((N * L * (D == 4 ? 16 : 8) + 4 * (int64_t)L * n_slices + 64) + 3) & ~(int64_t)3;
+}
 
 int binned_log2_slice(int F, int log2T) {
   int ls = 0;
@@ -856,10 +860,10 @@ int binned_log2_slice(int F, int log2T) {
 }  // namespace
 
 namespace {
-int64_t binned_workspace(int L, int F, int log2T, int64_t N, int K) {
+int64_t binned_workspace(int L, int F, int log2T, int64_t N, int K, int D = 3) {
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
-  const int64_t n_rec_max = binned_rec_capacity(N, L, K * n_slices);
+  const int64_t n_rec_max = binned_rec_capacity(N, L, K * n_slices, D);
   return 4096 + (int64_t)K * L * n_slices * 4 * 3 + 16 + n_rec_max * 4 * (2 + F) + 256;
 }
 
@@ -867,14 +871,17 @@ int64_t binned_workspace(int L, int F, int log2T, int64_t N, int K) {
 // cursor and maximum becomes (sub-field, level); N = slots of the sorted layout.
 int scatter_binned_impl(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                         int64_t plane_stride, float* dtable, float* const* dtables, int K, const int* chunk_field, int accumulate,
-                        const uint32_t* slice_counts, int absmax_ready, void* workspace, hipStream_t s) {
+                        const uint32_t* slice_counts, int absmax_ready, void* workspace, hipStream_t s, int D = 3, int64_t period = 0,
+                        float out_scale = 1.0f) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
-  PS_REQUIRE(N * L * 8 + 4096 + 4 * (int64_t)K * L * 256 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
+  PS_REQUIRE(D == 3 || (D == 4 && K == 1 && chunk_field == nullptr), "ps_grid_scatter_binned: 3-D grids, or one 4-D grid");
+  PS_REQUIRE(period == 0 || (period > 0 && N <= 2 * period), "ps_grid_scatter_binned: at most two position sets per gradient plane");
+  PS_REQUIRE(N * L * (D == 4 ? 16 : 8) + 4096 + 4 * (int64_t)K * L * 256 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
   PS_REQUIRE(K * L <= 1024, "ps_grid_scatter_binned: at most 1024 (sub-field, level) pairs");
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
   PS_REQUIRE(n_slices <= kMaxSlices, "ps_grid_scatter_binned: too many slices");
-  const int64_t n_rec_max = binned_rec_capacity(N, L, K * n_slices);
+  const int64_t n_rec_max = binned_rec_capacity(N, L, K * n_slices, D);
   const int n_items = K * L * n_slices;
   PS_REQUIRE(((uintptr_t)workspace & 15) == 0, "ps_grid_scatter_binned: workspace must be 16-byte aligned");
   char* ws = (char*)workspace;
@@ -895,35 +902,43 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
   int headroom = 62 - 26;  // 8N <= 2^26 contributions per row
   {
     int bits = 0;
-    while (((int64_t)1 << bits) < N * 8) ++bits;
+    while (((int64_t)1 << bits) < N * (D == 4 ? 16 : 8)) ++bits;
     if (bits > 26) headroom = 62 - bits;
   }
-  const int64_t chunks = (N + kBinPoints - 1) / kBinPoints;
   const size_t lds = (size_t)(1 << ls) * F * 8;
-#define PS_LAUNCH_BINNED(FF)                                                                                              \
+#define PS_LAUNCH_BINNED(FF) PS_LAUNCH_BINNED_D(FF, 3)
+#define PS_LAUNCH_BINNED_D(FF, DD)                                                                                            \
   {                                                                                                                       \
     static bool attr_set = false;                                                                                         \
     if (!attr_set) {                                                                                                      \
       hipFuncSetAttribute((const void*)accumulate_kernel<FF>, hipFuncAttributeMaxDynamicSharedMemorySize, kAccBytes);     \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
+    const int64_t chunks = (N + bin_points(DD) - 1) / bin_points(DD);                                                     \
     if (N > 0) {                                                                                                          \
       if (slice_counts == nullptr)                                                                                        \
-        bin_kernel<FF, true><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,          \
-                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr); \
+        bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,      \
+                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period); \
     }                                                                                                                     \
     stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                           \
     if (N > 0)                                                                                                            \
-      bin_kernel<FF, false><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,           \
+      bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,       \
                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
-                                                                           absmax_ready ? nullptr : gmax_bits);           \
+                                                                           absmax_ready ? nullptr : gmax_bits, period);   \
     accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
-                                                               n_rec_max, headroom, accumulate, dtable, dtables);         \
+                                                               n_rec_max, headroom, accumulate, dtable, dtables, out_scale); \
   }
-  if (F == 1) PS_LAUNCH_BINNED(1)
-  if (F == 2) PS_LAUNCH_BINNED(2)
-  if (F == 4) PS_LAUNCH_BINNED(4)
+  if (D == 3) {
+    if (F == 1) PS_LAUNCH_BINNED(1)
+    if (F == 2) PS_LAUNCH_BINNED(2)
+    if (F == 4) PS_LAUNCH_BINNED(4)
+  } else {
+    if (F == 1) PS_LAUNCH_BINNED_D(1, 4)
+    if (F == 2) PS_LAUNCH_BINNED_D(2, 4)
+    if (F == 4) PS_LAUNCH_BINNED_D(4, 4)
+  }
 #undef PS_LAUNCH_BINNED
+#undef PS_LAUNCH_BINNED_D
   PS_CHECK_LAUNCH();
 }
 }  // namespace
@@ -947,4 +962,16 @@ extern "C" int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, con
   PS_REQUIRE(n_slots % ps::kMsChunk == 0, "ps_grid_scatter_binned_ms: the sorted layout is a whole number of chunks");
   return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, n_slots, plane_stride, nullptr, dtables, K, chunk_field, /*accumulate=*/dst_is_zero ? 2 : 1,
                              slice_counts, absmax_ready, workspace, (hipStream_t)stream);
+}
+
+// ---- 4-D grid of the dynamic field (csrc/dynamic.hip; BASELINE cfg 4): same record streams and accumulate kernel, 8 x-pairs
+// per (point, level).  x [M,4]; M <= 2 * period position sets share one gradient plane when period > 0 (point m takes row
+// m mod period of dfeat); the table gradient is multiplied by out_scale.
+extern "C" int64_t ps_grid4_scatter_workspace(int L, int F, int log2T, int64_t M) { return binned_workspace(L, F, log2T, M, 1, 4); }
+
+extern "C" int ps_grid4_scatter_binned(const float* x, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t M,
+                                       int64_t period, int64_t plane_stride, float out_scale, float* dtable, int accumulate,
+                                       void* workspace, void* stream) {
+  return scatter_binned_impl(x, dfeat, scalings, L, F, log2T, M, plane_stride, dtable, nullptr, 1, nullptr, accumulate, nullptr, 0,
+                             workspace, (hipStream_t)stream, 4, period, out_scale);
 }

@@ -245,9 +245,9 @@ def _main_spec(LF, hidden, hidden_color, app_dim) -> MainSpec:
     return _MAIN_SPECS[key]
 
 
-def _main_forward(ctx, table_needs_grad, u, sel, dirs, app, S, table, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, wb):
-    """shared forward of the main-field nodes: encode (+ record counts for the table backward) -> fused MLP kernel.
-    Stores everything the shared backward needs on ctx (tensors are returned for save_for_backward)."""
+def _stack_forward(ctx, keep_acts, feat, N, sel, dirs, app, S, g: GridCfg, want_rgb, want_sem, n_base, n_sem, wb):
+    """the fused MLP stack of a main field (base MLP -> density, semantic head, colour head) on given feature planes [L,N,F];
+    stores what _stack_backward needs on ctx and returns (tensors to save), (sigma, rgb, sem)"""
     layers = _layers(wb)
     base, sem_l, rgb_l = layers[:n_base], layers[n_base:n_base + n_sem], layers[n_base + n_sem:]
     hidden, hidden_color = base[0][0].shape[0], rgb_l[0][0].shape[0]
@@ -256,10 +256,7 @@ def _main_forward(ctx, table_needs_grad, u, sel, dirs, app, S, table, scalings, 
         raise ValueError(f"colour head expects SH16 + geo15 + app{A} inputs, got an appearance embedding of width "
                          f"{0 if app is None else app.shape[1]}")
     spec = _main_spec(g.out_dim, hidden, hidden_color, A)
-    N = u.shape[0]
-    dev = u.device
-    table = _f32(table, "hash table")
-    feat, counts = _encode(u, table, scalings, g, count=table_needs_grad)
+    dev = feat.device
     packed = spec.pack(base, sem_l, rgb_l, dev)
     sigma = torch.empty(N, device=dev)
     rgb = torch.empty(N, 3, device=dev) if want_rgb else None
@@ -268,18 +265,65 @@ def _main_forward(ctx, table_needs_grad, u, sel, dirs, app, S, table, scalings, 
     app_c = _f32(app) if (app is not None and want_rgb) else None
     # training forward of the full field: keep the hidden activations for the backward (no recompute there)
     acts = None
-    if KEEP_ACTIVATIONS and table_needs_grad and want_rgb and want_sem and N > 0:
+    if KEEP_ACTIVATIONS and keep_acts and want_rgb and want_sem and N > 0:
         acts = torch.empty((N + 15) // 16 * 16, lib().ps_main_field_act_width(g.out_dim, hidden, hidden_color), device=dev)
     with prof.region("main_field_fwd"):
         check(lib().ps_main_field_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                       _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb), _p(sem),
                                       _p(acts), _stream()), "ps_main_field_fwd")
-    ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), [tuple(W.shape) for W, _ in layers], n_base, n_sem,
-                want_rgb, want_sem)
-    ctx.sinks = (grad_sink(table), layer_sinks(layers))
+    ctx.stack_meta = (g, hidden, hidden_color, A, S, [tuple(W.shape) for W, _ in layers], n_base, n_sem, want_rgb, want_sem)
+    ctx.layer_sinks = layer_sinks(layers)
+    return (dirs, app_c, packed, acts), (sigma, rgb, sem)
+
+
+def _stack_backward(ctx, sel, dirs, app, feat, packed, acts, d_sigma, d_rgb, d_sem, weights):
+    """fused MLP backward + weight-gradient reduction.  weights != None: d_rgb / d_sem are per-RAY gradients (see
+    ps_main_field_bwd).  -> (dapp, d(feature planes), [dW0, db0, ...] with None for in-place gradients)"""
+    g, hidden, hidden_color, A, S, shapes, n_base, n_sem, want_rgb, want_sem = ctx.stack_meta
+    if d_rgb is None or d_sem is None:
+        acts = None  # a head without gradient: the recompute kernel skips it
+    spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+    N = sel.shape[0]
+    dev = sel.device
+    pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    offs = (ctypes.c_int64 * 6)()
+    check(lib().ps_main_field_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart),
+                                    offs), "ps_main_field_sizes")
+    assert pf.value == spec.packed and gf.value == spec.g_total, (pf.value, spec.packed, gf.value, spec.g_total)
+    assert list(offs) == spec.p_off + spec.g_off, (list(offs), spec.p_off, spec.g_off)
+    gpart = torch.empty(npart.value, spec.g_total, device=dev)
+    dfeat = torch.empty_like(feat)
+    dapp = torch.zeros_like(app) if app is not None else None
+    # (the per-level |d(feature)| maxima are NOT tracked in this kernel, unlike the proposal backward: at its register
+    #  pressure the 8 extra live values cost more (+0.2 ms) than the separate 0.13 ms absmax pass)
+    dzb = _dzb_scratch(N, dev) if acts is not None else None
+    with prof.region("main_field_bwd"):
+        for stages in _bwd_stages(dzb):
+            check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                          _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
+                                          _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), stages, _stream()), "ps_main_field_bwd")
+    descs = []
+    for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
+                        (spec.rgb, spec.g_off[2], shapes[n_base + n_sem:])):
+        descs += sp.unpack_descs(gpart, off, sh)
+    grads = unpack_layers(descs, npart.value, spec.g_total, dev, ctx.layer_sinks)  # all layers in one launch
+    flat = flatten_grads(grads)
+    assert len(flat) == 2 * len(shapes)
+    return dapp, dfeat, flat
+
+
+def _main_forward(ctx, table_needs_grad, u, sel, dirs, app, S, table, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, wb):
+    """shared forward of the main-field nodes: encode (+ record counts for the table backward) -> fused MLP kernel.
+    Stores everything the shared backward needs on ctx (tensors are returned for save_for_backward)."""
+    table = _f32(table, "hash table")
+    feat, counts = _encode(u, table, scalings, g, count=table_needs_grad)
+    (dirs, app_c, packed, acts), outs = _stack_forward(ctx, table_needs_grad, feat, u.shape[0], sel, dirs, app, S, g, want_rgb, want_sem,
+                                                       n_base, n_sem, wb)
+    ctx.meta = (g, tuple(table.shape), want_rgb, want_sem)
+    ctx.table_sink = grad_sink(table)
     ctx.table_ref = table
     ctx.direct = direct_params(table, *wb)
-    return (u, sel, dirs, app_c, scalings, feat, packed, counts, acts), (sigma, rgb, sem)
+    return (u, sel, dirs, app_c, scalings, feat, packed, counts, acts), outs
 
 
 def _dzb_scratch(n_points: int, dev):
@@ -301,42 +345,51 @@ def _bwd_stages(dzb):
 
 
 def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
-    """shared backward: fused MLP backward -> table scatter -> weight-gradient reduction.  weights != None: d_rgb / d_sem are
-    per-RAY gradients (see ps_main_field_bwd).  -> (dapp, dtable | None, [dW0, db0, ...] with None for in-place gradients)"""
+    """shared backward: fused MLP backward -> table scatter -> weight-gradient reduction.
+    -> (dapp, dtable | None, [dW0, db0, ...] with None for in-place gradients)"""
     u, sel, dirs, app, scalings, feat, packed, counts, acts = saved
-    g, hidden, hidden_color, A, S, tshape, shapes, n_base, n_sem, want_rgb, want_sem = ctx.meta
-    if d_rgb is None or d_sem is None:
-        acts = None  # a head without gradient: the recompute kernel skips it
-    spec = _main_spec(g.out_dim, hidden, hidden_color, A)
-    N = u.shape[0]
-    dev = u.device
-    pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
-    offs = (ctypes.c_int64 * 6)()
-    check(lib().ps_main_field_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart),
-                                    offs), "ps_main_field_sizes")
-    assert pf.value == spec.packed and gf.value == spec.g_total, (pf.value, spec.packed, gf.value, spec.g_total)
-    assert list(offs) == spec.p_off + spec.g_off, (list(offs), spec.p_off, spec.g_off)
-    gpart = torch.empty(npart.value, spec.g_total, device=dev)
-    dfeat = torch.empty_like(feat)
-    dapp = torch.zeros_like(app) if app is not None else None
-    # (the per-level |d(feature)| maxima are NOT tracked in this kernel, unlike the proposal backward: at its register
-    #  pressure the 8 extra live values cost more (+0.2 ms) than the separate 0.13 ms absmax pass)
-    dzb = _dzb_scratch(N, dev) if acts is not None else None
-    with prof.region("main_field_bwd"):
-        for stages in _bwd_stages(dzb):
-            check(lib().ps_main_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                          _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                          _p(weights), N, _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), stages, _stream()), "ps_main_field_bwd")
-    dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.sinks[0], counts, sink_owner=ctx.table_ref)
-    descs = []
-    for sp, off, sh in ((spec.base, spec.g_off[0], shapes[:n_base]), (spec.sem, spec.g_off[1], shapes[n_base:n_base + n_sem]),
-                        (spec.rgb, spec.g_off[2], shapes[n_base + n_sem:])):
-        descs += sp.unpack_descs(gpart, off, sh)
-    grads = unpack_layers(descs, npart.value, spec.g_total, dev, ctx.sinks[1])  # all layers in one launch
-    flat = flatten_grads(grads)
+    g, tshape, _, _ = ctx.meta
+    dapp, dfeat, flat = _stack_backward(ctx, sel, dirs, app, feat, packed, acts, d_sigma, d_rgb, d_sem, weights)
+    dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.table_sink, counts, sink_owner=ctx.table_ref)
     mark_touched(ctx.direct)
-    assert len(flat) == 2 * len(shapes)
     return dapp, dtable, flat
+
+
+class _MainStack(torch.autograd.Function):
+    """The fused MLP stack of a main field on feature planes that come from somewhere else (the dynamic branch of the dual
+    field, presight_amd/dynamic.py): the gradient w.r.t. the planes is returned instead of being scattered into a table."""
+
+    @staticmethod
+    def forward(ctx, feat, sel, dirs, app, S, g: GridCfg, want_rgb, want_sem, n_base, n_sem, *wb):
+        feat = _f32(feat)
+        N = sel.shape[0]
+        (dirs, app_c, packed, acts), (sigma, rgb, sem) = _stack_forward(ctx, feat.requires_grad, feat, N, sel, dirs, app, S, g, want_rgb,
+                                                                        want_sem, n_base, n_sem, wb)
+        ctx.save_for_backward(sel, dirs, app_c, feat, packed, acts)
+        ctx.want = (want_rgb, want_sem)
+        ctx.direct = direct_params(*wb)
+        empty = torch.empty(0, device=feat.device)
+        return sigma, (rgb if want_rgb else empty), (sem if want_sem else empty)
+
+    @staticmethod
+    def backward(ctx, dsigma, drgb, dsem):
+        sel, dirs, app, feat, packed, acts = ctx.saved_tensors
+        want_rgb, want_sem = ctx.want
+        d_sigma = _f32(dsigma) if dsigma is not None else None
+        d_rgb = _f32(drgb) if (want_rgb and drgb is not None) else None
+        d_sem = _f32(dsem) if (want_sem and dsem is not None) else None
+        dapp, dfeat, flat = _stack_backward(ctx, sel, dirs, app, feat, packed, acts, d_sigma, d_rgb, d_sem, None)
+        mark_touched(ctx.direct)
+        return (dfeat, None, None, dapp, None, None, None, None, None, None, *flat)
+
+
+def main_stack(feat: Tensor, sel: Tensor, dirs: Optional[Tensor], app: Optional[Tensor], S: int, g: GridCfg, base, sem, rgb,
+               want_rgb: bool = True, want_sem: bool = True):
+    """-> (density [N], rgb [N,3], semantics [N,64]) of the main-field MLP stack on feature planes feat [L,N,F]"""
+    flat = []
+    for W, b in list(base) + list(sem) + list(rgb):
+        flat += [W, b]
+    return _MainStack.apply(feat, sel, dirs, app, S, g, want_rgb, want_sem, len(base), len(sem), *flat)
 
 
 class _MainField(torch.autograd.Function):

@@ -99,6 +99,8 @@ class Trainer:
         vid = batch["video_ids"] if "video_ids" in batch else batch["video_id"]  # synthetic batches / the reference's collated key
         meta = {"video_id": vid.view(-1, 1), "directions_norm": dn}
         times = batch.get("times")
+        if times is None and "cam_times" in s and getattr(m, "dynamic_field", None) is not None:
+            times = s["cam_times"][batch["ray_indices"][:, 0]]  # ray time = normalised timestamp of its camera frame
         rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1], metadata=meta, times=None if times is None else times.view(-1, 1))
         if self.update_props_every_step:
             m.proposal_sampler._steps_since_update = 1 << 30  # proposal nets receive gradients EVERY step (upper bound of the schedule)
