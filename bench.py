@@ -80,6 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--global-depth-clip", action="store_true", help="expected-depth clip bounds over ALL ranks' batches")
     ap.add_argument("--fixed-batches", action="store_true", help="recycle 4 pre-made batches instead of the device chunk feed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg3 / cfg4 / extraction measurements of the default line")
     return ap.parse_args(argv)
 
 
@@ -417,6 +418,105 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=()):
     return rows
 
 
+def end_to_end_ceilings(cfg):
+    """(flop_per_ray, hash_bytes_per_ray) of one training ray, SURVEY.md 8d: MLP flops (fwd + 2x bwd) and hash-table bytes (gather
+    fwd, read + write bwd); proposal nets counted every step"""
+    m = cfg["model"]
+    L, F = m["num_levels"], m["features_per_level"]
+    mac_main = (L * F) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3)
+    flop_ray = 3 * 2 * (64 * mac_main + 192 * 576)
+    byte_ray = 3 * (64 * L * 8 * F * 4 + 192 * 8 * 8 * 4)
+    if "dynamic" in cfg:  # cfg 4: the dynamic branch's MLP stack + flow MLP, 3 position sets x 16 corners of its 4-D grid
+        dy = cfg["dynamic"]
+        Ld, Fd = dy["dynamic_num_levels"], dy["dynamic_features_per_level"]
+        mac_dyn = (Ld * Fd) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3) + (Ld * Fd * 64 + 64 * 64 + 64 * 6)
+        flop_ray += 3 * 2 * 64 * mac_dyn
+        byte_ray += 3 * 64 * (3 * Ld * 16 * Fd * 4)
+    return flop_ray, byte_ray
+
+
+def secondary_training_lines(config, shapes, dev):
+    """Short single-GPU measurements of another BASELINE configuration for the `secondary` block of the default line (so that the
+    driver's own run carries them): per (rays, steps, warmup) in `shapes` -> ms/step, rays/s, the three longest kernel regions,
+    fraction of the binding ceiling.  One model build for all shapes."""
+    import gc
+
+    import torch
+
+    from presight_amd import prof
+
+    cfg = CONFIGS[config]
+    model, scene = build_model(dev, seed=42, config=config)
+    trainer = Trainer(model, scene, 1, exchange="allreduce")
+    flop_ray, byte_ray = end_to_end_ceilings(cfg)
+    ceil = min(FP32_MFMA_PEAK_TFLOPS * 1e12 / flop_ray, HBM_PEAK_GBS * 1e9 / byte_ray)
+    n_params = sum(p.numel() for p in trainer.grads.params)
+    lines = {}
+    for rays, steps, warmup in shapes:
+        batches = make_batches(scene, dev, 2, 0, rays=rays)
+        for i in range(warmup):
+            trainer.step(batches[i % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            trainer.step(batches[i % 2])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        prof.enable(True)
+        for i in range(2):
+            trainer.step(batches[i % 2])
+        kern = prof.summary()
+        prof.enable(False)
+        # ("main_field_bwd" is the sum of the three stage regions when those are timed)
+        per_step = {k: n * ms / 2 for k, (n, ms) in kern.items() if k != "main_field_bwd" or "main_bwd_sem_kernel" not in kern}
+        top = sorted(per_step.items(), key=lambda kv: -kv[1])[:3]
+        lines[rays] = {"workload": cfg["workload"], "rays_per_step": rays, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3,
+                       "value": rays / dt, "unit": "rays/s", "parameters": n_params,
+                       "top3_regions_ms_per_step": {k: round(v, 3) for k, v in top}, "frac_of_binding": rays / dt / ceil}
+        del batches
+    del trainer, model, scene
+    gc.collect()
+    torch.cuda.empty_cache()
+    return lines
+
+
+def secondary_extract_line(dev, res=512, passes=2):
+    """BASELINE cfg 5 on one GPU, as `--config extract` measures it (see extract_main), for the `secondary` block"""
+    import gc
+
+    import torch
+
+    from presight_amd.extract import dense_tile_query, voxelize
+
+    model, scene = build_model(dev, seed=42, config="cfg2")
+    model.eval()
+    aabb = scene["aabbs"][0]
+    probe = dense_tile_query(model, aabb, res=64, density_threshold=-1.0)
+    thr = float(torch.quantile(probe["densities"][:: max(1, probe["densities"].numel() // 100000)], 0.9))
+    del probe
+
+    def one_pass():
+        out = dense_tile_query(model, aabb, res=res, chunk=1 << 23, start=0, count=res ** 3, density_threshold=thr)
+        return out, voxelize(out["points"], out["features"], None, voxel=0.4, min_bound=out["min_bound"], points_max=out["points_max"])
+
+    one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        out, vox = one_pass()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / passes
+    flop_pt = 2 * (16 * 2 * 64 + 64 * 80 + 3 * 64 * 64) + 2 * 2 * 576
+    line = {"workload": f"BASELINE cfg 5: dense {res}^3 lattice of one tile (cfg-2 fields), 3 field queries + fp16 features + threshold + bit-exact "
+                        "voxel index + voxel down-sampling", "ms_per_step": dt * 1e3, "value": res ** 3 / dt, "unit": "points/s", "passes": passes,
+            "kept_points": int(out["points"].shape[0]), "voxels": int(vox["key"].shape[0]),
+            "frac_of_binding": res ** 3 / dt * flop_pt / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    del model, scene, out, vox
+    gc.collect()
+    torch.cuda.empty_cache()
+    return line
+
+
 # --------------------------------------------------------------------------------------------------------- extraction bench
 def extract_main(args) -> int:
     """python bench.py --config extract [--gpus N]: BASELINE configs[4], prior extraction of one tile as a dense 512^3 lattice
@@ -664,17 +764,7 @@ def main():
                                 else (None, "not collected for this shape"))
         # end-to-end ceilings per training ray: MLP flops (fwd + 2x bwd) against the fp32 matrix peak, hash bytes
         # (gather fwd, read + write bwd) against HBM; the binding (lower) ceiling is the fp32 MFMA one
-        m = cfg["model"]
-        L, F = m["num_levels"], m["features_per_level"]
-        mac_main = (L * F) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3)
-        flop_ray = 3 * 2 * (64 * mac_main + 192 * 576)
-        byte_ray = 3 * (64 * L * 8 * F * 4 + 192 * 8 * 8 * 4)
-        if "dynamic" in cfg:  # cfg 4: the dynamic branch's MLP stack + flow MLP, 3 position sets x 16 corners of its 4-D grid
-            dy = cfg["dynamic"]
-            Ld, Fd = dy["dynamic_num_levels"], dy["dynamic_features_per_level"]
-            mac_dyn = (Ld * Fd) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3) + (Ld * Fd * 64 + 64 * 64 + 64 * 6)
-            flop_ray += 3 * 2 * 64 * mac_dyn
-            byte_ray += 3 * 64 * (3 * Ld * 16 * Fd * 4)
+        flop_ray, byte_ray = end_to_end_ceilings(cfg)
         ceil_mfma, ceil_hbm = FP32_MFMA_PEAK_TFLOPS * 1e12 / flop_ray, HBM_PEAK_GBS * 1e9 / byte_ray
         per_gpu = value / world
         line = {
@@ -704,6 +794,36 @@ def main():
             "psnr_vs_random_targets": psnr,
             "loss": float(sum(v.detach() for v in loss_dict.values())),
         }
+        if world == 1 and args.config == "cfg2" and not args.no_secondary and rays == RAYS:
+            # the other single-GPU BASELINE shapes, a few steps each (cfg 2 is the line itself; their own full runs: --config ...)
+            if feed is not None:
+                feed.close()
+            last_batch[0] = None
+            del trainer, model, feed, batches, out, loss_dict
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            sec = {}
+
+            def run_sec(keys, fn):
+                t_sec = time.perf_counter()
+                try:
+                    res = fn()
+                except Exception as e:  # a secondary figure must never take the headline line down
+                    res = {k: {"error": f"{type(e).__name__}: {e}"} for k in keys}
+                for k in keys:
+                    sec[k] = res[k]
+                sec[keys[0]]["wall_s_incl_model_build"] = round(time.perf_counter() - t_sec, 1)
+
+            def cfg3():
+                r = secondary_training_lines("cfg3", [(65536, 3, 2), (8192, 5, 2)], dev)
+                return {"cfg3_65536": r[65536], "cfg3_8192": r[8192]}
+
+            run_sec(["cfg3_65536", "cfg3_8192"], cfg3)
+            run_sec(["cfg4_65536"], lambda: {"cfg4_65536": secondary_training_lines("cfg4", [(65536, 3, 2)], dev)[65536]})
+            run_sec(["extract_512"], lambda: {"extract_512": secondary_extract_line(dev)})
+            line["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]

@@ -403,7 +403,10 @@ extern "C" int ps_grid_scatter(const float* u, const float* dfeat, const float* 
 namespace {
 
 constexpr int kBinThreads = 256;
-constexpr int bin_points_per_thread(int D) { return D == 4 ? 1 : 2; }
+#ifndef PS_BIN_PPT
+#define PS_BIN_PPT 2
+#endif
+constexpr int bin_points_per_thread(int D) { return D == 4 ? 1 : PS_BIN_PPT; }
 constexpr int bin_points(int D) { return kBinThreads * bin_points_per_thread(D); }  // points per workgroup
 constexpr int kMaxSlices = 256;
 constexpr int kAccBytes = 128 * 1024;
@@ -433,15 +436,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
   constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
   constexpr int NP = D == 4 ? 8 : 4;  // x-pairs per (point, level)
   // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record.
-  // The staging area holds the common case (4 pair records per point + slack); split pairs can push a workgroup past it
-  // (only where a level's resolution exceeds the slice size), those records go straight to their final position.
-  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * NP + kBinPoints * NP / 16;
+  // The staging area holds exactly the NP pair records of every point; the second record of a SPLIT pair (rare, see below)
+  // never enters it.
+  constexpr int kRec = COUNT_ONLY ? 1 : kBinPoints * NP;
   __shared__ unsigned cnt[kMaxSlices], off[kMaxSlices + 1], gbase[kMaxSlices];
   __shared__ unsigned s_idx[kRec];
   __shared__ float s_val[F + 1][kRec];  // plane F holds ox
   __shared__ unsigned char s_slice[kRec];
   const int n_slices = 1 << (log2T - log2_slice);
-  const int64_t chunks = (N + kBinPoints - 1) / kBinPoints;
   // chunk-major: the workgroups in flight spread over all L levels, so their stream reservations (returning global atomics
   // on the 2 cache lines of a level's cursors) contend 1/L as much, and the L reads of a chunk's points hit in L2
   const int level = (int)(blockIdx.x % L);
@@ -460,99 +462,133 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
   // hashes, weights, local position inside the slice bucket.  The two corners of an x-pair (ceil/floor in x) have
   // hashes that differ by cx^fx = 2^(t+1)-1 (low bits only), so they almost always live in the same slice: they travel
   // as ONE record {row of the floor corner, t, q[F] = w_yz * g[F], ox}; the accumulate kernel expands it.  A pair whose
-  // xor reaches the slice bits (probability ~2^-log2_slice) is split into two single-corner records (t = 31).
+  // xor reaches the slice bits -- x crosses a multiple of the slice's row count: impossible while the level's resolution is
+  // below it (all of cfg 2), probability ~2^-log2_slice otherwise -- is SPLIT into two single-corner records (t = 31): the
+  // floor corner takes the pair's slot, the ceil corner is emitted on a rare side path (one global reservation and one
+  // uncoalesced write per record).  Keeping that second record out of the common path halves its per-thread record slots.
   // pairs per point-level, in (y,z) corner order: (c,c) (f,c) (c,f) (f,f) [D = 4: at ceil t, then the same four at floor t]
   float gmax_local = 0.f;  // write pass: max |d(feature)| of this thread's points (the accumulate kernel's fixed-point scale)
-  uint32_t r_slice[kBinPointsPerThread][2 * NP], r_pos[kBinPointsPerThread][2 * NP], r_idx[kBinPointsPerThread][2 * NP];
-  float r_val[kBinPointsPerThread][2 * NP][F], r_ox[kBinPointsPerThread][2 * NP];
-#pragma unroll
-  for (int q = 0; q < kBinPointsPerThread; ++q) {
+  uint32_t r_slice[kBinPointsPerThread][NP], r_pos[kBinPointsPerThread][NP], r_idx[kBinPointsPerThread][NP];
+  float r_val[kBinPointsPerThread][NP][F], r_ox[kBinPointsPerThread][NP];
+  bool any_split = false;
+  // one point's cell, hashes and weights (also recomputed on the split side path)
+  struct Pt {
+    bool ok;
+    float g[F], ox;
+    uint32_t fx, cx, hyz[NP], xdiff;
+    float wyz[NP];
+  };
+  auto point = [&](int q) {
+    Pt p;
     const int64_t n = first + q * kBinThreads + threadIdx.x;
-    const bool ok = n < N;
-    float g[F];
+    p.ok = n < N;
 #pragma unroll
-    for (int f = 0; f < F; ++f) g[f] = 0.f;
-    ps::Cell c = ps::make_cell(ok ? u[n * D] : 0.f, ok ? u[n * D + 1] : 0.f, ok ? u[n * D + 2] : 0.f, s);
+    for (int f = 0; f < F; ++f) p.g[f] = 0.f;
+    ps::Cell c = ps::make_cell(p.ok ? u[n * D] : 0.f, p.ok ? u[n * D + 1] : 0.f, p.ok ? u[n * D + 2] : 0.f, s);
     const int64_t ng = (period > 0 && n >= period) ? n - period : n;
-    if (ok) {
-      if constexpr (F == 1) g[0] = g_plane[ng];
+    if (p.ok) {
+      if constexpr (F == 1) p.g[0] = g_plane[ng];
       if constexpr (F == 2) {
         const f32x2 t = *reinterpret_cast<const f32x2*>(g_plane + ng * 2);
-        g[0] = t.x;
-        g[1] = t.y;
+        p.g[0] = t.x;
+        p.g[1] = t.y;
       }
       if constexpr (F == 4) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(g_plane + ng * 4);
-        g[0] = t.x;
-        g[1] = t.y;
-        g[2] = t.z;
-        g[3] = t.w;
-      }
-    }
-    if constexpr (!COUNT_ONLY) {
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const float a = fabsf(g[f]);
-        gmax_local = (a == a) ? fmaxf(gmax_local, a) : __builtin_inff();  // a NaN stays visible as "non-finite"
+        p.g[0] = t.x;
+        p.g[1] = t.y;
+        p.g[2] = t.z;
+        p.g[3] = t.w;
       }
     }
     const uint32_t yc = (uint32_t)c.cy * 2654435761u, yf = (uint32_t)c.fy * 2654435761u;
     const uint32_t zc = (uint32_t)c.cz * 805459861u, zf = (uint32_t)c.fz * 805459861u;
-    uint32_t hyz[NP];
-    float wyz[NP];
-    {
-      const float oy = c.oy, oz = c.oz, uy = 1.0f - oy, uz = 1.0f - oz;
-      const uint32_t h4[4] = {yc ^ zc, yf ^ zc, yc ^ zf, yf ^ zf};
-      const float w4[4] = {oy * oz, uy * oz, oy * uz, uy * uz};
-      if constexpr (D == 4) {
+    const float oy = c.oy, oz = c.oz, uy = 1.0f - oy, uz = 1.0f - oz;
+    const uint32_t h4[4] = {yc ^ zc, yf ^ zc, yc ^ zf, yf ^ zf};
+    const float w4[4] = {oy * oz, uy * oz, oy * uz, uy * uz};
+    if constexpr (D == 4) {
 #pragma clang fp contract(off)
-        const float st = (ok ? u[n * D + 3] : 0.f) * s;
-        const float flt = floorf(st), ot = st - flt;
-        const uint32_t tc = (uint32_t)(int)ceilf(st) * 3674653429u, tf = (uint32_t)(int)flt * 3674653429u;
+      const float st = (p.ok ? u[n * D + 3] : 0.f) * s;
+      const float flt = floorf(st), ot = st - flt;
+      const uint32_t tc = (uint32_t)(int)ceilf(st) * 3674653429u, tf = (uint32_t)(int)flt * 3674653429u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          hyz[k] = h4[k] ^ tc;
-          hyz[4 + k] = h4[k] ^ tf;
-          wyz[k] = w4[k] * ot;
-          wyz[4 + k] = w4[k] * (1.0f - ot);
-        }
-      } else {
+      for (int k = 0; k < 4; ++k) {
+        p.hyz[k] = h4[k] ^ tc;
+        p.hyz[4 + k] = h4[k] ^ tf;
+        p.wyz[k] = w4[k] * ot;
+        p.wyz[4 + k] = w4[k] * (1.0f - ot);
+      }
+    } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          hyz[k] = h4[k];
-          wyz[k] = w4[k];
-        }
+      for (int k = 0; k < 4; ++k) {
+        p.hyz[k] = h4[k];
+        p.wyz[k] = w4[k];
       }
     }
-    const uint32_t xdiff = ((uint32_t)c.cx ^ (uint32_t)c.fx) & mask;  // 0 (exact integer) or 2^(t+1)-1
-    const bool together = (xdiff >> log2_slice) == 0u;
-    const uint32_t tcode = xdiff == 0u ? 30u : (uint32_t)(31 - __clz((int)xdiff));  // t (xdiff = 2^(t+1)-1), 30 = same row
+    p.fx = (uint32_t)c.fx;
+    p.cx = (uint32_t)c.cx;
+    p.ox = c.ox;
+    p.xdiff = (p.cx ^ p.fx) & mask;  // 0 (exact integer) or 2^(t+1)-1
+    return p;
+  };
+#pragma unroll
+  for (int q = 0; q < kBinPointsPerThread; ++q) {
+    const Pt p = point(q);
+    if constexpr (!COUNT_ONLY) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float a = fabsf(p.g[f]);
+        gmax_local = (a == a) ? fmaxf(gmax_local, a) : __builtin_inff();  // a NaN stays visible as "non-finite"
+      }
+    }
+    const bool together = (p.xdiff >> log2_slice) == 0u;
+    const uint32_t tcode = p.xdiff == 0u ? 30u : (uint32_t)(31 - __clz((int)p.xdiff));  // t (xdiff = 2^(t+1)-1), 30 = same row
+    const float wf = together ? 1.0f : 1.0f - p.ox;  // single floor corner of a split pair: its weight is folded into the values
+    bool any_rec = false;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const uint32_t hf = ((uint32_t)c.fx ^ hyz[k]) & mask, hc = ((uint32_t)c.cx ^ hyz[k]) & mask;
+      const uint32_t hf = (p.fx ^ p.hyz[k]) & mask;
       bool any = false;
-      float qv[F];
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        qv[f] = wyz[k] * g[f];
-        any |= (qv[f] != 0.0f);
+        const float qv = p.wyz[k] * p.g[f];
+        any |= (qv != 0.0f);
+        r_val[q][k][f] = qv * wf;
       }
-      // slot 2k: the pair (or the floor corner of a split pair); slot 2k+1: the ceil corner of a split pair
-      r_slice[q][2 * k] = hf >> log2_slice;
-      r_idx[q][2 * k] = (hf & low) | ((together ? tcode : 31u) << 16) ;
-      r_ox[q][2 * k] = together ? c.ox : 0.0f;  // single floor corner: weight (1-ox) folded into the values below
-      r_slice[q][2 * k + 1] = hc >> log2_slice;
-      r_idx[q][2 * k + 1] = (hc & low) | (31u << 16);
-      r_ox[q][2 * k + 1] = 0.0f;
+      r_slice[q][k] = hf >> log2_slice;
+      r_idx[q][k] = (hf & low) | ((together ? tcode : 31u) << 16);
+      r_ox[q][k] = together ? p.ox : 0.0f;
+      const bool emit = p.ok && any;
+      any_rec |= emit;
+      r_pos[q][k] = emit ? atomicAdd(&cnt[r_slice[q][k]], 1u) : 0xffffffffu;  // ds_add_rtn_u32
+    }
+    any_split |= any_rec && !together && p.ox != 0.0f;
+  }
+  if (__builtin_expect(__ballot(any_split) != 0ull, 0)) {
+    // split pairs: the ceil-x corner of every emitted pair as a single-corner record in ITS slice's stream
 #pragma unroll
-      for (int f = 0; f < F; ++f) {
-        r_val[q][2 * k][f] = together ? qv[f] : qv[f] * (1.0f - c.ox);
-        r_val[q][2 * k + 1][f] = qv[f] * c.ox;
+    for (int q = 0; q < kBinPointsPerThread; ++q) {
+      const Pt p = point(q);
+      if (!p.ok || (p.xdiff >> log2_slice) == 0u || p.ox == 0.0f) continue;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        float qv[F];
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          qv[f] = p.wyz[k] * p.g[f];
+          any |= (qv[f] != 0.0f);
+        }
+        if (!any) continue;
+        const uint32_t hc = (p.cx ^ p.hyz[k]) & mask;
+        const unsigned dst = atomicAdd(&cursors[level * n_slices + (hc >> log2_slice)], 1u);
+        if constexpr (!COUNT_ONLY) {
+          rec_idx[dst] = (hc & low) | (31u << 16);
+#pragma unroll
+          for (int f = 0; f < F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = qv[f] * p.ox;
+          rec_val[(int64_t)F * n_rec_max + dst] = 0.0f;
+        }
       }
-      const bool emit0 = ok && any;
-      const bool emit1 = ok && any && !together && c.ox != 0.0f;
-      r_pos[q][2 * k] = emit0 ? atomicAdd(&cnt[r_slice[q][2 * k]], 1u) : 0xffffffffu;  // ds_add_rtn_u32
-      r_pos[q][2 * k + 1] = emit1 ? atomicAdd(&cnt[r_slice[q][2 * k + 1]], 1u) : 0xffffffffu;
     }
   }
   __syncthreads();
@@ -608,14 +644,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
         published = __hip_atomic_load(gmax_track + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    // stage the records in bucket order.  The bucket offsets of all 16 record slots are fetched first: written as "read the
+    // stage the records in bucket order.  The bucket offsets of all record slots are fetched first: written as "read the
     // offset, store the record" per slot, every slot exposed an LDS round trip (the compiler keeps the read behind the
     // previous slot's stores)
-    unsigned r_dst[kBinPointsPerThread][2 * NP];
+    unsigned r_dst[kBinPointsPerThread][NP];
 #pragma unroll
     for (int q = 0; q < kBinPointsPerThread; ++q)
 #pragma unroll
-      for (int k = 0; k < 2 * NP; ++k) {
+      for (int k = 0; k < NP; ++k) {
         const unsigned o = off[r_slice[q][k]];  // unconditional (r_slice is always a valid slice): no branch around the LDS read
         r_dst[q][k] = (r_pos[q][k] != 0xffffffffu) ? o + r_pos[q][k] : 0xffffffffu;
       }
@@ -623,7 +659,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
 #pragma unroll
     for (int q = 0; q < kBinPointsPerThread; ++q)
 #pragma unroll
-      for (int k = 0; k < 2 * NP; ++k) {
+      for (int k = 0; k < NP; ++k) {
         const unsigned p = r_dst[q][k];
         if (p < (unsigned)kRec) {
           s_idx[p] = r_idx[q][k];
@@ -636,22 +672,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
     if ((int)threadIdx.x < n_slices) gbase[threadIdx.x] = my_base;
     if (my_bits > published) atomicMax(gmax_track + level, my_bits);  // (published stays 0xffffffff where nothing was requested)
     __syncthreads();
-    if (off[n_slices] > (unsigned)kRec) {  // staging area full (workgroup-uniform): the rest goes out uncoalesced
-#pragma unroll
-      for (int q = 0; q < kBinPointsPerThread; ++q)
-#pragma unroll
-        for (int k = 0; k < 2 * NP; ++k) {
-          if (r_pos[q][k] != 0xffffffffu && off[r_slice[q][k]] + r_pos[q][k] >= (unsigned)kRec) {
-            const int64_t dst = (int64_t)gbase[r_slice[q][k]] + r_pos[q][k];
-            rec_idx[dst] = r_idx[q][k];
-#pragma unroll
-            for (int f = 0; f < F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = r_val[q][k][f];
-            rec_val[(int64_t)F * n_rec_max + dst] = r_ox[q][k];
-          }
-        }
-    }
     // coalesced runs to the slice streams
-    const unsigned total = min(off[n_slices], (unsigned)kRec);
+    const unsigned total = off[n_slices];
     constexpr int kOut = 4;  // records per thread and round: their LDS look-ups (slice -> stream position) are issued together
     for (unsigned p0 = threadIdx.x; p0 < total; p0 += kBinThreads * kOut) {
       unsigned sl[kOut];
