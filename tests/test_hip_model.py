@@ -72,11 +72,20 @@ def test_training_step_matches_reference(gold_model):
         assert_threshold_depth(out[k], G["T_" + k], G[f"T_weights_{lvl}"], out["ray_samples_list"][lvl].ebins, what=k)
     gt = {"rgb": batch["rgb"].to(dev), "features": batch["features"].to(dev), "sky": batch["sky"].to(dev)}
     ld = model.get_loss_dict(out, gt)
-    # the interlevel loss divides fp32 cumsums by very narrow PDF-resampled bins, which amplifies summation-order
-    # differences (see tests/test_hip_losses.py), hence 1e-2 there
-    loose = {"interlevel_loss": 1e-2}
+    # The interlevel loss divides fp32 cumsums by very narrow PDF-resampled bins, which amplifies summation-order differences
+    # (tests/test_hip_losses.py).  Its tolerance is COMPUTED: the distance between the fp32 and the fp64 run of the pinned oracle
+    # on the fixture's inputs = the rounding noise any fp32 evaluation of this loss carries, the reference's own included.
+    from conftest import to_double
+    from oracle import nerf_oracle as O
+
+    with torch.no_grad():
+        anneal = float(G["T_anneal"])
+        l32 = O.loss_dict(O.model_forward(P, cfg, scene, batch, training=True, anneal=anneal), batch, cfg)
+        l64 = O.loss_dict(O.model_forward(to_double(P), cfg, to_double(scene), to_double(batch), training=True, anneal=anneal), to_double(batch), cfg)
     for k, v in ld.items():
-        close(v, G["TL_" + k], rtol=loose.get(k, 5e-4), atol=1e-7)
+        noise = abs(float(l32[k]) - float(l64[k]))
+        assert abs(float(l32[k]) - float(G["TL_" + k])) <= 5e-4 * abs(float(G["TL_" + k])) + 4 * noise + 1e-7, k  # the oracle restates the fixture
+        close(v, G["TL_" + k], rtol=5e-4, atol=1e-7 + 4 * noise)
     sum(ld.values()).backward()
     g_ref = {k[3:]: t(G[k]) for k in G if k.startswith("TG_")}
     assert len(g_ref) == len(P)

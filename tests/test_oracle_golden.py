@@ -303,6 +303,36 @@ def test_whole_model_training_step(gold_model):
     assert n_checked == len(P)
 
 
+def test_whole_model_training_step_k8_production_shape(gold_model_k8):
+    """the oracle against the REFERENCE's own training step with K = 8 routed sub-fields at the production shape (L10 F4 up to
+    resolution 16384, 64-wide MLPs): pins the restatement of the router + sub-field loop where the HIP multi-sub-field path is
+    then tested against it at K = 16"""
+    from conftest import model_k8_setup
+
+    G = gold_model_k8
+    cfg, scene, P, batch = model_k8_setup(G)
+    L, out, grads = O.train_step(P, cfg, scene, batch, anneal=float(G["T_anneal"]))
+    for i in range(3):
+        close(out["weights_list"][i], G[f"T_weights_{i}"], rtol=1e-4, atol=1e-6)
+    for k in ["rgb", "accumulation", "expected_depth", "semantics"]:
+        close(out[k], G["T_" + k], rtol=1e-4, atol=1e-5)
+    for k in ["depth", "prop_depth_0", "prop_depth_1"]:
+        close(out[k], G["T_" + k], rtol=1e-5, atol=1e-6)
+    for k, v in L.items():
+        close(v, G["TL_" + k], rtol=2e-4, atol=1e-7)
+    n_checked = 0
+    for k in G:
+        if k.startswith("TG_"):
+            ref = t(G[k])
+            close(grads[k[3:]], ref, rtol=2e-3, atol=3e-4 * float(ref.abs().max()) + 1e-7)
+            n_checked += 1
+    assert n_checked == int(G["n_grads"]) and n_checked > 100
+    # sub-fields the reference never called (grad None there) have exactly zero gradients here
+    for name, g in grads.items():
+        if "TG_" + name not in G:
+            assert float(g.abs().max()) == 0.0, name
+
+
 def test_whole_model_eval_and_extraction(gold_model):
     G = gold_model
     cfg, scene, P, batch = model_fixture_setup(G)
