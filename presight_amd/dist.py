@@ -27,6 +27,38 @@ import torch.distributed as dist
 from torch import Tensor
 
 
+class CommLog:
+    """Per-rank log of every collective this module issues, in ISSUE order: sequence number, kind, bucket, bytes, stream.  NCCL /
+    gloo pair collectives by issue order, so a hang is diagnosed by diffing the ranks' logs: the first line that differs (or the
+    last line one rank has and the other lacks) is the mismatched collective.  PRESIGHT_COMM_LOG=<path with {rank}> turns it on
+    (one flushed line per collective: what is on disk when a rank hangs is what it issued); the last 256 entries are always kept
+    in memory (CommLog.tail())."""
+
+    def __init__(self):
+        import collections
+        import os
+
+        self.seq = 0
+        self.ring = collections.deque(maxlen=256)
+        self.file = None
+        path = os.environ.get("PRESIGHT_COMM_LOG")
+        if path:
+            self.file = open(path.replace("{rank}", os.environ.get("RANK", "0")), "a", buffering=1)
+
+    def issue(self, kind: str, bucket, nbytes: int, stream: str, step=None):
+        self.seq += 1
+        line = f"{self.seq} {kind} bucket={bucket} bytes={nbytes} stream={stream} step={step}"
+        self.ring.append(line)
+        if self.file is not None:
+            self.file.write(line + "\n")
+
+    def tail(self, n: int = 16):
+        return list(self.ring)[-n:]
+
+
+COMM_LOG = CommLog()
+
+
 def _mark_touched(p):
     """autograd's own accumulation finished for p (post-accumulate-grad hook); the HIP backward nodes that write gradients
     in place call presight_amd.ops.mark_touched, which ends up here too"""
@@ -115,6 +147,7 @@ class FlatGrads:
         self.group_flags: Optional[Tensor] = None   # int32 [n_groups], 1 = the group's sub-field received samples this step
         self.group_steps: Optional[Tensor] = None   # int32 [n_groups], torch.optim.Adam's state["step"] of the group
         self.n_groups = 0
+        self.step_no = 0  # zero_() calls so far (only labels the lines of COMM_LOG)
 
     def define_groups(self, groups: Sequence[Sequence[torch.nn.Parameter]]):
         """Parameters whose "received a gradient this step" is only known ON THE DEVICE: the sub-fields of a routed tile (the
@@ -155,6 +188,7 @@ class FlatGrads:
             for a, b in self._dirty:
                 self.flat[a:b].zero_()
         self._dirty = None
+        self.step_no += 1
         if self.n_groups:
             self.group_flags.zero_()
         for p in self.params:
@@ -167,6 +201,7 @@ class FlatGrads:
         flags = [bool(p._ps_touched) for p in self.params]
         if self.flags_may_differ_across_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             t = torch.tensor(flags, dtype=torch.int32, device=self.flat.device)  # DDP: a parameter used on ANY rank gets a gradient
+            COMM_LOG.issue("all_reduce_max_host_flags", "-", 4 * len(flags), "current", self.step_no)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             flags = [bool(v) for v in t.tolist()]
         return flags
@@ -261,6 +296,8 @@ class FlatGrads:
 
         def issue():
             seg.div_(world)
+            COMM_LOG.issue("reduce_scatter" if self.mode == "sharded" else "all_reduce", b["index"], 4 * (e - a),
+                           "side" if self._comm_stream is not None else "current", self.step_no)
             if self.mode == "sharded":
                 n = (e - a) // world
                 b["work"] = dist.reduce_scatter_tensor(seg[rank * n:(rank + 1) * n], seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
@@ -282,6 +319,7 @@ class FlatGrads:
     def finish_exchange(self):
         """after backward: launch the buckets that are still local (in order), then make the compute stream wait for all of them"""
         if self.n_groups and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
+            COMM_LOG.issue("all_reduce_max_flags", "-", 4 * self.group_flags.numel(), "current", self.step_no)
             dist.all_reduce(self.group_flags, op=dist.ReduceOp.MAX, group=self._group)  # device tensor, stream-ordered: no host sync
         if not self._buckets:
             return self.all_reduce_mean(self._group)
@@ -329,6 +367,7 @@ class FlatGrads:
                 continue  # nothing in this bucket was updated on any rank
             n = (e - a) // world
             seg = flat_params[a:e]
+            COMM_LOG.issue("all_gather_params", b["index"], 4 * (e - a), "side" if self._comm_stream is not None else "current", self.step_no)
             if self._comm_stream is not None:
                 with torch.cuda.stream(self._comm_stream):
                     self._comm_stream.wait_event(ev)
@@ -352,6 +391,7 @@ class FlatGrads:
             a, e = b["range"]
             n = (e - a) // world
             seg = flat[a:e]
+            COMM_LOG.issue("all_gather_state", b["index"], 4 * (e - a), "current", self.step_no)
             dist.all_gather_into_tensor(seg, seg[rank * n:(rank + 1) * n].clone(), group=self._group)
 
     def wait_params(self, bucket: Optional[int] = None):
@@ -368,6 +408,7 @@ class FlatGrads:
             return None
         world = dist.get_world_size(group)
         self.flat.div_(world)
+        COMM_LOG.issue("all_reduce_flat", "-", 4 * self.total, "current", self.step_no)
         self.stats["collectives"] += 1
         self.stats["bytes"] += 2 * 4 * self.total * (world - 1) // world
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -380,6 +421,7 @@ def global_depth_clip(group: Optional[dist.ProcessGroup] = None):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
         t = torch.stack([-minmax[0], minmax[1]])
+        COMM_LOG.issue("all_reduce_max_depth_clip", "-", 8, "current")
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         minmax[0] = -t[0]
         minmax[1] = t[1]

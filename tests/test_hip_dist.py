@@ -227,6 +227,13 @@ def _run_bench_two_ranks(extra, timeout=300):
         if os.path.exists(dump.replace("{rank}", str(r))):
             os.remove(dump.replace("{rank}", str(r)))
     env.update(PRESIGHT_HANG_DUMP="200", PRESIGHT_HANG_DUMP_FILE=dump)
+    # per-collective sequence log of both ranks (presight_amd.dist.CommLog): the first differing / missing line names the collective
+    # a hang is stuck in; kept in gpurun_out/ when the run does not end cleanly
+    comm = os.path.join(dump_dir, "dp2_comm_rank{rank}.log")
+    for r in (0, 1):
+        if os.path.exists(comm.replace("{rank}", str(r))):
+            os.remove(comm.replace("{rank}", str(r)))
+    env["PRESIGHT_COMM_LOG"] = comm
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rays", "4096",
            "--no-cpu-baseline"] + extra
     hung = lambda: [r for r in (0, 1) if os.path.exists(dump.replace("{rank}", str(r))) and os.path.getsize(dump.replace("{rank}", str(r))) > 0]  # noqa: E731
@@ -243,6 +250,10 @@ def _run_bench_two_ranks(extra, timeout=300):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["comm"]["ranks"] == 2
     assert line["comm"]["backend"] == ("nccl" if two_gpus else "gloo")
+    logs = [open(comm.replace("{rank}", str(r))).read().splitlines() for r in (0, 1)]
+    assert logs[0] == logs[1] and len(logs[0]) > 10, "the ranks issued different collective sequences"
+    for r in (0, 1):
+        os.remove(comm.replace("{rank}", str(r)))
     return line
 
 

@@ -303,11 +303,19 @@ def test_sharded_exchange_gloo_world2(tmp_path):
     """reduce-scatter -> update of the owned shard -> all-gather (presight_amd.dist mode "sharded"): bit-equal replicas"""
     script = tmp_path / "worker_sharded.py"
     script.write_text(_WORKER_SHARDED.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", PRESIGHT_COMM_LOG=str(tmp_path / "comm_{rank}.log"))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29733", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+    # the per-collective sequence log (presight_amd.dist.CommLog): both ranks issued the SAME collectives in the SAME order -- what
+    # NCCL / gloo need, and what the next hang will be diagnosed with (first differing / missing line)
+    logs = [(tmp_path / f"comm_{r_}.log").read_text().splitlines() for r_ in range(2)]
+    assert logs[0] == logs[1] and len(logs[0]) >= 7, logs
+    kinds = [ln.split()[1] for ln in logs[0]]
+    assert kinds[:2] == ["reduce_scatter", "reduce_scatter"] and kinds.count("all_gather_params") == 3 and "all_reduce_max_depth_clip" in kinds
+    assert [int(ln.split()[0]) for ln in logs[0]] == list(range(1, len(logs[0]) + 1))
+    assert "bucket=0 bytes=96" in logs[0][0] and "step=1" in logs[0][0]
 
 
 def test_bench_launcher_and_arguments():
