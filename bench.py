@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 RAYS = 65536
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: xGMI, point-to-point, ~153 GB/s per link and direction, 7 links per GPU
 
 CONFIGS = {
     # iNGPField constructor defaults = BASELINE cfg 2 (ns/fields/PreSight/ingp_field.py:74-84); proposal nets nerfacto_nusc_ms.py:114-121
@@ -517,6 +518,20 @@ def secondary_extract_line(dev, res=512, passes=2):
     return line
 
 
+def exchange_model(bytes_on_link_per_rank: float, world: int, step_ms_single: float = None) -> dict:
+    """The scaling model of DESIGN.md section 6, evaluated for this run: a rank sends (and receives) `bytes_on_link_per_rank` per
+    step -- (N-1)/N of every reduce-scattered / all-gathered byte, twice that for an all-reduce.  xGMI is point-to-point: with the
+    direct (all-to-all) algorithm every peer link carries 1/(N-1) of it concurrently -> t = bytes / ((N-1) * link rate); a ring
+    moves everything over ONE link per direction -> t = bytes / link rate.  RCCL picks between them; both bounds are printed next
+    to the measured exposed time, which is what is left after the overlap with backward / the next step's sampling."""
+    if world <= 1:
+        return None
+    direct = bytes_on_link_per_rank / ((world - 1) * XGMI_LINK_GBS * 1e9) * 1e3
+    ring = bytes_on_link_per_rank / (XGMI_LINK_GBS * 1e9) * 1e3
+    return {"link_GBps_per_direction": XGMI_LINK_GBS, "peer_links_used": world - 1, "predicted_ms_all_links": direct,
+            "predicted_ms_ring_one_link": ring}
+
+
 # --------------------------------------------------------------------------------------------------------- extraction bench
 def extract_main(args) -> int:
     """python bench.py --config extract [--gpus N]: BASELINE configs[4], prior extraction of one tile as a dense 512^3 lattice
@@ -789,7 +804,8 @@ def main():
             "comm": None if world == 1 else {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                                              "collectives_per_step": comm["collectives"] / args.steps,
                                              "bytes_on_link_per_rank_per_step": comm["bytes"] / args.steps,
-                                             "exchange_exposed_ms": kern.get("exchange_exposed", (0, None))[1]},
+                                             "exchange_exposed_ms": kern.get("exchange_exposed", (0, None))[1],
+                                             "model": exchange_model(comm["bytes"] / args.steps, world)},
             "replicas_max_abs_diff": replica_diff,
             "psnr_vs_random_targets": psnr,
             "loss": float(sum(v.detach() for v in loss_dict.values())),
@@ -828,6 +844,12 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
             line["psnr_vs_oracle"] = _PSNR_VS_ORACLE
+        if world > 1:
+            mdl = line["comm"]["model"]
+            print(f"bench.py: gradient exchange per step and rank: {line['comm']['bytes_on_link_per_rank_per_step'] / 1e6:.1f} MB on the links; "
+                  f"predicted {mdl['predicted_ms_all_links']:.2f} ms over all {world - 1} peer links ({mdl['predicted_ms_ring_one_link']:.2f} ms as a "
+                  f"one-link ring) vs {line['comm']['exchange_exposed_ms']} ms measured EXPOSED (not hidden under backward / sampling); "
+                  f"step {ms:.2f} ms", file=sys.stderr)
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:

@@ -358,24 +358,30 @@ int ps_ms_mark_groups(const int32_t* field_start, int K, const int32_t* group_of
 /* x4[n] = (u[n], times[n / S]): the static field's normalised positions u [N,3] + the rays' normalised timestamps [N / S] */
 int ps_dyn_points(const float* u, const float* times, int S, int64_t N, float* x4 /*[N,4]*/, void* stream);
 /* 4-D multiresolution hash grid on level planes feat[l][n][f].  e0 == NULL: feat = H4(x), x [N,4].
- * e0 != NULL (temporal aggregation): x [2N,4] = forward-warped then backward-warped positions, feat = (e0 + H4(x[n]) + H4(x[N+n])) / 3 */
+ * e0 != NULL (temporal aggregation): x [2N,4] = forward-warped then backward-warped positions, feat = (e0 + H4(x[n]) + H4(x[N+n])) / 3.
+ * slice_counts (nullable, [L * ps_grid_scatter_slices(F, log2T)] uint32, NOT cleared here): += the records the binned table
+ * backward will emit for the encoded positions, so that ps_grid4_scatter_binned needs no counting pass. */
 int ps_grid4_encode(const float* x, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
-                    int64_t plane_stride, const float* e0 /*nullable*/, float* feat, void* stream);
+                    int64_t plane_stride, const float* e0 /*nullable*/, float* feat, uint32_t* slice_counts /*nullable*/, void* stream);
 /* dx[m][0..3) = g_scale * sum_l scalings[l] * <dfeat[l][m mod period], d H4[l] / d x_a> for the spatial axes (the hash grid is
  * multilinear inside a cell; exactly integer coordinates have zero derivative, like autograd through ceil / floor).
  * x [M,4], M <= 2 * period when period > 0 (two position sets share one gradient plane), dx [M,3]. */
 int ps_grid4_input_grad(const float* x, const float* dfeat, const float* table, const float* scalings, int L, int F, int log2T,
                         int64_t M, int64_t period, int64_t plane_stride, float g_scale, float* dx, void* stream);
 /* table gradient of the 4-D grid: the binned fixed-point scatter of ps_grid_scatter_binned with 8 x-pair records per (point,
- * level); dtable (+)= out_scale * scatter(dfeat); accumulate as ps_grid_scatter_binned; workspace of ps_grid4_scatter_workspace */
+ * level); dtable (+)= out_scale * scatter(d(features)); accumulate as ps_grid_scatter_binned; workspace of
+ * ps_grid4_scatter_workspace.  x [M,4].  period > 0: up to three position sets of `period` points in ONE launch -- point m < period
+ * takes row m of dfeat, m >= period row (m - period) mod period of dfeat_b (NULL: of dfeat): the unwarped set with d(e0) and both
+ * warped sets with d(aggregated features).  slice_counts (nullable): record counts of ps_grid4_encode for exactly these M points. */
 int64_t ps_grid4_scatter_workspace(int L, int F, int log2T, int64_t M);
-int ps_grid4_scatter_binned(const float* x, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t M,
-                            int64_t period, int64_t plane_stride, float out_scale, float* dtable, int accumulate, void* workspace,
-                            void* stream);
+int ps_grid4_scatter_binned(const float* x, const float* dfeat, const float* dfeat_b /*nullable*/, const float* scalings, int L, int F,
+                            int log2T, int64_t M, int64_t period, int64_t plane_stride, float out_scale, float* dtable, int accumulate,
+                            const uint32_t* slice_counts /*nullable*/, void* workspace, void* stream);
 /* flow MLP Linear(L*F, H) ReLU Linear(H, H) ReLU Linear(H, 6) on the fp32 matrix cores; packed as ps_mlp_pack_layers packs a
  * 3-layer stack (ps_flow_sizes: packed / gradient block sizes, partial blocks ps_flow_bwd writes).
  * fwd: xw [2N,4] <- (u + s*flow[0:3], t + dt) for n < N, (u + s*flow[3:6], t - dt) for N + n (x4 [N,4] = (u, t)).
- * bwd: dxw [2N,3] = gradient w.r.t. the warped positions (ps_grid4_input_grad); de0 = dagg / 3 + d(e0 via the flow MLP). */
+ * bwd: dxw [2N,3] = gradient w.r.t. the warped positions (ps_grid4_input_grad); de0 = dagg + 3 * d(e0 via the flow MLP), i.e.
+ * THREE TIMES d(e0): the factor 1/3 of the aggregation is applied once, for all three position sets, by the table scatter. */
 int ps_flow_sizes(int LF, int hidden, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/, int* n_parts /*host*/);
 int ps_flow_fwd(const float* e0, int64_t plane_stride, int LF, int F, int hidden, const float* packed, const float* x4, int64_t N,
                 float flow_scale, float dt, float* xw, void* stream);

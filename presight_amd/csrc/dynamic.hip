@@ -103,14 +103,41 @@ __device__ __forceinline__ void load_row(const float* o, float (&v)[F]) {
   for (int f = 0; f < F; ++f) v[f] = r.v[f];
 }
 
+// records the binned table backward will emit for one position (encode.hip bin_kernel, D = 4): one per (y,z,t) combination in
+// the slice of the floor-x corner (counted by the floor lane), one more in the slice of the ceil-x corner when the pair straddles a
+// slice boundary (counted by the ceil lane); an upper bound -- the backward drops records whose gradient is exactly zero
+__device__ __forceinline__ void count_records4(const Cell4& c, uint32_t mask, int log2_slice, int side, unsigned* __restrict__ cnt) {
+  const bool together = ((((uint32_t)c.cx ^ (uint32_t)c.fx) & mask) >> log2_slice) == 0u;
+  if (side != 0 && together) return;
+  const uint32_t xs = (uint32_t)(side ? c.cx : c.fx);
+  const uint32_t yc = (uint32_t)c.cy * kPrimeY, yf = (uint32_t)c.fy * kPrimeY;
+  const uint32_t zc = (uint32_t)c.cz * kPrimeZ, zf = (uint32_t)c.fz * kPrimeZ;
+  const uint32_t tc = (uint32_t)c.ct * kPrimeT, tf = (uint32_t)c.ft * kPrimeT;
+  const uint32_t hyz[4] = {xs ^ yc ^ zc, xs ^ yf ^ zc, xs ^ yc ^ zf, xs ^ yf ^ zf};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    atomicAdd(&cnt[((hyz[k] ^ tc) & mask) >> log2_slice], 1u);
+    atomicAdd(&cnt[((hyz[k] ^ tf) & mask) >> log2_slice], 1u);
+  }
+}
+
+constexpr int kEnc4MaxSlices = 256;
+
 // feat[l][n] = H4(x[n])                                              (e0 == null, x [N,4])
 // feat[l][n] = (e0[l][n] + H4(x[n]) + H4(x[N + n])) / 3              (e0 != null, x [2N,4]: forward- and backward-warped sets)
-template <int F>
+// COUNT: slice_counts[level][slice] += the records of the table backward for the positions this launch encodes
+template <int F, bool COUNT>
 __global__ __launch_bounds__(256) void grid4_encode_kernel(const float* __restrict__ x, const float* __restrict__ table,
                                                            const float* __restrict__ scalings, int L, int log2T, int64_t N,
                                                            int64_t plane_stride, const float* __restrict__ e0, float* __restrict__ feat,
-                                                           int group, int parts) {
+                                                           int group, int parts, unsigned* __restrict__ slice_counts, int log2_slice) {
 #pragma clang fp contract(off)
+  __shared__ unsigned cnt[COUNT ? kEnc4MaxSlices : 1];
+  const int n_slices = COUNT ? (1 << (log2T - log2_slice)) : 0;
+  if constexpr (COUNT) {
+    for (int i = threadIdx.x; i < n_slices; i += 256) cnt[i] = 0u;
+    __syncthreads();  // (before the early return below: every thread of a workgroup takes the same branch there)
+  }
   const int64_t chunks = (N + 127) / 128;  // 128 points per pass of a 256-thread workgroup
   const int64_t groups = (chunks + group - 1) / group;
   int level;
@@ -127,15 +154,26 @@ __global__ __launch_bounds__(256) void grid4_encode_kernel(const float* __restri
     const bool ok = n < N;  // both lanes of a pair agree; inactive pairs still take part in the DPP swap
     const int64_t nn = ok ? n : N - 1;
     float v[F];
-    encode4_pair<F>(tl, make_cell4(*reinterpret_cast<const f32x4*>(x + nn * 4), scale), mask, side, v);
+    const Cell4 ca = make_cell4(*reinterpret_cast<const f32x4*>(x + nn * 4), scale);
+    encode4_pair<F>(tl, ca, mask, side, v);
+    if constexpr (COUNT)
+      if (ok) count_records4(ca, mask, log2_slice, side, cnt);
     if (e0 != nullptr) {
       float vb[F], v0[F];
-      encode4_pair<F>(tl, make_cell4(*reinterpret_cast<const f32x4*>(x + (N + nn) * 4), scale), mask, side, vb);
+      const Cell4 cb = make_cell4(*reinterpret_cast<const f32x4*>(x + (N + nn) * 4), scale);
+      encode4_pair<F>(tl, cb, mask, side, vb);
+      if constexpr (COUNT)
+        if (ok) count_records4(cb, mask, log2_slice, side, cnt);
       load_row<F>(e0 + level * plane_stride + nn * F, v0);
 #pragma unroll
       for (int f = 0; f < F; ++f) v[f] = ((v0[f] + v[f]) + vb[f]) / 3.0f;
     }
     if (ok && side == 0) store_row<F>(feat + level * plane_stride + n * F, v);
+  }
+  if constexpr (COUNT) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_slices; i += 256)
+      if (cnt[i]) atomicAdd(&slice_counts[level * n_slices + i], cnt[i]);
   }
 }
 
@@ -231,7 +269,9 @@ __global__ __launch_bounds__(256) void flow_fwd_kernel(const float* __restrict__
 }
 
 // backward: d(flow) = flow_scale * d(warped position) (dxw [2N,3] from grid4_input_grad_kernel); writes
-// de0 = dagg / 3 + d(e0 through the flow MLP) and one partial weight-gradient block per workgroup.
+// de0x3 = dagg + 3 * d(e0 through the flow MLP) = THREE TIMES d(e0) (all three position sets then share the factor 1/3 of the
+// aggregation, which the table scatter applies once: ps_grid4_scatter_binned out_scale) and one partial weight-gradient block
+// per workgroup.
 template <class M, int PB>
 __global__ __launch_bounds__(256) void flow_bwd_kernel(const float* __restrict__ e0, int64_t plane_stride, int LF, int F,
                                                        const float* __restrict__ packed, const float* __restrict__ dxw,
@@ -281,7 +321,7 @@ __global__ __launch_bounds__(256) void flow_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-      for (int t = 0; t < M::KS0; ++t) dxin[pb][t] = da[pb][t] / 3.0f + dxin[pb][t];
+      for (int t = 0; t < M::KS0; ++t) dxin[pb][t] = da[pb][t] + 3.0f * dxin[pb][t];
     store_dfeat<M::KS0, PB>(de0, fc, F, first, N, dxin);
   }
   __syncthreads();
@@ -403,8 +443,10 @@ extern "C" int ps_dyn_points(const float* u, const float* times, int S, int64_t 
   PS_CHECK_LAUNCH();
 }
 
+extern "C" int ps_grid_scatter_slices(int F, int log2T);  // encode.hip: table slices per level of the binned backward
+
 extern "C" int ps_grid4_encode(const float* x, const float* table, const float* scalings, int L, int F, int log2T, int64_t N,
-                               int64_t plane_stride, const float* e0, float* feat, void* stream) {
+                               int64_t plane_stride, const float* e0, float* feat, uint32_t* slice_counts, void* stream) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid4_encode: features_per_level must be 1, 2 or 4");
   if (N == 0) return 0;
   PS_REQUIRE(((uintptr_t)x & 15) == 0, "ps_grid4_encode: positions must be 16-byte aligned [.,4] rows");
@@ -413,8 +455,17 @@ extern "C" int ps_grid4_encode(const float* x, const float* table, const float* 
   const int P = enc_parts(L);
   const dim3 grid((unsigned)(8 * (int64_t)(L * P / 8) * ((groups + P - 1) / P)));  // enc_item: L * P is a multiple of 16
   hipStream_t s = (hipStream_t)stream;
-#define X(FF) \
-  if (F == FF) grid4_encode_kernel<FF><<<grid, 256, 0, s>>>(x, table, scalings, L, log2T, N, plane_stride, e0, feat, group, P);
+  const int n_slices = ps_grid_scatter_slices(F, log2T);
+  PS_REQUIRE(slice_counts == nullptr || n_slices <= kEnc4MaxSlices, "ps_grid4_encode: too many table slices");
+  int ls = 0;
+  while ((n_slices << ls) < (1 << log2T)) ++ls;
+#define X(FF)                                                                                                                              \
+  if (F == FF) {                                                                                                                           \
+    if (slice_counts != nullptr)                                                                                                           \
+      grid4_encode_kernel<FF, true><<<grid, 256, 0, s>>>(x, table, scalings, L, log2T, N, plane_stride, e0, feat, group, P, slice_counts, ls);  \
+    else                                                                                                                                   \
+      grid4_encode_kernel<FF, false><<<grid, 256, 0, s>>>(x, table, scalings, L, log2T, N, plane_stride, e0, feat, group, P, nullptr, ls);      \
+  }
   X(1) X(2) X(4)
 #undef X
   PS_CHECK_LAUNCH();

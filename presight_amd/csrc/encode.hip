@@ -423,7 +423,8 @@ __device__ __forceinline__ float fixed_scale(unsigned gmax_bits, int headroom_lo
 //                     advanced by the reservations; records are written at their exact final position.
 // D = 3: u [N,3].  D = 4 (dynamic.hip, the (x,y,z,t) grid of the dynamic field): u [N,4], 8 x-pairs per (point, level) -- the
 // (y,z) combinations at the ceil-t corner, then at the floor-t corner -- and half as many points per workgroup.
-// period > 0: point n >= period takes the d(feature) row n - period (two position sets sharing one gradient plane).
+// period > 0 (up to three position sets of `period` points each, dynamic.hip): point n < period takes row n of dfeat, a point
+// n >= period takes row (n - period) mod period of dfeat_b (dfeat itself when dfeat_b is null).
 template <int F, bool COUNT_ONLY, int D = 3>
 __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restrict__ u, const float* __restrict__ dfeat,
                                                           const float* __restrict__ scalings, int L, int log2T,
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
                                                           float* __restrict__ rec_val, const int* __restrict__ chunk_field,
                                                           unsigned* __restrict__ gmax_track /* nullable: per-level max |dfeat| bits */,
-                                                          int64_t period) {
+                                                          int64_t period, const float* __restrict__ dfeat_b) {
   constexpr int kBinPointsPerThread = bin_points_per_thread(D);
   constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
   constexpr int NP = D == 4 ? 8 : 4;  // x-pairs per (point, level)
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
   __syncthreads();
   const float s = scalings[level];
   const uint32_t mask = (1u << log2T) - 1u, low = (1u << log2_slice) - 1u;
-  const float* g_plane = dfeat + level * plane_stride;
+  const float* g_plane_a = dfeat + level * plane_stride;
+  const float* g_plane_b = (dfeat_b != nullptr ? dfeat_b : dfeat) + level * plane_stride;
   // hashes, weights, local position inside the slice bucket.  The two corners of an x-pair (ceil/floor in x) have
   // hashes that differ by cx^fx = 2^(t+1)-1 (low bits only), so they almost always live in the same slice: they travel
   // as ONE record {row of the floor corner, t, q[F] = w_yz * g[F], ox}; the accumulate kernel expands it.  A pair whose
@@ -485,7 +487,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
 #pragma unroll
     for (int f = 0; f < F; ++f) p.g[f] = 0.f;
     ps::Cell c = ps::make_cell(p.ok ? u[n * D] : 0.f, p.ok ? u[n * D + 1] : 0.f, p.ok ? u[n * D + 2] : 0.f, s);
-    const int64_t ng = (period > 0 && n >= period) ? n - period : n;
+    int64_t ng = n;
+    const float* g_plane = g_plane_a;
+    if (period > 0 && n >= period) {
+      ng = n - period;
+      if (ng >= period) ng -= period;
+      g_plane = g_plane_b;
+    }
     if (p.ok) {
       if constexpr (F == 1) p.g[0] = g_plane[ng];
       if constexpr (F == 2) {
@@ -894,10 +902,10 @@ int64_t binned_workspace(int L, int F, int log2T, int64_t N, int K, int D = 3) {
 int scatter_binned_impl(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                         int64_t plane_stride, float* dtable, float* const* dtables, int K, const int* chunk_field, int accumulate,
                         const uint32_t* slice_counts, int absmax_ready, void* workspace, hipStream_t s, int D = 3, int64_t period = 0,
-                        float out_scale = 1.0f) {
+                        float out_scale = 1.0f, const float* dfeat_b = nullptr) {
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
   PS_REQUIRE(D == 3 || (D == 4 && K == 1 && chunk_field == nullptr), "ps_grid_scatter_binned: 3-D grids, or one 4-D grid");
-  PS_REQUIRE(period == 0 || (period > 0 && N <= 2 * period), "ps_grid_scatter_binned: at most two position sets per gradient plane");
+  PS_REQUIRE(period == 0 || (period > 0 && N <= 3 * period), "ps_grid_scatter_binned: at most three position sets");
   PS_REQUIRE(N * L * (D == 4 ? 16 : 8) + 4096 + 4 * (int64_t)K * L * 256 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
   PS_REQUIRE(K * L <= 1024, "ps_grid_scatter_binned: at most 1024 (sub-field, level) pairs");
   const int ls = binned_log2_slice(F, log2T);
@@ -940,13 +948,13 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
     if (N > 0) {                                                                                                          \
       if (slice_counts == nullptr)                                                                                        \
         bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,      \
-                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period); \
+                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period, dfeat_b); \
     }                                                                                                                     \
     stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                           \
     if (N > 0)                                                                                                            \
       bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,       \
                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
-                                                                           absmax_ready ? nullptr : gmax_bits, period);   \
+                                                                           absmax_ready ? nullptr : gmax_bits, period, dfeat_b); \
     accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
                                                                n_rec_max, headroom, accumulate, dtable, dtables, out_scale); \
   }
@@ -987,13 +995,14 @@ extern "C" int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, con
 }
 
 // ---- 4-D grid of the dynamic field (csrc/dynamic.hip; BASELINE cfg 4): same record streams and accumulate kernel, 8 x-pairs
-// per (point, level).  x [M,4]; M <= 2 * period position sets share one gradient plane when period > 0 (point m takes row
-// m mod period of dfeat); the table gradient is multiplied by out_scale.
+// per (point, level).  x [M,4]; with period > 0 up to three position sets of `period` points: set 0 takes its gradient rows from
+// dfeat, the other sets from dfeat_b (null: dfeat) row m mod period; the table gradient is multiplied by out_scale.
+// slice_counts (nullable): record counts per (level, slice) from ps_grid4_encode -> no counting pass.
 extern "C" int64_t ps_grid4_scatter_workspace(int L, int F, int log2T, int64_t M) { return binned_workspace(L, F, log2T, M, 1, 4); }
 
-extern "C" int ps_grid4_scatter_binned(const float* x, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t M,
-                                       int64_t period, int64_t plane_stride, float out_scale, float* dtable, int accumulate,
-                                       void* workspace, void* stream) {
-  return scatter_binned_impl(x, dfeat, scalings, L, F, log2T, M, plane_stride, dtable, nullptr, 1, nullptr, accumulate, nullptr, 0,
-                             workspace, (hipStream_t)stream, 4, period, out_scale);
+extern "C" int ps_grid4_scatter_binned(const float* x, const float* dfeat, const float* dfeat_b, const float* scalings, int L, int F,
+                                       int log2T, int64_t M, int64_t period, int64_t plane_stride, float out_scale, float* dtable,
+                                       int accumulate, const uint32_t* slice_counts, void* workspace, void* stream) {
+  return scatter_binned_impl(x, dfeat, scalings, L, F, log2T, M, plane_stride, dtable, nullptr, 1, nullptr, accumulate, slice_counts, 0,
+                             workspace, (hipStream_t)stream, 4, period, out_scale, dfeat_b);
 }

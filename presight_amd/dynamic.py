@@ -68,13 +68,14 @@ class HashEncoding4D(nn.Module):
         return planes.permute(1, 0, 2).reshape(*x4.shape[:-1], self.get_out_dim())
 
 
-def encode4(x4: Tensor, table: Tensor, scalings: Tensor, g: F.GridCfg, e0: Optional[Tensor] = None) -> Tensor:
-    """feature planes [L, N, F]; with e0 (x4 [2N,4] = forward- then backward-warped positions): (e0 + H4 + H4) / 3"""
+def encode4(x4: Tensor, table: Tensor, scalings: Tensor, g: F.GridCfg, e0: Optional[Tensor] = None, counts: Optional[Tensor] = None) -> Tensor:
+    """feature planes [L, N, F]; with e0 (x4 [2N,4] = forward- then backward-warped positions): (e0 + H4 + H4) / 3.
+    counts (int32 [L * slices], accumulated into): record counts of the binned table backward for these positions"""
     N = x4.shape[0] if e0 is None else x4.shape[0] // 2
     feat = torch.empty(g.num_levels, N, g.features_per_level, device=x4.device)
     with prof.region("grid4_encode"):
         check(lib().ps_grid4_encode(_p(x4), _p(table), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
-                                    N * g.features_per_level, _p(e0), _p(feat), _stream()), "ps_grid4_encode")
+                                    N * g.features_per_level, _p(e0), _p(feat), _p(counts), _stream()), "ps_grid4_encode")
     return feat
 
 
@@ -89,38 +90,46 @@ def _flow_spec(LF: int, hidden: int) -> MlpSpec:
 
 
 class _DynFeatures(torch.autograd.Function):
-    """x4 [N,4] -> temporally aggregated dynamic features (planes [L,N,F]); one node for encode, flow MLP, warp, the two warped
-    encodes and the aggregation.  Backward: d(feat) -> d(warped positions) -> flow MLP -> d(e0) -> two binned table scatters."""
+    """(u [N,3], ray times [N // S]) -> temporally aggregated dynamic features (planes [L,N,F]); one node for the positions, the
+    encode, the flow MLP + warp, the two warped encodes and the aggregation.  The three position sets live in ONE [3N,4] buffer
+    (unwarped | forward-warped | backward-warped).  Backward: d(feat) -> d(warped positions) -> flow MLP -> 3 d(e0) -> one binned
+    table scatter over all 3N positions (record counts from the forward encodes)."""
 
     @staticmethod
-    def forward(ctx, x4, table, scalings, g: F.GridCfg, flow_scale, dt, *wb):
-        x4 = _f32(x4, "positions")
+    def forward(ctx, u, times, S, table, scalings, g: F.GridCfg, flow_scale, dt, *wb):
+        u = _f32(u, "positions")
         table = _f32(table, "hash table")
-        N, dev = x4.shape[0], x4.device
+        N, dev = u.shape[0], u.device
         layers = F._layers(wb)
         hidden = layers[0][0].shape[0]
         spec = _flow_spec(g.out_dim, hidden)
         packed = spec.pack(layers, dev)
-        e0 = encode4(x4, table, scalings, g)
-        xw = torch.empty(2 * N, 4, device=dev)
+        xall = torch.empty(3 * N, 4, device=dev)
+        x4, xw = xall[:N], xall[N:]
+        check(lib().ps_dyn_points(_p(u), _p(_f32(times).reshape(-1)), max(int(S), 1), N, _p(x4), _stream()), "ps_dyn_points")
+        counts = None
+        if ctx.needs_input_grad[3]:
+            counts = torch.zeros(g.num_levels * lib().ps_grid_scatter_slices(g.features_per_level, g.log2_hashmap_size), device=dev,
+                                 dtype=torch.int32)
+        e0 = encode4(x4, table, scalings, g, counts=counts)
         with prof.region("flow_fwd"):
             check(lib().ps_flow_fwd(_p(e0), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(packed), _p(x4), N,
                                     float(flow_scale), float(dt), _p(xw), _stream()), "ps_flow_fwd")
-        feat = encode4(xw, table, scalings, g, e0=e0)
-        ctx.save_for_backward(x4, xw, e0, packed, scalings, table)
+        feat = encode4(xw, table, scalings, g, e0=e0, counts=counts)
+        ctx.save_for_backward(xall, e0, packed, scalings, table, counts)
         ctx.meta = (g, hidden, float(flow_scale), tuple(table.shape), [tuple(W.shape) for W, _ in layers])
         ctx.sinks = (grad_sink(table), layer_sinks(layers))
-        ctx.table_ref = table
         ctx.direct = direct_params(table, *wb)
         return feat
 
     @staticmethod
     def backward(ctx, dagg):
-        x4, xw, e0, packed, scalings, table = ctx.saved_tensors
+        xall, e0, packed, scalings, table, counts = ctx.saved_tensors
         g, hidden, flow_scale, tshape, shapes = ctx.meta
         spec = _flow_spec(g.out_dim, hidden)
         dagg = _f32(dagg)
-        N, dev = x4.shape[0], x4.device
+        N, dev = e0.shape[1], e0.device
+        xw = xall[N:]
         L, Fpl, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
         ps = N * Fpl
         dxw = torch.empty(2 * N, 3, device=dev)
@@ -131,22 +140,19 @@ class _DynFeatures(torch.autograd.Function):
         check(lib().ps_flow_sizes(g.out_dim, hidden, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart)), "ps_flow_sizes")
         assert pf.value == spec.packed and gf.value == spec.g_total, (pf.value, spec.packed, gf.value, spec.g_total)
         gpart = torch.empty(npart.value, spec.g_total, device=dev)
-        de0 = torch.empty_like(e0)
+        de0x3 = torch.empty_like(e0)  # 3 d(e0): the aggregation's 1/3 is applied by the scatter, once for all three sets
         with prof.region("flow_bwd"):
-            check(lib().ps_flow_bwd(_p(e0), ps, g.out_dim, Fpl, hidden, _p(packed), _p(dxw), _p(dagg), N, flow_scale, _p(de0), _p(gpart),
+            check(lib().ps_flow_bwd(_p(e0), ps, g.out_dim, Fpl, hidden, _p(packed), _p(dxw), _p(dagg), N, flow_scale, _p(de0x3), _p(gpart),
                                     _stream()), "ps_flow_bwd")
         sink = ctx.sinks[0]
         dtable = sink if sink is not None else torch.zeros(tshape, device=dev)
-        ws = F._workspace(lib().ps_grid4_scatter_workspace(L, Fpl, l2t, 2 * N), dev)
+        ws = F._workspace(lib().ps_grid4_scatter_workspace(L, Fpl, l2t, 3 * N), dev)
         with prof.region("grid4_scatter"):
-            # the unwarped set with d(e0), then both warped sets with d(feat) / 3 (they share the gradient plane)
-            check(lib().ps_grid4_scatter_binned(_p(x4), _p(de0), _p(scalings), L, Fpl, l2t, N, 0, ps, 1.0, _p(dtable), 1, _p(ws), _stream()),
-                  "ps_grid4_scatter_binned")
-            check(lib().ps_grid4_scatter_binned(_p(xw), _p(dagg), _p(scalings), L, Fpl, l2t, 2 * N, N, ps, 1.0 / 3.0, _p(dtable), 1, _p(ws),
-                                                _stream()), "ps_grid4_scatter_binned")
+            check(lib().ps_grid4_scatter_binned(_p(xall), _p(de0x3), _p(dagg), _p(scalings), L, Fpl, l2t, 3 * N, N, ps, 1.0 / 3.0, _p(dtable), 1,
+                                                _p(counts), _p(ws), _stream()), "ps_grid4_scatter_binned")
         grads = spec.unpack_grads(gpart, npart.value, spec.g_total, 0, shapes, ctx.sinks[1])
         mark_touched(ctx.direct)
-        return (None, None if sink is not None else dtable, None, None, None, None, *flatten_grads(grads))
+        return (None, None, None, None if sink is not None else dtable, None, None, None, None, *flatten_grads(grads))
 
 
 class _Blend(torch.autograd.Function):
@@ -226,20 +232,18 @@ class DynamicField(nn.Module):
         self.rgb_head = MLP(in_dim=16 + geo_feat_dim + appearance_embedding_dim, num_layers=3, layer_width=hidden_dim_color, out_dim=3,
                             activation=nn.ReLU(), out_activation=nn.Sigmoid())
 
-    def features(self, x4: Tensor) -> Tensor:
+    def features(self, u: Tensor, times: Tensor, S: int) -> Tensor:
+        """u [N,3] (normalised positions), times [N // S] -> aggregated feature planes [L,N,F]"""
         e = self.encoding
         flat = []
         for W, b in self.flow_head.layer_params():
             flat += [W, b]
-        return _DynFeatures.apply(x4, e.hash_table, e.scalings_on(x4.device), e.cfg(), self.flow_scale, self.time_step, *flat)
+        return _DynFeatures.apply(u, times, S, e.hash_table, e.scalings_on(u.device), e.cfg(), self.flow_scale, self.time_step, *flat)
 
     def evaluate(self, u: Tensor, sel: Tensor, times: Tensor, ray_dirs: Optional[Tensor], app: Optional[Tensor], S: int,
                  want_rgb: bool = True, want_sem: bool = True):
         """u [N,3] / sel [N] of the static field (iNGPField.points), times [N // S] -> (sigma_d [N], rgb_d [N,3], sem_d [N,64])"""
-        N = u.shape[0]
-        x4 = torch.empty(N, 4, device=u.device)
-        check(lib().ps_dyn_points(_p(_f32(u)), _p(_f32(times).reshape(-1)), max(S, 1), N, _p(x4), _stream()), "ps_dyn_points")
-        feat = self.features(x4)
+        feat = self.features(u, times, S)
         return F.main_stack(feat, sel, ray_dirs, app, S, self.encoding.cfg(), self.mlp_base_mlp.layer_params(),
                             self.semantic_head.layer_params(), self.rgb_head.layer_params(), want_rgb=want_rgb, want_sem=want_sem)
 

@@ -84,16 +84,31 @@ def test_grid4_table_and_position_gradients(dev, L, F, log2T):
     ws = FO._workspace(lib().ps_grid4_scatter_workspace(L, F, log2T, 2 * N), dev)
     d0p, dwp = _rows_to_planes(d0, L, F).to(dev), _rows_to_planes(dw, L, F).to(dev)
     x0d, xwd, scd, tabd = x0.to(dev), xw.to(dev), sc.to(dev), table.to(dev)
-    check(lib().ps_grid4_scatter_binned(_p(x0d), _p(d0p), _p(scd), L, F, log2T, N, 0, N * F, 1.0, _p(dt), 1, _p(ws), _stream()), "scatter")
-    check(lib().ps_grid4_scatter_binned(_p(xwd), _p(dwp), _p(scd), L, F, log2T, 2 * N, N, N * F, 1.0 / 3.0, _p(dt), 1, _p(ws), _stream()), "scatter")
+    ws = FO._workspace(lib().ps_grid4_scatter_workspace(L, F, log2T, 3 * N), dev)
+    check(lib().ps_grid4_scatter_binned(_p(x0d), _p(d0p), None, _p(scd), L, F, log2T, N, 0, N * F, 1.0, _p(dt), 1, None, _p(ws), _stream()), "scatter")
+    check(lib().ps_grid4_scatter_binned(_p(xwd), _p(dwp), None, _p(scd), L, F, log2T, 2 * N, N, N * F, 1.0 / 3.0, _p(dt), 1, None, _p(ws), _stream()),
+          "scatter")
     ref = tab.grad
     err = float((dt.cpu() - ref).abs().max()) / float(ref.abs().max())
     assert err < 2e-6, err
-    # bit-reproducible (integer accumulation)
-    dt2 = torch.zeros_like(dt)
-    check(lib().ps_grid4_scatter_binned(_p(x0d), _p(d0p), _p(scd), L, F, log2T, N, 0, N * F, 1.0, _p(dt2), 1, _p(ws), _stream()), "scatter")
-    check(lib().ps_grid4_scatter_binned(_p(xwd), _p(dwp), _p(scd), L, F, log2T, 2 * N, N, N * F, 1.0 / 3.0, _p(dt2), 1, _p(ws), _stream()), "scatter")
-    assert torch.equal(dt, dt2)
+    # the product path: all three position sets in ONE launch (set 0 with 3 d(e0), the warped sets with d(feat), everything times
+    # 1/3), record counts from the forward encodes instead of a counting pass; bit-reproducible (integer accumulation)
+    from presight_amd.dynamic import encode4
+
+    xall = torch.cat([x0d, xwd])
+    counts = torch.zeros(L * lib().ps_grid_scatter_slices(F, log2T), device=dev, dtype=torch.int32)
+    e0 = encode4(x0d, tabd, scd, gcfg, counts=counts)
+    encode4(xwd, tabd, scd, gcfg, e0=e0, counts=counts)
+    d0x3 = (3.0 * d0p).contiguous()
+    outs = []
+    for rep_ in range(2):
+        dt3 = torch.zeros_like(dt)
+        check(lib().ps_grid4_scatter_binned(_p(xall), _p(d0x3), _p(dwp), _p(scd), L, F, log2T, 3 * N, N, N * F, 1.0 / 3.0, _p(dt3), 1, _p(counts),
+                                            _p(ws), _stream()), "scatter")
+        outs.append(dt3)
+    assert torch.equal(outs[0], outs[1])
+    err3 = float((outs[0].cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err3 < 2e-6, err3
     dx = torch.empty(2 * N, 3, device=dev)
     check(lib().ps_grid4_input_grad(_p(xwd), _p(dwp), _p(tabd), _p(scd), L, F, log2T, 2 * N, N, N * F, 1.0 / 3.0, _p(dx), _stream()), "input_grad")
     refx = xwg.grad[:, :3]
@@ -171,10 +186,9 @@ def test_dynamic_features_forward_backward(dev):
         feat_ref, parts = D.dynamic_features(Pg, cfg, u, tt, return_parts=True)
         wgt = torch.randn(feat_ref.shape, generator=g)
         (feat_ref * wgt).sum().backward()
-        x4 = torch.cat([u, tt[:, None]], -1).to(dev)
         df = model.dynamic_field
         model.zero_grad(set_to_none=True)
-        feat = df.features(x4)
+        feat = df.features(u.to(dev), tt.to(dev), 1)
         rows = _planes_to_rows(feat)
         torch.testing.assert_close(rows.cpu(), feat_ref.detach(), rtol=2e-5, atol=2e-6)
         (rows * wgt.to(dev)).sum().backward()
