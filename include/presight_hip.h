@@ -350,6 +350,35 @@ int ps_adam_step_ranges(float* p, const float* g, float* m, float* v, int n_rang
  * points; group_of_field [K] device int32, < 0 = no group.  Called by the routed backward nodes; no host synchronisation. */
 int ps_ms_mark_groups(const int32_t* field_start, int K, const int32_t* group_of_field, int32_t* flags, void* stream);
 
+/* ---- factored semantic path of the training render node (one sub-field).  The semantic head's input is a linear function of the
+ * base MLP's hidden layer (no activation on the base output, ns/fields/PreSight/ingp_field.py:130-151) and its output is
+ * composited linearly over the ray (ns/models/PreSight/nerfacto_nusc_ms.py:530), so (1) base layer 1 rows 16..79 and semantic
+ * layer 0 are merged into one layer on the hidden activations, (2) the semantic output layer is applied once per ray to the
+ * composited last hidden activations.  Same function / parameters / gradients as ps_main_field_fwd + ps_composite_fwd, 8192 of
+ * the 26752 MACs per sample less in the forward and 16384 less in the backward (fp32 sums re-associated).
+ * ps_merge_linear_fwd: Wm [O,I] = W0 [O,K] We [K,I], bm = W0 be + b0; _bwd adds the chain-rule gradients of the four tensors.
+ * ps_main_field_f_*: as ps_main_field_fwd / _bwd with packed = [base (L*F -> hidden -> 16) | semantic (hidden -> 64 merged, 64 -> 64)
+ *   | colour head]; sem_hidden [N,64] = last hidden activations per sample; dsem_hidden [R,64] = v of ps_sem_out_bwd (per ray);
+ *   acts [ceil(N/16)*16, act_width], dzb_scratch [ceil(N/16)*16, dzb_width] (ps_main_field_f_sizes), weights required.
+ * ps_sem_out_fwd: sem [R,64] = H W^T + b acc (H [R,64] = composited hidden activations, acc [R] = sum of the weights, unclamped).
+ * ps_sem_out_bwd: v [R,64] = dsem W, cray [R] = <dsem, b> (joins d(acc)), dW [64,64] += dsem^T H, db [64] += dsem^T acc. */
+int ps_merge_linear_fwd(const float* W0, const float* b0, const float* We, const float* be, int O, int K, int I, float* Wm, float* bm,
+                        void* stream);
+int ps_merge_linear_bwd(const float* dWm, const float* dbm, const float* W0, const float* We, const float* be, int O, int K, int I,
+                        float* dW0, float* db0, float* dWe, float* dbe, void* stream);
+int ps_main_field_f_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
+                          int* n_parts /*host*/, int64_t* offsets /*host [6]*/, int* act_width /*host*/, int* dzb_width /*host*/);
+int ps_main_field_f_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
+                        const float* dirs, const float* app, int S, int A, const float* packed, int64_t N, float* sigma, float* rgb,
+                        float* sem_hidden, float* acts, void* stream);
+int ps_main_field_f_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
+                        const float* dirs, const float* app, int S, int A, const float* packed, const float* dsigma, const float* drgb,
+                        const float* dsem_hidden, const float* weights, int64_t N, float* dfeat, float* dapp, float* gpart,
+                        const float* acts, float* dzb_scratch, int stages, void* stream);
+int ps_sem_out_fwd(const float* H, const float* acc, const float* W, const float* b, int64_t R, int C, float* sem, void* stream);
+int ps_sem_out_bwd(const float* dsem, const float* H, const float* acc, const float* W, const float* b, int64_t R, int C, float* v,
+                   float* cray, float* dW, float* db, void* stream);
+
 /* ---- BASELINE cfg 4: dynamic branch of the dual (static + dynamic) field -- csrc/dynamic.hip.  The reference has no dynamic /
  * flow field ("no counterpart"); these entry points implement the model DEFINED by
  * oracle/dual_oracle.py, whose conventions are those of the static stack (ns/fields/PreSight/ingp_field.py:168-267 for the MLP

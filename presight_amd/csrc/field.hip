@@ -408,17 +408,32 @@ struct MainArgs {
   float* dapp_pt;
 };
 
-template <int KS0_, int HB_, int HBC_>
+// FACT (the factored semantic path of the training render node, one sub-field): the semantic head's input is a LINEAR function
+// of the base MLP's hidden layer (the base output has no activation, ingp_field.py:130-151) and its output is composited
+// LINEARLY over the ray (nerfacto_nusc_ms.py:530), so
+//   * base layer 1 rows 16..79 and semantic layer 0 are merged into ONE 64 x 64 layer on the hidden activations
+//     (W' = W_sem0 W_base1[16:80], b' = W_sem0 b_base1[16:80] + b_sem0: ps_merge_linear, once per step) -- the base MLP ends
+//     in 16 outputs (sigma_raw | geo15), the semantic stack in the kernels is  h1 -> ReLU(W' h1 + b') -> ReLU(W_sem1 . + b_sem1);
+//   * the semantic head's last (linear) layer is applied ONCE PER RAY to the composited hidden activations
+//     (sum_n w_n (W h_n + b) = W (sum_n w_n h_n) + b sum_n w_n: ps_sem_out_fwd / _bwd), the kernels hand out h_n.
+// 8192 of the 26752 MACs per sample disappear from the forward and 16384 from the backward; the function, its parameters and
+// their gradients are the reference's (fp32 rounding of the re-associated sums aside).
+template <int KS0_, int HB_, int HBC_, bool FACT_ = false>
 struct MainCfg {
-  using Base = MlpT<KS0_, HB_, 5, 2>;
-  using Sem = MlpT<16, 4, 4, 3>;
+  static constexpr bool FACT = FACT_;
+  static constexpr int ZB_NB = FACT_ ? 1 : 5;  // 16-neuron blocks of the base output
+  using Base = MlpT<KS0_, HB_, ZB_NB, 2>;
+  using Sem = std::conditional_t<FACT_, MlpT<HB_ * 4, 4, 4, 2>, MlpT<16, 4, 4, 3>>;
   using Rgb = MlpT<12, HBC_, 1, 3>;
   static constexpr int P_BASE = 0, P_SEM = Base::PACKED, P_RGB = P_SEM + Sem::PACKED, PACKED = P_RGB + Rgb::PACKED;
   static constexpr int G_BASE = 0, G_SEM = Base::GPACKED, G_RGB = G_SEM + Sem::GPACKED, GPACKED = G_RGB + Rgb::GPACKED;
   static constexpr int FW_BASE = 0, FW_SEM = Base::FW, FW_RGB = FW_SEM + Sem::FW, FW = FW_RGB + Rgb::FW;
   // columns of the kept activations (D-register order: block nb, lane group g, register r = neuron 16nb + 4g + r)
-  static constexpr int ACT_H1 = 0, ACT_ZB = ACT_H1 + HB_ * 16, ACT_S1 = ACT_ZB + 80, ACT_S2 = ACT_S1 + 64, ACT_C1 = ACT_S2 + 64,
+  static constexpr int ACT_H1 = 0, ACT_ZB = ACT_H1 + HB_ * 16, ACT_S1 = ACT_ZB + ZB_NB * 16, ACT_S2 = ACT_S1 + 64, ACT_C1 = ACT_S2 + 64,
                        ACT_C2 = ACT_C1 + HBC_ * 16, ACT_CO = ACT_C2 + HBC_ * 16, ACT_W = ACT_CO + 16;
+  // d(base output) workspace of the three-kernel backward, register order: block 0 = d(sigma_raw | geo15) from the colour kernel,
+  // then d(semantic embedding) [64] / FACT: d(base hidden layer) [HB * 16] from the semantic kernel
+  static constexpr int DZB_W = 16 + (FACT_ ? HB_ * 16 : 64);
   static constexpr int SCR_ROWS = Base::SCRATCH_ROWS > Sem::SCRATCH_ROWS
                                       ? (Base::SCRATCH_ROWS > Rgb::SCRATCH_ROWS ? Base::SCRATCH_ROWS : Rgb::SCRATCH_ROWS)
                                       : (Sem::SCRATCH_ROWS > Rgb::SCRATCH_ROWS ? Sem::SCRATCH_ROWS : Rgb::SCRATCH_ROWS);
@@ -538,7 +553,8 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   fetch(first + stride, nxt);
   for (; first < a.N; first += stride) {
     PS_STAMP(tm, 0)
-    float zb[PB][20], dirv[PB][3], appv[PB][4];
+    float zb[PB][C::ZB_NB * 4], dirv[PB][3], appv[PB][4];
+    float h1f[C::FACT ? PB : 1][C::FACT ? Base::HB * 4 : 1];  // FACT: the base hidden layer feeds the semantic stack
     int op_cur[PB];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
@@ -554,7 +570,13 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       PS_STAMP(tm, 2)
       if (a.acts != nullptr) {
         store_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
-        store_act<5, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb);
+        store_act<C::ZB_NB, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb);
+      }
+      if constexpr (C::FACT) {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+          for (int t = 0; t < Base::HB * 4; ++t) h1f[pb][t] = h1[pb][t];
       }
     }
     if (a.sigma != nullptr && g == 0) {
@@ -565,12 +587,24 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     PS_STAMP(tm, 3)
     bool consumed = false;
     if (a.sem != nullptr) {
-      float sin_[PB][16], s1[PB][16], s2[PB][16], so[PB][16];
+      float s1[PB][16], s2[PB][16], so[PB][16];
+      if constexpr (C::FACT) {
+        // merged first layer on the base hidden layer, second layer; `so` = the last HIDDEN activations (the output layer is
+        // applied per ray after compositing)
+        mlp_forward<Sem, PB>(LdsW{lds + C::FW_SEM}, h1f, s1, s2 /*unused*/, so);
+        relu_inplace<PB, 16>(so);
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb)
+        for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][4 + t];
-      mlp_forward<Sem, PB>(LdsW{lds + C::FW_SEM}, sin_, s1, s2, so);
+          for (int t = 0; t < 16; ++t) s2[pb][t] = so[pb][t];
+      } else {
+        float sin_[PB][16];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+          for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][(C::FACT ? 0 : 4) + t];
+        mlp_forward<Sem, PB>(LdsW{lds + C::FW_SEM}, sin_, s1, s2, so);
+      }
       PS_STAMP(tm, 4)
       // the next tile's inputs are taken over HERE: the youngest stores in flight are the base stage's, a whole semantic MLP old
       __builtin_amdgcn_sched_barrier(0);
@@ -919,26 +953,34 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
   gather(first + stride, ga);
   for (; first < a.N; first += stride) {
     PS_STAMP(tm, 0)
-    float sin_[PB][16], s1[PB][16], s2[PB][16];
+    float sin_[PB][Sem::KS0], s1[PB][16], s2[PB][16];
     load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
     load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
+    if constexpr (C::FACT)
+      load_act<Sem::KS0 / 4, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, sin_);  // the base hidden layer = the merged first layer's input
+    else
+      load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
     PS_STAMP(tm, 1)
-    float dsin[PB][16];
+    float dsin[PB][Sem::L0::IB * 4];
+    if constexpr (C::FACT) {
+      // `so` = w[n] * (W_out^T d(semantics of the ray)) is the gradient w.r.t. the last hidden activations s2 (the output layer was
+      // applied per ray): ReLU mask, then the two layers of the in-kernel stack; the result is d(base hidden layer)
+      relu_mask<PB, 16>(so, s2);
+    }
     mlp_backward_acc<Sem, PB, true>(
         pk, scratch, acc,
-        [&](float (&x)[PB][16]) {
+        [&](float (&x)[PB][Sem::KS0]) {
 #pragma unroll
           for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) x[pb][t] = sin_[pb][t];
+            for (int t = 0; t < Sem::KS0; ++t) x[pb][t] = sin_[pb][t];
         },
         s1, s2, so, dsin, tm);
     __builtin_amdgcn_sched_barrier(0);
     consume();                            // tile i+1's operands (requested a whole tile ago)
     gather(first + 2 * stride, ga);
     __builtin_amdgcn_sched_barrier(0);
-    store_act<4, PB>(a.dzb, 80, 16, first, a.N, dsin);
+    store_act<Sem::L0::IB, PB>(a.dzb, C::DZB_W, 16, first, a.N, dsin);  // FACT: d(base hidden layer) from the semantic stack
     PS_STAMP(tm, 8)
   }
 #if defined(PS_TIMING)
@@ -1116,7 +1158,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
       }
       dz0[pb][0] += ds_cur[pb] * trunc_exp_grad(zb0[pb][0]);  // (ds is 0 outside lane group 0 / past the end: fetched with the head)
     }
-    store_act<1, PB>(a.dzb, 80, 0, first, a.N, dz0);
+    store_act<1, PB>(a.dzb, C::DZB_W, 0, first, a.N, dz0);
     PS_STAMP(tm, 9)
   }
 #if defined(PS_TIMING)
@@ -1146,36 +1188,50 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
   const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
   int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
   // (consumed at the end of the previous tile, before its stores: see main_bwd_sem_kernel)
-  float dzb_next[PB][20], dzb[PB][20];
+  constexpr int DZ = C::DZB_W / 4;  // registers of one point block's d(base output) (+ FACT: d(hidden) from the semantic stack)
+  float dzb_next[PB][DZ], dzb[PB][DZ];
   auto consume = [&]() {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-      for (int t = 0; t < 20; ++t) {
+      for (int t = 0; t < DZ; ++t) {
         dzb[pb][t] = dzb_next[pb][t];
         asm volatile("" : "+v"(dzb[pb][t]));  // a real copy, made HERE (the wait for the load must not sink below the stores)
       }
   };
-  load_act<5, PB>(a.dzb, 80, 0, first, a.N, dzb_next);
+  load_act<DZ / 4, PB>(a.dzb, C::DZB_W, 0, first, a.N, dzb_next);
   consume();
-  load_act<5, PB>(a.dzb, 80, 0, first + stride, a.N, dzb_next);
+  load_act<DZ / 4, PB>(a.dzb, C::DZB_W, 0, first + stride, a.N, dzb_next);
   for (; first < a.N; first += stride) {
     float h1[PB][Base::HB * 4], xin[PB][Base::KS0];
     load_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
     load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, xin);
     float dx[PB][Base::L0::IB * 4];
-    mlp_backward_acc<Base, PB, true>(
-        pk, scratch, acc,
-        [&](float (&x)[PB][Base::KS0]) {
+    auto make_x = [&](float (&x)[PB][Base::KS0]) {
 #pragma unroll
-          for (int pb = 0; pb < PB; ++pb)
+      for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-            for (int t = 0; t < Base::KS0; ++t) x[pb][t] = xin[pb][t];
-        },
-        h1, h1, dzb, dx);
+        for (int t = 0; t < Base::KS0; ++t) x[pb][t] = xin[pb][t];
+    };
+    if constexpr (C::FACT) {
+      float dz[PB][4];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dz[pb][t] = dzb[pb][t];
+      // the semantic stack's gradient joins d(hidden) between the 16-wide output layer and the ReLU mask
+      mlp_backward_acc<Base, PB, true>(pk, scratch, acc, make_x, h1, h1, dz, dx, nullptr, [&](float (&dh)[PB][Base::HB * 4]) {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+          for (int t = 0; t < Base::HB * 4; ++t) dh[pb][t] += dzb[pb][4 + t];
+      });
+    } else {
+      mlp_backward_acc<Base, PB, true>(pk, scratch, acc, make_x, h1, h1, dzb, dx);
+    }
     __builtin_amdgcn_sched_barrier(0);
     consume();
-    load_act<5, PB>(a.dzb, 80, 0, first + 2 * stride, a.N, dzb_next);
+    load_act<DZ / 4, PB>(a.dzb, C::DZB_W, 0, first + 2 * stride, a.N, dzb_next);
     __builtin_amdgcn_sched_barrier(0);
     store_dfeat<Base::KS0, PB>(a.dfeat, fc, a.F, first, a.N, dx);
   }
@@ -1355,9 +1411,50 @@ extern "C" int ps_main_field_act_width(int LF, int hidden, int hidden_color) {
   return 0;
 }
 
+// the factored semantic path (MainCfg<..., FACT = true>): sizes of its packed / gradient blocks, kept activations and workspace
+extern "C" int ps_main_field_f_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t* packed_floats, int64_t* grad_floats,
+                                     int* n_parts, int64_t* offsets /*[6]*/, int* act_width, int* dzb_width) {
+#define X(lf, h, hc)                                               \
+  if (LF == lf && hidden == h && hidden_color == hc) {             \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;        \
+    *packed_floats = C::PACKED;                                    \
+    *grad_floats = C::GPACKED;                                     \
+    *n_parts = grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256); \
+    if (offsets) {                                                 \
+      offsets[0] = C::P_BASE;                                      \
+      offsets[1] = C::P_SEM;                                       \
+      offsets[2] = C::P_RGB;                                       \
+      offsets[3] = C::G_BASE;                                      \
+      offsets[4] = C::G_SEM;                                       \
+      offsets[5] = C::G_RGB;                                       \
+    }                                                              \
+    if (act_width) *act_width = C::ACT_W;                          \
+    if (dzb_width) *dzb_width = C::DZB_W;                          \
+    return 0;                                                      \
+  }
+  PS_MAIN_CFGS(X)
+#undef X
+  ps_set_error("ps_main_field_f: unsupported (L*F, hidden, hidden_color)");
+  return -2;
+}
+
 namespace {
-int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
+int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool fact = false) {
   if (a.N == 0) return 0;
+  if (fact) {
+    PS_REQUIRE(a.perm == nullptr && a.sem != nullptr && a.rgb != nullptr && a.sigma != nullptr,
+               "ps_main_field_f_fwd: one sub-field, all three outputs");
+#define X(lf, h, hc)                                                                                                  \
+  if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;                                                           \
+    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+    PS_CHECK_LAUNCH();                                                                                                \
+  }
+    PS_MAIN_CFGS(X)
+#undef X
+    ps_set_error("ps_main_field_f_fwd: unsupported (L*F, hidden, hidden_color)");
+    return -2;
+  }
   PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field_fwd: appearance dim must be <= 16");
   PS_REQUIRE(a.N < (int64_t(1) << 31), "ps_main_field_fwd: at most 2^31 - 1 points per call");
   PS_REQUIRE(a.acts == nullptr || (a.sem != nullptr && a.rgb != nullptr), "ps_main_field_fwd: activations are kept for full evaluations only");
@@ -1379,9 +1476,26 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s) {
 }
 
 // stages: which kernels of the three-kernel backward this call launches (bit 0 semantic head, 1 colour head, 2 base MLP)
-int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStream_t s) {
+int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStream_t s, bool fact = false) {
   const int st = stages & 7;
   if (a.N == 0) return 0;
+  if (fact) {
+    PS_REQUIRE(a.perm == nullptr && a.acts != nullptr && a.dzb != nullptr && a.w != nullptr && a.drgb != nullptr && a.dsem != nullptr,
+               "ps_main_field_f_bwd: one sub-field, kept activations, the workspace and per-ray gradients are required");
+#define X(lf, h, hc)                                                                                                  \
+  if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;                                                           \
+    const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256);                                     \
+    if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);      \
+    if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);      \
+    if (st & 4) main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);     \
+    PS_CHECK_LAUNCH();                                                                                                \
+  }
+    PS_MAIN_CFGS(X)
+#undef X
+    ps_set_error("ps_main_field_f_bwd: unsupported (L*F, hidden, hidden_color)");
+    return -2;
+  }
   PS_REQUIRE(a.acts == nullptr || (a.drgb != nullptr && a.dsem != nullptr), "ps_main_field_bwd: kept activations need both head gradients");
   PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field_bwd: appearance dim must be <= 16");
   PS_REQUIRE(a.N < (int64_t(1) << 31), "ps_main_field_bwd: at most 2^31 - 1 points per call");
@@ -1493,3 +1607,30 @@ extern "C" int ps_debug_timing_fwd(unsigned long long* out /*host[16]*/, int res
   return (int)e;
 }
 #endif
+
+// ---- factored semantic path (MainCfg FACT): the same arguments as ps_main_field_fwd / _bwd; `packed` holds [base (L*F -> hidden ->
+// 16) | semantic stack (hidden -> 64 merged, 64 -> 64) | colour head], `sem` receives the LAST HIDDEN activations of the semantic
+// head per sample, dsem is W_out^T d(semantics) per ray (ps_sem_out_bwd)
+extern "C" int ps_main_field_f_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                   const float* sel, const float* dirs, const float* app, int S, int A, const float* packed, int64_t N,
+                                   float* sigma, float* rgb, float* sem_hidden, float* acts, void* stream) {
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem_hidden; a.acts = acts; a.K = 1;
+  PS_REQUIRE(acts != nullptr, "ps_main_field_f_fwd: the factored path keeps its activations");
+  PS_REQUIRE(a.A <= 16 && a.S > 0 && N < (int64_t(1) << 31), "ps_main_field_f_fwd: appearance dim <= 16, at most 2^31 - 1 points");
+  return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream, true);
+}
+
+extern "C" int ps_main_field_f_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                   const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                   const float* dsigma, const float* drgb, const float* dsem_hidden, const float* weights, int64_t N,
+                                   float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch, int stages, void* stream) {
+  MainArgs a{};
+  a.dzb = dzb_scratch;
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem_hidden; a.w = weights; a.dfeat = dfeat; a.dapp = dapp;
+  a.gpart = gpart; a.acts = const_cast<float*>(acts); a.K = 1;
+  PS_REQUIRE(a.A <= 16 && a.S > 0 && N < (int64_t(1) << 31), "ps_main_field_f_bwd: appearance dim <= 16, at most 2^31 - 1 points");
+  return main_bwd_impl(a, hidden, hidden_color, stages, (hipStream_t)stream, true);
+}

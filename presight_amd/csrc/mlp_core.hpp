@@ -845,11 +845,18 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
 // flight when this starts: the last layer's input (h2 / h1) is staged late (H_LATE), and `make_x(x)` produces the first
 // layer's input right before it is needed (the colour head builds it from gathered per-ray data).
 // H1_LATE: the middle layer's input h1 is staged late as well (a narrow last layer gives the loads too little cover).
-template <class M, int PB, bool WANT_DX, bool H1_LATE = false, class W, class MakeX>
+// `post_last(dh)` runs on the gradient w.r.t. the last hidden layer right after the last layer's data backward (before the ReLU
+// mask): a second consumer of that hidden layer adds its gradient there (the factored main field: the semantic head hangs off
+// the base MLP's hidden layer).
+struct NoPost {
+  template <class T>
+  __device__ __forceinline__ void operator()(T&) const {}
+};
+template <class M, int PB, bool WANT_DX, bool H1_LATE = false, class W, class MakeX, class PostLast = NoPost>
 __device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restrict__ scratch, MlpAcc<M>& acc, const MakeX& make_x,
                                                  const float (&h1)[PB][M::HB * 4], const float (&h2)[PB][M::HB * 4],
                                                  const float (&dz)[PB][M::NBO * 4], float (&dx)[PB][M::L0::IB * 4],
-                                                 PsTimer* tm = nullptr) {
+                                                 PsTimer* tm = nullptr, const PostLast& post_last = PostLast()) {
   using L0 = typename M::L0;
   using L1 = typename M::L1;
   using LZ = typename M::LZ;
@@ -866,6 +873,7 @@ __device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restr
   if constexpr (M::NL == 3) {
     float a1[L1::KSO];
     layer_bwd_pipe_core<LZ, PB, true, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h2, dh, [&]() { frags_bwd_block<L1>(t1, 0, a1); }, tm, 2);
+    post_last(dh);
     relu_mask<PB, M::HB * 4>(dh, h2);
     float dh1[PB][M::HB * 4];
     layer_bwd_pipe_core<L1, PB, true, true, H1_LATE>(t1, a1, scratch, acc.l1.dw, acc.l1.dbp, dh, h1, dh1, req0, tm, 4);
@@ -874,6 +882,7 @@ __device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restr
     layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh1, x, dx, NoPrefetch(), tm, 6);
   } else {
     layer_bwd_pipe_core<LZ, PB, true, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h1, dh, req0, tm, 2);
+    post_last(dh);
     relu_mask<PB, M::HB * 4>(dh, h1);
     make_x(x);
     layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh, x, dx, NoPrefetch(), tm, 6);

@@ -463,6 +463,170 @@ class _MainFieldRender(torch.autograd.Function):
         return (None, None, None, dapp, None, None, None, dtable, None, None, None, None, *flat)
 
 
+# ------------------------------------------------------------------------------------------------ factored semantic path
+# The training render node of ONE sub-field with two algebraic rewrites of the semantic branch (csrc/field.hip MainCfg FACT,
+# csrc/factored.hip): base layer 1 rows 16..79 merged with semantic layer 0, semantic output layer applied per ray after
+# compositing.  PRESIGHT_FACTORED=0 selects the unfactored node (same results to fp32 re-association).
+FACTORED = os.environ.get("PRESIGHT_FACTORED", "1") != "0"
+
+
+class MainSpecF:
+    def __init__(self, LF: int, hidden: int, hidden_color: int, app_dim: int):
+        self.base = MlpSpec([LF, hidden, 16])
+        self.sem = MlpSpec([hidden, 64, SEM_DIM], first_colmap=chain_colmap(hidden // 4, hidden), ks0=hidden // 4)
+        self.rgb = MlpSpec([16 + GEO_DIM + app_dim, hidden_color, hidden_color, 3], first_colmap=colour_colmap(app_dim), ks0=12)
+        self.p_off = [0, self.base.packed, self.base.packed + self.sem.packed]
+        self.packed = self.p_off[2] + self.rgb.packed
+        self.g_off = [0, self.base.g_total, self.base.g_total + self.sem.g_total]
+        self.g_total = self.g_off[2] + self.rgb.g_total
+        pf, gf, npart, aw, dw = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        offs = (ctypes.c_int64 * 6)()
+        check(lib().ps_main_field_f_sizes(LF, hidden, hidden_color, 1, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart), offs,
+                                          ctypes.byref(aw), ctypes.byref(dw)), "ps_main_field_f_sizes")
+        assert pf.value == self.packed and gf.value == self.g_total and list(offs) == self.p_off + self.g_off, (pf.value, self.packed, list(offs))
+        self.act_width, self.dzb_width = aw.value, dw.value
+
+
+_MAIN_SPECS_F: dict = {}
+
+
+def _main_spec_f(LF, hidden, hidden_color, app_dim) -> MainSpecF:
+    key = (LF, hidden, hidden_color, app_dim)
+    if key not in _MAIN_SPECS_F:
+        _MAIN_SPECS_F[key] = MainSpecF(LF, hidden, hidden_color, app_dim)
+    return _MAIN_SPECS_F[key]
+
+
+def factored_supported(base, sem, rgb) -> bool:
+    """2-layer base MLP ending in 1 + 15 + 64 outputs, 3-layer 64-wide semantic head: the PreSight layout"""
+    return (FACTORED and len(base) == 2 and len(sem) == 3 and len(rgb) == 3 and base[1][0].shape[0] == BASE_OUT
+            and sem[0][0].shape == (64, SEM_DIM) and sem[2][0].shape == (SEM_DIM, 64) and base[0][0].shape[0] % 16 == 0)
+
+
+class _MainFieldRenderF(torch.autograd.Function):
+    """_MainFieldRender on the factored semantic path (one sub-field, training, S <= 64)"""
+
+    @staticmethod
+    def forward(ctx, u, sel, dirs, app, S, ebins, threshold, table, scalings, g: GridCfg, *wb):
+        from . import ops
+
+        (Wb0, bb0), (Wb1, bb1), (Ws0, bs0), (Ws1, bs1), (Ws2, bs2), r0, r1, r2 = _layers(wb)
+        hidden, hidden_color = Wb0.shape[0], r0[0].shape[0]
+        A = r0[0].shape[1] - 16 - GEO_DIM
+        if (0 if app is None else app.shape[1]) != A:
+            raise ValueError(f"colour head expects SH16 + geo15 + app{A} inputs, got an appearance embedding of width "
+                             f"{0 if app is None else app.shape[1]}")
+        spec = _main_spec_f(g.out_dim, hidden, hidden_color, A)
+        N, dev = u.shape[0], u.device
+        R = ebins.shape[0]
+        table = _f32(table, "hash table")
+        train = ctx.needs_input_grad[7]
+        feat, counts = _encode(u, table, scalings, g, count=train)
+        # merged first semantic layer: W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0
+        Wb1, bb1, Ws0, bs0 = _f32(Wb1), _f32(bb1), _f32(Ws0), _f32(bs0)
+        Wm, bm = torch.empty(64, hidden, device=dev), torch.empty(64, device=dev)
+        check(lib().ps_merge_linear_fwd(_p(Ws0), _p(bs0), Wb1.data_ptr() + 4 * 16 * hidden, bb1.data_ptr() + 4 * 16, 64, SEM_DIM, hidden,
+                                        _p(Wm), _p(bm), _stream()), "ps_merge_linear_fwd")
+        packed = torch.empty(spec.packed, device=dev)
+        descs = spec.base.pack_descs([(Wb0, bb0), (Wb1[:16], bb1[:16])], packed[: spec.base.packed])
+        descs += spec.sem.pack_descs([(Wm, bm), (Ws1, bs1)], packed[spec.p_off[1]: spec.p_off[1] + spec.sem.packed])
+        descs += spec.rgb.pack_descs([r0, r1, r2], packed[spec.p_off[2]:])
+        pack_layers(descs)
+        sigma, rgb_s, hid_s = torch.empty(N, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, SEM_DIM, device=dev)
+        acts = torch.empty((N + 15) // 16 * 16, spec.act_width, device=dev)
+        dirs = _f32(dirs)
+        app_c = _f32(app) if app is not None else None
+        with prof.region("main_field_fwd"):
+            check(lib().ps_main_field_f_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color, _p(sel),
+                                            _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb_s), _p(hid_s), _p(acts),
+                                            _stream()), "ps_main_field_f_fwd")
+        ebins = _f32(ebins)
+        w = torch.empty(R, S, device=dev)
+        check(lib().ps_weights_fwd(_p(ebins), _p(sigma), R, S, _p(w), _stream()), "ps_weights_fwd")
+        rgb, hid = torch.empty(R, 3, device=dev), torch.empty(R, SEM_DIM, device=dev)
+        acc, depth, expd = torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev)
+        minmax = ops._minmax_init(dev).clone()
+        check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), _p(hid_s), R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth), _p(expd),
+                                     _p(hid), _p(minmax), _stream()), "ps_composite_fwd")
+        sem = torch.empty(R, SEM_DIM, device=dev)
+        Ws2, bs2 = _f32(Ws2), _f32(bs2)
+        check(lib().ps_sem_out_fwd(_p(hid), _p(acc), _p(Ws2), _p(bs2), R, SEM_DIM, _p(sem), _stream()), "ps_sem_out_fwd")
+        ops._apply_minmax_hook(minmax)
+        raw = expd.clone()
+        check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
+        ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, hid_s, raw, expd, hid, acc, Wm, bm)
+        ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), spec)
+        ctx.params = wb
+        ctx.table_sink = grad_sink(table)
+        ctx.table_ref = table
+        ctx.direct = direct_params(table, *wb)
+        ctx.mark_non_differentiable(depth)
+        return rgb, acc, depth, expd, sem, w
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, _d_depth, d_exp, d_sem, d_w_ext):
+        (u, sel, dirs, app, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, hid_s, raw, expd, hid, acc, Wm, bm) = ctx.saved_tensors
+        g, hidden, hidden_color, A, S, tshape, spec = ctx.meta
+        wb = ctx.params
+        (Wb0, bb0), (Wb1, bb1), (Ws0, bs0), (Ws1, bs1), (Ws2, bs2), r0, r1, r2 = _layers(wb)
+        R, dev, N = w.shape[0], w.device, u.shape[0]
+        # gradient destinations: the parameters' in-place sinks where the owner opted in, fresh zero tensors (returned) otherwise
+        dst, ret = [], []
+        for t in wb:
+            gs = grad_sink(t)
+            if gs is not None:
+                dst.append(gs)
+                ret.append(None)
+            else:
+                z = torch.zeros_like(t, dtype=torch.float32)
+                dst.append(z)
+                ret.append(z)
+        (dWb0, dbb0, dWb1, dbb1, dWs0, dbs0, dWs1, dbs1, dWs2, dbs2, dWr0, dbr0, dWr1, dbr1, dWr2, dbr2) = dst
+        d_rgb = _f32(d_rgb) if d_rgb is not None else torch.zeros(R, 3, device=dev)
+        d_sem = _f32(d_sem) if d_sem is not None else torch.zeros(R, SEM_DIM, device=dev)
+        # output layer of the semantic head, per ray: v = W_out^T d(sem), d(acc) += <d(sem), b_out>, dW_out / db_out
+        v, cray = torch.empty(R, SEM_DIM, device=dev), torch.empty(R, 1, device=dev)
+        check(lib().ps_sem_out_bwd(_p(d_sem), _p(hid), _p(acc), _p(_f32(Ws2)), _p(_f32(bs2)), R, SEM_DIM, _p(v), _p(cray), _p(dWs2), _p(dbs2),
+                                   _stream()), "ps_sem_out_bwd")
+        d_acc = cray if d_acc is None else _f32(d_acc) + cray
+        if d_exp is not None:
+            d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
+        dw = torch.empty_like(w)
+        check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s), _p(hid_s), _p(d_rgb), _p(d_acc), _p(v), _p(d_exp), R, S, SEM_DIM, _p(dw), None,
+                                     None, _stream()), "ps_composite_bwd")
+        if d_w_ext is not None:
+            dw.add_(_f32(d_w_ext))  # losses that act on the weights directly (distortion, line of sight)
+        dsig = torch.empty_like(sigma)
+        check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
+        pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        check(lib().ps_main_field_f_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart), None,
+                                          None, None), "ps_main_field_f_sizes")
+        gpart = torch.empty(npart.value, spec.g_total, device=dev)
+        dfeat = torch.empty_like(feat)
+        dapp = torch.zeros_like(app) if app is not None else None
+        dzb = torch.empty((N + 15) // 16 * 16, spec.dzb_width, device=dev)
+        with prof.region("main_field_bwd"):
+            for stages in _bwd_stages(dzb):
+                check(lib().ps_main_field_f_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                                _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(dsig), _p(d_rgb), _p(v), _p(w), N,
+                                                _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), stages, _stream()), "ps_main_field_f_bwd")
+        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.table_sink, counts, sink_owner=ctx.table_ref)
+        # weight gradients: partial blocks -> torch layout.  Base layer 1: rows 0..15 (sigma_raw | geo15) directly, rows 16..79
+        # through the merged layer (chain rule of W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0)
+        dWm, dbm = torch.zeros_like(Wm), torch.zeros_like(bm)
+        descs = spec.base.unpack_descs(gpart, spec.g_off[0], [tuple(Wb0.shape), (16, hidden)])
+        descs += spec.sem.unpack_descs(gpart, spec.g_off[1], [(64, hidden), (64, 64)])
+        descs += spec.rgb.unpack_descs(gpart, spec.g_off[2], [tuple(r0[0].shape), tuple(r1[0].shape), tuple(r2[0].shape)])
+        sinks = [(dWb0, dbb0), (dWb1[:16], dbb1[:16]), (dWm, dbm), (dWs1, dbs1), (dWr0, dbr0), (dWr1, dbr1), (dWr2, dbr2)]
+        unpack_layers(descs, npart.value, spec.g_total, dev, sinks)
+        Wb1c, bb1c = _f32(Wb1), _f32(bb1)
+        check(lib().ps_merge_linear_bwd(_p(dWm), _p(dbm), _p(_f32(Ws0)), Wb1c.data_ptr() + 4 * 16 * hidden, bb1c.data_ptr() + 4 * 16, 64, SEM_DIM,
+                                        hidden, _p(dWs0), _p(dbs0), dWb1.data_ptr() + 4 * 16 * hidden, dbb1.data_ptr() + 4 * 16, _stream()),
+              "ps_merge_linear_bwd")
+        mark_touched(ctx.direct)
+        return (None, None, None, dapp, None, None, None, dtable, None, None, *ret)
+
+
 def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor], ebins: Tensor, table: Tensor, scalings: Tensor,
                       g: GridCfg, base, sem, rgb, threshold: float = 0.5):
     """-> (rgb [R,3], accumulation [R,1] (unclamped), threshold depth [R,1], expected depth [R,1], semantics [R,64],
@@ -473,6 +637,8 @@ def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor
     flat = []
     for W, b in list(base) + list(sem) + list(rgb):
         flat += [W, b]
+    if factored_supported(base, sem, rgb) and torch.is_grad_enabled():
+        return _MainFieldRenderF.apply(u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, *flat)
     return _MainFieldRender.apply(u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, len(base), len(sem), *flat)
 
 
