@@ -406,6 +406,10 @@ struct MainArgs {
   // multi-sub-field three-kernel backward: d(appearance) per POINT [N, A] in the caller's order, written (the sorted layout
   // scatters the samples of a ray over the workgroups: 16 float atomics per point otherwise); the caller sums over the samples
   float* dapp_pt;
+  // factored path (MainCfg FACT): per-ray part of the colour head's first pre-activation [R, hidden_color] (forward input) and the
+  // per-16-point-block sums of the gradient w.r.t. it [ceil(N/16), hidden_color] (backward output); S % 16 == 0
+  const float* rray;
+  float* dr_part;
 };
 
 // FACT (the factored semantic path of the training render node, one sub-field): the semantic head's input is a LINEAR function
@@ -424,7 +428,10 @@ struct MainCfg {
   static constexpr int ZB_NB = FACT_ ? 1 : 5;  // 16-neuron blocks of the base output
   using Base = MlpT<KS0_, HB_, ZB_NB, 2>;
   using Sem = std::conditional_t<FACT_, MlpT<HB_ * 4, 4, 4, 2>, MlpT<16, 4, 4, 3>>;
-  using Rgb = MlpT<12, HBC_, 1, 3>;
+  // FACT: the colour head's first layer sees the 15 geometry features only (one 16-neuron block of the base output); its
+  // direction (SH16) and appearance columns are the same for all samples of a ray and arrive as a per-ray pre-activation term
+  // (ps_ray_colour_fwd -> MainArgs::rray), their gradients leave as per-block sums (MainArgs::dr_part -> ps_ray_colour_bwd)
+  using Rgb = MlpT<FACT_ ? 4 : 12, HBC_, 1, 3>;
   static constexpr int P_BASE = 0, P_SEM = Base::PACKED, P_RGB = P_SEM + Sem::PACKED, PACKED = P_RGB + Rgb::PACKED;
   static constexpr int G_BASE = 0, G_SEM = Base::GPACKED, G_RGB = G_SEM + Sem::GPACKED, GPACKED = G_RGB + Rgb::GPACKED;
   static constexpr int FW_BASE = 0, FW_SEM = Base::FW, FW_RGB = FW_SEM + Sem::FW, FW = FW_RGB + Rgb::FW;
@@ -504,6 +511,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   fc.init(a.plane_stride, a.LF, a.F);
   struct In {
     float x[PB][Base::KS0], sel[PB], dirv[PB][3], appv[PB][4];
+    f32x4 rr[C::FACT ? PB : 1][C::FACT ? Rgb::HB : 1];  // FACT: the ray's colour-head term for this lane's neurons 16nb + 4g..4g+3
     int op[PB];  // the point's index in the caller's arrays, -1: no such point
   };
   auto fetch = [&](int64_t first, In& v) {
@@ -519,12 +527,18 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         r = ray_index(op >= 0 ? op : 0, a.S);
       else
         r = ray_index(p < a.N ? p : a.N - 1, a.S);
+      if constexpr (C::FACT) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) v.dirv[pb][k] = (a.rgb != nullptr && first < a.N) ? a.dirs[r * 3 + k] : 0.0f;
+        for (int nb = 0; nb < Rgb::HB; ++nb)
+          v.rr[pb][nb] = first < a.N ? *reinterpret_cast<const f32x4*>(a.rray + r * (Rgb::HB * 16) + 16 * nb + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int c = 4 * t + g;
-        v.appv[pb][t] = (a.rgb != nullptr && a.app != nullptr && c < a.A && first < a.N) ? a.app[r * a.A + c] : 0.0f;
+        for (int k = 0; k < 3; ++k) v.dirv[pb][k] = (a.rgb != nullptr && first < a.N) ? a.dirs[r * 3 + k] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int c = 4 * t + g;
+          v.appv[pb][t] = (a.rgb != nullptr && a.app != nullptr && c < a.A && first < a.N) ? a.app[r * a.A + c] : 0.0f;
+        }
       }
     }
   };
@@ -535,9 +549,15 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     for (int pb = 0; pb < PB; ++pb) {  // real copies, made HERE (the wait for the loads must not sink below later stores)
 #pragma unroll
       for (int t = 0; t < Base::KS0; ++t) asm volatile("" : "+v"(cur.x[pb][t]));
+      if constexpr (C::FACT) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(cur.appv[pb][t]));
-      asm volatile("" : "+v"(cur.sel[pb]), "+v"(cur.dirv[pb][0]), "+v"(cur.dirv[pb][1]), "+v"(cur.dirv[pb][2]), "+v"(cur.op[pb]));
+        for (int nb = 0; nb < Rgb::HB; ++nb) asm volatile("" : "+v"(cur.rr[pb][nb]));
+        asm volatile("" : "+v"(cur.sel[pb]), "+v"(cur.op[pb]));
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(cur.appv[pb][t]));
+        asm volatile("" : "+v"(cur.sel[pb]), "+v"(cur.dirv[pb][0]), "+v"(cur.dirv[pb][1]), "+v"(cur.dirv[pb][2]), "+v"(cur.op[pb]));
+      }
     }
   };
   PsTimer* tm = nullptr;
@@ -555,14 +575,20 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     PS_STAMP(tm, 0)
     float zb[PB][C::ZB_NB * 4], dirv[PB][3], appv[PB][4];
     float h1f[C::FACT ? PB : 1][C::FACT ? Base::HB * 4 : 1];  // FACT: the base hidden layer feeds the semantic stack
+    f32x4 rr[C::FACT ? PB : 1][C::FACT ? Rgb::HB : 1];
     int op_cur[PB];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       op_cur[pb] = cur.op[pb];
+      if constexpr (C::FACT) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) dirv[pb][k] = cur.dirv[pb][k];
+        for (int nb = 0; nb < Rgb::HB; ++nb) rr[pb][nb] = cur.rr[pb][nb];
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) appv[pb][t] = cur.appv[pb][t];
+        for (int k = 0; k < 3; ++k) dirv[pb][k] = cur.dirv[pb][k];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) appv[pb][t] = cur.appv[pb][t];
+      }
     }
     {
       float h1[PB][Base::HB * 4], h2[PB][Base::HB * 4];
@@ -633,20 +659,36 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (a.rgb != nullptr) {
-      float cin[PB][12], c1[PB][Rgb::HB * 4], c2[PB][Rgb::HB * 4], co[PB][4];
+      float cin[PB][Rgb::KS0], c1[PB][Rgb::HB * 4], c2[PB][Rgb::HB * 4], co[PB][4];
+      if constexpr (C::FACT) {
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        float sh[16];
-        sh4((dirv[pb][0] + 1.0f) / 2.0f, (dirv[pb][1] + 1.0f) / 2.0f, (dirv[pb][2] + 1.0f) / 2.0f, sh);
+        for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float v0 = sh[4 * t], v1 = sh[4 * t + 1], v2 = sh[4 * t + 2], v3 = sh[4 * t + 3];
-          cin[pb][t] = g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));  // component 4t+g without dynamic register indexing
-          cin[pb][4 + t] = zb[pb][t];
-          cin[pb][8 + t] = appv[pb][t];
+          for (int t = 0; t < 4; ++t) cin[pb][t] = zb[pb][t];
+        // first layer on the geometry features; the ray's direction / appearance term joins the pre-activations before the ReLU
+        mlp_forward<Rgb, PB>(LdsW{lds + C::FW_RGB}, cin, c1, c2, co, [&](float (&h)[PB][Rgb::HB * 4]) {
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int nb = 0; nb < Rgb::HB; ++nb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[pb][4 * nb + r] += rr[pb][nb][r];
+        });
+      } else {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+          float sh[16];
+          sh4((dirv[pb][0] + 1.0f) / 2.0f, (dirv[pb][1] + 1.0f) / 2.0f, (dirv[pb][2] + 1.0f) / 2.0f, sh);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float v0 = sh[4 * t], v1 = sh[4 * t + 1], v2 = sh[4 * t + 2], v3 = sh[4 * t + 3];
+            cin[pb][t] = g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));  // component 4t+g without dynamic register indexing
+            cin[pb][4 + t] = zb[pb][t];
+            cin[pb][8 + t] = appv[pb][t];
+          }
         }
+        mlp_forward<Rgb, PB>(LdsW{lds + C::FW_RGB}, cin, c1, c2, co);
       }
-      mlp_forward<Rgb, PB>(LdsW{lds + C::FW_RGB}, cin, c1, c2, co);
       PS_STAMP(tm, 7)
       if (a.acts != nullptr) {
         store_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
@@ -1086,33 +1128,62 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t r = ray_head[pb];
       ray_of[pb] = r;
+      if constexpr (!C::FACT) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) dirv[pb][k] = a.dirs[r * 3 + k];
+        for (int k = 0; k < 3; ++k) dirv[pb][k] = a.dirs[r * 3 + k];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int c = 4 * t + g;
-        appv[pb][t] = (a.app != nullptr && c < a.A) ? a.app[r * a.A + c] : 0.0f;
+        for (int t = 0; t < 4; ++t) {
+          const int c = 4 * t + g;
+          appv[pb][t] = (a.app != nullptr && c < a.A) ? a.app[r * a.A + c] : 0.0f;
+        }
       }
     }
     PS_STAMP(tm, 1)
-    float dcin[PB][12];
-    mlp_backward_acc<Rgb, PB, true, true>(
-        pk, scratch, acc,
-        [&](float (&cin)[PB][12]) {
+    float dcin[PB][Rgb::L0::IB * 4];
+    if constexpr (C::FACT) {
+      // first layer on the geometry features only; the gradient w.r.t. its pre-activations, summed over the 16 points of a block
+      // (one ray: S % 16 == 0), is what the per-ray direction / appearance term receives (ps_ray_colour_bwd)
+      mlp_backward_acc<Rgb, PB, true, true>(
+          pk, scratch, acc,
+          [&](float (&cin)[PB][Rgb::KS0]) {
 #pragma unroll
-          for (int pb = 0; pb < PB; ++pb) {
-            float sh[16];
-            sh4((dirv[pb][0] + 1.0f) / 2.0f, (dirv[pb][1] + 1.0f) / 2.0f, (dirv[pb][2] + 1.0f) / 2.0f, sh);
+            for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float v0 = sh[4 * t], v1 = sh[4 * t + 1], v2 = sh[4 * t + 2], v3 = sh[4 * t + 3];
-              cin[pb][t] = g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
-              cin[pb][4 + t] = zb0[pb][t];
-              cin[pb][8 + t] = appv[pb][t];
+              for (int t = 0; t < 4; ++t) cin[pb][t] = zb0[pb][t];
+          },
+          c1, c2, co, dcin, tm, NoPost(),
+          [&](float (&dh)[PB][Rgb::HB * 4]) {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+              const int64_t blk = first / 16 + pb;
+#pragma unroll
+              for (int nb = 0; nb < Rgb::HB; ++nb) {
+                f32x4 sum;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] = ps_row16_sum(dh[pb][4 * nb + r]);
+                if (j == 0 && blk * 16 < a.N) *reinterpret_cast<f32x4*>(a.dr_part + blk * (Rgb::HB * 16) + 16 * nb + 4 * g) = sum;
+              }
             }
-          }
-        },
-        c1, c2, co, dcin, tm);
+          });
+    } else {
+      mlp_backward_acc<Rgb, PB, true, true>(
+          pk, scratch, acc,
+          [&](float (&cin)[PB][12]) {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+              float sh[16];
+              sh4((dirv[pb][0] + 1.0f) / 2.0f, (dirv[pb][1] + 1.0f) / 2.0f, (dirv[pb][2] + 1.0f) / 2.0f, sh);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const float v0 = sh[4 * t], v1 = sh[4 * t + 1], v2 = sh[4 * t + 2], v3 = sh[4 * t + 3];
+                cin[pb][t] = g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
+                cin[pb][4 + t] = zb0[pb][t];
+                cin[pb][8 + t] = appv[pb][t];
+              }
+            }
+          },
+          c1, c2, co, dcin, tm);
+    }
     __builtin_amdgcn_sched_barrier(0);
     consume();
     fetch_head(first + 2 * stride, hd);
@@ -1126,33 +1197,38 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
       const int64_t p = first + pb * 16 + j;
       const int64_t op = orig_index<MS>(a.perm, p, a.N);
       bool pt_ok = p < a.N;
-      if constexpr (MS) {
-        pt_ok = op >= 0;
-        const int rid = pt_ok ? (int)ray_of[pb] : -1;
-        bool same = true;
-        same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-        same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-        same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x141, 0xF, 0xF, false);  // row_half_mirror
-        same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x140, 0xF, 0xF, false);  // row_mirror
-        const unsigned long long ok = __ballot(same && pt_ok);
-        block_in_ray = ((ok >> (16 * g)) & 0xffffull) == 0xffffull;
-      }
+      if constexpr (C::FACT) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        dz0[pb][t] = dcin[pb][4 + t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
-        if (MS && a.dapp_pt != nullptr) {
-          const int c = 4 * t + g;
-          if (pt_ok && c < a.A) a.dapp_pt[op * a.A + c] = dcin[pb][8 + t];
-        } else if (a.dapp != nullptr) {
-          const int c = 4 * t + g;
-          float v = pt_ok ? dcin[pb][8 + t] : 0.0f;
-          float vs = v;
-          if constexpr (MS) vs = ps_row16_sum(v);
-          if (block_in_ray) {
-            if constexpr (!MS) vs = ps_row16_sum(v);
-            if (j == 0 && first + pb * 16 < a.N && c < a.A) unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, vs);
-          } else if (pt_ok && c < a.A) {
-            unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, v);
+        for (int t = 0; t < 4; ++t) dz0[pb][t] = dcin[pb][t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
+      } else {
+        if constexpr (MS) {
+          pt_ok = op >= 0;
+          const int rid = pt_ok ? (int)ray_of[pb] : -1;
+          bool same = true;
+          same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+          same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+          same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x141, 0xF, 0xF, false);  // row_half_mirror
+          same &= rid == __builtin_amdgcn_update_dpp(0, rid, 0x140, 0xF, 0xF, false);  // row_mirror
+          const unsigned long long ok = __ballot(same && pt_ok);
+          block_in_ray = ((ok >> (16 * g)) & 0xffffull) == 0xffffull;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          dz0[pb][t] = dcin[pb][4 + t];  // geo slots (the sigma_raw slot has zero weights -> exactly 0)
+          if (MS && a.dapp_pt != nullptr) {
+            const int c = 4 * t + g;
+            if (pt_ok && c < a.A) a.dapp_pt[op * a.A + c] = dcin[pb][8 + t];
+          } else if (a.dapp != nullptr) {
+            const int c = 4 * t + g;
+            float v = pt_ok ? dcin[pb][8 + t] : 0.0f;
+            float vs = v;
+            if constexpr (MS) vs = ps_row16_sum(v);
+            if (block_in_ray) {
+              if constexpr (!MS) vs = ps_row16_sum(v);
+              if (j == 0 && first + pb * 16 < a.N && c < a.A) unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, vs);
+            } else if (pt_ok && c < a.A) {
+              unsafeAtomicAdd(a.dapp + ray_of[pb] * a.A + c, v);
+            }
           }
         }
       }
@@ -1447,7 +1523,8 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;                                                           \
-    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+    static const int max_blocks = getenv("PS_MAIN_FWD_BLOCKS") ? atoi(getenv("PS_MAIN_FWD_BLOCKS")) : 256;                  \
+    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, max_blocks), kMainFwdWaves * 64, 0, s>>>(a); \
     PS_CHECK_LAUNCH();                                                                                                \
   }
     PS_MAIN_CFGS(X)
@@ -1608,29 +1685,34 @@ extern "C" int ps_debug_timing_fwd(unsigned long long* out /*host[16]*/, int res
 }
 #endif
 
-// ---- factored semantic path (MainCfg FACT): the same arguments as ps_main_field_fwd / _bwd; `packed` holds [base (L*F -> hidden ->
-// 16) | semantic stack (hidden -> 64 merged, 64 -> 64) | colour head], `sem` receives the LAST HIDDEN activations of the semantic
-// head per sample, dsem is W_out^T d(semantics) per ray (ps_sem_out_bwd)
+// ---- factored path (MainCfg FACT, csrc/factored.hip): `packed` holds [base (L*F -> hidden -> 16) | semantic stack (hidden -> 64 merged,
+// 64 -> 64) | colour head with a geometry-only first layer]; ray_colour [N / S, hidden_color] is the per-ray part of the colour
+// head's first layer (ps_ray_colour_fwd); `sem_hidden` receives the LAST HIDDEN activations of the semantic head per sample;
+// dsem_hidden is W_out^T d(semantics) per ray (ps_sem_out_bwd); dray_part [N / 16, hidden_color] receives the per-block sums of the
+// gradient of ray_colour (-> ps_ray_colour_bwd).  S % 16 == 0: a 16-sample block never straddles two rays.
 extern "C" int ps_main_field_f_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
-                                   const float* sel, const float* dirs, const float* app, int S, int A, const float* packed, int64_t N,
-                                   float* sigma, float* rgb, float* sem_hidden, float* acts, void* stream) {
+                                   const float* sel, const float* ray_colour, int S, const float* packed, int64_t N, float* sigma,
+                                   float* rgb, float* sem_hidden, float* acts, void* stream) {
   MainArgs a{};
-  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.rray = ray_colour; a.S = S;
   a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem_hidden; a.acts = acts; a.K = 1;
-  PS_REQUIRE(acts != nullptr, "ps_main_field_f_fwd: the factored path keeps its activations");
-  PS_REQUIRE(a.A <= 16 && a.S > 0 && N < (int64_t(1) << 31), "ps_main_field_f_fwd: appearance dim <= 16, at most 2^31 - 1 points");
+  PS_REQUIRE(acts != nullptr && ray_colour != nullptr, "ps_main_field_f_fwd: the factored path keeps its activations and needs the per-ray colour term");
+  PS_REQUIRE(a.S > 0 && a.S % 16 == 0 && N % a.S == 0 && N < (int64_t(1) << 31),
+             "ps_main_field_f_fwd: samples per ray a multiple of 16, whole rays, at most 2^31 - 1 points");
   return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream, true);
 }
 
 extern "C" int ps_main_field_f_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
-                                   const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
-                                   const float* dsigma, const float* drgb, const float* dsem_hidden, const float* weights, int64_t N,
-                                   float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch, int stages, void* stream) {
+                                   const float* sel, int S, const float* packed, const float* dsigma, const float* drgb,
+                                   const float* dsem_hidden, const float* weights, int64_t N, float* dfeat, float* dray_part, float* gpart,
+                                   const float* acts, float* dzb_scratch, int stages, void* stream) {
   MainArgs a{};
   a.dzb = dzb_scratch;
-  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
-  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem_hidden; a.w = weights; a.dfeat = dfeat; a.dapp = dapp;
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.S = S;
+  a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem_hidden; a.w = weights; a.dfeat = dfeat; a.dr_part = dray_part;
   a.gpart = gpart; a.acts = const_cast<float*>(acts); a.K = 1;
-  PS_REQUIRE(a.A <= 16 && a.S > 0 && N < (int64_t(1) << 31), "ps_main_field_f_bwd: appearance dim <= 16, at most 2^31 - 1 points");
+  PS_REQUIRE(dray_part != nullptr, "ps_main_field_f_bwd: the per-block gradient of the per-ray colour term is required");
+  PS_REQUIRE(a.S > 0 && a.S % 16 == 0 && N % a.S == 0 && N < (int64_t(1) << 31),
+             "ps_main_field_f_bwd: samples per ray a multiple of 16, whole rays, at most 2^31 - 1 points");
   return main_bwd_impl(a, hidden, hidden_color, stages, (hipStream_t)stream, true);
 }

@@ -746,11 +746,17 @@ struct MlpT {
           : L1::SCRATCH_ROWS;
 };
 
-// forward through all layers, keeping the post-ReLU hidden activations (needed by backward)
-template <class M, int PB, class W>
+struct NoPost {
+  template <class T>
+  __device__ __forceinline__ void operator()(T&) const {}
+};
+
+// forward through all layers, keeping the post-ReLU hidden activations (needed by backward).  `post_first(h1)` runs on the first
+// layer's pre-activations before their ReLU (a per-point term that is added there: the per-ray part of the colour head's input).
+template <class M, int PB, class W, class PostFirst = NoPost>
 __device__ __forceinline__ void mlp_forward(const W& params, const float (&x)[PB][M::KS0],
                                             float (&h1)[PB][M::HB * 4], float (&h2)[PB][M::HB * 4],
-                                            float (&z)[PB][M::NBO * 4]) {
+                                            float (&z)[PB][M::NBO * 4], const PostFirst& post_first = PostFirst()) {
   using L0 = typename M::L0;
   using L1 = typename M::L1;
   using LZ = typename M::LZ;
@@ -761,12 +767,14 @@ __device__ __forceinline__ void mlp_forward(const W& params, const float (&x)[PB
   if constexpr (M::NL == 3) {
     FwdFrags<L1> a1;
     layer_fwd_pf<L0, PB>(p0, a0, x, h1, [&]() { first_frags_fwd<L1>(p1, a1); });
+    post_first(h1);
     relu_inplace<PB, M::HB * 4>(h1);
     layer_fwd_pf<L1, PB>(p1, a1, h1, h2, [&]() { first_frags_fwd<LZ>(pz, az); });
     relu_inplace<PB, M::HB * 4>(h2);
     layer_fwd_pf<LZ, PB>(pz, az, h2, z, NoPrefetch());
   } else {
     layer_fwd_pf<L0, PB>(p0, a0, x, h1, [&]() { first_frags_fwd<LZ>(pz, az); });
+    post_first(h1);
     relu_inplace<PB, M::HB * 4>(h1);
     layer_fwd_pf<LZ, PB>(pz, az, h1, z, NoPrefetch());
   }
@@ -848,15 +856,13 @@ __device__ __forceinline__ void mlp_backward(const W& params, float* __restrict_
 // `post_last(dh)` runs on the gradient w.r.t. the last hidden layer right after the last layer's data backward (before the ReLU
 // mask): a second consumer of that hidden layer adds its gradient there (the factored main field: the semantic head hangs off
 // the base MLP's hidden layer).
-struct NoPost {
-  template <class T>
-  __device__ __forceinline__ void operator()(T&) const {}
-};
-template <class M, int PB, bool WANT_DX, bool H1_LATE = false, class W, class MakeX, class PostLast = NoPost>
+// `pre_first(d)` sees the gradient w.r.t. the FIRST layer's pre-activations (after the ReLU mask), before that layer's backward.
+template <class M, int PB, bool WANT_DX, bool H1_LATE = false, class W, class MakeX, class PostLast = NoPost, class PreFirst = NoPost>
 __device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restrict__ scratch, MlpAcc<M>& acc, const MakeX& make_x,
                                                  const float (&h1)[PB][M::HB * 4], const float (&h2)[PB][M::HB * 4],
                                                  const float (&dz)[PB][M::NBO * 4], float (&dx)[PB][M::L0::IB * 4],
-                                                 PsTimer* tm = nullptr, const PostLast& post_last = PostLast()) {
+                                                 PsTimer* tm = nullptr, const PostLast& post_last = PostLast(),
+                                                 const PreFirst& pre_first = PreFirst()) {
   using L0 = typename M::L0;
   using L1 = typename M::L1;
   using LZ = typename M::LZ;
@@ -878,12 +884,14 @@ __device__ __forceinline__ void mlp_backward_acc(const W& params, float* __restr
     float dh1[PB][M::HB * 4];
     layer_bwd_pipe_core<L1, PB, true, true, H1_LATE>(t1, a1, scratch, acc.l1.dw, acc.l1.dbp, dh, h1, dh1, req0, tm, 4);
     relu_mask<PB, M::HB * 4>(dh1, h1);
+    pre_first(dh1);
     make_x(x);
     layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh1, x, dx, NoPrefetch(), tm, 6);
   } else {
     layer_bwd_pipe_core<LZ, PB, true, true, true>(tz, az, scratch, acc.lz.dw, acc.lz.dbp, dz, h1, dh, req0, tm, 2);
     post_last(dh);
     relu_mask<PB, M::HB * 4>(dh, h1);
+    pre_first(dh);
     make_x(x);
     layer_bwd_pipe_core<L0, PB, WANT_DX, true>(t0, a0, scratch, acc.l0.dw, acc.l0.dbp, dh, x, dx, NoPrefetch(), tm, 6);
   }

@@ -466,7 +466,8 @@ class _MainFieldRender(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ factored semantic path
 # The training render node of ONE sub-field with two algebraic rewrites of the semantic branch (csrc/field.hip MainCfg FACT,
 # csrc/factored.hip): base layer 1 rows 16..79 merged with semantic layer 0, semantic output layer applied per ray after
-# compositing.  PRESIGHT_FACTORED=0 selects the unfactored node (same results to fp32 re-association).
+# compositing, and the direction / appearance columns of the colour head's first layer evaluated once per ray.
+# PRESIGHT_FACTORED=0 selects the unfactored node (same results to fp32 re-association).
 FACTORED = os.environ.get("PRESIGHT_FACTORED", "1") != "0"
 
 
@@ -474,7 +475,8 @@ class MainSpecF:
     def __init__(self, LF: int, hidden: int, hidden_color: int, app_dim: int):
         self.base = MlpSpec([LF, hidden, 16])
         self.sem = MlpSpec([hidden, 64, SEM_DIM], first_colmap=chain_colmap(hidden // 4, hidden), ks0=hidden // 4)
-        self.rgb = MlpSpec([16 + GEO_DIM + app_dim, hidden_color, hidden_color, 3], first_colmap=colour_colmap(app_dim), ks0=12)
+        # the kernel's first colour layer reads base-output block 0 (sigma_raw | geo15) only: k-steps 4..7 of colour_colmap
+        self.rgb = MlpSpec([16 + GEO_DIM + app_dim, hidden_color, hidden_color, 3], first_colmap=colour_colmap(app_dim)[16:32], ks0=4)
         self.p_off = [0, self.base.packed, self.base.packed + self.sem.packed]
         self.packed = self.p_off[2] + self.rgb.packed
         self.g_off = [0, self.base.g_total, self.base.g_total + self.sem.g_total]
@@ -497,10 +499,12 @@ def _main_spec_f(LF, hidden, hidden_color, app_dim) -> MainSpecF:
     return _MAIN_SPECS_F[key]
 
 
-def factored_supported(base, sem, rgb) -> bool:
-    """2-layer base MLP ending in 1 + 15 + 64 outputs, 3-layer 64-wide semantic head: the PreSight layout"""
+def factored_supported(base, sem, rgb, S: int = 16) -> bool:
+    """2-layer base MLP ending in 1 + 15 + 64 outputs, 3-layer 64-wide semantic head (the PreSight layout), and a sample count per
+    ray that is a multiple of the kernels' 16-point block (a block then belongs to ONE ray)"""
     return (FACTORED and len(base) == 2 and len(sem) == 3 and len(rgb) == 3 and base[1][0].shape[0] == BASE_OUT
-            and sem[0][0].shape == (64, SEM_DIM) and sem[2][0].shape == (SEM_DIM, 64) and base[0][0].shape[0] % 16 == 0)
+            and sem[0][0].shape == (64, SEM_DIM) and sem[2][0].shape == (SEM_DIM, 64) and base[0][0].shape[0] % 16 == 0
+            and S > 0 and S % 16 == 0)
 
 
 class _MainFieldRenderF(torch.autograd.Function):
@@ -536,10 +540,13 @@ class _MainFieldRenderF(torch.autograd.Function):
         acts = torch.empty((N + 15) // 16 * 16, spec.act_width, device=dev)
         dirs = _f32(dirs)
         app_c = _f32(app) if app is not None else None
+        Wr0 = _f32(r0[0])
+        ray_colour = torch.empty(R, hidden_color, device=dev)
+        check(lib().ps_ray_colour_fwd(_p(dirs), _p(app_c), _p(Wr0), R, A, hidden_color, _p(ray_colour), _stream()), "ps_ray_colour_fwd")
         with prof.region("main_field_fwd"):
             check(lib().ps_main_field_f_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color, _p(sel),
-                                            _p(dirs), _p(app_c), max(S, 1), A, _p(packed), N, _p(sigma), _p(rgb_s), _p(hid_s), _p(acts),
-                                            _stream()), "ps_main_field_f_fwd")
+                                            _p(ray_colour), S, _p(packed), N, _p(sigma), _p(rgb_s), _p(hid_s), _p(acts), _stream()),
+                  "ps_main_field_f_fwd")
         ebins = _f32(ebins)
         w = torch.empty(R, S, device=dev)
         check(lib().ps_weights_fwd(_p(ebins), _p(sigma), R, S, _p(w), _stream()), "ps_weights_fwd")
@@ -603,13 +610,17 @@ class _MainFieldRenderF(torch.autograd.Function):
                                           None, None), "ps_main_field_f_sizes")
         gpart = torch.empty(npart.value, spec.g_total, device=dev)
         dfeat = torch.empty_like(feat)
-        dapp = torch.zeros_like(app) if app is not None else None
+        dapp = torch.empty_like(app) if app is not None else None
         dzb = torch.empty((N + 15) // 16 * 16, spec.dzb_width, device=dev)
+        dray = torch.empty(N // 16, hidden_color, device=dev)
         with prof.region("main_field_bwd"):
             for stages in _bwd_stages(dzb):
                 check(lib().ps_main_field_f_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                                _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(packed), _p(dsig), _p(d_rgb), _p(v), _p(w), N,
-                                                _p(dfeat), _p(dapp), _p(gpart), _p(acts), _p(dzb), stages, _stream()), "ps_main_field_f_bwd")
+                                                _p(sel), S, _p(packed), _p(dsig), _p(d_rgb), _p(v), _p(w), N, _p(dfeat), _p(dray), _p(gpart),
+                                                _p(acts), _p(dzb), stages, _stream()), "ps_main_field_f_bwd")
+        # direction / appearance columns of the colour head's first layer and d(appearance), per ray
+        check(lib().ps_ray_colour_bwd(_p(dray), _p(dirs), _p(app), _p(_f32(r0[0])), R, S, A, hidden_color, _p(dWr0), _p(dapp), _stream()),
+              "ps_ray_colour_bwd")
         dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.table_sink, counts, sink_owner=ctx.table_ref)
         # weight gradients: partial blocks -> torch layout.  Base layer 1: rows 0..15 (sigma_raw | geo15) directly, rows 16..79
         # through the merged layer (chain rule of W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0)
@@ -637,7 +648,7 @@ def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor
     flat = []
     for W, b in list(base) + list(sem) + list(rgb):
         flat += [W, b]
-    if factored_supported(base, sem, rgb) and torch.is_grad_enabled():
+    if factored_supported(base, sem, rgb, S) and torch.is_grad_enabled():
         return _MainFieldRenderF.apply(u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, *flat)
     return _MainFieldRender.apply(u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, len(base), len(sem), *flat)
 

@@ -303,10 +303,12 @@ def test_fused_render_node_matches_separate_nodes(samples):
         torch.testing.assert_close(gb[k] / s, ga[k] / s, rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
     assert float(ga["field.fields.0.mlp_base_grid.hash_table"].abs().max()) > 0
     # The FACTORED node (the training default: base layer 1 rows 16..79 merged with semantic layer 0, semantic output layer applied per
-    # ray after compositing) evaluates the same function with re-associated fp32 sums: density, colour, depths are the same kernels'
-    # results bit for bit, the semantics agree to fp32 rounding, every gradient to the summation-order tolerance above
-    for k in ("rgb", "accumulation", "depth", "expected_depth"):
+    # ray after compositing, direction / appearance columns of the colour head's first layer evaluated per ray) computes the same
+    # function with re-associated fp32 sums: density and depths come from the same arithmetic bit for bit, colour (a sigmoid output
+    # in [0, 1]: a few ulp of 1) and semantics agree to fp32 rounding, every gradient to the summation-order tolerance above
+    for k in ("accumulation", "depth", "expected_depth"):
         torch.testing.assert_close(oc[k], oa[k], rtol=0, atol=0, msg=lambda m: f"factored {k}: {m}")
+    torch.testing.assert_close(oc["rgb"], oa["rgb"], rtol=0, atol=4 * 2.0 ** -24, msg=lambda m: f"factored rgb: {m}")
     torch.testing.assert_close(oc["semantics"], oa["semantics"], rtol=2e-5, atol=2e-6)
     for k in la:
         torch.testing.assert_close(lc[k], la[k], rtol=2e-5, atol=1e-9, msg=lambda m: f"factored {k}: {m}")
