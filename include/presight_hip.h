@@ -363,9 +363,12 @@ int ps_ms_mark_groups(const int32_t* field_start, int K, const int32_t* group_of
  * ps_ray_colour_bwd: dray_part [R*S/16, HC] (from ps_main_field_f_bwd) reduced per ray; dW0's SH / appearance columns += , dapp [R,A] written.
  * ps_main_field_f_*: as ps_main_field_fwd / _bwd with packed = [base (L*F -> hidden -> 16) | semantic (hidden -> 64 merged, 64 -> 64)
  *   | colour head whose first layer takes the 16 base outputs only (column map: geo15 -> torch columns 16..30)]; ray_colour is added
- *   to that layer's pre-activations; S % 16 == 0 and N % S == 0; sem_hidden [N,64] = last hidden activations per sample;
- *   dsem_hidden [R,64] = v of ps_sem_out_bwd (per ray); acts [N, act_width], dzb_scratch [N, dzb_width] (ps_main_field_f_sizes),
- *   weights required; dray_part [N/16, HC] = per-16-sample-block sums of d(ray_colour).
+ *   to that layer's pre-activations; S % 32 == 0 and N % S == 0.  The forward renders the semantic branch itself: ebins [R,S+1] in,
+ *   weights [N] (ps_weights_fwd's formula; ns/model_components/ray_samplers.py get_weights) and sem_hidden_ray [R,64] = sum_n w_n *
+ *   (last hidden activations of the semantic head) out; sigma [N], rgb [N,3] per sample; acts [N, act_width], dzb_scratch
+ *   [N, dzb_width] (ps_main_field_f_sizes).  Backward: dsem_hidden [R,64] = v of ps_sem_out_bwd (per ray), drgb [R,3] per ray,
+ *   weights required; stage 1 writes dweights_sem [N] = <v_ray, last hidden activations> (add to d(weights) before
+ *   ps_weights_bwd) and needs no dsigma; stages 2 | 4 need dsigma; dray_part [N/16, HC] = per-16-sample-block sums of d(ray_colour).
  * ps_sem_out_fwd: sem [R,64] = H W^T + b acc (H [R,64] = composited hidden activations, acc [R] = sum of the weights, unclamped).
  * ps_sem_out_bwd: v [R,64] = dsem W, cray [R] = <dsem, b> (joins d(acc)), dW [64,64] += dsem^T H, db [64] += dsem^T acc. */
 int ps_merge_linear_fwd(const float* W0, const float* b0, const float* We, const float* be, int O, int K, int I, float* Wm, float* bm,
@@ -375,12 +378,12 @@ int ps_merge_linear_bwd(const float* dWm, const float* dbm, const float* W0, con
 int ps_main_field_f_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
                           int* n_parts /*host*/, int64_t* offsets /*host [6]*/, int* act_width /*host*/, int* dzb_width /*host*/);
 int ps_main_field_f_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
-                        const float* ray_colour, int S, const float* packed, int64_t N, float* sigma, float* rgb, float* sem_hidden,
-                        float* acts, void* stream);
+                        const float* ray_colour, const float* ebins, int S, const float* packed, int64_t N, float* sigma, float* rgb,
+                        float* weights, float* sem_hidden_ray, float* acts, void* stream);
 int ps_main_field_f_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel, int S,
                         const float* packed, const float* dsigma, const float* drgb, const float* dsem_hidden, const float* weights,
-                        int64_t N, float* dfeat, float* dray_part, float* gpart, const float* acts, float* dzb_scratch, int stages,
-                        void* stream);
+                        int64_t N, float* dfeat, float* dray_part, float* dweights_sem, float* gpart, const float* acts,
+                        float* dzb_scratch, int stages, void* stream);
 int ps_ray_colour_fwd(const float* dirs, const float* app, const float* W0, int64_t R, int A, int HC, float* ray_colour, void* stream);
 int ps_ray_colour_bwd(const float* dray_part, const float* dirs, const float* app, const float* W0, int64_t R, int S, int A, int HC,
                       float* dW0, float* dapp, void* stream);

@@ -60,6 +60,19 @@ __device__ __forceinline__ float ps_dpp_add(float v, const int ctrl_tag) {
   }
   return v + __builtin_bit_cast(float, y);
 }
+// v of the lane `N` places to the left in the same row of 16 lanes (0 where there is none): DPP row_shr
+template <int N>
+__device__ __forceinline__ float ps_row_shr(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xF, 0xF, true));
+}
+// inclusive prefix sum within each row of 16 lanes (four DPP adds, no LDS crossbar)
+__device__ __forceinline__ float ps_row16_incl_scan(float v) {
+  v += ps_row_shr<1>(v);
+  v += ps_row_shr<2>(v);
+  v += ps_row_shr<4>(v);
+  v += ps_row_shr<8>(v);
+  return v;
+}
 __device__ __forceinline__ float ps_row16_sum(float v) {
   v = ps_dpp_add(v, 0);
   v = ps_dpp_add(v, 1);

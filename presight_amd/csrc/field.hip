@@ -93,18 +93,22 @@ __device__ __forceinline__ void store_act(float* __restrict__ acts, int stride, 
     }
   }
 }
-template <int NBLK, int PB>
+// CLAMP: the loads are unconditional, blocks past the end read the last block instead (callers that only ever USE whole in-range
+// tiles: a conditional load is a branch plus a merge with a constant, and such merges of values still in flight made the
+// compiler place s_waitcnt vmcnt(0) right behind the load or at the loop's back edge)
+template <int NBLK, int PB, bool CLAMP = false>
 __device__ __forceinline__ void load_act(const float* __restrict__ acts, int stride, int col0, int64_t first, int64_t N,
                                          float (&v)[PB][NBLK * 4]) {
   const int lane = ps_lane();
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
-    const int64_t blk = first / 16 + pb;
+    int64_t blk = first / 16 + pb;
+    if constexpr (CLAMP) blk = blk * 16 < N ? blk : (N - 1) / 16;
     const float* base = acts + blk * (int64_t)stride * 16 + (int64_t)col0 * 16 + lane * 4;
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb) {
       f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (blk * 16 < N) t = *reinterpret_cast<const f32x4*>(base + nb * 256);
+      if (CLAMP || blk * 16 < N) t = *reinterpret_cast<const f32x4*>(base + nb * 256);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[pb][4 * nb + r] = t[r];
     }
@@ -410,6 +414,14 @@ struct MainArgs {
   // per-16-point-block sums of the gradient w.r.t. it [ceil(N/16), hidden_color] (backward output); S % 16 == 0
   const float* rray;
   float* dr_part;
+  // factored path, compositing of the semantic head fused in (S % (16 PB) == 0: the tiles of a ray run back to back on one wave):
+  // forward: bin edges [R, S+1] in, rendering weights [N] and the composited last-hidden activations [R, 64] out (no per-sample
+  // [N, 64] array leaves the kernel); backward (semantic kernel): <W_out^T d(semantics of the ray), last hidden activations> per
+  // sample [N] out = the semantic head's part of d(weights)
+  const float* ebins;
+  float* w_out;
+  float* hid_ray;
+  float* dw_sem;
 };
 
 // FACT (the factored semantic path of the training render node, one sub-field): the semantic head's input is a LINEAR function
@@ -512,9 +524,33 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   struct In {
     float x[PB][Base::KS0], sel[PB], dirv[PB][3], appv[PB][4];
     f32x4 rr[C::FACT ? PB : 1][C::FACT ? Rgb::HB : 1];  // FACT: the ray's colour-head term for this lane's neurons 16nb + 4g..4g+3
+    float e0[C::FACT ? PB : 1], e1[C::FACT ? PB : 1];   // FACT: the sample's bin edges (subtracted after `consume`: a fetch only issues loads)
     int op[PB];  // the point's index in the caller's arrays, -1: no such point
   };
   auto fetch = [&](int64_t first, In& v) {
+    if constexpr (C::FACT) {
+      // whole tiles only (N % (16 PB) == 0) and every feature column exists (L*F % 4 == 0): the loads are UNCONDITIONAL, with the
+      // point index clamped for the tiles requested past the end (never consumed).  A conditional load is a branch plus a merge of
+      // the loaded value with a constant, and that merge made the compiler copy the prefetched registers at the loop's back edge
+      // -- behind an s_waitcnt vmcnt(0) that exposed the whole memory latency once per tile (phase timer: 3.5 k of 34 k cycles).
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j;
+        const int64_t pc = p < a.N ? p : a.N - 1;
+        const float* row = a.feat + pc * a.F;
+#pragma unroll
+        for (int t = 0; t < Base::KS0; ++t) v.x[pb][t] = row[fc.off[t]];
+        v.op[pb] = (int)pc;
+        v.sel[pb] = a.sel[pc];
+        const int64_t r = ray_index(pc, a.S);
+#pragma unroll
+        for (int nb = 0; nb < Rgb::HB; ++nb) v.rr[pb][nb] = *reinterpret_cast<const f32x4*>(a.rray + r * (Rgb::HB * 16) + 16 * nb + 4 * g);
+        const float* e = a.ebins + r * (a.S + 1) + (pc - r * a.S);
+        v.e0[pb] = e[0];
+        v.e1[pb] = e[1];
+      }
+      return;
+    }
     load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, v.x);
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
@@ -527,18 +563,12 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         r = ray_index(op >= 0 ? op : 0, a.S);
       else
         r = ray_index(p < a.N ? p : a.N - 1, a.S);
-      if constexpr (C::FACT) {
 #pragma unroll
-        for (int nb = 0; nb < Rgb::HB; ++nb)
-          v.rr[pb][nb] = first < a.N ? *reinterpret_cast<const f32x4*>(a.rray + r * (Rgb::HB * 16) + 16 * nb + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      } else {
+      for (int k = 0; k < 3; ++k) v.dirv[pb][k] = (a.rgb != nullptr && first < a.N) ? a.dirs[r * 3 + k] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v.dirv[pb][k] = (a.rgb != nullptr && first < a.N) ? a.dirs[r * 3 + k] : 0.0f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int c = 4 * t + g;
-          v.appv[pb][t] = (a.rgb != nullptr && a.app != nullptr && c < a.A && first < a.N) ? a.app[r * a.A + c] : 0.0f;
-        }
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * t + g;
+        v.appv[pb][t] = (a.rgb != nullptr && a.app != nullptr && c < a.A && first < a.N) ? a.app[r * a.A + c] : 0.0f;
       }
     }
   };
@@ -552,7 +582,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       if constexpr (C::FACT) {
 #pragma unroll
         for (int nb = 0; nb < Rgb::HB; ++nb) asm volatile("" : "+v"(cur.rr[pb][nb]));
-        asm volatile("" : "+v"(cur.sel[pb]), "+v"(cur.op[pb]));
+        asm volatile("" : "+v"(cur.sel[pb]), "+v"(cur.op[pb]), "+v"(cur.e0[pb]), "+v"(cur.e1[pb]));
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(cur.appv[pb][t]));
@@ -566,12 +596,28 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   tm_.start();
   tm = &tm_;
 #endif
-  const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
-  int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
-  fetch(first, nxt);
+  // Tile order.  A wave walks UNITS of `tpu` consecutive tiles; unit u of wave (j, wave) is number (j NW + wave) + i n NW.  Plain
+  // calls: one tile per unit (the round-robin order).  FACT: unit = ray (S / (16 PB) tiles), so that the wave carries the ray's
+  // optical depth and its weighted sums of the semantic activations in registers from tile to tile.
+  struct TileIt {
+    int64_t first;
+    int k;
+  };
+  const int tpu = C::FACT ? a.S / (16 * PB) : 1;
+  const int64_t unit_jump = ((int64_t)tr.n * NW - 1) * tpu * (16 * PB) + 16 * PB;  // last tile of a unit -> first tile of the wave's next unit
+  auto advance = [&](TileIt t) {
+    if (t.k + 1 < tpu) return TileIt{t.first + 16 * PB, t.k + 1};
+    return TileIt{t.first + unit_jump, 0};
+  };
+  TileIt it0{tr.first_pt + ((int64_t)tr.j * NW + wave) * tpu * (16 * PB), 0};
+  TileIt it1 = advance(it0), it2 = advance(it1);
+  fetch(it0.first, nxt);
   consume();
-  fetch(first + stride, nxt);
-  for (; first < a.N; first += stride) {
+  fetch(it1.first, nxt);
+  float carry = 0.0f;                    // FACT: optical depth of the ray up to this tile
+  float racc[C::FACT ? 16 : 1] = {0.f};  // FACT: this lane's part of sum_n w_n s_n (neurons 16nb + 4g + r, samples j, j + 16, ...)
+  for (; it0.first < a.N; it0 = it1, it1 = it2, it2 = advance(it2)) {
+    const int64_t first = it0.first;
     PS_STAMP(tm, 0)
     float zb[PB][C::ZB_NB * 4], dirv[PB][3], appv[PB][4];
     float h1f[C::FACT ? PB : 1][C::FACT ? Base::HB * 4 : 1];  // FACT: the base hidden layer feeds the semantic stack
@@ -605,14 +651,39 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
           for (int t = 0; t < Base::HB * 4; ++t) h1f[pb][t] = h1[pb][t];
       }
     }
-    if (a.sigma != nullptr && g == 0) {
+    float wq[C::FACT ? PB : 1];  // FACT: the rendering weight of this lane's sample (all four lane groups)
+    if constexpr (C::FACT) {
+      // rendering weights of the tile's samples (ns/model_components/ray_samplers.py get_weights: alpha_n T_n with
+      // T_n = exp(-sum_{m<n} sigma_m delta_m)), row 0 of the wave = the 16 samples of a block; the other rows compute unused values
+      // (sigma_raw lives in row 0 of the wave; it is broadcast to the four rows first, every row then forms the same weights with
+      // row-local DPP scans: one trip through the LDS crossbar per block instead of seven)
+      float sig[PB], dd[PB], ex[PB], tot[PB];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        sig[pb] = expf(__shfl(zb[pb][0], j, 64)) * cur.sel[pb];
+        dd[pb] = (cur.e1[pb] - cur.e0[pb]) * sig[pb];
+        const float incl = ps_row16_incl_scan(dd[pb]);
+        tot[pb] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 15));
+        ex[pb] = ps_row_shr<1>(incl);
+      }
+      if (it0.k == 0) carry = 0.0f;
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        wq[pb] = nan_to_num((1.0f - expf(-dd[pb])) * expf(-(carry + ex[pb])));
+        carry += tot[pb];
+        if (g == 0) {
+          a.sigma[first + pb * 16 + j] = sig[pb];
+          a.w_out[first + pb * 16 + j] = wq[pb];
+        }
+      }
+    } else if (a.sigma != nullptr && g == 0) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb)
         if (op_cur[pb] >= 0) a.sigma[op_cur[pb]] = expf(zb[pb][0]) * cur.sel[pb];
     }
     PS_STAMP(tm, 3)
     bool consumed = false;
-    if (a.sem != nullptr) {
+    if (C::FACT || a.sem != nullptr) {
       float s1[PB][16], s2[PB][16], so[PB][16];
       if constexpr (C::FACT) {
         // merged first layer on the base hidden layer, second layer; `so` = the last HIDDEN activations (the output layer is
@@ -642,13 +713,33 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         store_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
         store_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
       }
+      if constexpr (C::FACT) {
+        // composited last-hidden activations of the ray: per-lane partial sums over the tiles, one cross-lane sum per ray
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        if (op_cur[pb] >= 0) {
+        for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb)
-            *reinterpret_cast<f32x4*>(a.sem + (int64_t)op_cur[pb] * 64 + 16 * nb + 4 * g) =
-                (f32x4){so[pb][4 * nb], so[pb][4 * nb + 1], so[pb][4 * nb + 2], so[pb][4 * nb + 3]};
+          for (int t = 0; t < 16; ++t) racc[t] = fmaf(so[pb][t], wq[pb], racc[t]);
+        if (it0.k == tpu - 1) {
+          const int64_t r = ray_index(first, a.S);
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            f32x4 sum;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum[q] = ps_row16_sum(racc[4 * nb + q]);
+            if (j == 0) *reinterpret_cast<f32x4*>(a.hid_ray + r * 64 + 16 * nb + 4 * g) = sum;
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) racc[t] = 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+          if (op_cur[pb] >= 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+              *reinterpret_cast<f32x4*>(a.sem + (int64_t)op_cur[pb] * 64 + 16 * nb + 4 * g) =
+                  (f32x4){so[pb][4 * nb], so[pb][4 * nb + 1], so[pb][4 * nb + 2], so[pb][4 * nb + 3]};
+          }
         }
       }
     }
@@ -705,7 +796,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         }
       }
     }
-    fetch(first + 2 * stride, nxt);
+    fetch(it2.first, nxt);
     PS_STAMP(tm, 8)
   }
 #if defined(PS_TIMING)
@@ -961,6 +1052,17 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
     f32x4 d[PB][4];
   };
   auto gather = [&](int64_t first, Gather& v) {
+    if constexpr (C::FACT) {  // whole tiles, per-ray gradients: unconditional loads (clamped past the end, never used there)
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j, pc = p < a.N ? p : a.N - 1;
+        v.w[pb] = a.w[pc];
+        const float* src = a.dsem + ray_index(pc, a.S) * 64 + 4 * g;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) v.d[pb][nb] = *reinterpret_cast<const f32x4*>(src + 16 * nb);
+      }
+      return;
+    }
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t op = orig_index<MS>(a.perm, first + pb * 16 + j, a.N);
@@ -981,14 +1083,16 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
   // (and the next gather is issued) at the END of a tile, BEFORE its stores go out; the only waits behind the stores then come
   // 4 k cycles later, when everything has long arrived.
   Gather ga;
-  float so[PB][16];
+  float so[PB][16], w_cur[C::FACT ? PB : 1];
   auto consume = [&]() {
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb)
+    for (int pb = 0; pb < PB; ++pb) {
+      if constexpr (C::FACT) w_cur[pb] = ga.w[pb];  // FACT: `so` holds the ray's gradient unscaled until its dot product is taken
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = ga.d[pb][nb][r] * ga.w[pb];
+        for (int r = 0; r < 4; ++r) so[pb][4 * nb + r] = C::FACT ? ga.d[pb][nb][r] : ga.d[pb][nb][r] * ga.w[pb];
+    }
   };
   gather(first, ga);
   consume();
@@ -996,17 +1100,30 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
   for (; first < a.N; first += stride) {
     PS_STAMP(tm, 0)
     float sin_[PB][Sem::KS0], s1[PB][16], s2[PB][16];
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
-    load_act<4, PB>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
+    load_act<4, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
+    load_act<4, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
     if constexpr (C::FACT)
-      load_act<Sem::KS0 / 4, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, sin_);  // the base hidden layer = the merged first layer's input
+      load_act<Sem::KS0 / 4, PB, true>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, sin_);  // the base hidden layer = the merged first layer's input
     else
       load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
     PS_STAMP(tm, 1)
     float dsin[PB][Sem::L0::IB * 4];
+    float dws[C::FACT ? PB : 1];
     if constexpr (C::FACT) {
-      // `so` = w[n] * (W_out^T d(semantics of the ray)) is the gradient w.r.t. the last hidden activations s2 (the output layer was
-      // applied per ray): ReLU mask, then the two layers of the in-kernel stack; the result is d(base hidden layer)
+      // the semantic head's part of d(weight of the sample) = <v_ray, s2_n>, v = W_out^T d(semantics of the ray)
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        float dot = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dot = fmaf(so[pb][t], s2[pb][t], dot);
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        dws[pb] = dot;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) so[pb][t] *= w_cur[pb];
+      }
+      // `so` = w[n] * v is the gradient w.r.t. the last hidden activations s2 (the output layer was applied per ray): ReLU mask,
+      // then the two layers of the in-kernel stack; the result is d(base hidden layer)
       relu_mask<PB, 16>(so, s2);
     }
     mlp_backward_acc<Sem, PB, true>(
@@ -1023,6 +1140,13 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
     gather(first + 2 * stride, ga);
     __builtin_amdgcn_sched_barrier(0);
     store_act<Sem::L0::IB, PB>(a.dzb, C::DZB_W, 16, first, a.N, dsin);  // FACT: d(base hidden layer) from the semantic stack
+    if constexpr (C::FACT) {
+      if (g == 0) {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+          if (first + pb * 16 + j < a.N) a.dw_sem[first + pb * 16 + j] = dws[pb];
+      }
+    }
     PS_STAMP(tm, 8)
   }
 #if defined(PS_TIMING)
@@ -1052,9 +1176,28 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
   struct Head {
     float co[PB][4], w[PB], dr[PB][3], c2[PB][Rgb::HB * 4];
     float ds[PB];  // d(sigma) * selector of the point (lane group 0), 0 elsewhere: the density gradient joins d(base output 0)
+    float sel[C::FACT ? PB : 1];  // FACT: ds holds the raw d(sigma), the selector and the lane-group mask are applied in `consume`
     int64_t ray[PB];
   };
   auto fetch_head = [&](int64_t first, Head& h) {
+    if constexpr (C::FACT) {
+      // whole tiles: unconditional loads in every lane (clamped past the end), the products and the lane-group mask are applied
+      // in `consume` -- a product formed here waits for its two loads on the spot, one full memory latency per tile
+      load_act<1, PB, true>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, h.co);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j, pc = p < a.N ? p : a.N - 1;
+        const int64_t r = ray_index(pc, a.S);
+        h.ray[pb] = r;
+        h.ds[pb] = a.dsigma[pc];
+        h.sel[pb] = a.sel[pc];
+        h.w[pb] = a.w[pc];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) h.dr[pb][k] = a.drgb[r * 3 + k];
+      }
+      load_act<Rgb::HB, PB, true>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, h.c2);
+      return;
+    }
     load_act<1, PB>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, h.co);
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
@@ -1089,7 +1232,10 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       ray_head[pb] = hd.ray[pb];
-      ds_head[pb] = hd.ds[pb];
+      if constexpr (C::FACT)
+        ds_head[pb] = g == 0 ? hd.ds[pb] * hd.sel[pb] : 0.0f;
+      else
+        ds_head[pb] = hd.ds[pb];
       asm volatile("" : "+v"(ds_head[pb]));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1097,6 +1243,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
         if (k < 3) {
           const float sg = 1.0f / (1.0f + expf(-hd.co[pb][k]));
           d = hd.w[pb] * hd.dr[pb][k] * sg * (1.0f - sg);  // dr is zero outside lane group 0 / past the end
+          if constexpr (C::FACT) d = g == 0 ? d : 0.0f;    // (FACT: every lane loaded the ray's gradient)
         }
         co[pb][k] = d;
       }
@@ -1122,8 +1269,8 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
     int64_t ray_of[PB];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) ds_cur[pb] = ds_head[pb];
-    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
-    load_act<1, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);  // sigma_raw | geo15
+    load_act<Rgb::HB, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
+    load_act<1, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);  // sigma_raw | geo15
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t r = ray_head[pb];
@@ -1275,13 +1422,22 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
         asm volatile("" : "+v"(dzb[pb][t]));  // a real copy, made HERE (the wait for the load must not sink below the stores)
       }
   };
-  load_act<DZ / 4, PB>(a.dzb, C::DZB_W, 0, first, a.N, dzb_next);
+  load_act<DZ / 4, PB, C::FACT>(a.dzb, C::DZB_W, 0, first, a.N, dzb_next);
   consume();
-  load_act<DZ / 4, PB>(a.dzb, C::DZB_W, 0, first + stride, a.N, dzb_next);
+  load_act<DZ / 4, PB, C::FACT>(a.dzb, C::DZB_W, 0, first + stride, a.N, dzb_next);
   for (; first < a.N; first += stride) {
     float h1[PB][Base::HB * 4], xin[PB][Base::KS0];
-    load_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
-    load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, xin);
+    load_act<Base::HB, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
+    if constexpr (C::FACT) {  // whole tiles, every feature column exists (checked by the launcher)
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const float* row = a.feat + (first + pb * 16 + (ps_lane() & 15)) * a.F;
+#pragma unroll
+        for (int t = 0; t < Base::KS0; ++t) xin[pb][t] = row[fc.off[t]];
+      }
+    } else {
+      load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, xin);
+    }
     float dx[PB][Base::L0::IB * 4];
     auto make_x = [&](float (&x)[PB][Base::KS0]) {
 #pragma unroll
@@ -1307,7 +1463,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     consume();
-    load_act<DZ / 4, PB>(a.dzb, C::DZB_W, 0, first + 2 * stride, a.N, dzb_next);
+    load_act<DZ / 4, PB, C::FACT>(a.dzb, C::DZB_W, 0, first + 2 * stride, a.N, dzb_next);
     __builtin_amdgcn_sched_barrier(0);
     store_dfeat<Base::KS0, PB>(a.dfeat, fc, a.F, first, a.N, dx);
   }
@@ -1518,8 +1674,8 @@ namespace {
 int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool fact = false) {
   if (a.N == 0) return 0;
   if (fact) {
-    PS_REQUIRE(a.perm == nullptr && a.sem != nullptr && a.rgb != nullptr && a.sigma != nullptr,
-               "ps_main_field_f_fwd: one sub-field, all three outputs");
+    PS_REQUIRE(a.perm == nullptr && a.hid_ray != nullptr && a.rgb != nullptr && a.sigma != nullptr,
+               "ps_main_field_f_fwd: one sub-field, all outputs");
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;                                                           \
@@ -1687,32 +1843,40 @@ extern "C" int ps_debug_timing_fwd(unsigned long long* out /*host[16]*/, int res
 
 // ---- factored path (MainCfg FACT, csrc/factored.hip): `packed` holds [base (L*F -> hidden -> 16) | semantic stack (hidden -> 64 merged,
 // 64 -> 64) | colour head with a geometry-only first layer]; ray_colour [N / S, hidden_color] is the per-ray part of the colour
-// head's first layer (ps_ray_colour_fwd); `sem_hidden` receives the LAST HIDDEN activations of the semantic head per sample;
-// dsem_hidden is W_out^T d(semantics) per ray (ps_sem_out_bwd); dray_part [N / 16, hidden_color] receives the per-block sums of the
-// gradient of ray_colour (-> ps_ray_colour_bwd).  S % 16 == 0: a 16-sample block never straddles two rays.
+// head's first layer (ps_ray_colour_fwd).  The forward also RENDERS the semantic branch: from the bin edges ebins [N / S, S + 1] it
+// forms the rendering weights (written to `weights` [N]; ps_weights_fwd's formula) and hands out the composited LAST HIDDEN
+// activations of the semantic head per ray, sem_hidden_ray [N / S, 64] (-> ps_sem_out_fwd); density [N] and colour [N, 3] stay per
+// sample.  Backward: dsem_hidden is W_out^T d(semantics) per ray (ps_sem_out_bwd); stage 1 (semantic kernel) needs only the
+// weights and writes dweights_sem [N] = the semantic head's part of d(weights); stages 2 | 4 need d(sigma) (after the composite /
+// weights backward that consumes dweights_sem); dray_part [N / 16, hidden_color] receives the per-block sums of the gradient of
+// ray_colour (-> ps_ray_colour_bwd).  S % 32 == 0: the tiles of a ray are whole and run back to back on one wavefront.
 extern "C" int ps_main_field_f_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
-                                   const float* sel, const float* ray_colour, int S, const float* packed, int64_t N, float* sigma,
-                                   float* rgb, float* sem_hidden, float* acts, void* stream) {
+                                   const float* sel, const float* ray_colour, const float* ebins, int S, const float* packed, int64_t N,
+                                   float* sigma, float* rgb, float* weights, float* sem_hidden_ray, float* acts, void* stream) {
   MainArgs a{};
-  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.rray = ray_colour; a.S = S;
-  a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem_hidden; a.acts = acts; a.K = 1;
-  PS_REQUIRE(acts != nullptr && ray_colour != nullptr, "ps_main_field_f_fwd: the factored path keeps its activations and needs the per-ray colour term");
-  PS_REQUIRE(a.S > 0 && a.S % 16 == 0 && N % a.S == 0 && N < (int64_t(1) << 31),
-             "ps_main_field_f_fwd: samples per ray a multiple of 16, whole rays, at most 2^31 - 1 points");
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.rray = ray_colour; a.ebins = ebins; a.S = S;
+  a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.w_out = weights; a.hid_ray = sem_hidden_ray; a.acts = acts; a.K = 1;
+  PS_REQUIRE(acts != nullptr && ray_colour != nullptr && ebins != nullptr && sigma != nullptr && rgb != nullptr && weights != nullptr &&
+                 sem_hidden_ray != nullptr,
+             "ps_main_field_f_fwd: the factored path keeps its activations and produces all of its outputs");
+  PS_REQUIRE(a.S > 0 && a.S % (16 * kMainFwdPB) == 0 && N % a.S == 0 && N < (int64_t(1) << 31) && LF % 4 == 0,
+             "ps_main_field_f_fwd: samples per ray a multiple of 32, whole rays, at most 2^31 - 1 points, L*F a multiple of 4");
   return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream, true);
 }
 
 extern "C" int ps_main_field_f_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                    const float* sel, int S, const float* packed, const float* dsigma, const float* drgb,
-                                   const float* dsem_hidden, const float* weights, int64_t N, float* dfeat, float* dray_part, float* gpart,
-                                   const float* acts, float* dzb_scratch, int stages, void* stream) {
+                                   const float* dsem_hidden, const float* weights, int64_t N, float* dfeat, float* dray_part,
+                                   float* dweights_sem, float* gpart, const float* acts, float* dzb_scratch, int stages, void* stream) {
   MainArgs a{};
   a.dzb = dzb_scratch;
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.S = S;
   a.packed = packed; a.N = N; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem_hidden; a.w = weights; a.dfeat = dfeat; a.dr_part = dray_part;
-  a.gpart = gpart; a.acts = const_cast<float*>(acts); a.K = 1;
-  PS_REQUIRE(dray_part != nullptr, "ps_main_field_f_bwd: the per-block gradient of the per-ray colour term is required");
-  PS_REQUIRE(a.S > 0 && a.S % 16 == 0 && N % a.S == 0 && N < (int64_t(1) << 31),
-             "ps_main_field_f_bwd: samples per ray a multiple of 16, whole rays, at most 2^31 - 1 points");
+  a.dw_sem = dweights_sem; a.gpart = gpart; a.acts = const_cast<float*>(acts); a.K = 1;
+  PS_REQUIRE(((stages & 1) == 0 || dweights_sem != nullptr) && ((stages & 2) == 0 || dray_part != nullptr) &&
+                 ((stages & 2) == 0 || dsigma != nullptr),
+             "ps_main_field_f_bwd: an output / input of a requested stage is missing");
+  PS_REQUIRE(a.S > 0 && a.S % (16 * kMainFwdPB) == 0 && N % a.S == 0 && N < (int64_t(1) << 31) && LF % 4 == 0,
+             "ps_main_field_f_bwd: samples per ray a multiple of 32, whole rays, at most 2^31 - 1 points, L*F a multiple of 4");
   return main_bwd_impl(a, hidden, hidden_color, stages, (hipStream_t)stream, true);
 }

@@ -29,6 +29,13 @@ __device__ __forceinline__ bool normalize_contract(float px, float py, float pz,
   return sel;
 }
 
+// torch.nan_to_num of a float (nan -> 0, +-inf -> +-FLT_MAX)
+__device__ __forceinline__ float nan_to_num(float v) {
+  if (isnan(v)) return 0.0f;
+  if (isinf(v)) return v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  return v;
+}
+
 // real spherical harmonics, 4 levels (16 components), ns/utils/math.py:53-79
 __device__ __forceinline__ void sh4(float x, float y, float z, float (&o)[16]) {
   const float xx = x * x, yy = y * y, zz = z * z;

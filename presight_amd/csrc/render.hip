@@ -9,8 +9,10 @@
 //   weights   cameras/rays.py:128-150
 //   pdf       model_components/ray_samplers.py:305-372
 //   renderers model_components/renderers.py:70-117,286-383 ; nerfacto_nusc_ms.py:503-533
+#include <algorithm>
 #include <type_traits>
 #include "common.hpp"
+#include "pointwise_core.hpp"
 
 namespace {
 
@@ -21,11 +23,7 @@ __device__ __forceinline__ float spacing_inv(float x, float thr) { return x < 0.
 __device__ __forceinline__ float s_to_euclid(float s, float s_near, float s_far, float thr) {
   return spacing_inv(s * s_far + (1.0f - s) * s_near, thr);
 }
-__device__ __forceinline__ float nan_to_num(float v) {
-  if (isnan(v)) return 0.0f;
-  if (isinf(v)) return v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
-  return v;
-}
+using ps::nan_to_num;
 
 // ------------------------------------------------------------------------------------------ rays
 __global__ void generate_rays_kernel(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w,
@@ -235,14 +233,10 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------ composite
 // One wave per ray.  Lane c accumulates channel c of the C-dim features (C <= 64); lanes 0..2 also
 // the rgb channels; sample-indexed scalars (acc, depths) are done with CH samples per lane + shuffles.
-__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ weights, const float* __restrict__ ebins,
-                                                            const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
-                                                            int64_t R, int S, int C, float threshold, float* __restrict__ rgb,
-                                                            float* __restrict__ acc, float* __restrict__ depth,
-                                                            float* __restrict__ exp_depth, float* __restrict__ sem,
-                                                            float* __restrict__ minmax) {
-  const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= R) return;
+__device__ __forceinline__ void composite_ray(const float* __restrict__ weights, const float* __restrict__ ebins,
+                                              const float* __restrict__ rgb_s, const float* __restrict__ sem_s, int64_t ray, int S, int C,
+                                              float threshold, float* __restrict__ rgb, float* __restrict__ acc,
+                                              float* __restrict__ depth, float* __restrict__ exp_depth, float* __restrict__ sem) {
   const int lane = ps_lane();
   const float* w = weights + ray * S;
   const float* e = ebins + ray * (S + 1);
@@ -335,7 +329,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
   }
   // sample-parallel part
   const int CH = (S + 63) / 64;
-  float wl[kMaxCh], st[kMaxCh], local = 0.f, wt = 0.f, smin = 3.4e38f, smax = -3.4e38f;
+  float wl[kMaxCh], st[kMaxCh], local = 0.f, wt = 0.f;
 #pragma unroll
   for (int c = 0; c < kMaxCh; ++c) {
     const int s = lane * CH + c;
@@ -344,10 +338,6 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     st[c] = ok ? (e[s] + e[s + 1]) / 2.0f : 0.0f;
     local += wl[c];
     wt += wl[c] * st[c];
-    if (ok) {
-      smin = fminf(smin, st[c]);
-      smax = fmaxf(smax, st[c]);
-    }
   }
   const float incl = ps_wave_incl_scan(local);
   const float total = __shfl(incl, 63, 64);
@@ -364,24 +354,57 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) first = min(first, __shfl_xor(first, m, 64));
   const int idx = min(first, S - 1);
+  if (lane == 0) {
+    if (acc) acc[ray] = total;
+    if (depth) depth[ray] = (e[idx] + e[idx + 1]) / 2.0f;
+    if (exp_depth) exp_depth[ray] = wtsum / (total + 1e-10f);
+  }
+}
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ weights, const float* __restrict__ ebins,
+                                                            const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
+                                                            int64_t R, int S, int C, float threshold, float* __restrict__ rgb,
+                                                            float* __restrict__ acc, float* __restrict__ depth,
+                                                            float* __restrict__ exp_depth, float* __restrict__ sem) {
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray < R) composite_ray(weights, ebins, rgb_s, sem_s, ray, S, C, threshold, rgb, acc, depth, exp_depth, sem);
+}
+
+// Extrema of the sample mid-points (e[s] + e[s+1]) / 2 over the whole batch = the clip range of the expected depth
+// (ns/model_components/renderers.py:374-389: clip to [steps.min(), steps.max()]).  They depend on the bin edges only, so they are
+// a flat reduction over ebins [R, S + 1] by a FIXED number of workgroups, one atomic pair each: same-address global atomics
+// serialise at ~12 ns apiece, and when the compositing kernel published one pair per ray (or, later, per workgroup of a
+// grid-stride version) 65536 rays cost between 0.05 and 1.5 ms depending on how short the kernel was.
+__global__ __launch_bounds__(256) void midpoint_minmax_kernel(const float* __restrict__ ebins, int64_t R, int S, float* __restrict__ minmax) {
+  __shared__ float s_min[4], s_max[4];
+  float smin = 3.4e38f, smax = -3.4e38f;
+  const int64_t n = R * (S + 1);
+  const uint32_t row = (uint32_t)(S + 1);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const bool edge = n < (int64_t(1) << 32) ? ((uint32_t)i % row) == (uint32_t)S : (i % (S + 1)) == S;  // the last edge of a ray starts no sample
+    if (!edge) {
+      const float m = (ebins[i] + ebins[i + 1]) / 2.0f;
+      smin = fminf(smin, m);
+      smax = fmaxf(smax, m);
+    }
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     smin = fminf(smin, __shfl_xor(smin, m, 64));
     smax = fmaxf(smax, __shfl_xor(smax, m, 64));
   }
-  if (lane == 0) {
-    if (acc) acc[ray] = total;
-    if (depth) depth[ray] = (e[idx] + e[idx + 1]) / 2.0f;
-    if (exp_depth) exp_depth[ray] = wtsum / (total + 1e-10f);
-    if (minmax) {
-      // steps are positive: the int ordering of the bit patterns equals the float ordering.  Same-address global
-      // atomics serialise at ~12 ns each (65536 rays -> 1.5 ms, measured), so first look at the current extremum with
-      // a plain load (may be stale: it only ever moves in the safe direction) and skip the atomic unless this ray can
-      // still improve it; after the first few workgroups almost none do.
-      int* mm = reinterpret_cast<int*>(minmax);
-      if (__float_as_int(smin) < __builtin_nontemporal_load(mm)) atomicMin(mm, __float_as_int(smin));
-      if (__float_as_int(smax) > __builtin_nontemporal_load(mm + 1)) atomicMax(mm + 1, __float_as_int(smax));
-    }
+  if (ps_lane() == 0) {
+    s_min[threadIdx.x >> 6] = smin;
+    s_max[threadIdx.x >> 6] = smax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    smin = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    smax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    // steps are positive: the int ordering of the bit patterns equals the float ordering
+    int* mm = reinterpret_cast<int*>(minmax);
+    if (smin < 3.0e38f) atomicMin(mm, __float_as_int(smin));
+    if (smax > 0.0f) atomicMax(mm + 1, __float_as_int(smax));
   }
 }
 
@@ -594,9 +617,12 @@ extern "C" int ps_composite_fwd(const float* weights, const float* ebins, const 
                                 float* sem, float* minmax, void* stream) {
   PS_REQUIRE(S <= kMaxCh * 64 && C <= 64, "ps_composite_fwd: S must be <= 256 and C <= 64");
   if (R == 0) return 0;
-  composite_fwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, R, S, C,
-                                                                                threshold, rgb, acc, depth, exp_depth, sem,
-                                                                                minmax);
+  if (minmax != nullptr) {
+    const unsigned grid = (unsigned)std::min<int64_t>((R * (S + 1) + 1023) / 1024, 256);
+    midpoint_minmax_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(ebins, R, S, minmax);
+  }
+  composite_fwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, R, S, C, threshold, rgb,
+                                                                                acc, depth, exp_depth, sem);
   PS_CHECK_LAUNCH();
 }
 

@@ -7,6 +7,7 @@ ps_grid_scatter).  One call evaluates a whole PreSight field for a batch of poin
 Positions carry no gradient (the reference detaches the sampled bins, ray_samplers.py:360)."""
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from dataclasses import dataclass
@@ -466,7 +467,8 @@ class _MainFieldRender(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ factored semantic path
 # The training render node of ONE sub-field with two algebraic rewrites of the semantic branch (csrc/field.hip MainCfg FACT,
 # csrc/factored.hip): base layer 1 rows 16..79 merged with semantic layer 0, semantic output layer applied per ray after
-# compositing, and the direction / appearance columns of the colour head's first layer evaluated once per ray.
+# compositing, the direction / appearance columns of the colour head's first layer evaluated once per ray, and the rendering
+# weights + the compositing of the semantic branch done inside the field kernel (no per-sample [N, 64] array exists).
 # PRESIGHT_FACTORED=0 selects the unfactored node (same results to fp32 re-association).
 FACTORED = os.environ.get("PRESIGHT_FACTORED", "1") != "0"
 
@@ -499,12 +501,12 @@ def _main_spec_f(LF, hidden, hidden_color, app_dim) -> MainSpecF:
     return _MAIN_SPECS_F[key]
 
 
-def factored_supported(base, sem, rgb, S: int = 16) -> bool:
+def factored_supported(base, sem, rgb, S: int = 32) -> bool:
     """2-layer base MLP ending in 1 + 15 + 64 outputs, 3-layer 64-wide semantic head (the PreSight layout), and a sample count per
-    ray that is a multiple of the kernels' 16-point block (a block then belongs to ONE ray)"""
+    ray that is a multiple of the kernels' 32-point tile (a ray is then a whole number of tiles of one wavefront)"""
     return (FACTORED and len(base) == 2 and len(sem) == 3 and len(rgb) == 3 and base[1][0].shape[0] == BASE_OUT
             and sem[0][0].shape == (64, SEM_DIM) and sem[2][0].shape == (SEM_DIM, 64) and base[0][0].shape[0] % 16 == 0
-            and S > 0 and S % 16 == 0)
+            and S > 0 and S % 32 == 0)
 
 
 class _MainFieldRenderF(torch.autograd.Function):
@@ -536,7 +538,9 @@ class _MainFieldRenderF(torch.autograd.Function):
         descs += spec.sem.pack_descs([(Wm, bm), (Ws1, bs1)], packed[spec.p_off[1]: spec.p_off[1] + spec.sem.packed])
         descs += spec.rgb.pack_descs([r0, r1, r2], packed[spec.p_off[2]:])
         pack_layers(descs)
-        sigma, rgb_s, hid_s = torch.empty(N, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, SEM_DIM, device=dev)
+        sigma, rgb_s = torch.empty(N, device=dev), torch.empty(N, 3, device=dev)
+        w, hid = torch.empty(R, S, device=dev), torch.empty(R, SEM_DIM, device=dev)
+        ebins = _f32(ebins)
         acts = torch.empty((N + 15) // 16 * 16, spec.act_width, device=dev)
         dirs = _f32(dirs)
         app_c = _f32(app) if app is not None else None
@@ -545,23 +549,20 @@ class _MainFieldRenderF(torch.autograd.Function):
         check(lib().ps_ray_colour_fwd(_p(dirs), _p(app_c), _p(Wr0), R, A, hidden_color, _p(ray_colour), _stream()), "ps_ray_colour_fwd")
         with prof.region("main_field_fwd"):
             check(lib().ps_main_field_f_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color, _p(sel),
-                                            _p(ray_colour), S, _p(packed), N, _p(sigma), _p(rgb_s), _p(hid_s), _p(acts), _stream()),
-                  "ps_main_field_f_fwd")
-        ebins = _f32(ebins)
-        w = torch.empty(R, S, device=dev)
-        check(lib().ps_weights_fwd(_p(ebins), _p(sigma), R, S, _p(w), _stream()), "ps_weights_fwd")
-        rgb, hid = torch.empty(R, 3, device=dev), torch.empty(R, SEM_DIM, device=dev)
+                                            _p(ray_colour), _p(ebins), S, _p(packed), N, _p(sigma), _p(rgb_s), _p(w), _p(hid), _p(acts),
+                                            _stream()), "ps_main_field_f_fwd")
+        rgb = torch.empty(R, 3, device=dev)
         acc, depth, expd = torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev)
         minmax = ops._minmax_init(dev).clone()
-        check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), _p(hid_s), R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth), _p(expd),
-                                     _p(hid), _p(minmax), _stream()), "ps_composite_fwd")
+        check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), None, R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth), _p(expd),
+                                     None, _p(minmax), _stream()), "ps_composite_fwd")
         sem = torch.empty(R, SEM_DIM, device=dev)
         Ws2, bs2 = _f32(Ws2), _f32(bs2)
         check(lib().ps_sem_out_fwd(_p(hid), _p(acc), _p(Ws2), _p(bs2), R, SEM_DIM, _p(sem), _stream()), "ps_sem_out_fwd")
         ops._apply_minmax_hook(minmax)
         raw = expd.clone()
         check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
-        ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, hid_s, raw, expd, hid, acc, Wm, bm)
+        ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, raw, expd, hid, acc, Wm, bm)
         ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), spec)
         ctx.params = wb
         ctx.table_sink = grad_sink(table)
@@ -572,7 +573,7 @@ class _MainFieldRenderF(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_rgb, d_acc, _d_depth, d_exp, d_sem, d_w_ext):
-        (u, sel, dirs, app, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, hid_s, raw, expd, hid, acc, Wm, bm) = ctx.saved_tensors
+        (u, sel, dirs, app, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, raw, expd, hid, acc, Wm, bm) = ctx.saved_tensors
         g, hidden, hidden_color, A, S, tshape, spec = ctx.meta
         wb = ctx.params
         (Wb0, bb0), (Wb1, bb1), (Ws0, bs0), (Ws1, bs1), (Ws2, bs2), r0, r1, r2 = _layers(wb)
@@ -598,13 +599,6 @@ class _MainFieldRenderF(torch.autograd.Function):
         d_acc = cray if d_acc is None else _f32(d_acc) + cray
         if d_exp is not None:
             d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
-        dw = torch.empty_like(w)
-        check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s), _p(hid_s), _p(d_rgb), _p(d_acc), _p(v), _p(d_exp), R, S, SEM_DIM, _p(dw), None,
-                                     None, _stream()), "ps_composite_bwd")
-        if d_w_ext is not None:
-            dw.add_(_f32(d_w_ext))  # losses that act on the weights directly (distortion, line of sight)
-        dsig = torch.empty_like(sigma)
-        check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
         pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
         check(lib().ps_main_field_f_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart), None,
                                           None, None), "ps_main_field_f_sizes")
@@ -613,11 +607,33 @@ class _MainFieldRenderF(torch.autograd.Function):
         dapp = torch.empty_like(app) if app is not None else None
         dzb = torch.empty((N + 15) // 16 * 16, spec.dzb_width, device=dev)
         dray = torch.empty(N // 16, hidden_color, device=dev)
+        dw_sem = torch.empty(R, S, device=dev)
+
+        def field_bwd(stages, dsig):
+            check(lib().ps_main_field_f_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                            _p(sel), S, _p(packed), _p(dsig), _p(d_rgb), _p(v), _p(w), N, _p(dfeat), _p(dray), _p(dw_sem),
+                                            _p(gpart), _p(acts), _p(dzb), stages, _stream()), "ps_main_field_f_bwd")
+
+        # semantic kernel first: it needs the weights only and yields the semantic branch's part of d(weights)
+        timed = prof.enabled("main_bwd_sem_kernel")
         with prof.region("main_field_bwd"):
-            for stages in _bwd_stages(dzb):
-                check(lib().ps_main_field_f_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                                _p(sel), S, _p(packed), _p(dsig), _p(d_rgb), _p(v), _p(w), N, _p(dfeat), _p(dray), _p(gpart),
-                                                _p(acts), _p(dzb), stages, _stream()), "ps_main_field_f_bwd")
+            with prof.region("main_bwd_sem_kernel") if timed else contextlib.nullcontext():
+                field_bwd(1, None)
+        dw = torch.empty_like(w)
+        check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s), None, _p(d_rgb), _p(d_acc), None, _p(d_exp), R, S, SEM_DIM, _p(dw), None,
+                                     None, _stream()), "ps_composite_bwd")
+        dw.add_(dw_sem)
+        if d_w_ext is not None:
+            dw.add_(_f32(d_w_ext))  # losses that act on the weights directly (distortion, line of sight)
+        dsig = torch.empty_like(sigma)
+        check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
+        with prof.region("main_field_bwd", extend=True):
+            if timed:
+                for mask, name in ((2, "main_bwd_rgb_kernel"), (4, "main_bwd_base_kernel")):
+                    with prof.region(name):
+                        field_bwd(mask, dsig)
+            else:
+                field_bwd(6, dsig)
         # direction / appearance columns of the colour head's first layer and d(appearance), per ray
         check(lib().ps_ray_colour_bwd(_p(dray), _p(dirs), _p(app), _p(_f32(r0[0])), R, S, A, hidden_color, _p(dWr0), _p(dapp), _stream()),
               "ps_ray_colour_bwd")

@@ -27,7 +27,9 @@ def enabled(name: str = None) -> bool:
 
 
 @contextmanager
-def region(name: str):
+def region(name: str, extend: bool = False):
+    """extend: this interval belongs to the region's previous entry (one logical launch whose kernels are enqueued in two pieces
+    with other work in between); its time is added to that entry"""
     if not enabled(name):
         yield
         return
@@ -35,10 +37,13 @@ def region(name: str):
     a.record()
     yield
     b.record()
-    _events[name].append((a, b))
+    if extend and _events[name]:
+        _events[name][-1].append((a, b))
+    else:
+        _events[name].append([(a, b)])
 
 
 def summary():
     """name -> (launches, mean ms); synchronises."""
     torch.cuda.synchronize()
-    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in _events.items()}
+    return {k: (len(v), sum(a.elapsed_time(b) for e in v for a, b in e) / max(len(v), 1)) for k, v in _events.items()}

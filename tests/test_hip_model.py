@@ -276,7 +276,7 @@ def test_fused_render_node_matches_separate_nodes(samples):
     jit = [torch.rand(R, 1, generator=g).to(dev) for _ in range(3)]
     from presight_amd import field_ops
 
-    results = {}
+    results, aux = {}, {}
     for fused in (False, True, "factored"):
         model.fused_render = bool(fused)
         field_ops.FACTORED = fused == "factored"
@@ -288,6 +288,7 @@ def test_fused_render_node_matches_separate_nodes(samples):
         out = model(rb, jitters=jit)
         ld = model.get_loss_dict(out, batch)
         (sum(ld.values()) + out["expected_depth"].mean() * 0.1).backward()
+        aux[fused] = (out["weights_list"][-1][..., 0].detach().clone(), out["ray_samples_list"][-1].ebins.detach().clone())
         results[fused] = ({k: out[k].detach().clone() for k in ("rgb", "accumulation", "depth", "expected_depth", "semantics")},
                           {k: v.detach().clone() for k, v in ld.items()},
                           {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
@@ -303,15 +304,30 @@ def test_fused_render_node_matches_separate_nodes(samples):
         torch.testing.assert_close(gb[k] / s, ga[k] / s, rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
     assert float(ga["field.fields.0.mlp_base_grid.hash_table"].abs().max()) > 0
     # The FACTORED node (the training default: base layer 1 rows 16..79 merged with semantic layer 0, semantic output layer applied per
-    # ray after compositing, direction / appearance columns of the colour head's first layer evaluated per ray) computes the same
-    # function with re-associated fp32 sums: density and depths come from the same arithmetic bit for bit, colour (a sigmoid output
-    # in [0, 1]: a few ulp of 1) and semantics agree to fp32 rounding, every gradient to the summation-order tolerance above
-    for k in ("accumulation", "depth", "expected_depth"):
-        torch.testing.assert_close(oc[k], oa[k], rtol=0, atol=0, msg=lambda m: f"factored {k}: {m}")
-    torch.testing.assert_close(oc["rgb"], oa["rgb"], rtol=0, atol=4 * 2.0 ** -24, msg=lambda m: f"factored rgb: {m}")
+    # ray after compositing, direction / appearance columns of the colour head's first layer evaluated per ray, rendering weights and
+    # the semantic branch's compositing inside the field kernel) computes the same function with re-associated fp32 sums: every
+    # output agrees to fp32 rounding (the weights' optical-depth prefix sums run in another order: a few ulp of the weights), the
+    # threshold depth -- index work -- is the same sample except where the cumulative weight sits within rounding of the threshold
+    from conftest import assert_threshold_depth
+
+    assert_threshold_depth(oc["depth"], oa["depth"], *aux[False], what="factored depth")
+    torch.testing.assert_close(aux["factored"][0], aux[False][0], rtol=2e-6, atol=1e-7)  # the rendering weights themselves
+    for k in ("accumulation", "expected_depth"):
+        torch.testing.assert_close(oc[k], oa[k], rtol=2e-6, atol=2e-6, msg=lambda m: f"factored {k}: {m}")
+    torch.testing.assert_close(oc["rgb"], oa["rgb"], rtol=0, atol=8 * 2.0 ** -24, msg=lambda m: f"factored rgb: {m}")
     torch.testing.assert_close(oc["semantics"], oa["semantics"], rtol=2e-5, atol=2e-6)
     for k in la:
         torch.testing.assert_close(lc[k], la[k], rtol=2e-5, atol=1e-9, msg=lambda m: f"factored {k}: {m}")
+    # (the rays of this scene saturate: 1 - accumulation is 0 or one ulp, so the sky branch's gradients are that ulp times the
+    # output gradients -- 1e-8 of the other gradients and decided by the last bit of the accumulation; they are compared wherever
+    # the accumulations agree bit for bit, i.e. between the unfactored nodes above)
+    g_max = max(float(v.abs().max()) for v in ga.values())
+    bad = {}
     for k in ga:
         s = float(ga[k].abs().max()) + 1e-30
-        torch.testing.assert_close(gc[k] / s, ga[k] / s, rtol=1e-4, atol=2e-5, msg=lambda m: f"factored {k}: {m}")
+        if k.startswith("sky_model.") and s < 1e-6 * g_max:
+            continue
+        err = float(((gc[k] - ga[k]).abs() / s - 1e-4 * ga[k].abs() / s).max())
+        if not err <= 2e-5:
+            bad[k] = f"{err:.2e}"
+    assert not bad, f"factored gradients: {bad}"
