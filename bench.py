@@ -390,7 +390,7 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=()):
     mac_prop = 8 * 64 + 64
     rows = []
 
-    def add(name, region, bound, work, unit):
+    def add(name, region, bound, work, unit, executed=None):
         if region not in kern:
             return
         n, ms = kern[region]
@@ -398,18 +398,31 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=()):
             return
         peak = FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS
         ach = work / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
-        rows.append(dict(kernel=name, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_launch_ms=ms, launches=n,
-                         algorithmic=work, timed_region=region in live))
+        row = dict(kernel=name, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_launch_ms=ms, launches=n,
+                   algorithmic=work, timed_region=region in live)
+        if executed is not None:  # what the matrix cores actually execute (factored path: fewer MACs than the algorithm states)
+            row["executed"] = executed
+            row["frac_executed"] = executed / (ms * 1e-3) / 1e12 / peak
+        rows.append(row)
 
     mac_base, mac_sem, mac_rgb = (L * F) * 64 + 64 * 80, 3 * 64 * 64, 47 * 64 + 64 * 64 + 64 * 3
-    add("main_fwd_kernel", "main_field_fwd", "mfma", 2 * mac_main * n_main, "TFLOP/s")
+    # The factored render node (presight_amd/field_ops.py _MainFieldRenderF) runs the SAME function with fewer
+    # matrix operations per sample: base layer 1 ends in 16 outputs, the semantic stack is two 64x64 layers (first one merged,
+    # output layer per ray), the colour head's first layer sees the 16 base outputs only (direction / appearance term per ray).
+    # `executed` counts the MACs the MFMA units perform, padding included (outputs padded to 16 rows).
+    from presight_amd import field_ops
+    fact = field_ops.FACTORED and "dynamic" not in cfg and cfg["K"] == 1
+    ex_base, ex_sem, ex_rgb = (L * F) * 64 + 64 * 16, 2 * 64 * 64, 16 * 64 + 64 * 64 + 64 * 16
+    ex = (lambda macs, k: 2 * k * macs * n_main) if fact else (lambda macs, k: None)
+    add("main_fwd_kernel", "main_field_fwd", "mfma", 2 * mac_main * n_main, "TFLOP/s", ex(ex_base + ex_sem + ex_rgb, 1))
     if n_params:  # dense Adam: p, m, v read + written, g read = 28 bytes per parameter
         add("adam_ranges_kernel", "adam", "hbm", 28.0 * n_params, "GB/s")
     # the main backward is three kernels (semantic head, colour head, base MLP), timed one by one
-    add("main_bwd_sem_kernel", "main_bwd_sem_kernel", "mfma", 2 * 2 * mac_sem * n_main, "TFLOP/s")
-    add("main_bwd_rgb_kernel", "main_bwd_rgb_kernel", "mfma", 2 * 2 * mac_rgb * n_main, "TFLOP/s")
-    add("main_bwd_base_kernel", "main_bwd_base_kernel", "mfma", 2 * 2 * mac_base * n_main, "TFLOP/s")
-    add("main backward (the three kernels above, summed)", "main_field_bwd", "mfma", 2 * 2 * mac_main * n_main, "TFLOP/s")
+    add("main_bwd_sem_kernel", "main_bwd_sem_kernel", "mfma", 2 * 2 * mac_sem * n_main, "TFLOP/s", ex(ex_sem, 2))
+    add("main_bwd_rgb_kernel", "main_bwd_rgb_kernel", "mfma", 2 * 2 * mac_rgb * n_main, "TFLOP/s", ex(ex_rgb, 2))
+    add("main_bwd_base_kernel", "main_bwd_base_kernel", "mfma", 2 * 2 * mac_base * n_main, "TFLOP/s", ex(ex_base, 2))
+    add("main backward (the three kernels above, summed)", "main_field_bwd", "mfma", 2 * 2 * mac_main * n_main, "TFLOP/s",
+        ex(ex_base + ex_sem + ex_rgb, 2))
     add("prop_bwd_kernel (both fields)", "prop_field_bwd", "mfma", 2 * 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s")
     add("prop_fwd_kernel (both fields)", "prop_field_fwd", "mfma", 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s")
     add(f"grid_encode main (L{L} F{F})", f"grid_encode_L{L}F{F}", "hbm", n_main * L * 8 * F * 4, "GB/s")
@@ -792,7 +805,10 @@ def main():
             "roofline": None if dom is None else {
                 "bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
                 "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC)",
-                "traffic_source": traffic_src, "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"]},
+                "traffic_source": traffic_src, "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
+                # `achieved` prices the ALGORITHMIC flops of the unfactored network; the factored kernels execute
+                # fewer: frac_executed = matrix-core flops actually issued / duration / peak
+                "algorithmic_flops": dom["algorithmic"], "executed_flops": dom.get("executed"), "frac_executed": dom.get("frac_executed")},
             "roofline_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows],
             "end_to_end": {"flop_per_ray": flop_ray, "hash_bytes_per_ray": byte_ray, "ceiling_mfma_rays_per_s": ceil_mfma,
                            "ceiling_hbm_rays_per_s": ceil_hbm, "binding": "mfma" if ceil_mfma < ceil_hbm else "hbm",

@@ -81,6 +81,9 @@ __device__ __forceinline__ void publish_absmax(const float (&mx)[KS0], int LF, i
 template <int NBLK, int PB>
 __device__ __forceinline__ void store_act(float* __restrict__ acts, int stride, int col0, int64_t first, int64_t N,
                                           const float (&v)[PB][NBLK * 4]) {
+#if defined(PS_ABL_NOACT)
+  if (col0 != PS_ABL_NOACT) return;
+#endif
   const int lane = ps_lane();
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
