@@ -166,6 +166,80 @@ def test_main_field_vs_oracle_ray_batch(F, dev, which, backward, monkeypatch):
     close(sem2, sem_o)
 
 
+@pytest.mark.parametrize("which", ["cfg2", "prod"])
+def test_factored_render_node_vs_oracle(F, dev, which):
+    """The training render node of one sub-field (field + get_weights + renderers, field_ops.main_field_render) on its FACTORED path
+    (merged linear layers, per-ray semantic output layer and colour term, weights and the semantic branch's
+    compositing inside the field kernel) directly against the oracle's unfactored arithmetic: every rendered output and the gradient
+    of every parameter, of the appearance codes and of externally supplied d(weights)."""
+    torch.manual_seed(78)
+    cfg = O.default_config()
+    if which == "prod":
+        cfg["main"].update(num_levels=10, features_per_level=4, log2_hashmap_size=14, max_res=16384)
+    else:
+        cfg["main"]["log2_hashmap_size"] = 15
+    cfg["num_cameras"] = 60
+    P = O.make_params(cfg, seed=10, table_scale=0.2)
+    P["field.fields.0.mlp_base_mlp.layers.1.bias"][0] = -1.0  # unsaturated rays: every output carries gradient
+    scene = O.make_scene(cfg)
+    m = cfg["main"]
+    R, S = 70, 64
+    batch = O.make_batch(cfg, scene, R, step=2)
+    o, d, _, _ = O.generate_rays(batch["ray_indices"], scene["c2w"], scene["fx"], scene["fy"], scene["cx"], scene["cy"])
+    bins = O.spaced_bins(R, S, batch["jitter"][0])
+    eb = O.s_to_euclid(bins, torch.full((R, 1), 0.005), torch.full((R, 1), 50.0), 5.0)
+    mid = (eb[:, :-1] + eb[:, 1:]) / 2
+    pos = (o[:, None] + d[:, None] * mid[..., None]).reshape(-1, 3)
+    app = torch.randn(R, 16)
+    cots = dict(rgb=torch.rand(R, 3) - 0.5, acc=torch.rand(R, 1) - 0.5, exp=torch.rand(R, 1) - 0.5, sem=torch.rand(R, 64) - 0.5,
+                w=(torch.rand(R, S) - 0.5) * 0.1)
+
+    def scalar(rgb, acc, expd, sem, w):
+        return ((rgb * cots["rgb"].to(rgb.device)).sum() + (acc * cots["acc"].to(rgb.device)).sum() + (expd * cots["exp"].to(rgb.device)).sum()
+                + (sem * cots["sem"].to(rgb.device)).sum() + (w * cots["w"].to(rgb.device)).sum())
+
+    # oracle (per-sample heads, then get_weights and the renderers)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    appo = app.clone().requires_grad_(True)
+    app_s = appo[:, None, :].expand(R, S, 16).reshape(R * S, 16)
+    dir_s = d[:, None, :].expand(R, S, 3).reshape(-1, 3)
+    dens, emb = O.main_density(Pg, cfg, 0, pos, scene["aabbs"][0])
+    rgb_s, sem_s = O.main_heads(Pg, cfg, 0, dir_s, emb, app_s)
+    w_o = O.weights_from_density(eb[:, 1:] - eb[:, :-1], dens.reshape(R, S))
+    rgb_o = (w_o[..., None] * rgb_s.reshape(R, S, 3)).sum(1)
+    sem_o = (w_o[..., None] * sem_s.reshape(R, S, 64)).sum(1)
+    acc_o = w_o.sum(-1, keepdim=True)
+    exp_o = O.expected_depth(w_o, mid)
+    dep_o = O.threshold_depth(w_o, mid)
+    scalar(rgb_o, acc_o, exp_o, sem_o, w_o).backward()
+    # HIP, factored node
+    assert F.FACTORED
+    g = F.GridCfg(m["num_levels"], m["features_per_level"], m["log2_hashmap_size"])
+    sc = O.hash_scalings(m["num_levels"], m["base_res"], m["max_res"]).to(dev)
+    pre = "field.fields.0"
+    table = P[f"{pre}.mlp_base_grid.hash_table"].to(dev).requires_grad_(True)
+    base, sem, rgb = _layers(P, f"{pre}.mlp_base_mlp", dev), _layers(P, f"{pre}.semantic_head", dev), _layers(P, f"{pre}.rgb_head", dev)
+    assert F.factored_supported(base, sem, rgb, S)
+    appd = app.to(dev).requires_grad_(True)
+    u, sel = F.field_points(scene["aabbs"][0].to(dev), True, origins=o.to(dev), dirs=d.to(dev), ebins=eb.to(dev))
+    rgb_h, acc_h, dep_h, exp_h, sem_h, w_h = F.main_field_render(u, sel, d.to(dev), appd, eb.to(dev), table, sc, g, base, sem, rgb)
+    close(w_h, w_o, rtol=2e-4, atol=1e-7)
+    close(rgb_h, rgb_o)
+    close(acc_h, acc_o)
+    close(exp_h, exp_o)
+    close(sem_h, sem_o)
+    from conftest import assert_threshold_depth
+    assert_threshold_depth(dep_h, dep_o, w_o.detach(), eb, what="factored threshold depth")
+    params = [table] + [p for wb in base + sem + rgb for p in wb] + [appd]
+    names = [f"{pre}.mlp_base_grid.hash_table"] + [f"{pre}.mlp_base_mlp.layers.{i}.{k}" for i in range(2) for k in ("weight", "bias")] + \
+        [f"{pre}.semantic_head.layers.{i}.{k}" for i in range(3) for k in ("weight", "bias")] + \
+        [f"{pre}.rgb_head.layers.{i}.{k}" for i in range(3) for k in ("weight", "bias")]
+    grads = torch.autograd.grad(scalar(rgb_h, acc_h, exp_h, sem_h, w_h), params)
+    for n, gr in zip(names, grads[:-1]):
+        close_scaled(gr, Pg[n].grad, rtol=5e-4, atol=5e-5)
+    close_scaled(grads[-1], appo.grad, rtol=5e-4, atol=5e-5)
+
+
 def test_prop_field_vs_oracle_full_size_table(F, dev):
     cfg = O.default_config()
     P = {}
