@@ -194,7 +194,7 @@ class FlatGrads:
         for p in self.params:
             p._ps_touched = False
         for b in self._buckets:
-            b["seen"], b["launched"], b["work"] = 0, False, None
+            b["seen"], b["launched"], b["work"], b["ready"] = 0, False, None, None
         self._next_launch = 0
 
     def touched(self, group: Optional[dist.ProcessGroup] = None) -> List[bool]:
@@ -272,6 +272,11 @@ class FlatGrads:
         if not p._ps_touched:
             b["seen"] += 1
             if b["seen"] == b["n"]:
+                if self._comm_stream is not None:
+                    # the bucket's gradients are complete on the stream that is current NOW (the proposal networks' backward runs
+                    # on a side stream, samplers.prop_stream); the launch may happen later, from another stream's context
+                    b["ready"] = torch.cuda.Event()
+                    b["ready"].record()
                 self._launch_ready()
 
     def _launch_ready(self):
@@ -309,15 +314,26 @@ class FlatGrads:
 
         if self._comm_stream is not None:
             ev = torch.cuda.Event()
-            ev.record()  # everything enqueued so far on the compute stream = the complete gradients of this bucket
+            ev.record()  # everything enqueued so far on the current stream (incomplete buckets go out after backward, from the compute stream)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
+                if b.get("ready") is not None:
+                    self._comm_stream.wait_event(b["ready"])  # ... and on the stream that completed the bucket
                 issue()
         else:
             issue()
 
+    def _join_side_streams(self):
+        """gradients written in place by nodes that ran on the proposal networks' side stream (presight_amd.ops.side_stream) are
+        invisible to the autograd engine's stream bookkeeping: the current stream waits for them here, before the buffer is read"""
+        if self.flat.is_cuda:
+            from .ops import join_side_streams
+
+            join_side_streams()
+
     def finish_exchange(self):
         """after backward: launch the buckets that are still local (in order), then make the compute stream wait for all of them"""
+        self._join_side_streams()
         if self.n_groups and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
             COMM_LOG.issue("all_reduce_max_flags", "-", 4 * self.group_flags.numel(), "current", self.step_no)
             dist.all_reduce(self.group_flags, op=dist.ReduceOp.MAX, group=self._group)  # device tensor, stream-ordered: no host sync
@@ -404,6 +420,7 @@ class FlatGrads:
 
     def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
         """Average the flat gradient buffer over the ranks of `group` (no-op without an initialised process group)."""
+        self._join_side_streams()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return None
         world = dist.get_world_size(group)

@@ -76,7 +76,7 @@ KEEP_ACTIVATIONS = __import__("os").environ.get("PRESIGHT_KEEP_ACTIVATIONS", "1"
 def _workspace(nbytes: int, device) -> Tensor:
     """Scratch for the binned scatter, grown on demand and reused across steps (stream-ordered reuse is safe: every
     consumer of the previous contents was enqueued on the same stream before the next producer)."""
-    key = str(device)
+    key = (str(device), _stream())  # per stream: the proposal networks may run beside the main field (samplers.prop_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.05) + 4096, device=device, dtype=torch.uint8)

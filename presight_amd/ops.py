@@ -16,6 +16,33 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- side stream of the proposal networks (samplers.ProposalNetworkSampler.generate_ray_samples) ----------------------------
+# During training the proposal networks run on ONE side stream per device (PRESIGHT_PROP_STREAM=0: on the caller's stream), so
+# that autograd enqueues their backward beside the main field's.  Who has to wait for it:
+#   * gradients that leave a node as tensors reach their AccumulateGrad nodes through the autograd engine, which orders streams
+#     itself (and syncs the caller's stream with every leaf stream at the end of backward);
+#   * gradients written IN PLACE into an owner's sink (grad_sink: presight_amd.dist.FlatGrads) are invisible to the engine: the
+#     owner joins the side streams before it reads the buffer (FlatGrads.finish_exchange / all_reduce_mean, Trainer.step).
+_SIDE_STREAMS: dict = {}
+SIDE_STREAM = __import__("os").environ.get("PRESIGHT_PROP_STREAM", "1") != "0"
+
+
+def side_stream(device):
+    """the side stream of `device` (None: disabled / not a GPU); default priority (a high-priority one measured 0.25 ms slower)"""
+    if not SIDE_STREAM or device is None or device.type != "cuda":
+        return None
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def join_side_streams() -> None:
+    """the current stream of every device with a side stream waits (device side, no host sync) for what is enqueued there"""
+    for key, s in _SIDE_STREAMS.items():
+        torch.cuda.current_stream(s.device).wait_stream(s)
+
+
 def _f32(t: Tensor, name: str = "tensor") -> Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"presight_amd: {name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")

@@ -62,6 +62,7 @@ class HipAdam:
         s = _stream()
         if self.flat is not None:
             fg = self.flat_grads
+            fg._join_side_streams()
             idx = fg.touched_params()
             gid = [getattr(self.params[i], "_ps_group", None) if fg.n_groups else None for i in idx]
             for i, gr in zip(idx, gid):

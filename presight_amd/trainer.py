@@ -111,6 +111,7 @@ class Trainer:
         if self._seed is None:
             self._seed = torch.full((), self.loss_scale, device=loss.device)
         loss.backward(gradient=self._seed)
+        ops.join_side_streams()  # the proposal networks' backward ran on their side stream: the exchange / optimizer wait for it
         with prof.region("exchange_exposed"):
             self.grads.finish_exchange()
         with prof.region("adam"):

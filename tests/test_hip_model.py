@@ -216,6 +216,7 @@ def test_flat_gradients_and_fused_adam_match_autograd_path(gold_model):
     before = {k: p.detach().clone() for k, p in mB.named_parameters()}
     fg.zero_()
     run(mB, batch, bundleB)
+    fg.finish_exchange()  # (single process: only joins the proposal networks' side stream, as every owner of in-place gradients must)
     touched = dict(zip([id(p) for p in uniq], fg.touched()))
     n_untouched = 0
     for k, p in mB.named_parameters():
@@ -331,3 +332,49 @@ def test_fused_render_node_matches_separate_nodes(samples):
         if not err <= 2e-5:
             bad[k] = f"{err:.2e}"
     assert not bad, f"factored gradients: {bad}"
+
+
+def test_proposal_side_stream_changes_nothing_but_the_schedule():
+    """During training the proposal networks run on a side stream (presight_amd.ops.side_stream) so that their backward overlaps
+    the main field's; with plain autograd gradients (AccumulateGrad: the engine orders the streams) and with a flat in-place
+    gradient buffer (the owner joins the side stream) the losses and every gradient are what the single-stream run gives."""
+    import bench
+    from presight_amd import ops
+    from presight_amd.dist import FlatGrads
+    from presight_amd.trainer import Trainer
+
+    dev = torch.device("cuda:0")
+
+    def one(side: bool, flat: bool):
+        ops.SIDE_STREAM = side
+        try:
+            model, scene = bench.build_model(dev, seed=5, config="cfg2")
+            batch = bench.make_batches(scene, dev, 1, 0, rays=2048)[0]
+            torch.manual_seed(3)
+            if flat:
+                tr = Trainer(model, scene, 1, exchange="allreduce")
+                ld, _ = tr.step(batch)
+                torch.cuda.synchronize()
+                return {k: float(v) for k, v in ld.items()}, tr.opt.flat[0].detach().clone()
+            o, d, pa, dn = ops.generate_rays(batch["ray_indices"], scene["c2w"], scene["fx"], scene["fy"], scene["cx"], scene["cy"])
+            from presight_amd.rays import RayBundle
+
+            rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1], metadata={"video_id": batch["video_ids"][:, None], "directions_norm": dn})
+            model.train()
+            model.proposal_sampler._steps_since_update = 1 << 30
+            out = model(rb)
+            ld = model.get_loss_dict(out, batch)
+            sum(ld.values()).backward()
+            g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])  # read on the caller's stream, no sync
+            return {k: float(v) for k, v in ld.items()}, g
+        finally:
+            ops.SIDE_STREAM = True
+
+    for flat in (False, True):
+        (la, ga), (lb, gb) = one(False, flat), one(True, flat)
+        assert la == lb, (la, lb)
+        assert ga.shape == gb.shape
+        s = float(ga.abs().max())
+        # hash-table gradients are bit-reproducible (integer accumulation), MLP / embedding gradients use float atomics
+        torch.testing.assert_close(gb / s, ga / s, rtol=1e-4, atol=1e-6)
+        assert float(ga.abs().max()) > 0
