@@ -273,10 +273,15 @@ class FlatGrads:
             b["seen"] += 1
             if b["seen"] == b["n"]:
                 if self._comm_stream is not None:
-                    # the bucket's gradients are complete on the stream that is current NOW (the proposal networks' backward runs
-                    # on a side stream, samplers.prop_stream); the launch may happen later, from another stream's context
-                    b["ready"] = torch.cuda.Event()
-                    b["ready"].record()
+                    # the bucket's gradients are complete on the streams as they stand NOW (the proposal networks' backward runs
+                    # on side streams, ops.side_stream); the launch may happen later, from another stream's context
+                    from .ops import side_streams
+
+                    b["ready"] = []
+                    for st in [torch.cuda.current_stream(self.flat.device)] + side_streams(self.flat.device):
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        b["ready"].append(ev)
                 self._launch_ready()
 
     def _launch_ready(self):
@@ -317,8 +322,8 @@ class FlatGrads:
             ev.record()  # everything enqueued so far on the current stream (incomplete buckets go out after backward, from the compute stream)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
-                if b.get("ready") is not None:
-                    self._comm_stream.wait_event(b["ready"])  # ... and on the stream that completed the bucket
+                for rev in b.get("ready") or ():
+                    self._comm_stream.wait_event(rev)  # ... and on the streams that produced the bucket's gradients
                 issue()
         else:
             issue()
