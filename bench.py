@@ -476,11 +476,15 @@ def secondary_training_lines(config, shapes, dev):
             trainer.step(batches[i % 2])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        from presight_amd import ops as _ops
+
+        side_was, _ops.SIDE_STREAM = _ops.SIDE_STREAM, False  # per-region times with the chip to themselves
         prof.enable(True)
         for i in range(2):
             trainer.step(batches[i % 2])
         kern = prof.summary()
         prof.enable(False)
+        _ops.SIDE_STREAM = side_was
         # ("main_field_bwd" is the sum of the three stage regions when those are timed)
         per_step = {k: n * ms / 2 for k, (n, ms) in kern.items() if k != "main_field_bwd" or "main_bwd_sem_kernel" not in kern}
         top = sorted(per_step.items(), key=lambda kv: -kv[1])[:3]
@@ -745,10 +749,16 @@ def main():
     dt, (loss_dict, out) = timed(args.steps)
     psnr = float(model.get_metrics_dict(out, last_batch[0])["psnr"].detach())
     kern = prof.summary()
+    # (the per-kernel pass runs WITHOUT the proposal networks' side stream: a kernel's roofline row is its time with the chip to
+    # itself; in the timed steps the proposal backward overlaps the main field's)
+    from presight_amd import ops as _ops
+
+    side_was, _ops.SIDE_STREAM = _ops.SIDE_STREAM, False
     prof.enable(True)
     run(min(args.steps, 8))
     kern = {**prof.summary(), **kern}  # live figures win
     prof.enable(False)
+    _ops.SIDE_STREAM = side_was
     comm = dict(trainer.grads.stats)
     # secondary figure (NOT `value`): the reference's own steady-state proposal-update schedule after warm-up
     # (ray_samplers.py:586 + nerfacto_nusc_ms.py:300-305: gradients reach the proposal nets every 6th step)
@@ -815,6 +825,8 @@ def main():
                            "frac_of_binding": per_gpu / min(ceil_mfma, ceil_hbm), "frac_of_mfma": per_gpu / ceil_mfma,
                            "frac_of_hbm": per_gpu / ceil_hbm},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
+            "kernels_ms_note": "per-kernel pass without the proposal side stream (each kernel alone on the chip); the timed steps overlap "
+                               "the proposal networks' backward with the main field's" if side_was else "single stream",
             "value_reference_schedule": world * rays * n_sched / dt_sched,
             "other_scaling": other,
             "comm": None if world == 1 else {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
