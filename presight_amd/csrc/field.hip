@@ -81,9 +81,6 @@ __device__ __forceinline__ void publish_absmax(const float (&mx)[KS0], int LF, i
 template <int NBLK, int PB>
 __device__ __forceinline__ void store_act(float* __restrict__ acts, int stride, int col0, int64_t first, int64_t N,
                                           const float (&v)[PB][NBLK * 4]) {
-#if defined(PS_ABL_NOACT)
-  if (col0 != PS_ABL_NOACT) return;
-#endif
   const int lane = ps_lane();
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
@@ -1682,8 +1679,7 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;                                                           \
-    static const int max_blocks = getenv("PS_MAIN_FWD_BLOCKS") ? atoi(getenv("PS_MAIN_FWD_BLOCKS")) : 256;                  \
-    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, max_blocks), kMainFwdWaves * 64, 0, s>>>(a); \
+    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
     PS_CHECK_LAUNCH();                                                                                                \
   }
     PS_MAIN_CFGS(X)
