@@ -46,10 +46,14 @@ class Trainer:
                  lr: float = 1e-2, eps: float = 1e-15, weight_decay: float = 1e-5, loss_scale: float = 2.0 ** 10):
         self.model, self.scene, self.world = model, scene, world
         groups = model.get_param_groups()
-        # bucket-major order, in the order backward COMPLETES the groups: "fields" (main field, sky, embeddings) are finished
-        # before the proposal networks' backward starts, so their exchange runs underneath it; a group that receives no
-        # gradient in a step (proposal nets off-schedule) is one contiguous range to skip
-        order = [k for k in ("fields", "proposal_networks") if k in groups] + sorted(k for k in groups if k not in ("fields", "proposal_networks"))
+        # bucket-major order, in the order backward COMPLETES the groups on the GPU (buckets are exchanged strictly in this order).
+        # With the proposal networks on their side stream (ops.side_stream) their chain ends ~0.5 ms before the main
+        # chain writes its last gradient (the main hash table's), so "proposal_networks" goes first and its all-reduce runs under
+        # the main chain's tail; on one stream "fields" (main field, sky, embeddings) are finished before the proposal backward
+        # starts and travel underneath it.  A group that receives no gradient in a step (proposal nets off-schedule) is one
+        # contiguous range to skip.
+        first = ("proposal_networks", "fields") if (ops.SIDE_STREAM and torch.cuda.is_available()) else ("fields", "proposal_networks")
+        order = [k for k in first if k in groups] + sorted(k for k in groups if k not in first)
         seen, uniq, sizes = set(), [], []
         for k in order:
             n0 = len(uniq)

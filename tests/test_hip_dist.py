@@ -180,8 +180,9 @@ def _tiny_model(dev, K=1):
 
 def test_trainer_buckets_on_gpu_single_rank(dev):
     """bench.Trainer with the bucketed exchange armed (no process group: launches are bookkeeping only): both buckets are
-    handed over DURING backward in completion order (fields, then proposal networks), every parameter receives exactly one
-    contribution, and a second in-place contribution after the hand-over raises."""
+    handed over DURING backward, strictly in the trainer's bucket order (the order the GPU completes them: proposal networks on
+    their side stream first, then fields), every parameter receives exactly one contribution, and a second in-place contribution
+    after the hand-over raises."""
     import bench
     from presight_amd.ops import mark_touched
 
@@ -190,14 +191,15 @@ def test_trainer_buckets_on_gpu_single_rank(dev):
     groups = model.get_param_groups()
     uid = {id(p) for p in tr.grads.params}
     order = []
-    tr.grads.enable_overlap([[p for p in groups[k] if id(p) in uid] for k in ("fields", "proposal_networks")])
+    assert tr.group_names == ["proposal_networks", "fields"]
+    tr.grads.enable_overlap([[p for p in groups[k] if id(p) in uid] for k in tr.group_names])
     launch = tr.grads._launch
     tr.grads._launch = lambda b: (order.append(b["index"]), launch(b))[1]
     batches = bench.make_batches(scene, dev, 2, 0, rays=512)
     for i in range(2):
         order.clear()
         tr.step(batches[i])
-        assert order == [0, 1], order  # fields complete first (main field is the last forward op), proposal nets second
+        assert order == [0, 1], order  # bucket order, although the host finishes enqueueing the fields' backward first
     assert all(b["launched"] for b in tr.grads._buckets)
     with pytest.raises(RuntimeError, match="second gradient"):
         mark_touched([tr.grads.params[0]])
@@ -208,8 +210,8 @@ def test_trainer_buckets_on_gpu_single_rank(dev):
     model.proposal_sampler.step_cb(50000)  # past the "first 10 steps always update" rule of ray_samplers.py:586
     model.proposal_sampler._steps_since_update = 0
     tr.step(batches[0])
-    n_fields = tr.grads.bucket_params[0][1]
-    assert all(s == 3 for s in tr.opt.steps[:n_fields]) and all(s == 2 for s in tr.opt.steps[n_fields:])
+    n_prop = tr.grads.bucket_params[0][1]
+    assert all(s == 2 for s in tr.opt.steps[:n_prop]) and all(s == 3 for s in tr.opt.steps[n_prop:])
 
 
 def _run_bench_two_ranks(extra, timeout=300):
