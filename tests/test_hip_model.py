@@ -355,7 +355,10 @@ def test_proposal_side_stream_changes_nothing_but_the_schedule():
                 tr = Trainer(model, scene, 1, exchange="allreduce")
                 ld, _ = tr.step(batch)
                 torch.cuda.synchronize()
-                return {k: float(v) for k, v in ld.items()}, tr.opt.flat[0].detach().clone()
+                # (the trainer's bucket order, hence the layout of its flat buffers, follows the stream setting: compare by name;
+                # the gradients -- views into the flat buffer -- stay in place until the next step clears them)
+                return ({k: float(v) for k, v in ld.items()},
+                        torch.cat([p.grad.detach().reshape(-1) for _, p in sorted(model.named_parameters()) if p.grad is not None]).clone())
             o, d, pa, dn = ops.generate_rays(batch["ray_indices"], scene["c2w"], scene["fx"], scene["fy"], scene["cx"], scene["cy"])
             from presight_amd.rays import RayBundle
 
@@ -365,7 +368,7 @@ def test_proposal_side_stream_changes_nothing_but_the_schedule():
             out = model(rb)
             ld = model.get_loss_dict(out, batch)
             sum(ld.values()).backward()
-            g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])  # read on the caller's stream, no sync
+            g = torch.cat([p.grad.reshape(-1) for _, p in sorted(model.named_parameters()) if p.grad is not None])  # caller's stream, no sync
             return {k: float(v) for k, v in ld.items()}, g
         finally:
             ops.SIDE_STREAM = True
