@@ -94,7 +94,7 @@ __device__ __forceinline__ void store_act(float* __restrict__ acts, int stride, 
   }
 }
 // CLAMP: the loads are unconditional, blocks past the end read the last block instead (callers that only ever USE whole in-range
-// tiles: a conditional load is a branch plus a merge with a constant, and such merges of values still in flight made the
+// tiles -- the factored kernels, and the routed (MS) kernels, whose per-point working arrays live in the chunk-padded sorted layout: a conditional load is a branch plus a merge with a constant, and such merges of values still in flight made the
 // compiler place s_waitcnt vmcnt(0) right behind the load or at the loop's back edge)
 template <int NBLK, int PB, bool CLAMP = false>
 __device__ __forceinline__ void load_act(const float* __restrict__ acts, int stride, int col0, int64_t first, int64_t N,
@@ -551,13 +551,26 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       }
       return;
     }
-    load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, v.x);
+    if constexpr (MS) {  // the sorted layout pads every sub-field to whole chunks: unconditional loads, clamped past the end
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t p = first + pb * 16 + j, pc = p < a.N ? p : a.N - 1;
+        const float* row = a.feat + pc * a.F;
+#pragma unroll
+        for (int t = 0; t < Base::KS0; ++t) v.x[pb][t] = row[fc.off[t]];
+      }
+    } else {
+      load_feat<Base::KS0, PB>(a.feat, fc, a.F, first, a.N, v.x);
+    }
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t p = first + pb * 16 + j;
       const int64_t op = orig_index<MS>(a.perm, p, a.N);
       v.op[pb] = (int)op;
-      v.sel[pb] = (a.sigma != nullptr && p < a.N) ? a.sel[p] : 0.0f;
+      if constexpr (MS)
+        v.sel[pb] = a.sel[p < a.N ? p : a.N - 1];  // (padded slots carry selector 0)
+      else
+        v.sel[pb] = (a.sigma != nullptr && p < a.N) ? a.sel[p] : 0.0f;
       int64_t r;
       if constexpr (MS)
         r = ray_index(op >= 0 ? op : 0, a.S);
@@ -1100,12 +1113,12 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
   for (; first < a.N; first += stride) {
     PS_STAMP(tm, 0)
     float sin_[PB][Sem::KS0], s1[PB][16], s2[PB][16];
-    load_act<4, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
-    load_act<4, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
+    load_act<4, PB, C::FACT || MS>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
+    load_act<4, PB, C::FACT || MS>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
     if constexpr (C::FACT)
       load_act<Sem::KS0 / 4, PB, true>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, sin_);  // the base hidden layer = the merged first layer's input
     else
-      load_act<4, PB>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
+      load_act<4, PB, MS>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
     PS_STAMP(tm, 1)
     float dsin[PB][Sem::L0::IB * 4];
     float dws[C::FACT ? PB : 1];
@@ -1198,7 +1211,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
       load_act<Rgb::HB, PB, true>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, h.c2);
       return;
     }
-    load_act<1, PB>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, h.co);
+    load_act<1, PB, MS>(a.acts, C::ACT_W, C::ACT_CO, first, a.N, h.co);
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t p = first + pb * 16 + j;
@@ -1220,7 +1233,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
         for (int k = 0; k < 3; ++k) h.dr[pb][k] = src[k];
       }
     }
-    load_act<Rgb::HB, PB>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, h.c2);
+    load_act<Rgb::HB, PB, MS>(a.acts, C::ACT_W, C::ACT_C2, first, a.N, h.c2);
   };
   const int64_t stride = (int64_t)tr.n * NW * 16 * PB;
   int64_t first = tr.first_pt + ((int64_t)tr.j * NW + wave) * 16 * PB;
@@ -1269,8 +1282,8 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_rgb_kernel(MainArgs a) {
     int64_t ray_of[PB];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) ds_cur[pb] = ds_head[pb];
-    load_act<Rgb::HB, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
-    load_act<1, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);  // sigma_raw | geo15
+    load_act<Rgb::HB, PB, C::FACT || MS>(a.acts, C::ACT_W, C::ACT_C1, first, a.N, c1);
+    load_act<1, PB, C::FACT || MS>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb0);  // sigma_raw | geo15
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t r = ray_head[pb];
@@ -1422,13 +1435,13 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
         asm volatile("" : "+v"(dzb[pb][t]));  // a real copy, made HERE (the wait for the load must not sink below the stores)
       }
   };
-  load_act<DZ / 4, PB, C::FACT>(a.dzb, C::DZB_W, 0, first, a.N, dzb_next);
+  load_act<DZ / 4, PB, C::FACT || MS>(a.dzb, C::DZB_W, 0, first, a.N, dzb_next);
   consume();
-  load_act<DZ / 4, PB, C::FACT>(a.dzb, C::DZB_W, 0, first + stride, a.N, dzb_next);
+  load_act<DZ / 4, PB, C::FACT || MS>(a.dzb, C::DZB_W, 0, first + stride, a.N, dzb_next);
   for (; first < a.N; first += stride) {
     float h1[PB][Base::HB * 4], xin[PB][Base::KS0];
-    load_act<Base::HB, PB, C::FACT>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
-    if constexpr (C::FACT) {  // whole tiles, every feature column exists (checked by the launcher)
+    load_act<Base::HB, PB, C::FACT || MS>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
+    if constexpr (C::FACT || MS) {  // whole tiles (the routed layout pads every sub-field to whole chunks), every feature column exists
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const float* row = a.feat + (first + pb * 16 + (ps_lane() & 15)) * a.F;
@@ -1463,7 +1476,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     consume();
-    load_act<DZ / 4, PB, C::FACT>(a.dzb, C::DZB_W, 0, first + 2 * stride, a.N, dzb_next);
+    load_act<DZ / 4, PB, C::FACT || MS>(a.dzb, C::DZB_W, 0, first + 2 * stride, a.N, dzb_next);
     __builtin_amdgcn_sched_barrier(0);
     store_dfeat<Base::KS0, PB>(a.dfeat, fc, a.F, first, a.N, dx);
   }
