@@ -207,6 +207,13 @@ int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, in
  * Outputs sigma [N], rgb [N,3], sem [N,64]; any of them may be NULL to skip that head. */
 int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t* packed_floats /*host*/,
                         int64_t* grad_floats /*host*/, int* n_parts /*host*/, int64_t* offsets /*host [6]*/);
+/* inference forward with a gated semantic head (prior extraction: ns/scripts/extract_priors.py:133-150 drops the points whose mean
+ * density stays below the threshold): sigma [N] for every point; sem [N,64] only for the 32-point tiles in which some point has
+ * (gate_a[n] + gate_b[n] + sigma[n]) / 3 >= gate_threshold -- the other rows are left UNWRITTEN.  gate_a / gate_b [N]: the two
+ * proposal fields' densities.  Pass the caller's threshold lowered by a few ulp. */
+int ps_main_field_fwd_gated(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
+                            const float* packed, int64_t N, const float* gate_a, const float* gate_b, float gate_threshold,
+                            float* sigma, float* sem, void* stream);
 int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                       const float* sel, const float* dirs, const float* app, int S, int A, const float* packed, int64_t N,
                       float* sigma, float* rgb, float* sem, float* acts /* nullable: [ceil(N/16)*16, ps_main_field_act_width], register order */,

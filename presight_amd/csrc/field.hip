@@ -422,6 +422,11 @@ struct MainArgs {
   float* w_out;
   float* hid_ray;
   float* dw_sem;
+  // gated inference forward (ps_main_field_fwd_gated, prior extraction): the semantic head of a 32-point tile is evaluated only
+  // if some point of the tile has (gate_a[n] + gate_b[n] + sigma[n]) / 3 >= gate_thr; the semantics of the other tiles stay unwritten
+  const float* gate_a;
+  const float* gate_b;
+  float gate_thr;
 };
 
 // FACT (the factored semantic path of the training render node, one sub-field): the semantic head's input is a LINEAR function
@@ -525,6 +530,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     float x[PB][Base::KS0], sel[PB], dirv[PB][3], appv[PB][4];
     f32x4 rr[C::FACT ? PB : 1][C::FACT ? Rgb::HB : 1];  // FACT: the ray's colour-head term for this lane's neurons 16nb + 4g..4g+3
     float e0[C::FACT ? PB : 1], e1[C::FACT ? PB : 1];   // FACT: the sample's bin edges (subtracted after `consume`: a fetch only issues loads)
+    float ga[PB], gb[PB];                               // gated inference forward: the two other densities of the point
     int op[PB];  // the point's index in the caller's arrays, -1: no such point
   };
   auto fetch = [&](int64_t first, In& v) {
@@ -571,6 +577,8 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         v.sel[pb] = a.sel[p < a.N ? p : a.N - 1];  // (padded slots carry selector 0)
       else
         v.sel[pb] = (a.sigma != nullptr && p < a.N) ? a.sel[p] : 0.0f;
+      v.ga[pb] = (!MS && a.gate_a != nullptr && p < a.N) ? a.gate_a[p] : 0.0f;
+      v.gb[pb] = (!MS && a.gate_a != nullptr && p < a.N) ? a.gate_b[p] : 0.0f;
       int64_t r;
       if constexpr (MS)
         r = ray_index(op >= 0 ? op : 0, a.S);
@@ -600,6 +608,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(cur.appv[pb][t]));
         asm volatile("" : "+v"(cur.sel[pb]), "+v"(cur.dirv[pb][0]), "+v"(cur.dirv[pb][1]), "+v"(cur.dirv[pb][2]), "+v"(cur.op[pb]));
+        asm volatile("" : "+v"(cur.ga[pb]), "+v"(cur.gb[pb]));
       }
     }
   };
@@ -696,7 +705,22 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     }
     PS_STAMP(tm, 3)
     bool consumed = false;
-    if (C::FACT || a.sem != nullptr) {
+    bool run_sem = C::FACT || a.sem != nullptr;
+    if constexpr (!C::FACT && !MS) {
+      if (a.gate_a != nullptr) {  // (workgroup-uniform pointer; the ballot makes the decision wave-uniform)
+        bool hit = false;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+          const int64_t p = first + pb * 16 + j;
+          if (g == 0 && p < a.N) {
+            const float mean = ((cur.ga[pb] + cur.gb[pb]) + expf(zb[pb][0]) * cur.sel[pb]) / 3.0f;  // ps_mean_density's formula
+            hit |= mean >= a.gate_thr;
+          }
+        }
+        run_sem = run_sem && __ballot(hit) != 0ull;
+      }
+    }
+    if (run_sem) {
       float s1[PB][16], s2[PB][16], so[PB][16];
       if constexpr (C::FACT) {
         // merged first layer on the base hidden layer, second layer; `so` = the last HIDDEN activations (the output layer is
@@ -1784,6 +1808,22 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
   MainArgs a{};
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
   a.packed = packed; a.N = N; a.sigma = sigma; a.rgb = rgb; a.sem = sem; a.acts = acts; a.K = 1;
+  return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
+}
+
+// Inference forward with a GATED semantic head (prior extraction, ns/scripts/extract_priors.py:133-150: points whose mean density
+// of the three fields stays below the threshold are dropped right after the query): density for every point; the semantic head
+// -- 12 288 of the 19 456 MACs of a point -- only for the 32-point tiles in which some point has
+// (gate_a[n] + gate_b[n] + sigma[n]) / 3 >= gate_threshold.  sem rows of the other tiles are NOT written.  Pass the caller's
+// threshold lowered by a few ulp: the caller decides with ps_mean_density's separately rounded arithmetic.
+extern "C" int ps_main_field_fwd_gated(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                       const float* sel, const float* packed, int64_t N, const float* gate_a, const float* gate_b,
+                                       float gate_threshold, float* sigma, float* sem, void* stream) {
+  PS_REQUIRE(gate_a != nullptr && gate_b != nullptr && sigma != nullptr && sem != nullptr, "ps_main_field_fwd_gated: null argument");
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.S = 1; a.A = 0;
+  a.packed = packed; a.N = N; a.sigma = sigma; a.sem = sem; a.K = 1;
+  a.gate_a = gate_a; a.gate_b = gate_b; a.gate_thr = gate_threshold;
   return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
 }
 

@@ -40,18 +40,34 @@ def lattice_points(aabb: Tensor, res: int, start: int, count: int, device) -> Te
 
 
 @torch.no_grad()
-def query_priors(model, pts: Tensor) -> Tuple[Tensor, Tensor]:
-    """-> (mean density [n], features fp16 [n,64]); pts are in the model's (scaled) frame."""
+def _query_raw(model, pts: Tensor, density_threshold: Optional[float] = None) -> Tuple[Tensor, Tensor]:
+    """-> (mean density [n], semantics fp32 [n,64] as the field returns them).  With a threshold (and two proposal fields) the main
+    field skips its semantic head for the 32-point tiles that cannot contain a kept point: those rows are uninitialised."""
     dens = [p.density_fn(pts).reshape(-1) for p in model.proposal_networks]
-    d_main, sem = model.field.density_and_semantics(pts)  # one pass of the main field for both (the reference makes three)
+    gate = None
+    if density_threshold is not None and len(dens) == 2:
+        thr = float(density_threshold)
+        gate = (dens[0], dens[1], thr - 1e-5 * abs(thr) - 1e-30)  # a few ulp below the caller's own comparison
+    d_main, sem = model.field.density_and_semantics(pts, gate)  # one pass of the main field for both (the reference makes three)
     dens.append(d_main.reshape(-1))
     if len(dens) == 3:
         out = torch.empty_like(dens[0])
         check(lib().ps_mean_density(_p(dens[0]), _p(dens[1]), _p(dens[2]), out.numel(), _p(out), _stream()), "ps_mean_density")
     else:
         out = torch.stack(dens, 0).mean(0)
-    feats = sem.reshape(-1, sem.shape[-1]).clip(0.0, 1.0).to(torch.float16)
-    return out, feats
+    return out, sem.reshape(-1, sem.shape[-1])
+
+
+def query_priors(model, pts: Tensor, density_threshold: Optional[float] = None):
+    """-> (mean density [n], features fp16 [n,64]); pts are in the model's (scaled) frame.
+    With `density_threshold`: -> (mean density [n], keep mask [n], features fp16 of the KEPT points [kept,64]) -- the clip to [0, 1]
+    and the fp16 conversion (ns/scripts/extract_priors.py:136-138) are element-wise, so selecting the rows above the threshold
+    first gives the same values while touching a tenth of the 2 GB of semantics per 8 M points."""
+    out, sem = _query_raw(model, pts, density_threshold)
+    if density_threshold is None:
+        return out, sem.clip(0.0, 1.0).to(torch.float16)
+    keep = out > density_threshold
+    return out, keep, sem[keep].clip(0.0, 1.0).to(torch.float16)
 
 
 # ------------------------------------------------------------------------------------------------ voxel down-sampling
@@ -293,11 +309,10 @@ def dense_tile_query(model, aabb: Tensor, res: int = 512, chunk: int = 1 << 22, 
     for s in range(start, start + total, chunk):
         n = min(chunk, start + total - s)
         pts = lattice_points(aabb, res, s, n, dev)
-        dens, feats = query_priors(model, pts)
-        m = dens > density_threshold
+        dens, m, feats = query_priors(model, pts, density_threshold)
         P = pts[m] / pose_scale_factor
         keep_pts.append(P)
-        keep_feat.append(feats[m])
+        keep_feat.append(feats)
         keep_dens.append(dens[m])
         keep_idx.append(voxel_index(P, voxel, min_bound))
     cat = lambda xs, empty: torch.cat(xs) if xs else empty  # noqa: E731

@@ -669,6 +669,28 @@ def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor
     return _MainFieldRender.apply(u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, len(base), len(sem), *flat)
 
 
+def main_field_gated(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, base, sem, rgb, gate_a: Tensor, gate_b: Tensor,
+                     threshold: float):
+    """Inference query of the prior extraction (no autograd): -> (density [N], semantics [N,64]) where the semantic head is only
+    evaluated for the 32-point tiles in which some point has mean(gate_a, gate_b, density) >= threshold; the other rows of the
+    semantics are UNINITIALISED (ns/scripts/extract_priors.py:133-150 drops those points).  gate_a / gate_b: the proposal fields'
+    densities of the same points."""
+    layers = list(base) + list(sem) + list(rgb)
+    hidden, hidden_color = base[0][0].shape[0], rgb[0][0].shape[0]
+    A = rgb[0][0].shape[1] - 16 - GEO_DIM
+    spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+    N, dev = u.shape[0], u.device
+    with torch.no_grad():
+        feat, _ = _encode(u, _f32(table, "hash table"), scalings, g, count=False)
+        packed = spec.pack(list(base), list(sem), list(rgb), dev)
+        sigma, semantics = torch.empty(N, device=dev), torch.empty(N, SEM_DIM, device=dev)
+        with prof.region("main_field_fwd"):
+            check(lib().ps_main_field_fwd_gated(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                                                _p(sel), _p(packed), N, _p(_f32(gate_a).reshape(-1)), _p(_f32(gate_b).reshape(-1)),
+                                                float(threshold), _p(sigma), _p(semantics), _stream()), "ps_main_field_fwd_gated")
+    return sigma, semantics
+
+
 def main_field(u: Tensor, sel: Tensor, dirs: Optional[Tensor], app: Optional[Tensor], S: int, table: Tensor, scalings: Tensor,
                g: GridCfg, base: Sequence[Tuple[Tensor, Tensor]], sem: Sequence[Tuple[Tensor, Tensor]],
                rgb: Sequence[Tuple[Tensor, Tensor]], want_rgb: bool = True, want_sem: bool = True):

@@ -312,12 +312,20 @@ class iNGPFieldMS(nn.Module):
             d = self._ms_points(positions, want_sem=False)[0]
         return d.view(*positions.shape[:-1], 1)
 
-    def density_and_semantics(self, positions: Tensor) -> Tuple[Tensor, Tensor]:
+    def density_and_semantics(self, positions: Tensor, gate: Optional[Tuple[Tensor, Tensor, float]] = None) -> Tuple[Tensor, Tensor]:
         """(density [*bs,1], semantics [*bs,64]) from ONE evaluation of the field.  The reference's prior extraction calls
         density_fn and semantic_fn separately (ns/scripts/extract_priors.py:133-138) and semantic_fn re-runs density_fn
-        (ingp_field.py:256): the hash encode and the base MLP run three times per point there, once here."""
+        (ingp_field.py:256): the hash encode and the base MLP run three times per point there, once here.
+        gate = (density_a, density_b, threshold) (one sub-field, inference): the semantic head is skipped for the 32-point tiles in
+        which no point reaches mean(density_a, density_b, density) >= threshold -- those rows of the semantics are uninitialised
+        (field_ops.main_field_gated)."""
         def run(f: iNGPField, pos):
             u, sel = f.points(pos=pos)
+            if gate is not None and not torch.is_grad_enabled():
+                f._require_fused()
+                gr = f.mlp_base_grid
+                return F.main_field_gated(u, sel, gr.hash_table, gr.scalings_on(u.device), _grid_cfg(gr), f.mlp_base_mlp.layer_params(),
+                                          f.semantic_head.layer_params(), f.rgb_head.layer_params(), gate[0], gate[1], gate[2])
             d, _, s = f.evaluate(u, sel, None, None, 1, want_rgb=False, want_sem=True)
             return d, s
 
