@@ -861,11 +861,11 @@ def main():
                 sec[keys[0]]["wall_s_incl_model_build"] = round(time.perf_counter() - t_sec, 1)
 
             def cfg3():
-                r = secondary_training_lines("cfg3", [(65536, 3, 2), (8192, 5, 2)], dev)
+                r = secondary_training_lines("cfg3", [(65536, 4, 2), (8192, 12, 4)], dev)
                 return {"cfg3_65536": r[65536], "cfg3_8192": r[8192]}
 
             run_sec(["cfg3_65536", "cfg3_8192"], cfg3)
-            run_sec(["cfg4_65536"], lambda: {"cfg4_65536": secondary_training_lines("cfg4", [(65536, 3, 2)], dev)[65536]})
+            run_sec(["cfg4_65536"], lambda: {"cfg4_65536": secondary_training_lines("cfg4", [(65536, 4, 2)], dev)[65536]})
             run_sec(["extract_512"], lambda: {"extract_512": secondary_extract_line(dev)})
             line["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
