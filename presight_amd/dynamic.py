@@ -108,7 +108,7 @@ class _DynFeatures(torch.autograd.Function):
         x4, xw = xall[:N], xall[N:]
         check(lib().ps_dyn_points(_p(u), _p(_f32(times).reshape(-1)), max(int(S), 1), N, _p(x4), _stream()), "ps_dyn_points")
         counts = None
-        if ctx.needs_input_grad[3]:
+        if F._training(ctx.needs_input_grad[3]):
             counts = torch.zeros(g.num_levels * lib().ps_grid_scatter_slices(g.features_per_level, g.log2_hashmap_size), device=dev,
                                  dtype=torch.int32)
         e0 = encode4(x4, table, scalings, g, counts=counts)
@@ -238,7 +238,7 @@ class DynamicField(nn.Module):
         flat = []
         for W, b in self.flow_head.layer_params():
             flat += [W, b]
-        return _DynFeatures.apply(u, times, S, e.hash_table, e.scalings_on(u.device), e.cfg(), self.flow_scale, self.time_step, *flat)
+        return F._apply(_DynFeatures, u, times, S, e.hash_table, e.scalings_on(u.device), e.cfg(), self.flow_scale, self.time_step, *flat)
 
     def evaluate(self, u: Tensor, sel: Tensor, times: Tensor, ray_dirs: Optional[Tensor], app: Optional[Tensor], S: int,
                  want_rgb: bool = True, want_sem: bool = True):

@@ -10,6 +10,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
+import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -64,6 +65,26 @@ def _encode(u: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, count: bool 
         check(lib().ps_grid_encode(_p(u), _p(table), _p(scalings), g.num_levels, g.features_per_level, g.log2_hashmap_size, N,
                                    N * g.features_per_level, _p(feat), _p(counts), _stream()), "ps_grid_encode")
     return feat, counts
+
+
+_CALL = threading.local()
+
+
+def _apply(fn, *args):
+    """fn.apply(*args) with the CALLER's grad mode on record.  Inside a Function.forward grad mode is always off, and
+    ctx.needs_input_grad ignores torch.no_grad(): without this an inference call on trainable parameters would still count the
+    table backward's records during the hash encode and keep 1.4 KB of activations per point for a backward that never comes."""
+    prev = getattr(_CALL, "grad", True)
+    _CALL.grad = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _CALL.grad = prev
+
+
+def _training(needs_grad) -> bool:
+    """needs_input_grad of a node's parameters AND grad mode was on where the node was applied"""
+    return bool(needs_grad) and getattr(_CALL, "grad", True)
 
 
 _WORKSPACES = {}
@@ -148,7 +169,7 @@ class _PropField(torch.autograd.Function):
         spec = _prop_spec(g.out_dim, hidden)
         N = u.shape[0]
         table = _f32(table, "hash table")
-        feat, counts = _encode(u, table, scalings, g, count=ctx.needs_input_grad[2])
+        feat, counts = _encode(u, table, scalings, g, count=_training(ctx.needs_input_grad[2]))
         packed = spec.pack(layers, u.device)
         sigma = torch.empty(N, device=u.device)
         with prof.region("prop_field_fwd"):
@@ -189,7 +210,7 @@ def prop_field(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g: GridC
     flat = []
     for W, b in layers:
         flat += [W, b]
-    return _PropField.apply(u, sel, table, scalings, g, *flat)
+    return _apply(_PropField, u, sel, table, scalings, g, *flat)
 
 
 # ------------------------------------------------------------------------------------------------ main field
@@ -364,7 +385,7 @@ class _MainStack(torch.autograd.Function):
     def forward(ctx, feat, sel, dirs, app, S, g: GridCfg, want_rgb, want_sem, n_base, n_sem, *wb):
         feat = _f32(feat)
         N = sel.shape[0]
-        (dirs, app_c, packed, acts), (sigma, rgb, sem) = _stack_forward(ctx, feat.requires_grad, feat, N, sel, dirs, app, S, g, want_rgb,
+        (dirs, app_c, packed, acts), (sigma, rgb, sem) = _stack_forward(ctx, _training(feat.requires_grad), feat, N, sel, dirs, app, S, g, want_rgb,
                                                                         want_sem, n_base, n_sem, wb)
         ctx.save_for_backward(sel, dirs, app_c, feat, packed, acts)
         ctx.want = (want_rgb, want_sem)
@@ -390,13 +411,13 @@ def main_stack(feat: Tensor, sel: Tensor, dirs: Optional[Tensor], app: Optional[
     flat = []
     for W, b in list(base) + list(sem) + list(rgb):
         flat += [W, b]
-    return _MainStack.apply(feat, sel, dirs, app, S, g, want_rgb, want_sem, len(base), len(sem), *flat)
+    return _apply(_MainStack, feat, sel, dirs, app, S, g, want_rgb, want_sem, len(base), len(sem), *flat)
 
 
 class _MainField(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, sel, dirs, app, S, table, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, *wb):
-        saved, (sigma, rgb, sem) = _main_forward(ctx, ctx.needs_input_grad[5], u, sel, dirs, app, S, table, scalings, g, want_rgb,
+        saved, (sigma, rgb, sem) = _main_forward(ctx, _training(ctx.needs_input_grad[5]), u, sel, dirs, app, S, table, scalings, g, want_rgb,
                                                  want_sem, n_base, n_sem, wb)
         ctx.save_for_backward(*saved)
         empty = torch.empty(0, device=u.device)
@@ -422,7 +443,7 @@ class _MainFieldRender(torch.autograd.Function):
     def forward(ctx, u, sel, dirs, app, S, ebins, threshold, table, scalings, g: GridCfg, n_base, n_sem, *wb):
         from . import ops
 
-        saved, (sigma, rgb_s, sem_s) = _main_forward(ctx, ctx.needs_input_grad[7], u, sel, dirs, app, S, table, scalings, g, True, True,
+        saved, (sigma, rgb_s, sem_s) = _main_forward(ctx, _training(ctx.needs_input_grad[7]), u, sel, dirs, app, S, table, scalings, g, True, True,
                                                      n_base, n_sem, wb)
         R = ebins.shape[0]
         dev = u.device
@@ -526,7 +547,7 @@ class _MainFieldRenderF(torch.autograd.Function):
         N, dev = u.shape[0], u.device
         R = ebins.shape[0]
         table = _f32(table, "hash table")
-        train = ctx.needs_input_grad[7]
+        train = _training(ctx.needs_input_grad[7])
         feat, counts = _encode(u, table, scalings, g, count=train)
         # merged first semantic layer: W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0
         Wb1, bb1, Ws0, bs0 = _f32(Wb1), _f32(bb1), _f32(Ws0), _f32(bs0)
@@ -665,8 +686,8 @@ def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor
     for W, b in list(base) + list(sem) + list(rgb):
         flat += [W, b]
     if factored_supported(base, sem, rgb, S) and torch.is_grad_enabled():
-        return _MainFieldRenderF.apply(u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, *flat)
-    return _MainFieldRender.apply(u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, len(base), len(sem), *flat)
+        return _apply(_MainFieldRenderF, u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, *flat)
+    return _apply(_MainFieldRender, u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, len(base), len(sem), *flat)
 
 
 def main_field_gated(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, base, sem, rgb, gate_a: Tensor, gate_b: Tensor,
@@ -698,7 +719,7 @@ def main_field(u: Tensor, sel: Tensor, dirs: Optional[Tensor], app: Optional[Ten
     flat = []
     for W, b in list(base) + list(sem) + list(rgb):
         flat += [W, b]
-    return _MainField.apply(u, sel, dirs, app, S, table, scalings, g, want_rgb, want_sem, len(base), len(sem), *flat)
+    return _apply(_MainField, u, sel, dirs, app, S, table, scalings, g, want_rgb, want_sem, len(base), len(sem), *flat)
 
 
 # ================================================================================================ multi-sub-field ("MS") path
@@ -915,7 +936,7 @@ class _PropFieldMS(torch.autograd.Function):
         hidden = layers[0][0][0].shape[0]
         spec = _prop_spec(g.out_dim, hidden)
         dev = u.device
-        train = any(ctx.needs_input_grad[5:5 + K])
+        train = _training(any(ctx.needs_input_grad[5:5 + K]))
         feat, counts = _ms_encode(lay, u, tables, scalings, g, count=train)
         st = _MsStacks.get("prop", [spec], ([0], [0]), spec.packed, spec.g_total, layers, lib().ps_prop_field_parts_ms(1 << 40, K))
         st.pack()
@@ -956,7 +977,7 @@ def ms_prop_field(lay: MsLayout, u: Tensor, sel: Tensor, tables: Sequence[Tensor
     for layers in layers_per_field:
         for W, b in layers:
             flat += [W, b]
-    return _PropFieldMS.apply(lay, u, sel, scalings, g, *tables, *flat)
+    return _apply(_PropFieldMS, lay, u, sel, scalings, g, *tables, *flat)
 
 
 def _ms_main_forward(ctx, train, lay: MsLayout, u, sel, dirs, app, S, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, params):
@@ -1028,7 +1049,7 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
 class _MainFieldMS(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lay: MsLayout, u, sel, dirs, app, S, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, *params):
-        train = any(ctx.needs_input_grad[12:12 + lay.K])
+        train = _training(any(ctx.needs_input_grad[12:12 + lay.K]))
         saved, (sigma, rgb, sem) = _ms_main_forward(ctx, train, lay, u, sel, dirs, app, S, scalings, g, want_rgb, want_sem, n_base, n_sem,
                                                     params)
         ctx.save_for_backward(*saved)
@@ -1053,7 +1074,7 @@ class _MainFieldRenderMS(torch.autograd.Function):
     def forward(ctx, lay: MsLayout, u, sel, dirs, app, S, ebins, threshold, scalings, g: GridCfg, n_base, n_sem, *params):
         from . import ops
 
-        train = any(ctx.needs_input_grad[12:12 + lay.K])
+        train = _training(any(ctx.needs_input_grad[12:12 + lay.K]))
         saved, (sigma, rgb_s, sem_s) = _ms_main_forward(ctx, train, lay, u, sel, dirs, app, S, scalings, g, True, True, n_base, n_sem, params)
         R = ebins.shape[0]
         dev = u.device
@@ -1106,7 +1127,7 @@ def _ms_params(tables, base, sem, rgb):
 def ms_main_field(lay: MsLayout, u, sel, dirs, app, S, tables, scalings, g: GridCfg, base, sem, rgb, want_rgb=True, want_sem=True):
     """-> (density [N], rgb [N,3], semantics [N,64]) in the caller's point order; base/sem/rgb: per sub-field layer lists.
     Point n belongs to ray n // S (dirs [R,3], app [R,A])."""
-    return _MainFieldMS.apply(lay, u, sel, dirs, app, S, scalings, g, want_rgb, want_sem, len(base[0]), len(sem[0]), *tables,
+    return _apply(_MainFieldMS, lay, u, sel, dirs, app, S, scalings, g, want_rgb, want_sem, len(base[0]), len(sem[0]), *tables,
                               *_ms_params(tables, base, sem, rgb))
 
 
@@ -1115,7 +1136,7 @@ def ms_main_field_render(lay: MsLayout, u, sel, dirs, app, ebins, tables, scalin
     S = ebins.shape[1] - 1
     if S > 64:
         raise NotImplementedError("ms_main_field_render: at most 64 samples per ray")
-    return _MainFieldRenderMS.apply(lay, u, sel, dirs, app, S, ebins, float(threshold), scalings, g, len(base[0]), len(sem[0]), *tables,
+    return _apply(_MainFieldRenderMS, lay, u, sel, dirs, app, S, ebins, float(threshold), scalings, g, len(base[0]), len(sem[0]), *tables,
                                     *_ms_params(tables, base, sem, rgb))
 
 
