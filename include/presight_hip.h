@@ -210,7 +210,11 @@ int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t
 /* inference forward with a gated semantic head (prior extraction: ns/scripts/extract_priors.py:133-150 drops the points whose mean
  * density stays below the threshold): sigma [N] for every point; sem [N,64] only for the 32-point tiles in which some point has
  * (gate_a[n] + gate_b[n] + sigma[n]) / 3 >= gate_threshold -- the other rows are left UNWRITTEN.  gate_a / gate_b [N]: the two
- * proposal fields' densities.  Pass the caller's threshold lowered by a few ulp. */
+ * proposal fields' densities.  Pass the caller's threshold lowered by a few ulp.  The kernel evaluates the MERGED network: base
+ * output rows 16..79 folded into the semantic head's first layer (ps_merge_linear_fwd), packed = [base (L*F -> hidden -> 16) |
+ * semantic head (hidden -> 64 merged, 64 -> 64, 64 -> 64) | colour head (unused)] with the sizes of ps_main_field_gated_sizes.
+ * Densities bit-identical to ps_main_field_fwd, semantics equal to fp32 rounding. */
+int ps_main_field_gated_sizes(int LF, int hidden, int hidden_color, int64_t* packed_floats /*host*/, int64_t* offsets /*host [3]*/);
 int ps_main_field_fwd_gated(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
                             const float* packed, int64_t N, const float* gate_a, const float* gate_b, float gate_threshold,
                             float* sigma, float* sem, void* stream);

@@ -439,12 +439,16 @@ struct MainArgs {
 //     (sum_n w_n (W h_n + b) = W (sum_n w_n h_n) + b sum_n w_n: ps_sem_out_fwd / _bwd), the kernels hand out h_n.
 // 8192 of the 26752 MACs per sample disappear from the forward and 16384 from the backward; the function, its parameters and
 // their gradients are the reference's (fp32 rounding of the re-associated sums aside).
-template <int KS0_, int HB_, int HBC_, bool FACT_ = false>
+// MERGE_ (inference forward only: ps_main_field_fwd_gated): rewrite 1 alone -- base output layer rows 16..79 merged into the semantic
+// head's first layer, so the base MLP ends in 16 outputs and the three-layer head (merged, 64 -> 64, 64 -> 64) reads the base hidden
+// layer; everything else (per-sample outputs, conditional loads, colour head) is the plain kernel.
+template <int KS0_, int HB_, int HBC_, bool FACT_ = false, bool MERGE_ = false>
 struct MainCfg {
   static constexpr bool FACT = FACT_;
-  static constexpr int ZB_NB = FACT_ ? 1 : 5;  // 16-neuron blocks of the base output
+  static constexpr bool MERGED = FACT_ || MERGE_;  // the semantic stack hangs off the base HIDDEN layer
+  static constexpr int ZB_NB = MERGED ? 1 : 5;     // 16-neuron blocks of the base output
   using Base = MlpT<KS0_, HB_, ZB_NB, 2>;
-  using Sem = std::conditional_t<FACT_, MlpT<HB_ * 4, 4, 4, 2>, MlpT<16, 4, 4, 3>>;
+  using Sem = std::conditional_t<FACT_, MlpT<HB_ * 4, 4, 4, 2>, std::conditional_t<MERGE_, MlpT<HB_ * 4, 4, 4, 3>, MlpT<16, 4, 4, 3>>>;
   // FACT: the colour head's first layer sees the 15 geometry features only (one 16-neuron block of the base output); its
   // direction (SH16) and appearance columns are the same for all samples of a ray and arrive as a per-ray pre-activation term
   // (ps_ray_colour_fwd -> MainArgs::rray), their gradients leave as per-block sums (MainArgs::dr_part -> ps_ray_colour_bwd)
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     const int64_t first = it0.first;
     PS_STAMP(tm, 0)
     float zb[PB][C::ZB_NB * 4], dirv[PB][3], appv[PB][4];
-    float h1f[C::FACT ? PB : 1][C::FACT ? Base::HB * 4 : 1];  // FACT: the base hidden layer feeds the semantic stack
+    float h1f[C::MERGED ? PB : 1][C::MERGED ? Base::HB * 4 : 1];  // merged first layer: the base hidden layer feeds the semantic stack
     f32x4 rr[C::FACT ? PB : 1][C::FACT ? Rgb::HB : 1];
     int op_cur[PB];
 #pragma unroll
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         store_act<Base::HB, PB>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, h1);
         store_act<C::ZB_NB, PB>(a.acts, C::ACT_W, C::ACT_ZB, first, a.N, zb);
       }
-      if constexpr (C::FACT) {
+      if constexpr (C::MERGED) {
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
@@ -731,12 +735,14 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
           for (int t = 0; t < 16; ++t) s2[pb][t] = so[pb][t];
+      } else if constexpr (C::MERGED) {
+        mlp_forward<Sem, PB>(LdsW{lds + C::FW_SEM}, h1f, s1, s2, so);  // merged first layer on the base hidden layer, then the head as it is
       } else {
         float sin_[PB][16];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-          for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][(C::FACT ? 0 : 4) + t];
+          for (int t = 0; t < 16; ++t) sin_[pb][t] = zb[pb][4 + t];
         mlp_forward<Sem, PB>(LdsW{lds + C::FW_SEM}, sin_, s1, s2, so);
       }
       PS_STAMP(tm, 4)
@@ -1708,8 +1714,23 @@ extern "C" int ps_main_field_f_sizes(int LF, int hidden, int hidden_color, int64
 }
 
 namespace {
-int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool fact = false) {
+int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool fact = false, bool merged = false) {
   if (a.N == 0) return 0;
+  if (merged) {
+    PS_REQUIRE(a.perm == nullptr && a.acts == nullptr && a.rgb == nullptr && a.sem != nullptr && a.sigma != nullptr,
+               "ps_main_field_fwd_gated: one sub-field, inference (no kept activations), density + semantics");
+    PS_REQUIRE(a.N < (int64_t(1) << 31), "ps_main_field_fwd_gated: at most 2^31 - 1 points per call");
+#define X(lf, h, hc)                                                                                                  \
+  if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>;                                                    \
+    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+    PS_CHECK_LAUNCH();                                                                                                \
+  }
+    PS_MAIN_CFGS(X)
+#undef X
+    ps_set_error("ps_main_field_fwd_gated: unsupported (L*F, hidden, hidden_color)");
+    return -2;
+  }
   if (fact) {
     PS_REQUIRE(a.perm == nullptr && a.hid_ray != nullptr && a.rgb != nullptr && a.sigma != nullptr,
                "ps_main_field_f_fwd: one sub-field, all outputs");
@@ -1813,9 +1834,12 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
 
 // Inference forward with a GATED semantic head (prior extraction, ns/scripts/extract_priors.py:133-150: points whose mean density
 // of the three fields stays below the threshold are dropped right after the query): density for every point; the semantic head
-// -- 12 288 of the 19 456 MACs of a point -- only for the 32-point tiles in which some point has
+// -- 12 288 of the 15 360 MACs of a point in this kernel -- only for the 32-point tiles in which some point has
 // (gate_a[n] + gate_b[n] + sigma[n]) / 3 >= gate_threshold.  sem rows of the other tiles are NOT written.  Pass the caller's
 // threshold lowered by a few ulp: the caller decides with ps_mean_density's separately rounded arithmetic.
+// The kernel runs the MERGED network (MainCfg MERGE_: base output rows 16..79 folded into the semantic head's first layer,
+// W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0 from ps_merge_linear_fwd): `packed` has the layout of
+// ps_main_field_gated_sizes.  Densities are bit-identical to ps_main_field_fwd, semantics agree to fp32 rounding.
 extern "C" int ps_main_field_fwd_gated(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                        const float* sel, const float* packed, int64_t N, const float* gate_a, const float* gate_b,
                                        float gate_threshold, float* sigma, float* sem, void* stream) {
@@ -1824,7 +1848,27 @@ extern "C" int ps_main_field_fwd_gated(const float* feat, int64_t plane_stride, 
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.S = 1; a.A = 0;
   a.packed = packed; a.N = N; a.sigma = sigma; a.sem = sem; a.K = 1;
   a.gate_a = gate_a; a.gate_b = gate_b; a.gate_thr = gate_threshold;
-  return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream);
+  return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream, false, true);
+}
+
+// packed / weight-fragment sizes of the gated inference forward: [base (L*F -> hidden -> 16) | semantic head with the merged first
+// layer (hidden -> 64 -> 64 -> 64) | colour head (layout of ps_main_field_fwd; unused)]
+extern "C" int ps_main_field_gated_sizes(int LF, int hidden, int hidden_color, int64_t* packed_floats, int64_t* offsets /*[3]*/) {
+#define X(lf, h, hc)                                               \
+  if (LF == lf && hidden == h && hidden_color == hc) {             \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>; \
+    *packed_floats = C::PACKED;                                    \
+    if (offsets) {                                                 \
+      offsets[0] = C::P_BASE;                                      \
+      offsets[1] = C::P_SEM;                                       \
+      offsets[2] = C::P_RGB;                                       \
+    }                                                              \
+    return 0;                                                      \
+  }
+  PS_MAIN_CFGS(X)
+#undef X
+  ps_set_error("ps_main_field_gated: unsupported (L*F, hidden, hidden_color)");
+  return -2;
 }
 
 extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,

@@ -690,20 +690,51 @@ def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor
     return _apply(_MainFieldRender, u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, len(base), len(sem), *flat)
 
 
+class MainSpecGated:
+    """packed layout of the gated inference forward (csrc/field.hip MainCfg MERGE_): base ending in 16 outputs, three-layer semantic
+    head whose first layer is the merged one and reads the base hidden layer, the colour head as in MainSpec (not evaluated)"""
+
+    def __init__(self, LF: int, hidden: int, hidden_color: int, app_dim: int):
+        self.base = MlpSpec([LF, hidden, 16])
+        self.sem = MlpSpec([hidden, 64, 64, SEM_DIM], first_colmap=chain_colmap(hidden // 4, hidden), ks0=hidden // 4)
+        self.rgb = MlpSpec([16 + GEO_DIM + app_dim, hidden_color, hidden_color, 3], first_colmap=colour_colmap(app_dim), ks0=12)
+        self.p_off = [0, self.base.packed, self.base.packed + self.sem.packed]
+        self.packed = self.p_off[2] + self.rgb.packed
+        pf, offs = ctypes.c_int64(), (ctypes.c_int64 * 3)()
+        check(lib().ps_main_field_gated_sizes(LF, hidden, hidden_color, ctypes.byref(pf), offs), "ps_main_field_gated_sizes")
+        assert pf.value == self.packed and list(offs) == self.p_off, (pf.value, self.packed, list(offs), self.p_off)
+
+
+_MAIN_SPECS_G: dict = {}
+
+
 def main_field_gated(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, base, sem, rgb, gate_a: Tensor, gate_b: Tensor,
                      threshold: float):
     """Inference query of the prior extraction (no autograd): -> (density [N], semantics [N,64]) where the semantic head is only
     evaluated for the 32-point tiles in which some point has mean(gate_a, gate_b, density) >= threshold; the other rows of the
     semantics are UNINITIALISED (ns/scripts/extract_priors.py:133-150 drops those points).  gate_a / gate_b: the proposal fields'
-    densities of the same points."""
-    layers = list(base) + list(sem) + list(rgb)
-    hidden, hidden_color = base[0][0].shape[0], rgb[0][0].shape[0]
+    densities of the same points.  The kernel runs the network with the base output layer's rows 16..79 merged into the semantic
+    head's first layer (rewrite 1): densities bit-identical to main_field, semantics equal to fp32 rounding."""
+    (Wb0, bb0), (Wb1, bb1) = base
+    (Ws0, bs0), (Ws1, bs1), (Ws2, bs2) = sem
+    hidden, hidden_color = Wb0.shape[0], rgb[0][0].shape[0]
     A = rgb[0][0].shape[1] - 16 - GEO_DIM
-    spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+    key = (g.out_dim, hidden, hidden_color, A)
+    if key not in _MAIN_SPECS_G:
+        _MAIN_SPECS_G[key] = MainSpecGated(*key)
+    spec = _MAIN_SPECS_G[key]
     N, dev = u.shape[0], u.device
     with torch.no_grad():
         feat, _ = _encode(u, _f32(table, "hash table"), scalings, g, count=False)
-        packed = spec.pack(list(base), list(sem), list(rgb), dev)
+        Wb1, bb1, Ws0, bs0 = _f32(Wb1), _f32(bb1), _f32(Ws0), _f32(bs0)
+        Wm, bm = torch.empty(64, hidden, device=dev), torch.empty(64, device=dev)
+        check(lib().ps_merge_linear_fwd(_p(Ws0), _p(bs0), Wb1.data_ptr() + 4 * 16 * hidden, bb1.data_ptr() + 4 * 16, 64, SEM_DIM, hidden,
+                                        _p(Wm), _p(bm), _stream()), "ps_merge_linear_fwd")
+        packed = torch.empty(spec.packed, device=dev)
+        descs = spec.base.pack_descs([(Wb0, bb0), (Wb1[:16], bb1[:16])], packed[: spec.base.packed])
+        descs += spec.sem.pack_descs([(Wm, bm), (Ws1, bs1), (Ws2, bs2)], packed[spec.p_off[1]: spec.p_off[1] + spec.sem.packed])
+        descs += spec.rgb.pack_descs(list(rgb), packed[spec.p_off[2]:])
+        pack_layers(descs)
         sigma, semantics = torch.empty(N, device=dev), torch.empty(N, SEM_DIM, device=dev)
         with prof.region("main_field_fwd"):
             check(lib().ps_main_field_fwd_gated(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
