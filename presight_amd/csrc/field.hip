@@ -729,7 +729,11 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
       if constexpr (C::FACT) {
         // merged first layer on the base hidden layer, second layer; `so` = the last HIDDEN activations (the output layer is
         // applied per ray after compositing)
+#if defined(PS_SEM_BF16X3)  // exploratory build (tools/build_variant.sh bf16x3 -DPS_SEM_BF16X3): NOT the product arithmetic
+        mlp_forward<Sem, PB, LdsW, NoPost, true>(LdsW{lds + C::FW_SEM}, h1f, s1, s2 /*unused*/, so);
+#else
         mlp_forward<Sem, PB>(LdsW{lds + C::FW_SEM}, h1f, s1, s2 /*unused*/, so);
+#endif
         relu_inplace<PB, 16>(so);
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb)

@@ -200,6 +200,69 @@ __device__ __forceinline__ void layer_fwd_pf(const W& params, const FwdFrags<LT>
   }
 }
 
+// ---- EXPLORATORY (never the product path: -DPS_SEM_BF16X3 builds only): the same layer with every fp32 operand split into two
+// bf16 terms (x = hi + lo, 16 mantissa bits kept) and three v_mfma_f32_16x16x32_bf16 per 32 inputs (hi*hi + hi*lo + lo*hi, fp32
+// accumulation): ~2^-16 relative error per product instead of 2^-24, 5.3x the matrix rate of the exact-fp32 MFMA.  The D -> B
+// register chaining is unchanged: element i of the 8-wide bf16 operand of k-step s is the fp32 k-step 8 s + i.
+typedef __bf16 ps_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void ps_split_bf16(const float (&v)[8], ps_bf16x8& hi, ps_bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hi[i] = (__bf16)v[i];
+    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+  }
+}
+template <class LT, int PB, class W, class Next>
+__device__ __forceinline__ void layer_fwd_pf_bf16x3(const W& params, const FwdFrags<LT>& first, const float (&vin)[PB][LT::KS],
+                                                    float (&vout)[PB][LT::NB * 4], const Next& next) {
+  static_assert(LT::KS % 8 == 0, "bf16x3 layer: inputs in groups of 32");
+  constexpr int S = LT::KS / 8;
+  ps_bf16x8 bh[PB][S], bl[PB][S];
+#pragma unroll
+  for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      float t8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t8[i] = vin[pb][8 * q + i];
+      ps_split_bf16(t8, bh[pb][q], bl[pb][q]);
+    }
+  FwdFrags<LT> cur = first, nxt;
+#pragma unroll
+  for (int nb = 0; nb < LT::NB; ++nb) {
+    f32x4 acc[PB];
+    if (nb + 1 < LT::NB)
+      fetch_fwd<LT>(params, nb + 1, nxt);
+    else
+      next();
+    __builtin_amdgcn_sched_barrier(0);
+    ps_bf16x8 ah[S], al[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      float t8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t8[i] = cur.a[8 * q + i];
+      ps_split_bf16(t8, ah[q], al[q]);
+    }
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) acc[pb] = cur.b;
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q], bh[pb][q], acc[pb], 0, 0, 0);  // small terms first
+        acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bl[pb][q], acc[pb], 0, 0, 0);
+        acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bh[pb][q], acc[pb], 0, 0, 0);
+      }
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vout[pb][4 * nb + r] = acc[pb][r];
+    if (nb + 1 < LT::NB) cur = nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <class LT, int PB, class W>
 __device__ __forceinline__ void layer_fwd(const W& params, const float (&vin)[PB][LT::KS], float (&vout)[PB][LT::NB * 4]) {
   FwdFrags<LT> a0;
@@ -753,7 +816,7 @@ struct NoPost {
 
 // forward through all layers, keeping the post-ReLU hidden activations (needed by backward).  `post_first(h1)` runs on the first
 // layer's pre-activations before their ReLU (a per-point term that is added there: the per-ray part of the colour head's input).
-template <class M, int PB, class W, class PostFirst = NoPost>
+template <class M, int PB, class W, class PostFirst = NoPost, bool BF16X3 = false>
 __device__ __forceinline__ void mlp_forward(const W& params, const float (&x)[PB][M::KS0],
                                             float (&h1)[PB][M::HB * 4], float (&h2)[PB][M::HB * 4],
                                             float (&z)[PB][M::NBO * 4], const PostFirst& post_first = PostFirst()) {
@@ -772,6 +835,11 @@ __device__ __forceinline__ void mlp_forward(const W& params, const float (&x)[PB
     layer_fwd_pf<L1, PB>(p1, a1, h1, h2, [&]() { first_frags_fwd<LZ>(pz, az); });
     relu_inplace<PB, M::HB * 4>(h2);
     layer_fwd_pf<LZ, PB>(pz, az, h2, z, NoPrefetch());
+  } else if constexpr (BF16X3) {  // (exploratory builds: both layers of a two-layer stack as split-bf16 products)
+    layer_fwd_pf_bf16x3<L0, PB>(p0, a0, x, h1, [&]() { first_frags_fwd<LZ>(pz, az); });
+    post_first(h1);
+    relu_inplace<PB, M::HB * 4>(h1);
+    layer_fwd_pf_bf16x3<LZ, PB>(pz, az, h1, z, NoPrefetch());
   } else {
     layer_fwd_pf<L0, PB>(p0, a0, x, h1, [&]() { first_frags_fwd<LZ>(pz, az); });
     post_first(h1);
