@@ -340,8 +340,10 @@ int ps_voxel_reduce(const int64_t* order, const int64_t* starts, const int64_t* 
 
 /* ---- f1 optimizer: torch.optim.Adam semantics (L2 weight decay added to the gradient, bias-corrected), in place.
  * Reference configuration: ns/configs/method_configs.py:158-168 (lr 1e-2, eps 1e-15, weight_decay 1e-5).
- * p, g, m, v: [n] fp32, 16-byte aligned; step counts from 1.  grad_scale multiplies g before the weight decay is added
- * (1 / loss scale: GradScaler.step unscales before the optimizer runs, ns/engine/optimizers.py:118-131, trainer.py:470-505). */
+ * p, g, m, v: [n] fp32, 16-byte aligned; step counts from 1.  grad_scale multiplies g before the weight decay is added:
+ * 1.0 = the reference's default (update_grad_scaler=False: optimizer.step() on the 2**10-scaled gradients, the weight decay is
+ * added to THOSE -- ns/engine/trainer.py:481-486, ns/engine/optimizers.py:133-140); 1 / loss scale = its update_grad_scaler=True
+ * branch (GradScaler.step unscales before the optimizer runs, ns/engine/optimizers.py:118-131). */
 int ps_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, float grad_scale, void* stream);
 /* The same update over n_ranges disjoint, non-empty ranges [start[i], start[i]+count[i]) (floats; start multiples of 4) of

@@ -766,6 +766,90 @@ def train_step(P, cfg, scene, batch, anneal: float = 1.0):
     return L, out, grads
 
 
+# --------------------------------------------------------------------------------------
+# f1  the training loop: schedules, Adam, N iterations (ns/engine/trainer.py:246-300, 463-505)
+# --------------------------------------------------------------------------------------
+def anneal_at(step: int, max_num_iters: int, slope: float = 10.0) -> float:
+    """proposal weight anneal, ns/models/PreSight/nerfacto_nusc_ms.py:423-434 (set_anneal callback, BEFORE each iteration)."""
+    x = float(np.clip(step / max_num_iters, 0, 1))
+    return slope * x / ((slope - 1) * x + 1)
+
+
+def proposal_update_sched(step: int, warmup: int, every: int = 5) -> float:
+    """ns/models/PreSight/nerfacto_nusc_ms.py:300-305."""
+    return float(np.clip(np.interp(step, [0, warmup], [0, every]), 1, every))
+
+
+def lr_at(t: int, lr_init: float, warmup_steps: int, milestones: Sequence[int], gamma: float = 0.33, start_factor: float = 0.01) -> float:
+    """learning rate after t scheduler steps: ChainedScheduler([LinearLR(start_factor 0.01, total_iters warmup_steps),
+    MultiStepLR(milestones, gamma 0.33)]), ns/engine/my_schedulers.py:50-70, in closed form."""
+    warm = start_factor + (1.0 - start_factor) * min(t, warmup_steps) / warmup_steps if warmup_steps else 1.0
+    return lr_init * warm * gamma ** sum(1 for m in milestones if m <= t)
+
+
+def adam_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, eps: float, weight_decay: float,
+                b1: float = 0.9, b2: float = 0.999):
+    """torch.optim.Adam (L2 weight decay added to the gradient, no amsgrad), in place; `step` = this parameter's own count of
+    updates including this one.  The gradient is whatever backward left in .grad: with PreSight's default
+    update_grad_scaler=False that is the 2**10-SCALED gradient, never unscaled (ns/engine/trainer.py:481-486,
+    ns/engine/optimizers.py:133-140) -- so weight_decay * p is added to 1024 * dL/dp."""
+    g = g + weight_decay * p
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def train_trajectory(P, cfg, scene, batches, max_iterations: int, loss_scale: float = 2.0 ** 10, lr: float = 1e-2, eps: float = 1e-15,
+                     weight_decay: float = 1e-5, proposal_update_every: int = 5, snapshots: Sequence[int] = ()):
+    """N = len(batches) training iterations as the reference's Trainer runs them for a PreSight method config with
+    `max_iterations` (ns/configs/method_configs.py:130-171: anneal / proposal warm-up over max_iterations // 10, LR warm-up over
+    max_iterations // 10, milestones at 1/4, 1/2, 3/4):
+      before:  set_anneal(step)                                                    nerfacto_nusc_ms.py:423-434
+      forward: proposal networks with gradients only when `updated`                ray_samplers.py:586, 601-606
+      backward of loss_scale * sum(loss_dict)                                      trainer.py:478-481 (GradScaler 2**10, never updated)
+      Adam on the scaled gradients for every parameter that received one (a parameter whose gradient is None -- proposal nets
+      off schedule, sub-fields without samples -- is skipped and keeps its step count)    optimizers.py:133-140
+      scheduler step                                                               trainer.py:499-505
+      after:   proposal_sampler.step_cb(step)                                      ray_samplers.py:566-569
+    -> dict(losses [N, 5] in loss_dict order, lr [N], anneal [N], updated [N], touched {name: [N]}, params (final), snaps {step: params})"""
+    Q = {k: v.detach().clone() for k, v in P.items()}
+    M = {k: torch.zeros_like(v) for k, v in Q.items()}
+    V = {k: torch.zeros_like(v) for k, v in Q.items()}
+    nstep = {k: 0 for k in Q}
+    warm = max_iterations // 10
+    miles = [max_iterations // 4, max_iterations // 2, max_iterations * 3 // 4]
+    steps_since_update, sampler_step = 0, 0
+    rec = dict(losses=[], lr=[], anneal=[], updated=[], touched={k: [] for k in Q}, snaps={})
+    for step, batch in enumerate(batches):
+        anneal = anneal_at(step, warm)
+        updated = steps_since_update > proposal_update_sched(sampler_step, warm, proposal_update_every) or sampler_step < 10
+        cur_lr = lr_at(step, lr, warm, miles)
+        Pg = {k: v.detach().clone().requires_grad_(True) for k, v in Q.items()}
+        out = model_forward(Pg, cfg, scene, batch, training=True, anneal=anneal, prop_requires_grad=updated)
+        L = loss_dict(out, batch, cfg)
+        (sum(L.values()) * loss_scale).backward()
+        if updated:
+            steps_since_update = 0
+        with torch.no_grad():
+            for k, pg in Pg.items():
+                rec["touched"][k].append(int(pg.grad is not None))
+                if pg.grad is not None:
+                    nstep[k] += 1
+                    adam_update(Q[k], pg.grad, M[k], V[k], nstep[k], cur_lr, eps, weight_decay)
+        sampler_step = step
+        steps_since_update += 1
+        rec["losses"].append([float(v.detach()) for v in L.values()])
+        rec["lr"].append(cur_lr)
+        rec["anneal"].append(anneal)
+        rec["updated"].append(int(updated))
+        if step in snapshots:
+            rec["snaps"][step] = {k: v.clone() for k, v in Q.items()}
+    rec["params"], rec["param_steps"] = Q, nstep
+    return rec
+
+
 def feature_colormap(feat: Tensor, dino_to_rgb: dict) -> Tensor:
     """PCA projection of 64-d features to RGB.  ns/utils/colormaps.py:212-234."""
     x = (feat - dino_to_rgb["mean"].to(feat)) @ dino_to_rgb["reduction_matrix"].to(feat)

@@ -113,8 +113,10 @@ __global__ void adam_commit_kernel(const int* __restrict__ flags, int* __restric
 }  // namespace
 
 // step >= 1; bias corrections bc1 = 1 - b1^step, bc2 = 1 - b2^step are evaluated on the host in double precision.
-// grad_scale multiplies the gradient before the weight decay is added (1 / loss scale: the reference's GradScaler.step unscales
-// the gradients before the optimizer sees them, ns/engine/optimizers.py:118-131).
+// grad_scale multiplies the gradient before the weight decay is added.  1.0 = the reference's default: PreSight runs
+// update_grad_scaler=False, so optimizer.step() sees the 2**10-scaled gradients and weight_decay * p is added to THOSE
+// (ns/engine/trainer.py:481-486, ns/engine/optimizers.py:133-140).  1 / loss scale = its update_grad_scaler=True branch, where
+// GradScaler.step unscales before the optimizer runs (ns/engine/optimizers.py:118-131).
 extern "C" int ps_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int step, float grad_scale, void* stream) {
   if (n == 0) return 0;

@@ -160,16 +160,23 @@ class FlatGrads:
         which also makes the host-side flags rank-independent (no flag all-reduce, no host sync)."""
         index = {id(p): i for i, p in enumerate(self.params)}
         n = 0
+        mine = set()
         for plist in groups:
             plist = [p for p in plist if id(p) in index]
             if not plist:
                 continue
             for p in plist:
-                if getattr(p, "_ps_group", None) is not None:
+                if id(p) in mine:
                     raise ValueError("FlatGrads.define_groups: a parameter belongs to two groups")
+                mine.add(id(p))
+                # a NEW owner takes the parameter over (a second Trainer / FlatGrads on the same model: exchange-mode comparisons,
+                # rebuilding the trainer after a checkpoint load); the previous owner's flags are no longer raised for it
                 p._ps_group = n
                 p._ps_group_owner = self
             n += 1
+        from . import field_ops  # (late: field_ops does not import this module)
+
+        field_ops._GROUP_TABLES.clear()  # mark_groups' cached group-id tables are keyed by the owner: drop the previous owner's
         self.n_groups = n
         dev = self.flat.device
         self.group_flags = torch.zeros(max(n, 1), device=dev, dtype=torch.int32)

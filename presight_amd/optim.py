@@ -16,9 +16,10 @@ from .ops import _p, _stream
 class HipAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-15,
                  weight_decay: float = 1e-5, flat_grads=None, grad_scale: float = 1.0):
-        """grad_scale: factor applied to every gradient inside the kernel before the weight decay is added -- 1 / loss_scale
-        when the backward pass was seeded with a loss scale (the reference's GradScaler.step unscales first,
-        ns/engine/optimizers.py:118-131).
+        """grad_scale: factor applied to every gradient inside the kernel before the weight decay is added.  1.0 (default) =
+        the reference's default path: with update_grad_scaler=False its Trainer calls optimizer.step() on the gradients exactly
+        as backward left them, loss scale included (ns/engine/trainer.py:481-486, optimizers.py:133-140).  1 / loss_scale = its
+        update_grad_scaler=True branch, where GradScaler.step unscales first (optimizers.py:118-131).
         flat_grads: a presight_amd.dist.FlatGrads over exactly `params` -> parameters and both moments are moved into
         flat buffers of the same layout (every parameter's storage is re-pointed to a view of the flat buffer, values
         kept) and the whole update is ONE kernel launch over the flat range instead of one per tensor."""
@@ -53,8 +54,10 @@ class HipAdam:
             self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
 
     @torch.no_grad()
-    def step(self):
-        """torch.optim.Adam semantics per PARAMETER: state["step"] (the bias-correction exponent) advances only for parameters
+    def step(self, skip=()):
+        """skip: indices of parameters whose update is withheld this step although they received a gradient (GradScaler.step
+        found an inf / nan in their group): treated like parameters without a gradient.
+        torch.optim.Adam semantics per PARAMETER: state["step"] (the bias-correction exponent) advances only for parameters
         that received a gradient this step; the others are skipped entirely (no decay, no moment update), like torch with
         grad None after zero_grad(set_to_none=True).  Proposal networks (a gradient every ~6th step after warm-up) and
         sub-fields that saw no sample therefore keep their own, smaller step counts."""
@@ -63,7 +66,10 @@ class HipAdam:
         if self.flat is not None:
             fg = self.flat_grads
             fg._join_side_streams()
-            idx = fg.touched_params()
+            idx = [i for i in fg.touched_params() if i not in skip]
+            if skip and fg.n_groups:  # device-decided groups of withheld parameters: lower their flags
+                for g_ in {getattr(self.params[i], "_ps_group", None) for i in skip} - {None}:
+                    fg.group_flags[g_] = 0
             gid = [getattr(self.params[i], "_ps_group", None) if fg.n_groups else None for i in idx]
             for i, gr in zip(idx, gid):
                 if gr is None:
@@ -97,7 +103,7 @@ class HipAdam:
             return
         for i, (p, m, v) in enumerate(zip(self.params, self.exp_avg, self.exp_avg_sq)):
             g = p.grad
-            if g is None:
+            if g is None or i in skip:
                 continue
             if not g.is_contiguous():
                 g = g.contiguous()

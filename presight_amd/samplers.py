@@ -190,7 +190,11 @@ class ProposalNetworkSampler(Sampler):
                 fn = density_fns[i_level]
                 arg = ray_samples if getattr(fn, "takes_ray_samples", False) else ray_samples.frustums.get_positions()
                 if updated and torch.is_grad_enabled():
-                    side = prop_stream(arg_device(arg))
+                    # positions handed to a plain density_fn are allocated on the caller's stream and owned by nobody after this call
+                    # (the caching allocator could hand their block out again while the side stream's backward still reads it):
+                    # only the RaySamples path -- whose tensors the model keeps alive in its outputs until the streams are joined --
+                    # goes to the side stream
+                    side = prop_stream(arg_device(arg)) if getattr(fn, "takes_ray_samples", False) else None
                     if side is None:
                         density = fn(arg)
                         weights = ray_samples.get_weights(density)
@@ -205,6 +209,10 @@ class ProposalNetworkSampler(Sampler):
                         cur = torch.cuda.current_stream()
                         side.wait_stream(cur)
                         with torch.cuda.stream(side):
+                            for obj in (ray_samples, ray_samples.ray_bundle):  # allocated on the compute stream, read on the side stream
+                                for tns in vars(obj).values():
+                                    if torch.is_tensor(tns) and tns.is_cuda:
+                                        tns.record_stream(side)
                             density = fn(arg)
                             weights = ray_samples.get_weights(density)
                         cur.wait_stream(side)

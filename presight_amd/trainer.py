@@ -1,7 +1,16 @@
 """One training iteration of the PreSight model on the HIP path: what ns/engine/trainer.py:463-505 (`train_iteration`) does
-per step -- optimizer.zero_grad, forward, get_loss_dict, backward of the loss-scaled sum (the reference's GradScaler: fixed
-2**10 while no inf/nan shows up), DDP gradient averaging, unscale + Adam (lr 1e-2, eps 1e-15, weight_decay 1e-5;
-ns/configs/method_configs.py:158-168) -- with the model's own training callbacks around it (trainer.py:252-267).
+per step -- optimizer.zero_grad, forward, get_loss_dict, backward of the loss-scaled sum, DDP gradient averaging, Adam
+(lr 1e-2, eps 1e-15, weight_decay 1e-5; ns/configs/method_configs.py:158-168), scheduler step -- with the model's own training
+callbacks around it (trainer.py:252-267).
+
+Loss scale.  The reference builds GradScaler(init_scale=2**10) even in fp32 (trainer.py:70-73,132) and PreSight runs it with
+`update_grad_scaler=False`: `grad_scaler.scale(loss).backward()` followed by `optimizers.optimizer_step_all()` = a plain
+`optimizer.step()` on the STILL-SCALED gradients (trainer.py:481-486, optimizers.py:133-140) -- nothing ever unscales.  Adam is
+invariant to the scale up to eps = 1e-15, but its L2 term is not: `weight_decay * p` is added to 1024 * dL/dp, i.e. the effective
+weight decay is 1e-5 / 1024.  That is the default here (grad_scale 1.0 inside the Adam kernel).  `update_grad_scaler=True` is the
+reference's other branch (optimizers.py:118-131, trainer.py:496-505): GradScaler.step per parameter group (unscale, skip the group's
+step on inf / nan), GradScaler.update (halve on inf, double after 2000 clean steps), and the schedulers are stepped only when the
+scale did not decrease.  Pinned by tests/golden/model_traj.npz (24 iterations of the reference's own loop).
 
 The reference's Trainer also owns logging, checkpoint rotation, the viewer and the datamanager; those are out of scope
 (SURVEY.md 8): this class is the timed region of bench.py and the object the parity tests step."""
@@ -15,7 +24,7 @@ import torch
 from . import ops, prof
 from .callbacks import TrainingCallbackAttributes, TrainingCallbackLocation
 from .dist import FlatGrads, global_depth_clip as _depth_hook
-from .optim import HipAdam
+from .optim import HipAdam, WarmupMultiStepSchedule
 from .rays import RayBundle
 
 
@@ -43,7 +52,12 @@ class Trainer:
                             updated parameters overlapped with the next step's ray generation / proposal sampling."""
 
     def __init__(self, model, scene: Dict, world: int = 1, exchange: str = "allreduce", global_depth_clip: bool = False,
-                 lr: float = 1e-2, eps: float = 1e-15, weight_decay: float = 1e-5, loss_scale: float = 2.0 ** 10):
+                 lr: float = 1e-2, eps: float = 1e-15, weight_decay: float = 1e-5, loss_scale: float = 2.0 ** 10,
+                 update_grad_scaler: bool = False, max_num_iterations: Optional[int] = None, schedule: Optional[Dict] = None):
+        """loss_scale = TrainerConfig.init_grad_scale, update_grad_scaler = TrainerConfig.update_grad_scaler (trainer.py:70-73).
+        max_num_iterations: builds the learning-rate schedule of the PreSight method configs (method_configs.py:158-168: warm-up over
+        max // 10 steps, x0.33 at max // 4, max // 2, 3 max // 4); `schedule` = explicit WarmupMultiStepSchedule keyword arguments;
+        neither: constant learning rate."""
         self.model, self.scene, self.world = model, scene, world
         groups = model.get_param_groups()
         # bucket-major order, in the order backward COMPLETES the groups on the GPU (buckets are exchanged strictly in this order).
@@ -83,12 +97,50 @@ class Trainer:
         if global_depth_clip and world > 1:
             ops.set_depth_clip_hook(_depth_hook())
         self.loss_scale = float(loss_scale)
-        # the backward pass is seeded with the loss scale; the optimizer kernel unscales (GradScaler.step: unscale_, then step)
-        self.opt = HipAdam(uniq, lr=lr, eps=eps, weight_decay=weight_decay, flat_grads=self.grads, grad_scale=1.0 / self.loss_scale)
+        self.update_grad_scaler = bool(update_grad_scaler)
+        self._growth_tracker = 0  # GradScaler defaults: growth_factor 2, backoff_factor 0.5, growth_interval 2000
+        self._bucket_sizes = sizes
+        # the backward pass is seeded with the loss scale; by default Adam steps on the scaled gradients like the reference
+        self.opt = HipAdam(uniq, lr=lr, eps=eps, weight_decay=weight_decay, flat_grads=self.grads,
+                           grad_scale=1.0 / self.loss_scale if self.update_grad_scaler else 1.0)
+        if schedule is None and max_num_iterations is not None:
+            schedule = dict(max_steps=max_num_iterations, warmup_steps=max_num_iterations // 10,
+                            milestones=[max_num_iterations // 4, max_num_iterations // 2, max_num_iterations * 3 // 4])
+        self.scheduler = WarmupMultiStepSchedule(self.opt, lr_init=lr, **schedule) if schedule is not None else None
         self.callbacks = model.get_training_callbacks(TrainingCallbackAttributes(optimizers=self.opt, grad_scaler=None, pipeline=None))
         self.step_idx = 0
         self._seed: Optional[torch.Tensor] = None
+        self._seed_value = self.loss_scale
         self.update_props_every_step = False
+
+    def _scaler_step(self) -> bool:
+        """update_grad_scaler=True: GradScaler.step per parameter group + GradScaler.update (optimizers.py:118-131,
+        trainer.py:496-498).  Like torch's GradScaler this reads the found-inf flags on the host (one sync per step).
+        -> whether the scale did NOT decrease (the schedulers are stepped only then)."""
+        fg = self.grads
+        fg._join_side_streams()
+        touched = set(fg.touched_params())
+        skip, any_inf, i = set(), False, 0
+        for n in self._bucket_sizes:
+            idx = [j for j in range(i, i + n) if j in touched]
+            i += n
+            if not idx:
+                continue  # optimizers.py:130: a group without gradients is not stepped (and reports no inf)
+            a, b = fg.offsets[idx[0]], fg.offsets[idx[-1]] + self.opt.params[idx[-1]].numel()
+            if not bool(torch.isfinite(fg.flat[a:b]).all()):
+                any_inf = True
+                skip.update(idx)
+        self.opt.grad_scale = 1.0 / self.loss_scale
+        self.opt.step(skip=skip)
+        if any_inf:
+            self.loss_scale *= 0.5
+            self._growth_tracker = 0
+        else:
+            self._growth_tracker += 1
+            if self._growth_tracker == 2000:
+                self.loss_scale *= 2.0
+                self._growth_tracker = 0
+        return not any_inf
 
     def _run_callbacks(self, where: TrainingCallbackLocation):
         for cb in self.callbacks:
@@ -108,18 +160,25 @@ class Trainer:
         rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1], metadata=meta, times=None if times is None else times.view(-1, 1))
         if self.update_props_every_step:
             m.proposal_sampler._steps_since_update = 1 << 30  # proposal nets receive gradients EVERY step (upper bound of the schedule)
-        out = m(rb)
+        out = m(rb, jitters=list(batch["jitter"])) if "jitter" in batch else m(rb)  # stored draws: parity runs only
         loss_dict = m.get_loss_dict(out, batch)
         # one concat + one reduction instead of a chain of scalar adds; the loss scale enters as the seed of the backward pass
         loss = torch.stack(list(loss_dict.values())).sum()
-        if self._seed is None:
+        if self._seed is None or float(self._seed_value) != self.loss_scale:
             self._seed = torch.full((), self.loss_scale, device=loss.device)
+            self._seed_value = self.loss_scale
         loss.backward(gradient=self._seed)
         ops.join_side_streams()  # the proposal networks' backward ran on their side stream: the exchange / optimizer wait for it
         with prof.region("exchange_exposed"):
             self.grads.finish_exchange()
         with prof.region("adam"):
-            self.opt.step()
+            if self.update_grad_scaler:
+                scale_kept = self._scaler_step()
+            else:
+                self.opt.step()  # on the scaled gradients (optimizer_step_all, optimizers.py:133-140)
+                scale_kept = True
+        if self.scheduler is not None and scale_kept:  # trainer.py:499-505
+            self.scheduler.step()
         self._run_callbacks(TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
         self.step_idx += 1
         return loss_dict, out

@@ -90,6 +90,49 @@ def model_k8_setup(G):
     return cfg, scene, P, batch
 
 
+@pytest.fixture(scope="session")
+def gold_model_traj():
+    return load_golden("model_traj")
+
+
+def model_traj_setup(G):
+    """(cfg, scene, params, batches) of tests/golden/model_traj.npz -- the reference's own 24-iteration training run (K = 3, the
+    reference's Optimizers / schedulers / callbacks); parameters are regenerated from the fixture's seed exactly as
+    tests/golden/make_golden.py::traj_setup made them"""
+    from oracle import nerf_oracle as O
+
+    cfg = O.tiny_config()
+    cfg["num_fields"] = 3
+    cfg["num_cameras"], cfg["num_videos"] = 24, 2
+    for p in [cfg["main"]] + cfg["props"]:
+        p["log2_hashmap_size"] = 9
+    scene = O.make_scene(cfg)
+    scene["centroids"], scene["aabbs"] = t(G["centroids"]), t(G["aabbs"])
+    P = O.make_params(cfg, seed=int(G["seed"]), table_scale=0.3)
+    for k in range(cfg["num_fields"]):
+        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = -2.5
+        for i in range(2):
+            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = -2.0
+    assert list(P) == [str(k) for k in G["keys"]]
+    n = int(G["n_steps"])
+    batches = [{k[2:]: (t(G[k][s]).float() if G[k].dtype == np.float16 else t(G[k][s])) for k in G if k.startswith("B_")} for s in range(n)]
+    return cfg, scene, P, batches
+
+
+def traj_param_error(got, ref, init):
+    """distance of two parameter sets after the same training run, per tensor, RELATIVE TO THE DISTANCE THE RUN MOVED THE TENSOR:
+    ||got - ref||_2 / ||ref - init||_2.  (Adam with eps = 1e-15 normalises every gradient entry: an entry whose gradient is pure
+    rounding noise still moves by +-lr, with a sign that any two fp32 evaluations may disagree on -- a max-norm over entries would
+    measure those coin flips; the 2-norm against the total movement measures whether the run was the same run.)"""
+    out = {}
+    for k, r in ref.items():
+        g = got[k].detach().cpu().double()
+        r = r.double()
+        moved = float((r - init[k].double()).norm())
+        out[k] = float((g - r).norm()) / max(moved, 1e-30) if moved > 0 else float((g - r).abs().max())
+    return out
+
+
 def grad_error_stats(named_grads, ref_grads):
     """Per-tensor max |got - ref| / max|ref| of a set of parameter gradients against the oracle's, as a sorted tensor plus the
     name of the worst one; tensors whose reference gradient is exactly zero must be exactly zero (asserted) and are counted."""
@@ -120,13 +163,16 @@ def to_double(x):
     return x
 
 
-def assert_grads_within_oracle_noise(named_grads, g32, g64, floor: float = 5e-5, factor: float = 4.0, what: str = "gradients"):
+def assert_grads_within_oracle_noise(named_grads, g32, g64, floor: float = 5e-5, factor: float = 4.0, what: str = "gradients",
+                                     cap: float = 1e-2, q90: float = 1e-3):
     """Parameter gradients against the fp32 oracle with a bound that is computed, not guessed: the fp32 oracle's own distance from
     its fp64 run.  ReLU networks amplify one-ulp differences into flipped units / moved samples, so single networks of an fp32 run
     can sit 1e-3 away from the exact gradient while the rest agrees to 1e-6; a flat tolerance is either blind or flaky.  A flipped
     unit perturbs every tensor of its network, so the noise is taken per NETWORK (all tensors of one sub-field of one module:
-    `...fields.K.*`): bound(tensor) = max(floor, factor * max over its network of max|g32 - g64| / max|g64|); errors are
-    max|got - g32| / max|g32|.  -> (sorted errors, names, bounds in the same order)"""
+    `...fields.K.*`): bound(tensor) = min(cap, max(floor, factor * max over its network of max|g32 - g64| / max|g64|)); errors are
+    max|got - g32| / max|g32|.  The computed bound is CAPPED (an ill-conditioned oracle network must not open a percent-level
+    window for every tensor of that network), the 90th percentile of all errors must stay below `q90`, and the networks whose
+    bound was inflated beyond 10 x floor are printed.  -> (sorted errors, names, bounds in the same order)"""
     import re
 
     def network(name):
@@ -147,10 +193,16 @@ def assert_grads_within_oracle_noise(named_grads, g32, g64, floor: float = 5e-5,
             assert float(got.abs().max()) == 0, f"{name}: the reference gradient is exactly zero"
             continue
         err = float((got - ref).abs().max()) / scale
-        rows.append((err, name, max(floor, factor * noise[network(name)])))
+        rows.append((err, name, min(cap, max(floor, factor * noise[network(name)]))))
     rows.sort()
+    inflated = sorted({network(n) for _, n, b in rows if b > 10 * floor})
+    if inflated:
+        print(f"{what}: oracle fp32-vs-fp64 noise inflates the bound of {[(n, f'{factor * noise[n]:.1e}') for n in inflated]}")
     bad = [(n, f"{e:.1e}", f"bound {b:.1e}") for e, n, b in rows if e > b]
     assert not bad, f"{what}: {bad}"
+    if rows:
+        e90 = rows[min(len(rows) - 1, int(0.9 * len(rows)))][0]
+        assert e90 < q90, f"{what}: 90th percentile of the per-tensor errors {e90:.1e} >= {q90:.1e}"
     return [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows]
 
 
@@ -182,3 +234,33 @@ def assert_threshold_depth(depth, depth_ref, weights_ref, ebins_ref, threshold: 
     tol = 16 * S * torch.finfo(torch.float32).eps  # fp32 summation of S weights <= 1
     assert bool((margin <= tol).all()), f"{what}: {n_bad} rays differ, cumulative weight {margin.max():.2e} away from the threshold (> {tol:.1e})"
     return n_bad
+
+
+def build_hip_model(cfg, scene, P, dev, **conf_overrides):
+    """presight_amd's NerfactoNuscMSModel for an oracle-style (cfg, scene, params) triple, parameters loaded through the
+    reference's state-dict keys (and their mlp_base aliases)"""
+    from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
+
+    m = cfg["main"]
+    conf = NerfactoNuscMSModelConfig(
+        near_plane=cfg["near"], far_plane=cfg["far"], piecewise_sampler_threshold=cfg["thr"], hidden_dim=m["hidden_dim"],
+        hidden_dim_color=m["hidden_dim_color"], num_levels=m["num_levels"], base_res=m["base_res"], max_res=m["max_res"],
+        log2_hashmap_size=m["log2_hashmap_size"], features_per_level=m["features_per_level"],
+        proposal_net_args_list=[dict(features_per_level=p["features_per_level"], log2_hashmap_size=p["log2_hashmap_size"],
+                                     num_levels=p["num_levels"], base_res=p["base_res"], max_res=p["max_res"],
+                                     hidden_dim=p["hidden_dim"], use_linear=False) for p in cfg["props"]],
+        implementation="hip", use_lidar_loss=False, distortion_loss_mult=cfg["distortion_loss_mult"],
+        sky_mlp_dims=cfg["sky"]["width"], num_sky_mlp_layers=cfg["sky"]["num_layers"], **conf_overrides)
+    model = NerfactoNuscMSModel(conf, num_train_cameras=cfg["num_cameras"], num_train_videos=cfg["num_videos"],
+                                dino_to_rgb=scene.get("dino_to_rgb"), centroids=scene["centroids"], aabbs=scene["aabbs"])
+    sd = model.state_dict()
+    missing = [k for k in P if k not in sd]
+    assert not missing, missing
+    full = dict(sd)
+    for k, v in P.items():
+        full[k] = v
+        alias = k.replace("mlp_base_grid.", "mlp_base.0.").replace("mlp_base_mlp.", "mlp_base.1.").replace("encoding.hash_table", "mlp_base.0.hash_table")
+        if alias in full:
+            full[alias] = v
+    model.load_state_dict(full)
+    return model.to(dev)

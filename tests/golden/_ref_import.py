@@ -1,7 +1,6 @@
 """Container-only helper: make the reference's pure-torch NeRF path importable.
 
-Used ONLY by tests/golden/make_golden.py (fixture generation) and by
-tests/test_oracle_vs_reference.py (skipped when /root/reference is absent).
+Used ONLY by tests/golden/make_golden.py (fixture generation).
 Nothing here is imported by the product, the gpu tests, smoke() or bench.py.
 
 The reference (vendored nerfstudio 0.3.3) imports many packages that are not in

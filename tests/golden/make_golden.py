@@ -338,7 +338,7 @@ def gold_depth_losses():
 
 
 # ---------------------------------------------------------------------------- fields + whole model
-def _build_ref_model(cfg, scene, P):
+def _build_ref_model(cfg, scene, P, **conf_overrides):
     mod = __import__("importlib").import_module("nerfstudio.models.PreSight.nerfacto_nusc_ms")
     m = cfg["main"]
     conf = mod.NerfactoNuscMSModelConfig(
@@ -350,7 +350,7 @@ def _build_ref_model(cfg, scene, P):
                                      num_levels=p["num_levels"], base_res=p["base_res"], max_res=p["max_res"],
                                      hidden_dim=p["hidden_dim"], use_linear=False) for p in cfg["props"]],
         implementation="torch", use_lidar_loss=False, distortion_loss_mult=cfg["distortion_loss_mult"],
-        sky_mlp_dims=cfg["sky"]["width"], num_sky_mlp_layers=cfg["sky"]["num_layers"],
+        sky_mlp_dims=cfg["sky"]["width"], num_sky_mlp_layers=cfg["sky"]["num_layers"], **conf_overrides,
     )
     conf.enable_collider = False
     conf.collider_params = None
@@ -644,12 +644,134 @@ def gold_datafeed():
     save("datafeed", **arrs)
 
 
+def traj_setup():
+    """(cfg, scene, params, schedule constants) of the training-trajectory fixture -- shared with tests/conftest.py through the
+    values stored in the fixture itself.  Three sub-fields whose centroids are placed so that routing is NOT uniform: c0 / c1
+    split the cameras (sky model: routed by ray origin), c2 sits 12 units above the rig, so only the far samples of rays pointing
+    upwards reach it -- a batch drawn from the lower image half leaves sub-field 2 of every routed module without samples."""
+    cfg = O.tiny_config()
+    cfg["num_fields"] = 3
+    cfg["num_cameras"], cfg["num_videos"] = 24, 2
+    for p in [cfg["main"]] + cfg["props"]:
+        p["log2_hashmap_size"] = 9
+    scene = O.make_scene(cfg)
+    scene["centroids"] = torch.tensor([[-0.5, 0.0, 0.0], [0.5, 0.0, 0.0], [0.0, 0.0, 12.0]])
+    ext = 2.25
+    scene["aabbs"] = torch.stack([torch.stack([c - ext, c + ext]) for c in scene["centroids"]])
+    P = O.make_params(cfg, seed=11, table_scale=0.3)
+    for k in range(cfg["num_fields"]):
+        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = -2.5
+        for i in range(2):
+            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = -2.0
+    return cfg, scene, P
+
+
+def gold_model_traj():
+    """N training iterations of the REFERENCE: its NerfactoNuscMSModel (K = 3), its own training callbacks (anneal + proposal
+    update schedule, nerfacto_nusc_ms.py:417-450), its Optimizers object (one torch.optim.Adam(lr 1e-2, eps 1e-15, wd 1e-5) and one
+    WarmupMultiStepScheduler per parameter group, method_configs.py:158-168 with max_iterations = 60) driven exactly as
+    Trainer.train_iteration does for PreSight's default update_grad_scaler=False (ns/engine/trainer.py:463-505):
+        zero_grad_all -> forward -> loss = sum(loss_dict) -> grad_scaler.scale(loss).backward() -> optimizer_step_all()
+        (Adam on the STILL-SCALED gradients, weight decay added to them) -> scheduler_step_all
+    torch's GradScaler disables itself on a CUDA-less host, so the fixed 2**10 scale (init_grad_scale, never updated) is applied
+    as a factor on the loss -- the same arithmetic grad_scaler.scale() performs on the GPU."""
+    eng_opt = __import__("importlib").import_module("nerfstudio.engine.optimizers")
+    eng_sch = __import__("importlib").import_module("nerfstudio.engine.my_schedulers")
+    eng_cb = __import__("importlib").import_module("nerfstudio.engine.callbacks")
+    cfg, scene, P = traj_setup()
+    MAX_IT, N_STEPS, R_, SCALE = 60, 24, 64, 2.0 ** 10
+    LOWER_HALF = (3, 12, 13, 18)   # batches drawn from image rows >= 450 (rays level or pointing down): sub-field 2 gets nothing
+    FRAMES_01 = (5, 13, 20)        # batches from the cameras of frames 0-1 only: sky sub-field 1 gets no ray
+    model, mod = _build_ref_model(cfg, scene, P, proposal_weights_anneal_max_num_iters=MAX_IT // 10, proposal_warmup=MAX_IT // 10)
+    groups = model.get_param_groups()
+    mk = lambda: {"optimizer": eng_opt.AdamOptimizerConfig(lr=1e-2, eps=1e-15, weight_decay=1e-5),  # noqa: E731
+                  "scheduler": eng_sch.WarmupMultiStepSchedulerConfig(max_steps=MAX_IT, milestones=[MAX_IT // 4, MAX_IT // 2, MAX_IT * 3 // 4],
+                                                                      warmup_steps=MAX_IT // 10)}
+    optimizers = eng_opt.Optimizers({"proposal_networks": mk(), "fields": mk()}, groups)
+    callbacks = model.get_training_callbacks(eng_cb.TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=None))
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    keys = [k for k in P]
+    batches = []
+    for step in range(N_STEPS):
+        b = O.make_batch(cfg, scene, R_, step=100 + step)
+        if step in LOWER_HALF:
+            b["ray_indices"][:, 1] = 450 + b["ray_indices"][:, 1] % 450
+        if step in FRAMES_01:
+            b["ray_indices"][:, 0] = b["ray_indices"][:, 0] % 12
+            b["video_ids"] = torch.clamp(b["ray_indices"][:, 0] // scene["frames_per_video"], max=cfg["num_videos"] - 1)
+        b["features"] = b["features"].to(torch.float16).float()  # stored as fp16: the run sees exactly the stored values
+        batches.append(b)
+    model.train()
+    # conditioning (see gold_model): rays that hit nothing at the initial parameters are labelled sky
+    for b in batches:
+        with torch.no_grad(), PatchedRand([b["jitter"][0], b["jitter"][1], b["jitter"][2]]):
+            acc0 = model(_with_meta(_ray_bundle(scene, b["ray_indices"]), b))["accumulation"][:, 0]
+        b["sky"] = torch.where(acc0 < 1e-3, torch.ones_like(b["sky"]), b["sky"])
+    model.proposal_sampler._steps_since_update = 0
+    model.proposal_sampler._step = 0
+    losses, lrs, updated, anneals, touched, snaps = [], [], [], [], [], {}
+    loss_names = None
+    for step in range(N_STEPS):
+        b = batches[step]
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=eng_cb.TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        lrs.append(optimizers.optimizers["fields"].param_groups[0]["lr"])
+        assert lrs[-1] == optimizers.optimizers["proposal_networks"].param_groups[0]["lr"]
+        anneals.append(float(model.proposal_sampler._anneal))
+        optimizers.zero_grad_all()
+        with PatchedRand([b["jitter"][0], b["jitter"][1], b["jitter"][2]]):
+            out = model(_with_meta(_ray_bundle(scene, b["ray_indices"]), b))
+        ld = model.get_loss_dict(out, {"rgb": b["rgb"], "features": b["features"], "sky": b["sky"]})
+        import functools
+        loss = functools.reduce(torch.add, ld.values())
+        (loss * SCALE).backward()
+        optimizers.optimizer_step_all()
+        optimizers.scheduler_step_all(step)
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=eng_cb.TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+        loss_names = list(ld.keys())
+        losses.append([float(v) for v in ld.values()])
+        named = dict(model.named_parameters())
+        touched.append([int(named[k].grad is not None) for k in keys])
+        updated.append(int(any(named[k].grad is not None for k in keys if k.startswith("proposal_networks."))))
+        if step in (11, N_STEPS - 1):
+            snaps[step] = {k: v.detach().clone() for k, v in model.state_dict().items() if k in P}
+    touched = np.array(touched, dtype=np.int8)
+    updated = np.array(updated, dtype=np.int8)
+    # what this fixture is for: off-schedule proposal steps and sub-fields without samples must actually occur
+    prop_keys = [i for i, k in enumerate(keys) if k.startswith("proposal_networks.")]
+    assert updated[:11].all() and updated.tolist()[11:] == [0, 0, 0, 0, 0, 1] * 2 + [0], updated  # ray_samplers.py:586 with warm-up 6
+    f2 = [i for i, k in enumerate(keys) if ".fields.2." in k and not k.startswith("sky_model")]
+    for s in range(N_STEPS):
+        if s in LOWER_HALF:
+            assert not touched[s, f2].any(), s
+    assert touched[[s for s in range(N_STEPS) if s not in LOWER_HALF and updated[s]]][:, f2].all()
+    s1 = [i for i, k in enumerate(keys) if k.startswith("sky_model.fields.1.")]
+    s2 = [i for i, k in enumerate(keys) if k.startswith("sky_model.fields.2.")]
+    assert not touched[list(FRAMES_01)][:, s1].any() and touched[[s for s in range(N_STEPS) if s not in FRAMES_01]][:, s1].all()
+    assert not touched[:, s2].any()
+    print("updated:", updated.tolist())
+    print("lr:", [f"{x:.5f}" for x in lrs])
+    print("total loss:", [f"{sum(l):.4f}" for l in losses])
+    arrs = dict(centroids=scene["centroids"], aabbs=scene["aabbs"], seed=np.array(11), max_iterations=np.array(MAX_IT),
+                n_steps=np.array(N_STEPS), loss_scale=np.array(SCALE), loss_names=np.array(loss_names), losses=np.array(losses, dtype=np.float64),
+                lr=np.array(lrs, dtype=np.float64), anneal=np.array(anneals, dtype=np.float64), updated=updated, touched=touched,
+                keys=np.array(keys))
+    for k in ("ray_indices", "video_ids", "rgb", "features", "sky", "jitter"):
+        v = torch.stack([b[k] for b in batches])
+        arrs["B_" + k] = v.to(torch.float16) if k == "features" else v   # (targets: fp16-representable values, half the bytes)
+    for step, sd in snaps.items():
+        for k, v in sd.items():
+            arrs[f"S{step}_" + k] = v
+    save("model_traj", **arrs)
+
+
 def _with_meta(rb, batch):
     rb.metadata["video_id"] = batch["video_ids"][:, None]
     return rb
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "model_k8", "extract", "datafeed"]
+    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "model_k8", "model_traj", "extract", "datafeed"]
     for w in which:
         globals()["gold_" + w]()

@@ -333,6 +333,40 @@ def test_whole_model_training_step_k8_production_shape(gold_model_k8):
             assert float(g.abs().max()) == 0.0, name
 
 
+def test_training_trajectory_matches_the_reference_loop(gold_model_traj):
+    """24 iterations of the REFERENCE's own training loop (its model, callbacks, Optimizers: torch.optim.Adam per parameter group
+    on the 2**10-scaled gradients, WarmupMultiStepScheduler; tests/golden/make_golden.py::gold_model_traj) against the oracle's
+    restatement of that loop: learning rate, anneal, the proposal update schedule (11 warm-up steps, then every 6th), which
+    parameters received a gradient in which step (off-schedule proposal networks, sub-fields without samples), the five losses
+    of every step and the parameters after 12 and 24 steps.  Bounds are computed: the oracle's own fp32-vs-fp64 distance."""
+    from conftest import model_traj_setup, to_double, traj_param_error
+
+    G = gold_model_traj
+    cfg, scene, P, batches = model_traj_setup(G)
+    M = int(G["max_iterations"])
+    r32 = O.train_trajectory(P, cfg, scene, batches, M, loss_scale=float(G["loss_scale"]), snapshots=(11,))
+    r64 = O.train_trajectory(to_double(P), cfg, to_double(scene), to_double(batches), M, loss_scale=float(G["loss_scale"]), snapshots=(11,))
+    assert r32["updated"] == G["updated"].tolist() and 0 in r32["updated"][11:] and 1 in r32["updated"][11:]
+    np.testing.assert_allclose(r32["lr"], G["lr"], rtol=1e-12)
+    np.testing.assert_allclose(r32["anneal"], G["anneal"], rtol=1e-12)
+    for i, k in enumerate(G["keys"]):
+        assert r32["touched"][str(k)] == G["touched"][:, i].tolist(), k
+    assert [str(n) for n in G["loss_names"]] == ["rgb_loss", "sky_loss", "semantic_loss", "interlevel_loss", "distortion_loss"]
+    l32, l64, ref = np.array(r32["losses"]), np.array(r64["losses"]), G["losses"]
+    bound = 1e-5 * np.abs(ref) + 4 * np.abs(l32 - l64) + 1e-9
+    assert (np.abs(l32 - ref) <= bound).all(), np.argwhere(np.abs(l32 - ref) > bound)
+    for tag, p32, p64 in (("S11", r32["snaps"][11], r64["snaps"][11]), ("S23", r32["params"], r64["params"])):
+        want = {k: t(G[f"{tag}_{k}"]) for k in P}
+        err, noise = traj_param_error(p32, want, P), traj_param_error(p32, p64, P)
+        bad = {k: (e, noise[k]) for k, e in err.items() if e > max(2e-5, 4 * noise[k])}
+        assert not bad, (tag, bad)
+    # the fixture separates the two loss-scale semantics by five orders of magnitude: Adam on UNSCALED gradients (weight decay
+    # 1024 x stronger relative to them) ends somewhere else
+    r1 = O.train_trajectory(P, cfg, scene, batches, M, loss_scale=1.0)
+    err1 = traj_param_error(r1["params"], {k: t(G[f"S23_{k}"]) for k in P}, P)
+    assert max(err1.values()) > 0.5
+
+
 def test_whole_model_eval_and_extraction(gold_model):
     G = gold_model
     cfg, scene, P, batch = model_fixture_setup(G)

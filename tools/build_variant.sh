@@ -7,7 +7,7 @@ mkdir -p $out/$name
 cd /root/repo/presight_amd/csrc
 for f in *.hip lib.cpp; do
   x=""; [[ $f == *.cpp ]] && x="-x hip"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -fno-gpu-rdc -Wno-unused-result -I. "$@" $x -c $f -o $out/$name/${f%.*}.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -I. "$@" $x -c $f -o $out/$name/${f%.*}.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/lib_$name.so $out/$name/*.o
