@@ -82,6 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--fixed-batches", action="store_true", help="recycle 4 pre-made batches instead of the device chunk feed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg3 / cfg4 / extraction measurements of the default line")
+    ap.add_argument("--psnr-steps", type=int, default=300, help="iterations of the learnable-scene training run behind `psnr_after_k_steps` (0: skip)")
     return ap.parse_args(argv)
 
 
@@ -106,7 +107,7 @@ def self_launch(args) -> int:
 
 
 # --------------------------------------------------------------------------------------------------------- workload
-def build_model(dev, seed, config="cfg2"):
+def build_model(dev, seed, config="cfg2", **overrides):
     import torch
 
     from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
@@ -115,6 +116,7 @@ def build_model(dev, seed, config="cfg2"):
     c = CONFIGS[config]
     common = dict(near_plane=0.005, far_plane=50.0, piecewise_sampler_threshold=5.0, implementation="hip", use_lidar_loss=False,
                   proposal_weights_anneal_max_num_iters=10000, proposal_warmup=10000, **c["model"])
+    common.update(overrides)
     scene = make_scene(1440, 6, K=c["K"])
     if "dynamic" in c:
         from presight_amd.dynamic import NerfactoNuscDualModel, NerfactoNuscDualModelConfig
@@ -351,6 +353,68 @@ def psnr_vs_oracle(O, cfg, scene, rays=1024):
             "max_abs_semantics": float((out["semantics"].cpu() - ref["semantics"]).abs().max()),
             "max_rel_expected_depth": float(((out["expected_depth"].cpu() - ref["expected_depth"]).abs()
                                              / ref["expected_depth"].abs().clamp_min(1e-6)).max())}
+
+
+# --------------------------------------------------------------------------------------------------------- training quality
+def psnr_after_k_steps(dev, config="cfg2", K=300, rays=RAYS, marks=6):
+    """"PSNR vs synthetic GT after K steps"  -- the quality half of BASELINE.json's metric as a TRAINING figure.  A
+    complete miniature run of the reference's loop (presight_amd.trainer.Trainer with max_num_iterations = K: anneal and proposal
+    warm-up over K // 10, LR warm-up over K // 10, x0.33 at K/4, K/2, 3K/4; the reference's proposal update schedule; Adam on the
+    2**10-scaled gradients) on a LEARNABLE scene: per-pixel targets rendered by a fixed teacher parameter set of the same model
+    (presight_amd/synthetic.py), 4 M training pixels served by the device chunk feed, 65 536 held-out rays.  PSNR = 10 log10(1/MSE)
+    of the eval render (ns/models/PreSight/nerfacto_nusc_ms.py:548-556) at `marks` + 1 evenly spaced checkpoints."""
+    import gc
+
+    import torch
+
+    from presight_amd.datafeed import ChunkFeed
+    from presight_amd.synthetic import TEACHER_FAR, TeacherScene, eval_psnr, shape_teacher_
+    from presight_amd.trainer import Trainer as _Trainer
+
+    t0 = time.perf_counter()
+    tmodel, scene = build_model(dev, seed=7, config=config, far_plane=TEACHER_FAR)
+    shape_teacher_(tmodel)
+    teacher = TeacherScene(tmodel, scene)
+    chunk = teacher.chunk(0, pixels=1 << 22)
+    g = torch.Generator(device=dev).manual_seed(99)
+    C, H, W = scene["c2w"].shape[0], scene["H"], scene["W"]
+    tri = torch.stack([torch.randint(0, C, (RAYS,), device=dev, generator=g), torch.randint(0, H, (RAYS,), device=dev, generator=g),
+                       torch.randint(0, W, (RAYS,), device=dev, generator=g)], -1)
+    tvid = torch.clamp(tri[:, 0] // scene["frames_per_video"], max=5)
+    test = teacher.targets(tri, tvid)
+    acc_q = [float(x) for x in torch.quantile(test["accumulation"], torch.tensor([0.05, 0.5, 0.95], device=dev))]
+    t_teacher = time.perf_counter() - t0
+    del teacher, tmodel
+    gc.collect()
+    torch.cuda.empty_cache()
+    model, scene = build_model(dev, seed=42, config=config, proposal_weights_anneal_max_num_iters=K // 10, proposal_warmup=K // 10)
+    tr = _Trainer(model, scene, 1, max_num_iterations=K)  # the reference's proposal update schedule and LR schedule
+    feed = ChunkFeed(lambda i: chunk, batch_size=rays, device=dev, world=1, rank=0)
+    at = sorted({round(K * i / marks) for i in range(marks + 1)})
+    psnr, rgb_loss = [], []
+    t1 = time.perf_counter()
+    for step in range(K + 1):
+        if step in at:
+            psnr.append(eval_psnr(model, scene, tri, tvid, test["rgb"]))
+        if step == K:
+            break
+        ld, _ = tr.step(feed.next_batch())
+        if step in (0, K - 1):
+            rgb_loss.append(float(ld["rgb_loss"].detach()))
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t1
+    feed.close()
+    res = {"workload": f"{K}-iteration run of the reference loop (max_num_iterations={K}) on the teacher-rendered scene, {rays} rays/step, "
+                       f"{config} model, 4 M training pixels, 65 536 held-out rays", "K": K, "at_steps": at,
+           "psnr_db": [round(x, 3) for x in psnr], "psnr_final_db": psnr[-1], "psnr_gain_db": psnr[-1] - psnr[0],
+           "monotone": all(b >= a - 0.25 for a, b in zip(psnr, psnr[1:])), "rgb_loss_first_last": rgb_loss,
+           "teacher": {"accumulation_q05_q50_q95": [round(x, 3) for x in acc_q], "sky_fraction": float(test["sky"].mean()),
+                       "rgb_std": float(test["rgb"].std())},
+           "seconds": {"teacher_render": round(t_teacher, 2), "train_and_eval": round(t_train, 2)}}
+    del tr, model, feed, chunk, test
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 # --------------------------------------------------------------------------------------------------------- roofline
@@ -868,6 +932,11 @@ def main():
             run_sec(["cfg4_65536"], lambda: {"cfg4_65536": secondary_training_lines("cfg4", [(65536, 4, 2)], dev)[65536]})
             run_sec(["extract_512"], lambda: {"extract_512": secondary_extract_line(dev)})
             line["secondary"] = sec
+        if world == 1 and args.config == "cfg2" and args.psnr_steps > 0:
+            try:
+                line["psnr_after_k_steps"] = psnr_after_k_steps(dev, "cfg2", K=args.psnr_steps)
+            except Exception as e:  # never takes the headline down
+                line["psnr_after_k_steps"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]

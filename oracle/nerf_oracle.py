@@ -653,13 +653,15 @@ def _routed(fn_per_field, assign: Tensor, K: int, outs_dims: Sequence[int]):
 # a14 + a17  whole-model forward (training or eval), losses, one training step
 # --------------------------------------------------------------------------------------
 def model_forward(P, cfg, scene, batch, training: bool = True, anneal: float = 1.0, prop_requires_grad: bool = True,
-                  main_override=None):
+                  main_override=None, prop_from_main: bool = False):
     """NerfactoNuscMSModel.forward (collider + get_outputs).
     ns/models/base_model.py:131-142, ns/models/PreSight/nerfacto_nusc_ms.py:452-546,
     ns/model_components/ray_samplers.py:572-614.
     main_override(static_eval, pos [R*S,3], dir_s, app_s, R, S) -> (sigma, rgb_s, sem_s, extras): hook used by
     oracle/dual_oracle.py (BASELINE cfg 4) to put a second field next to the static one; `static_eval()` evaluates the
-    reference's field exactly as below."""
+    reference's field exactly as below.
+    prop_from_main: the proposal levels are sampled from the MAIN field's density (the "teacher" of the learnable synthetic
+    scene places its samples by its own density: teacher_targets below)."""
     K = cfg["num_fields"]
     cent, aabbs = scene["centroids"], scene["aabbs"]
     o, d, _, _ = generate_rays(batch["ray_indices"], scene["c2w"], scene["fx"], scene["fy"], scene["cx"], scene["cy"])
@@ -687,7 +689,10 @@ def model_forward(P, cfg, scene, batch, training: bool = True, anneal: float = 1
             assign = route(pos, cent)
             ctx = torch.enable_grad() if (training and prop_requires_grad) else torch.no_grad()
             with ctx:
-                (sigma,) = _routed(lambda k, msk, i=lvl: (prop_density(P, cfg, i, k, pos[msk], aabbs[k]),), assign, K, [1])
+                if prop_from_main:
+                    (sigma,) = _routed(lambda k, msk: (main_density(P, cfg, k, pos[msk], aabbs[k])[0],), assign, K, [1])
+                else:
+                    (sigma,) = _routed(lambda k, msk, i=lvl: (prop_density(P, cfg, i, k, pos[msk], aabbs[k]),), assign, K, [1])
             w = weights_from_density(deltas, sigma.view(R, -1))
             bins_list.append(bins)
             weights_list.append(w)
@@ -848,6 +853,67 @@ def train_trajectory(P, cfg, scene, batches, max_iterations: int, loss_scale: fl
             rec["snaps"][step] = {k: v.clone() for k, v in Q.items()}
     rec["params"], rec["param_steps"] = Q, nstep
     return rec
+
+
+# --------------------------------------------------------------------------------------
+# learnable synthetic scene (SURVEY.md 8d "PSNR vs synthetic GT after K steps"): same construction as presight_amd/synthetic.py
+# --------------------------------------------------------------------------------------
+def teacher_params(cfg: dict, scene: dict, seed: int = 1234, max_res: float = 128, log_density=(-2.5, 2.0), rgb_gain: float = 32.0,
+                   sem_gain: float = 3.0, probe: int = 4096, init_seed: int = 77) -> Dict[str, Tensor]:
+    """The teacher of the learnable scene: make_params(init_seed) with the main hash tables redrawn U(-1, 1) on the levels of
+    resolution <= max_res and zero above; per sub-field the density head's output row rescaled / re-biased so that ln(density) has
+    mean / std `log_density` over `probe` points uniform in the sub-field's box; colour and semantic output layers amplified,
+    semantic output bias 0.5.  One generator, fixed draw order (tables in sorted key order, then the probe points of sub-field
+    0, 1, ...): identical to presight_amd.synthetic.shape_teacher_ (the same teacher on both sides, up to the fp32 rounding of the
+    probe statistics)."""
+    P = make_params(cfg, seed=init_seed)
+    g = torch.Generator().manual_seed(seed)
+    m = cfg["main"]
+    sc = hash_scalings(m["num_levels"], m["base_res"], m["max_res"])
+    for key in sorted(P):
+        if key.startswith("field.") and key.endswith("mlp_base_grid.hash_table"):
+            v = P[key]
+            L = sc.numel()
+            tab = torch.rand(v.shape, generator=g) * 2 - 1
+            tab.view(L, v.shape[0] // L, -1)[sc > max_res] = 0.0
+            v.copy_(tab)
+    for k in range(cfg["num_fields"]):
+        pre = f"field.fields.{k}"
+        box = scene["aabbs"][k]
+        pts = box[0] + (box[1] - box[0]) * torch.rand(probe, 3, generator=g)
+        with torch.no_grad():
+            sigma, _ = main_density(P, cfg, k, pts, box)
+        raw = torch.log(sigma.clamp_min(1e-30)).double()
+        mu, sdev = float(raw.mean()), float(raw.std())
+        gain = log_density[1] / sdev
+        W, b = P[f"{pre}.mlp_base_mlp.layers.1.weight"], P[f"{pre}.mlp_base_mlp.layers.1.bias"]
+        b0 = float(b[0])
+        W[0] *= gain
+        b[0] = log_density[0] - gain * (mu - b0)
+        P[f"{pre}.rgb_head.layers.2.weight"] *= rgb_gain
+        P[f"{pre}.semantic_head.layers.2.weight"] *= sem_gain
+        P[f"{pre}.semantic_head.layers.2.bias"].fill_(0.5)
+    return P
+
+
+def teacher_targets(Pt, cfg, scene, ray_indices: Tensor, video_ids: Tensor, sky_accumulation: float = 0.5, far: float = 5.0) -> Dict[str, Tensor]:
+    """per-pixel targets rendered by the teacher in eval mode, far plane `far` (beyond it the scene is empty), its samples placed by
+    its own density: rgb [n,3], features [n,64] clipped to [0,1], sky [n] = accumulation < 0.5"""
+    tc = dict(cfg)
+    tc["far"] = far
+    with torch.no_grad():
+        out = model_forward(Pt, tc, scene, dict(ray_indices=ray_indices, video_ids=video_ids), training=False, prop_from_main=True)
+    acc = out["accumulation"].reshape(-1)
+    return dict(rgb=out["rgb"], features=out["semantics"].clamp(0.0, 1.0), sky=(acc < sky_accumulation).to(acc.dtype),
+                accumulation=acc)
+
+
+def eval_psnr(P, cfg, scene, ray_indices: Tensor, video_ids: Tensor, target_rgb: Tensor) -> float:
+    """PSNR of the eval-mode render (no jitter, mean appearance code) against target pixels; eval clamps rgb to [0,1] before the
+    sky blend (renderers.py:221-228)"""
+    with torch.no_grad():
+        out = model_forward(P, cfg, scene, dict(ray_indices=ray_indices, video_ids=video_ids), training=False)
+    return psnr(out["rgb"], target_rgb)
 
 
 def feature_colormap(feat: Tensor, dino_to_rgb: dict) -> Tensor:

@@ -119,18 +119,29 @@ def model_traj_setup(G):
     return cfg, scene, P, batches
 
 
-def traj_param_error(got, ref, init):
+def traj_param_error(got, ref, init, trim: float = 0.01):
     """distance of two parameter sets after the same training run, per tensor, RELATIVE TO THE DISTANCE THE RUN MOVED THE TENSOR:
-    ||got - ref||_2 / ||ref - init||_2.  (Adam with eps = 1e-15 normalises every gradient entry: an entry whose gradient is pure
-    rounding noise still moves by +-lr, with a sign that any two fp32 evaluations may disagree on -- a max-norm over entries would
-    measure those coin flips; the 2-norm against the total movement measures whether the run was the same run.)"""
+    ||got - ref||_2 / ||ref - init||_2 over all entries but the `trim` fraction (at least one entry) with the largest |got - ref|.
+    Why trimmed: Adam with eps = 1e-15 normalises every gradient entry, so an entry whose gradient is pure rounding noise in some
+    step (a hash row reached only by samples of ~zero weight) still moves by +-lr in that step, with a sign any two fp32 evaluations
+    may disagree on: isolated entries differ by 2 lr (observed on MI355X: 1 of 1024 entries by 2.0e-4 = 2 x the first step's lr)
+    while the run as a whole is the same run.  The trimmed entries are bounded separately (traj_param_max_diff)."""
     out = {}
     for k, r in ref.items():
-        g = got[k].detach().cpu().double()
-        r = r.double()
-        moved = float((r - init[k].double()).norm())
-        out[k] = float((g - r).norm()) / max(moved, 1e-30) if moved > 0 else float((g - r).abs().max())
+        g = got[k].detach().cpu().double().flatten()
+        r = r.double().flatten()
+        d = (g - r).abs()
+        n_trim = max(1, int(trim * d.numel())) if d.numel() > 8 else 0
+        if n_trim:
+            d = torch.sort(d).values[:-n_trim]
+        moved = float((r - init[k].double().flatten()).norm())
+        out[k] = float(d.norm()) / max(moved, 1e-30) if moved > 0 else float(d.max())
     return out
+
+
+def traj_param_max_diff(got, ref):
+    """largest entry-wise |got - ref| over all tensors (the entries traj_param_error trims): a few Adam sign flips = a few lr"""
+    return max(float((got[k].detach().cpu().double() - r.double()).abs().max()) for k, r in ref.items())
 
 
 def grad_error_stats(named_grads, ref_grads):
@@ -164,15 +175,18 @@ def to_double(x):
 
 
 def assert_grads_within_oracle_noise(named_grads, g32, g64, floor: float = 5e-5, factor: float = 4.0, what: str = "gradients",
-                                     cap: float = 1e-2, q90: float = 1e-3):
+                                     cap: float = 5e-2, q90: float = 1e-3):
     """Parameter gradients against the fp32 oracle with a bound that is computed, not guessed: the fp32 oracle's own distance from
     its fp64 run.  ReLU networks amplify one-ulp differences into flipped units / moved samples, so single networks of an fp32 run
     can sit 1e-3 away from the exact gradient while the rest agrees to 1e-6; a flat tolerance is either blind or flaky.  A flipped
     unit perturbs every tensor of its network, so the noise is taken per NETWORK (all tensors of one sub-field of one module:
     `...fields.K.*`): bound(tensor) = min(cap, max(floor, factor * max over its network of max|g32 - g64| / max|g64|)); errors are
-    max|got - g32| / max|g32|.  The computed bound is CAPPED (an ill-conditioned oracle network must not open a percent-level
-    window for every tensor of that network), the 90th percentile of all errors must stay below `q90`, and the networks whose
-    bound was inflated beyond 10 x floor are printed.  -> (sorted errors, names, bounds in the same order)"""
+    max|got - g32| / max|g32|.  Three guards keep an ill-conditioned oracle network from opening a window a wrong gradient could
+    pass through: (1) the computed bound is CAPPED; (2) the 90th percentile of all per-tensor errors must stay below `q90`;
+    (3) every tensor of a network whose bound was inflated beyond 10 x floor must be AS CLOSE TO THE EXACT (fp64) GRADIENT AS THE
+    REFERENCE'S OWN fp32 RUN IS, in the 2-norm: ||got - g64|| / ||g64|| <= max(10 x floor, 2 x the network's largest
+    ||g32 - g64|| / ||g64||) -- a flipped unit moves single hash rows by percents (max-norm) but not the tensor as a whole, a
+    wrong gradient moves the whole tensor.  Inflated networks are printed.  -> (sorted errors, names, bounds in the same order)"""
     import re
 
     def network(name):
@@ -198,6 +212,18 @@ def assert_grads_within_oracle_noise(named_grads, g32, g64, floor: float = 5e-5,
     inflated = sorted({network(n) for _, n, b in rows if b > 10 * floor})
     if inflated:
         print(f"{what}: oracle fp32-vs-fp64 noise inflates the bound of {[(n, f'{factor * noise[n]:.1e}') for n in inflated]}")
+        rel2 = lambda a, b_: float((a.double() - b_.double()).norm()) / max(float(b_.double().norm()), 1e-300)  # noqa: E731
+        noise2 = {}
+        for _, n, _b in rows:
+            if network(n) in inflated:
+                noise2[network(n)] = max(noise2.get(network(n), 0.0), rel2(g32[n], g64[n]))
+        bad2 = []
+        for _, n, _b in rows:
+            if network(n) in inflated:
+                e2, b2 = rel2(named_grads[n].detach().cpu(), g64[n]), max(10 * floor, 2 * noise2[network(n)])
+                if e2 > b2:
+                    bad2.append((n, f"2-norm distance from the fp64 gradient {e2:.1e}", f"bound {b2:.1e} (the oracle's own fp32 run: {noise2[network(n)]:.1e})"))
+        assert not bad2, f"{what}: {bad2}"
     bad = [(n, f"{e:.1e}", f"bound {b:.1e}") for e, n, b in rows if e > b]
     assert not bad, f"{what}: {bad}"
     if rows:
@@ -264,3 +290,26 @@ def build_hip_model(cfg, scene, P, dev, **conf_overrides):
             full[alias] = v
     model.load_state_dict(full)
     return model.to(dev)
+
+
+def learnable_scene_setup(rays: int = 192, steps: int = 40, test_rays: int = 384):
+    """The learnable synthetic scene at fixture size, built by the ORACLE (oracle/nerf_oracle.py::teacher_params / teacher_targets;
+    presight_amd/synthetic.py is the same construction on the HIP side): tiny K = 1 model, a teacher parameter set, `steps` training
+    batches whose targets are the teacher's renders (+ stored jitters), a held-out test batch, and the student's initial parameters.
+    -> (cfg, scene, teacher params, batches, test batch, student params)"""
+    from oracle import nerf_oracle as O
+
+    cfg = O.tiny_config()
+    cfg["num_cameras"] = 24
+    for p in [cfg["main"]] + cfg["props"]:
+        p["log2_hashmap_size"] = 12
+    scene = O.make_scene(cfg)
+    Pt = O.teacher_params(cfg, scene, max_res=64)
+
+    def batch(step, n):
+        b = O.make_batch(cfg, scene, n, step=500 + step)
+        tgt = O.teacher_targets(Pt, cfg, scene, b["ray_indices"], b["video_ids"])
+        b.update(rgb=tgt["rgb"], features=tgt["features"], sky=tgt["sky"], accumulation=tgt["accumulation"])
+        return b
+
+    return cfg, scene, Pt, [batch(s, rays) for s in range(steps)], batch(9999, test_rays), O.make_params(cfg, seed=3)

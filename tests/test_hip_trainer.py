@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import build_hip_model, model_traj_setup, t, to_double, traj_param_error
+from conftest import build_hip_model, model_traj_setup, t, to_double, traj_param_error, traj_param_max_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def test_trainer_follows_the_reference_trajectory(gold_model_traj):
         lrs.append(tr.opt.lr)
         ld, out = tr.step(_dev_batch(batches[s], dev))
         assert abs(model.proposal_sampler._anneal - float(G["anneal"][s])) < 1e-12
-        losses.append([float(ld[str(n)]) for n in G["loss_names"]])
+        losses.append([float(ld[str(n)].detach()) for n in G["loss_names"]])
         steps_now = tr.opt.param_steps()
         for k, i in pidx.items():
             touched[k].append(steps_now[i] - steps_before[i])
@@ -64,10 +64,49 @@ def test_trainer_follows_the_reference_trajectory(gold_model_traj):
     for tag, mine, p32, p64 in (("S11", snaps[11], r32["snaps"][11], r64["snaps"][11]), ("S23", final, r32["params"], r64["params"])):
         want = {k: t(G[f"{tag}_{k}"]) for k in P}
         err, noise = traj_param_error(mine, want, P), traj_param_error(p32, p64, P)
-        bad = {k: (f"{e:.1e}", f"oracle noise {noise[k]:.1e}") for k, e in err.items() if e > max(1e-4, 4 * noise[k])}
+        bad = {k: (f"{e:.1e}", f"oracle noise {noise[k]:.1e}") for k, e in err.items() if e > max(5e-5, 4 * noise[k])}
         assert not bad, (tag, bad)
+        assert traj_param_max_diff(mine, want) <= 4 * float(G["lr"].max())  # the trimmed entries: a few Adam sign flips at most
         worst = max(worst, max(err.values()))
     print(f"24 reference iterations: max loss deviation {np.abs(got - ref).max():.1e}, worst parameter distance / movement {worst:.1e}")
+
+
+def test_learnable_scene_psnr_matches_the_oracle_run():
+    """"PSNR vs ref" as a TRAINING figure: the teacher-rendered scene at fixture size, the same 40-iteration
+    miniature run (max_iterations = 40) on the HIP trainer and on the oracle -- same targets, same stored jitters.  The teacher's
+    targets rendered by presight_amd.synthetic.TeacherScene equal the oracle's; the held-out eval PSNR rises on both sides and
+    lands within 0.1 dB of the oracle's."""
+    from conftest import learnable_scene_setup
+    from oracle import nerf_oracle as O
+    from presight_amd.synthetic import TEACHER_FAR, TeacherScene, eval_psnr
+    from presight_amd.trainer import Trainer
+
+    dev = torch.device("cuda:0")
+    cfg, scene, Pt, batches, test, P0 = learnable_scene_setup()
+    sdev = _scene_dev(scene, dev)
+    tcfg = dict(cfg)
+    tcfg["far"] = TEACHER_FAR
+    teacher = TeacherScene(build_hip_model(tcfg, scene, Pt, dev), sdev)
+    tgt = teacher.targets(test["ray_indices"].to(dev), test["video_ids"].to(dev))
+    for k, tol in (("rgb", 2e-5), ("features", 5e-5), ("accumulation", 2e-5)):
+        assert float((tgt[k].cpu().reshape(test[k].shape) - test[k]).abs().max()) < tol, k
+    assert torch.equal(tgt["sky"].cpu(), test["sky"])
+    K = len(batches)
+    model = build_hip_model(cfg, scene, P0, dev, proposal_weights_anneal_max_num_iters=K // 10, proposal_warmup=K // 10)
+    tr = Trainer(model, sdev, max_num_iterations=K)
+    tri, tvid, trgb = test["ray_indices"].to(dev), test["video_ids"].to(dev), test["rgb"].to(dev)
+    marks = (9, 19, 29, K - 1)
+    got = [eval_psnr(model, sdev, tri, tvid, trgb)]
+    for s in range(K):
+        tr.step(_dev_batch({k: v for k, v in batches[s].items() if k != "accumulation"}, dev))
+        if s in marks:
+            got.append(eval_psnr(model, sdev, tri, tvid, trgb))
+    r = O.train_trajectory(P0, cfg, scene, batches, K, snapshots=marks)
+    want = [O.eval_psnr(P0, cfg, scene, test["ray_indices"], test["video_ids"], test["rgb"])]
+    want += [O.eval_psnr(r["snaps"][s], cfg, scene, test["ray_indices"], test["video_ids"], test["rgb"]) for s in marks]
+    print("PSNR vs teacher after 0/10/20/30/40 iterations  HIP:", [round(x, 3) for x in got], " oracle:", [round(x, 3) for x in want])
+    assert got[-1] > got[0] + 6.0
+    assert all(abs(a - b) < 0.1 for a, b in zip(got, want)), (got, want)
 
 
 def test_update_grad_scaler_branch_skips_the_group_with_an_inf(gold_model_traj):
