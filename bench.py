@@ -454,19 +454,30 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=()):
     mac_prop = 8 * 64 + 64
     rows = []
 
-    def add(name, region, bound, work, unit, executed=None):
+    def add(name, region, bound, work, unit, executed=None, extra_regions=()):
+        """`frac` is what the hardware DID: matrix-core flops actually issued (padding included) / duration / peak for the MFMA rows --
+        never above 1 by construction -- and algorithmic bytes / duration / peak for the HBM rows.  `frac_algorithmic` prices the
+        flops the reference's unfactored network defines against the same duration: it exceeds `frac` where the
+        factored kernels do the same job with fewer matrix operations, and can exceed 1.  extra_regions: small launches that carry
+        work the kernel used to do (per-ray layers of the factored path); their time is added to the row's duration."""
         if region not in kern:
             return
         n, ms = kern[region]
         if not ms > 0:
             return
+        extra = {r: kern[r][1] * kern[r][0] / n for r in extra_regions if r in kern and kern[r][1] > 0}
+        ms_row = ms + sum(extra.values())
         peak = FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS
-        ach = work / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
-        row = dict(kernel=name, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, avg_launch_ms=ms, launches=n,
-                   algorithmic=work, timed_region=region in live)
-        if executed is not None:  # what the matrix cores actually execute (factored path: fewer MACs than the algorithm states)
-            row["executed"] = executed
-            row["frac_executed"] = executed / (ms * 1e-3) / 1e12 / peak
+        div = 1e12 if bound == "mfma" else 1e9
+        done = work if executed is None else executed
+        row = dict(kernel=name, bound=bound, achieved=done / (ms_row * 1e-3) / div, peak=peak, unit=unit, frac=done / (ms_row * 1e-3) / div / peak,
+                   avg_launch_ms=ms, launches=n, timed_region=region in live)
+        if bound == "mfma":
+            row.update(executed=done, algorithmic=work, frac_algorithmic=work / (ms_row * 1e-3) / div / peak)
+        else:
+            row.update(algorithmic=work)
+        if extra:
+            row.update(duration_ms_incl_moved_work=ms_row, moved_work_ms={k: round(v, 4) for k, v in extra.items()})
         rows.append(row)
 
     mac_base, mac_sem, mac_rgb = (L * F) * 64 + 64 * 80, 3 * 64 * 64, 47 * 64 + 64 * 64 + 64 * 3
@@ -476,19 +487,28 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=()):
     # `executed` counts the MACs the MFMA units perform, padding included (outputs padded to 16 rows).
     from presight_amd import field_ops
     fact = field_ops.FACTORED and "dynamic" not in cfg and cfg["K"] == 1
-    ex_base, ex_sem, ex_rgb = (L * F) * 64 + 64 * 16, 2 * 64 * 64, 16 * 64 + 64 * 64 + 64 * 16
-    ex = (lambda macs, k: 2 * k * macs * n_main) if fact else (lambda macs, k: None)
-    add("main_fwd_kernel", "main_field_fwd", "mfma", 2 * mac_main * n_main, "TFLOP/s", ex(ex_base + ex_sem + ex_rgb, 1))
+    LFp = (L * F + 3) // 4 * 4
+    if fact:
+        ex_base, ex_sem, ex_rgb = LFp * 64 + 64 * 16, 2 * 64 * 64, 16 * 64 + 64 * 64 + 64 * 16
+    else:  # the unfactored kernels: inputs padded to whole k-steps (47 -> 48), outputs to whole 16-row blocks (3 -> 16)
+        ex_base, ex_sem, ex_rgb = LFp * 64 + 64 * 80, 3 * 64 * 64, 48 * 64 + 64 * 64 + 64 * 16
+    ex = lambda macs, k: 2 * k * macs * n_main  # noqa: E731
+    add("main_fwd_kernel", "main_field_fwd", "mfma", 2 * mac_main * n_main, "TFLOP/s", ex(ex_base + ex_sem + ex_rgb, 1),
+        extra_regions=("sem_out_fwd", "ray_colour_fwd", "merge_linear_fwd") if fact else ())
     if n_params:  # dense Adam: p, m, v read + written, g read = 28 bytes per parameter
         add("adam_ranges_kernel", "adam", "hbm", 28.0 * n_params, "GB/s")
     # the main backward is three kernels (semantic head, colour head, base MLP), timed one by one
-    add("main_bwd_sem_kernel", "main_bwd_sem_kernel", "mfma", 2 * 2 * mac_sem * n_main, "TFLOP/s", ex(ex_sem, 2))
-    add("main_bwd_rgb_kernel", "main_bwd_rgb_kernel", "mfma", 2 * 2 * mac_rgb * n_main, "TFLOP/s", ex(ex_rgb, 2))
+    # (the merged layer's own rows of base layer 1 are priced with the semantic head in the factored split, as the kernels run them)
+    add("main_bwd_sem_kernel", "main_bwd_sem_kernel", "mfma", 2 * 2 * mac_sem * n_main, "TFLOP/s", ex(ex_sem, 2),
+        extra_regions=("sem_out_bwd", "merge_linear_bwd") if fact else ())
+    add("main_bwd_rgb_kernel", "main_bwd_rgb_kernel", "mfma", 2 * 2 * mac_rgb * n_main, "TFLOP/s", ex(ex_rgb, 2),
+        extra_regions=("ray_colour_bwd",) if fact else ())
     add("main_bwd_base_kernel", "main_bwd_base_kernel", "mfma", 2 * 2 * mac_base * n_main, "TFLOP/s", ex(ex_base, 2))
     add("main backward (the three kernels above, summed)", "main_field_bwd", "mfma", 2 * 2 * mac_main * n_main, "TFLOP/s",
-        ex(ex_base + ex_sem + ex_rgb, 2))
-    add("prop_bwd_kernel (both fields)", "prop_field_bwd", "mfma", 2 * 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s")
-    add("prop_fwd_kernel (both fields)", "prop_field_fwd", "mfma", 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s")
+        ex(ex_base + ex_sem + ex_rgb, 2), extra_regions=("sem_out_bwd", "merge_linear_bwd", "ray_colour_bwd") if fact else ())
+    # proposal MLP 8 -> 64 -> 1: the 64 x 8 layer runs on the matrix cores, the scalar head on the vector ALU (512 of 576 MACs executed as MFMA)
+    add("prop_bwd_kernel (both fields)", "prop_field_bwd", "mfma", 2 * 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s", 2 * 2 * 512 * (n_p0 + n_p1) / 2)
+    add("prop_fwd_kernel (both fields)", "prop_field_fwd", "mfma", 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s", 2 * 512 * (n_p0 + n_p1) / 2)
     add(f"grid_encode main (L{L} F{F})", f"grid_encode_L{L}F{F}", "hbm", n_main * L * 8 * F * 4, "GB/s")
     add("grid_encode proposal (L8 F1, mean of both)", "grid_encode_L8F1", "hbm", (n_p0 + n_p1) / 2 * 8 * 8 * 4, "GB/s")
     add(f"table backward main (absmax+bin+accumulate, L{L} F{F})", f"grid_scatter_L{L}F{F}", "hbm", 2 * n_main * L * 8 * F * 4, "GB/s")
@@ -880,9 +900,11 @@ def main():
                 "bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
                 "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC)",
                 "traffic_source": traffic_src, "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
-                # `achieved` prices the ALGORITHMIC flops of the unfactored network; the factored kernels execute
-                # fewer: frac_executed = matrix-core flops actually issued / duration / peak
-                "algorithmic_flops": dom["algorithmic"], "executed_flops": dom.get("executed"), "frac_executed": dom.get("frac_executed")},
+                # `achieved` / `frac`: the matrix-core flops the kernel actually ISSUES (padding included) / its HIP-event duration (+ the
+                # small per-ray launches that took over part of its work) / peak.  `frac_algorithmic` prices the flops of the reference's
+                # unfactored network (26 752 MAC per sample) against the same duration
+                "executed_flops": dom.get("executed"), "algorithmic_flops": dom["algorithmic"], "frac_algorithmic": dom.get("frac_algorithmic"),
+                "duration_ms_incl_moved_work": dom.get("duration_ms_incl_moved_work"), "moved_work_ms": dom.get("moved_work_ms")},
             "roofline_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows],
             "end_to_end": {"flop_per_ray": flop_ray, "hash_bytes_per_ray": byte_ray, "ceiling_mfma_rays_per_s": ceil_mfma,
                            "ceiling_hbm_rays_per_s": ceil_hbm, "binding": "mfma" if ceil_mfma < ceil_hbm else "hbm",

@@ -552,8 +552,9 @@ class _MainFieldRenderF(torch.autograd.Function):
         # merged first semantic layer: W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0
         Wb1, bb1, Ws0, bs0 = _f32(Wb1), _f32(bb1), _f32(Ws0), _f32(bs0)
         Wm, bm = torch.empty(64, hidden, device=dev), torch.empty(64, device=dev)
-        check(lib().ps_merge_linear_fwd(_p(Ws0), _p(bs0), Wb1.data_ptr() + 4 * 16 * hidden, bb1.data_ptr() + 4 * 16, 64, SEM_DIM, hidden,
-                                        _p(Wm), _p(bm), _stream()), "ps_merge_linear_fwd")
+        with prof.region("merge_linear_fwd"):
+            check(lib().ps_merge_linear_fwd(_p(Ws0), _p(bs0), Wb1.data_ptr() + 4 * 16 * hidden, bb1.data_ptr() + 4 * 16, 64, SEM_DIM, hidden,
+                                            _p(Wm), _p(bm), _stream()), "ps_merge_linear_fwd")
         packed = torch.empty(spec.packed, device=dev)
         descs = spec.base.pack_descs([(Wb0, bb0), (Wb1[:16], bb1[:16])], packed[: spec.base.packed])
         descs += spec.sem.pack_descs([(Wm, bm), (Ws1, bs1)], packed[spec.p_off[1]: spec.p_off[1] + spec.sem.packed])
@@ -567,7 +568,8 @@ class _MainFieldRenderF(torch.autograd.Function):
         app_c = _f32(app) if app is not None else None
         Wr0 = _f32(r0[0])
         ray_colour = torch.empty(R, hidden_color, device=dev)
-        check(lib().ps_ray_colour_fwd(_p(dirs), _p(app_c), _p(Wr0), R, A, hidden_color, _p(ray_colour), _stream()), "ps_ray_colour_fwd")
+        with prof.region("ray_colour_fwd"):
+            check(lib().ps_ray_colour_fwd(_p(dirs), _p(app_c), _p(Wr0), R, A, hidden_color, _p(ray_colour), _stream()), "ps_ray_colour_fwd")
         with prof.region("main_field_fwd"):
             check(lib().ps_main_field_f_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color, _p(sel),
                                             _p(ray_colour), _p(ebins), S, _p(packed), N, _p(sigma), _p(rgb_s), _p(w), _p(hid), _p(acts),
@@ -579,7 +581,8 @@ class _MainFieldRenderF(torch.autograd.Function):
                                      None, _p(minmax), _stream()), "ps_composite_fwd")
         sem = torch.empty(R, SEM_DIM, device=dev)
         Ws2, bs2 = _f32(Ws2), _f32(bs2)
-        check(lib().ps_sem_out_fwd(_p(hid), _p(acc), _p(Ws2), _p(bs2), R, SEM_DIM, _p(sem), _stream()), "ps_sem_out_fwd")
+        with prof.region("sem_out_fwd"):
+            check(lib().ps_sem_out_fwd(_p(hid), _p(acc), _p(Ws2), _p(bs2), R, SEM_DIM, _p(sem), _stream()), "ps_sem_out_fwd")
         ops._apply_minmax_hook(minmax)
         raw = expd.clone()
         check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
@@ -615,8 +618,9 @@ class _MainFieldRenderF(torch.autograd.Function):
         d_sem = _f32(d_sem) if d_sem is not None else torch.zeros(R, SEM_DIM, device=dev)
         # output layer of the semantic head, per ray: v = W_out^T d(sem), d(acc) += <d(sem), b_out>, dW_out / db_out
         v, cray = torch.empty(R, SEM_DIM, device=dev), torch.empty(R, 1, device=dev)
-        check(lib().ps_sem_out_bwd(_p(d_sem), _p(hid), _p(acc), _p(_f32(Ws2)), _p(_f32(bs2)), R, SEM_DIM, _p(v), _p(cray), _p(dWs2), _p(dbs2),
-                                   _stream()), "ps_sem_out_bwd")
+        with prof.region("sem_out_bwd"):
+            check(lib().ps_sem_out_bwd(_p(d_sem), _p(hid), _p(acc), _p(_f32(Ws2)), _p(_f32(bs2)), R, SEM_DIM, _p(v), _p(cray), _p(dWs2), _p(dbs2),
+                                       _stream()), "ps_sem_out_bwd")
         d_acc = cray if d_acc is None else _f32(d_acc) + cray
         if d_exp is not None:
             d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
@@ -656,8 +660,9 @@ class _MainFieldRenderF(torch.autograd.Function):
             else:
                 field_bwd(6, dsig)
         # direction / appearance columns of the colour head's first layer and d(appearance), per ray
-        check(lib().ps_ray_colour_bwd(_p(dray), _p(dirs), _p(app), _p(_f32(r0[0])), R, S, A, hidden_color, _p(dWr0), _p(dapp), _stream()),
-              "ps_ray_colour_bwd")
+        with prof.region("ray_colour_bwd"):
+            check(lib().ps_ray_colour_bwd(_p(dray), _p(dirs), _p(app), _p(_f32(r0[0])), R, S, A, hidden_color, _p(dWr0), _p(dapp), _stream()),
+                  "ps_ray_colour_bwd")
         dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.table_sink, counts, sink_owner=ctx.table_ref)
         # weight gradients: partial blocks -> torch layout.  Base layer 1: rows 0..15 (sigma_raw | geo15) directly, rows 16..79
         # through the merged layer (chain rule of W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0)
@@ -668,9 +673,10 @@ class _MainFieldRenderF(torch.autograd.Function):
         sinks = [(dWb0, dbb0), (dWb1[:16], dbb1[:16]), (dWm, dbm), (dWs1, dbs1), (dWr0, dbr0), (dWr1, dbr1), (dWr2, dbr2)]
         unpack_layers(descs, npart.value, spec.g_total, dev, sinks)
         Wb1c, bb1c = _f32(Wb1), _f32(bb1)
-        check(lib().ps_merge_linear_bwd(_p(dWm), _p(dbm), _p(_f32(Ws0)), Wb1c.data_ptr() + 4 * 16 * hidden, bb1c.data_ptr() + 4 * 16, 64, SEM_DIM,
-                                        hidden, _p(dWs0), _p(dbs0), dWb1.data_ptr() + 4 * 16 * hidden, dbb1.data_ptr() + 4 * 16, _stream()),
-              "ps_merge_linear_bwd")
+        with prof.region("merge_linear_bwd"):
+            check(lib().ps_merge_linear_bwd(_p(dWm), _p(dbm), _p(_f32(Ws0)), Wb1c.data_ptr() + 4 * 16 * hidden, bb1c.data_ptr() + 4 * 16, 64, SEM_DIM,
+                                            hidden, _p(dWs0), _p(dbs0), dWb1.data_ptr() + 4 * 16 * hidden, dbb1.data_ptr() + 4 * 16, _stream()),
+                  "ps_merge_linear_bwd")
         mark_touched(ctx.direct)
         return (None, None, None, dapp, None, None, None, dtable, None, None, *ret)
 

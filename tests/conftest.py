@@ -184,7 +184,7 @@ def assert_grads_within_oracle_noise(named_grads, g32, g64, floor: float = 5e-5,
     max|got - g32| / max|g32|.  Three guards keep an ill-conditioned oracle network from opening a window a wrong gradient could
     pass through: (1) the computed bound is CAPPED; (2) the 90th percentile of all per-tensor errors must stay below `q90`;
     (3) every tensor of a network whose bound was inflated beyond 10 x floor must be AS CLOSE TO THE EXACT (fp64) GRADIENT AS THE
-    REFERENCE'S OWN fp32 RUN IS, in the 2-norm: ||got - g64|| / ||g64|| <= max(10 x floor, 2 x the network's largest
+    REFERENCE'S OWN fp32 RUN IS, in the 2-norm: ||got - g64|| / ||g64|| <= max(10 x floor, factor x the network's largest
     ||g32 - g64|| / ||g64||) -- a flipped unit moves single hash rows by percents (max-norm) but not the tensor as a whole, a
     wrong gradient moves the whole tensor.  Inflated networks are printed.  -> (sorted errors, names, bounds in the same order)"""
     import re
@@ -220,7 +220,7 @@ def assert_grads_within_oracle_noise(named_grads, g32, g64, floor: float = 5e-5,
         bad2 = []
         for _, n, _b in rows:
             if network(n) in inflated:
-                e2, b2 = rel2(named_grads[n].detach().cpu(), g64[n]), max(10 * floor, 2 * noise2[network(n)])
+                e2, b2 = rel2(named_grads[n].detach().cpu(), g64[n]), max(10 * floor, factor * noise2[network(n)])
                 if e2 > b2:
                     bad2.append((n, f"2-norm distance from the fp64 gradient {e2:.1e}", f"bound {b2:.1e} (the oracle's own fp32 run: {noise2[network(n)]:.1e})"))
         assert not bad2, f"{what}: {bad2}"
