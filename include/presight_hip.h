@@ -218,6 +218,12 @@ int ps_main_field_gated_sizes(int LF, int hidden, int hidden_color, int64_t* pac
 int ps_main_field_fwd_gated(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
                             const float* packed, int64_t N, const float* gate_a, const float* gate_b, float gate_threshold,
                             float* sigma, float* sem, void* stream);
+/* the same gated query for the K routed sub-fields of a production tile (ns/fields/PreSight/ingp_field_ms.py:97-126 evaluated by
+ * ns/scripts/extract_priors.py:133-138): feat / sel in the sorted layout of ps_ms_route (n_slots), packed = K blocks of the
+ * ps_main_field_gated_sizes layout back to back, gate_a / gate_b / sigma / sem in the CALLER's point order (reached through perm). */
+int ps_main_field_fwd_gated_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
+                               const float* packed, int64_t n_slots, const float* gate_a, const float* gate_b, float gate_threshold,
+                               float* sigma, float* sem, const int32_t* perm, const int32_t* field_start, int K, void* stream);
 int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                       const float* sel, const float* dirs, const float* app, int S, int A, const float* packed, int64_t N,
                       float* sigma, float* rgb, float* sem, float* acts /* nullable: [ceil(N/16)*16, ps_main_field_act_width], register order */,
@@ -295,6 +301,30 @@ int ps_main_field_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F,
                                                WRITTEN; the caller sums it over the samples of a ray and dapp is left untouched
                                                (the sorted layout would otherwise cost 16 float atomics per point) */,
                          const int32_t* perm, const int32_t* field_start, int K, int stages /* as ps_main_field_bwd */, void* stream);
+/* The MERGED network as the TRAINING path of routed tiles (the production shape: K = 8..16 sub-fields,
+ * ns/configs/method_configs.py:87,141): per sub-field, base output rows 16..79 (the 64-d semantic embedding, no activation:
+ * ns/fields/PreSight/ingp_field.py:130-151) are folded into the semantic head's first layer -- W' = W_sem0 W_base1[16:],
+ * b' = W_sem0 b_base1[16:] + b_sem0 (ps_merge_linear_fwd_batch: K maps in one launch) -- so the base MLP ends in 16 outputs and the
+ * three-layer head reads the base hidden layer: 4096 of the 27 264 forward MACs and 8192 of the backward MACs per sample less, same
+ * function / parameters / gradients (fp32 sums re-associated).  Arguments as ps_main_field_fwd_ms / ps_main_field_bwd_ms; packed =
+ * K blocks [base (L*F -> hidden -> 16) | semantic head (hidden -> 64 merged, 64 -> 64, 64 -> 64) | colour head] of
+ * ps_main_field_m_sizes; acts [n_slots, act_width], dzb_scratch [n_slots, dzb_width]; three-kernel backward only (acts and
+ * dzb_scratch required).  The gradient block's first semantic slot holds d(W'), d(b'): ps_merge_linear_bwd_batch adds the chain-rule
+ * gradients to the four tensors of every sub-field.  ptrs: device table of K rows of addresses -- forward [W0, b0, We, be],
+ * backward [W0, We, be, dW0, db0, dWe, dbe]; Wm / dWm [K, O, I], bm / dbm [K, O] contiguous. */
+int ps_main_field_m_sizes(int LF, int hidden, int hidden_color, int64_t* packed_floats /*host*/, int64_t* grad_floats /*host*/,
+                          int64_t* offsets /*host [6]*/, int* act_width /*host*/, int* dzb_width /*host*/);
+int ps_main_field_m_fwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
+                           const float* dirs, const float* app, int S, int A, const float* packed, int64_t n_slots, float* sigma,
+                           float* rgb, float* sem, float* acts, const int32_t* perm, const int32_t* field_start, int K, void* stream);
+int ps_main_field_m_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
+                           const float* dirs, const float* app, int S, int A, const float* packed, const float* dsigma,
+                           const float* drgb, const float* dsem, const float* weights, int64_t n_slots, float* dfeat, float* dapp,
+                           float* gpart, const float* acts, float* dzb_scratch, float* dapp_points, const int32_t* perm,
+                           const int32_t* field_start, int K, int stages, void* stream);
+int ps_merge_linear_fwd_batch(const int64_t* ptrs /*device [K,4]*/, int n_fields, int O, int K, int I, float* Wm, float* bm, void* stream);
+int ps_merge_linear_bwd_batch(const int64_t* ptrs /*device [K,7]*/, int n_fields, const float* dWm, const float* dbm, int O, int K, int I,
+                              void* stream);
 /* fused sky field (ns/fields/PreSight/sky_field.py:95-110): per ray SH4((dir+1)/2) -> semantic head (16 -> 32 -> 32 -> 64) and
  * [SH | appearance] -> colour head (16+A -> 32 -> 32 -> 3, sigmoid), one kernel per direction; packed = [colour | semantic]
  * packed stacks (K of them back to back for the routed sky model, perm / field_start from ps_ms_route on the ray ORIGINS,

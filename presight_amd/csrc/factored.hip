@@ -318,6 +318,76 @@ extern "C" int ps_merge_linear_bwd(const float* dWm, const float* dbm, const flo
   PS_CHECK_LAUNCH();
 }
 
+// The same two maps for K sub-fields in ONE launch each (routed tiles: K merged layers per step).  ptrs: device table of K rows of
+// addresses (int64): forward [W0, b0, We, be], backward [W0, We, be, dW0, db0, dWe, dbe]; Wm / bm / dWm / dbm: [K, O, I] / [K, O]
+// contiguous.  blockIdx.y = sub-field.
+namespace {
+__global__ __launch_bounds__(256) void merge_linear_fwd_batch_kernel(const int64_t* __restrict__ ptrs, int O, int K, int I,
+                                                                     float* __restrict__ Wm, float* __restrict__ bm) {
+  const int64_t* row = ptrs + 4 * blockIdx.y;
+  const float *W0 = (const float*)row[0], *b0 = (const float*)row[1], *We = (const float*)row[2], *be = (const float*)row[3];
+  Wm += (size_t)blockIdx.y * O * I;
+  bm += (size_t)blockIdx.y * O;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < O * I) {
+    const int o = idx / I, i = idx % I;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(W0[o * K + k], We[k * I + i], s);
+    Wm[idx] = s;
+  } else if (idx < O * I + O) {
+    const int o = idx - O * I;
+    float s = b0[o];
+    for (int k = 0; k < K; ++k) s = fmaf(W0[o * K + k], be[k], s);
+    bm[o] = s;
+  }
+}
+}  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void merge_linear_bwd_batch_kernel(const int64_t* __restrict__ ptrs, const float* __restrict__ dWm,
+                                                                     const float* __restrict__ dbm, int O, int K, int I) {
+  const int64_t* row = ptrs + 7 * blockIdx.y;
+  const float *W0 = (const float*)row[0], *We = (const float*)row[1], *be = (const float*)row[2];
+  float *dW0 = (float*)row[3], *db0 = (float*)row[4], *dWe = (float*)row[5], *dbe = (float*)row[6];
+  dWm += (size_t)blockIdx.y * O * I;
+  dbm += (size_t)blockIdx.y * O;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < O * K) {
+    const int o = idx / K, k = idx % K;
+    float s = dbm[o] * be[k];
+    for (int i = 0; i < I; ++i) s = fmaf(dWm[o * I + i], We[k * I + i], s);
+    dW0[idx] += s;
+  } else if (idx < O * K + K * I) {
+    const int e = idx - O * K, k = e / I, i = e % I;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s = fmaf(W0[o * K + k], dWm[o * I + i], s);
+    dWe[e] += s;
+  } else if (idx < O * K + K * I + O) {
+    const int o = idx - O * K - K * I;
+    db0[o] += dbm[o];
+  } else if (idx < O * K + K * I + O + K) {
+    const int k = idx - O * K - K * I - O;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s = fmaf(W0[o * K + k], dbm[o], s);
+    dbe[k] += s;
+  }
+}
+}  // namespace
+
+extern "C" int ps_merge_linear_bwd_batch(const int64_t* ptrs, int n_fields, const float* dWm, const float* dbm, int O, int K, int I,
+                                         void* stream) {
+  PS_REQUIRE(ptrs && dWm && dbm && n_fields > 0 && O > 0 && K > 0 && I > 0, "ps_merge_linear_bwd_batch: null argument");
+  merge_linear_bwd_batch_kernel<<<dim3((unsigned)((O * K + K * I + O + K + 255) / 256), (unsigned)n_fields), 256, 0, (hipStream_t)stream>>>(
+      ptrs, dWm, dbm, O, K, I);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_merge_linear_fwd_batch(const int64_t* ptrs, int n_fields, int O, int K, int I, float* Wm, float* bm, void* stream) {
+  PS_REQUIRE(ptrs && Wm && bm && n_fields > 0 && O > 0 && K > 0 && I > 0, "ps_merge_linear_fwd_batch: null argument");
+  merge_linear_fwd_batch_kernel<<<dim3((unsigned)((O * I + O + 255) / 256), (unsigned)n_fields), 256, 0, (hipStream_t)stream>>>(ptrs, O, K, I, Wm, bm);
+  PS_CHECK_LAUNCH();
+}
+
 extern "C" int ps_sem_out_fwd(const float* H, const float* acc, const float* W, const float* b, int64_t R, int C, float* sem, void* stream) {
   PS_REQUIRE(C == kC, "ps_sem_out_fwd: 64 semantic channels");
   if (R == 0) return 0;

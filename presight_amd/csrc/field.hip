@@ -460,8 +460,8 @@ struct MainCfg {
   static constexpr int ACT_H1 = 0, ACT_ZB = ACT_H1 + HB_ * 16, ACT_S1 = ACT_ZB + ZB_NB * 16, ACT_S2 = ACT_S1 + 64, ACT_C1 = ACT_S2 + 64,
                        ACT_C2 = ACT_C1 + HBC_ * 16, ACT_CO = ACT_C2 + HBC_ * 16, ACT_W = ACT_CO + 16;
   // d(base output) workspace of the three-kernel backward, register order: block 0 = d(sigma_raw | geo15) from the colour kernel,
-  // then d(semantic embedding) [64] / FACT: d(base hidden layer) [HB * 16] from the semantic kernel
-  static constexpr int DZB_W = 16 + (FACT_ ? HB_ * 16 : 64);
+  // then d(semantic embedding) [64] / MERGED: d(base hidden layer) [HB * 16] from the semantic kernel
+  static constexpr int DZB_W = 16 + (MERGED ? HB_ * 16 : 64);
   static constexpr int SCR_ROWS = Base::SCRATCH_ROWS > Sem::SCRATCH_ROWS
                                       ? (Base::SCRATCH_ROWS > Rgb::SCRATCH_ROWS ? Base::SCRATCH_ROWS : Rgb::SCRATCH_ROWS)
                                       : (Sem::SCRATCH_ROWS > Rgb::SCRATCH_ROWS ? Sem::SCRATCH_ROWS : Rgb::SCRATCH_ROWS);
@@ -581,8 +581,8 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         v.sel[pb] = a.sel[p < a.N ? p : a.N - 1];  // (padded slots carry selector 0)
       else
         v.sel[pb] = (a.sigma != nullptr && p < a.N) ? a.sel[p] : 0.0f;
-      v.ga[pb] = (!MS && a.gate_a != nullptr && p < a.N) ? a.gate_a[p] : 0.0f;
-      v.gb[pb] = (!MS && a.gate_a != nullptr && p < a.N) ? a.gate_b[p] : 0.0f;
+      v.ga[pb] = (a.gate_a != nullptr && op >= 0) ? a.gate_a[op] : 0.0f;  // (the gates live in the caller's order)
+      v.gb[pb] = (a.gate_a != nullptr && op >= 0) ? a.gate_b[op] : 0.0f;
       int64_t r;
       if constexpr (MS)
         r = ray_index(op >= 0 ? op : 0, a.S);
@@ -710,13 +710,12 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     PS_STAMP(tm, 3)
     bool consumed = false;
     bool run_sem = C::FACT || a.sem != nullptr;
-    if constexpr (!C::FACT && !MS) {
+    if constexpr (!C::FACT) {
       if (a.gate_a != nullptr) {  // (workgroup-uniform pointer; the ballot makes the decision wave-uniform)
         bool hit = false;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-          const int64_t p = first + pb * 16 + j;
-          if (g == 0 && p < a.N) {
+          if (g == 0 && op_cur[pb] >= 0) {
             const float mean = ((cur.ga[pb] + cur.gb[pb]) + expf(zb[pb][0]) * cur.sel[pb]) / 3.0f;  // ps_mean_density's formula
             hit |= mean >= a.gate_thr;
           }
@@ -1149,8 +1148,8 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_sem_kernel(MainArgs a) {
     float sin_[PB][Sem::KS0], s1[PB][16], s2[PB][16];
     load_act<4, PB, C::FACT || MS>(a.acts, C::ACT_W, C::ACT_S2, first, a.N, s2);
     load_act<4, PB, C::FACT || MS>(a.acts, C::ACT_W, C::ACT_S1, first, a.N, s1);
-    if constexpr (C::FACT)
-      load_act<Sem::KS0 / 4, PB, true>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, sin_);  // the base hidden layer = the merged first layer's input
+    if constexpr (C::MERGED)
+      load_act<Sem::KS0 / 4, PB, C::FACT || MS>(a.acts, C::ACT_W, C::ACT_H1, first, a.N, sin_);  // the base hidden layer = the merged first layer's input
     else
       load_act<4, PB, MS>(a.acts, C::ACT_W, C::ACT_ZB + 16, first, a.N, sin_);  // base outputs 16..79 = the head's input
     PS_STAMP(tm, 1)
@@ -1492,7 +1491,7 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
 #pragma unroll
         for (int t = 0; t < Base::KS0; ++t) x[pb][t] = xin[pb][t];
     };
-    if constexpr (C::FACT) {
+    if constexpr (C::MERGED) {
       float dz[PB][4];
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb)
@@ -1720,19 +1719,26 @@ extern "C" int ps_main_field_f_sizes(int LF, int hidden, int hidden_color, int64
 namespace {
 int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool fact = false, bool merged = false) {
   if (a.N == 0) return 0;
-  if (merged) {
-    PS_REQUIRE(a.perm == nullptr && a.acts == nullptr && a.rgb == nullptr && a.sem != nullptr && a.sigma != nullptr,
-               "ps_main_field_fwd_gated: one sub-field, inference (no kept activations), density + semantics");
-    PS_REQUIRE(a.N < (int64_t(1) << 31), "ps_main_field_fwd_gated: at most 2^31 - 1 points per call");
+  if (merged) {  // MainCfg MERGE_: base output rows 16..79 folded into the semantic head's first layer (one or K sub-fields)
+    PS_REQUIRE(a.sem != nullptr && a.sigma != nullptr, "ps_main_field (merged network): density + semantics are always produced");
+    PS_REQUIRE(a.gate_a == nullptr || (a.acts == nullptr && a.rgb == nullptr), "ps_main_field_fwd_gated: inference (no kept activations, no colour)");
+    PS_REQUIRE(a.acts == nullptr || a.rgb != nullptr, "ps_main_field (merged network): activations are kept for full evaluations only");
+    PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field (merged network): appearance dim must be <= 16");
+    PS_REQUIRE(a.N < (int64_t(1) << 31), "ps_main_field (merged network): at most 2^31 - 1 points per call");
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>;                                                    \
-    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+    if (a.perm != nullptr) {                                                                                          \
+      a.packed_stride = C::PACKED;                                                                                    \
+      main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, true><<<ms_grid(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256, a.K), kMainFwdWaves * 64, 0, s>>>(a); \
+    } else {                                                                                                          \
+      main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+    }                                                                                                                 \
     PS_CHECK_LAUNCH();                                                                                                \
   }
     PS_MAIN_CFGS(X)
 #undef X
-    ps_set_error("ps_main_field_fwd_gated: unsupported (L*F, hidden, hidden_color)");
+    ps_set_error("ps_main_field (merged network): unsupported (L*F, hidden, hidden_color)");
     return -2;
   }
   if (fact) {
@@ -1770,9 +1776,35 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
 }
 
 // stages: which kernels of the three-kernel backward this call launches (bit 0 semantic head, 1 colour head, 2 base MLP)
-int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStream_t s, bool fact = false) {
+int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStream_t s, bool fact = false, bool merged = false) {
   const int st = stages & 7;
   if (a.N == 0) return 0;
+  if (merged) {  // MainCfg MERGE_, three-kernel backward on kept activations (one or K sub-fields)
+    PS_REQUIRE(a.acts != nullptr && a.dzb != nullptr && a.drgb != nullptr && a.dsem != nullptr,
+               "ps_main_field_m_bwd: kept activations, the workspace and both head gradients are required");
+    PS_REQUIRE(a.A <= 16 && a.S > 0 && a.N < (int64_t(1) << 31), "ps_main_field_m_bwd: appearance dim <= 16, at most 2^31 - 1 points");
+#define X(lf, h, hc)                                                                                                  \
+  if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>;                                                    \
+    if (a.perm != nullptr) {                                                                                          \
+      a.packed_stride = C::PACKED;                                                                                    \
+      const int grid = ms_grid(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256, a.K);                                        \
+      if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);    \
+      if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);    \
+      if (st & 4) main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);   \
+    } else {                                                                                                          \
+      const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256);                                   \
+      if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);   \
+      if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);   \
+      if (st & 4) main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
+    }                                                                                                                 \
+    PS_CHECK_LAUNCH();                                                                                                \
+  }
+    PS_MAIN_CFGS(X)
+#undef X
+    ps_set_error("ps_main_field_m_bwd: unsupported (L*F, hidden, hidden_color)");
+    return -2;
+  }
   if (fact) {
     PS_REQUIRE(a.perm == nullptr && a.acts != nullptr && a.dzb != nullptr && a.w != nullptr && a.drgb != nullptr && a.dsem != nullptr,
                "ps_main_field_f_bwd: one sub-field, kept activations, the workspace and per-ray gradients are required");
@@ -1873,6 +1905,78 @@ extern "C" int ps_main_field_gated_sizes(int LF, int hidden, int hidden_color, i
 #undef X
   ps_set_error("ps_main_field_gated: unsupported (L*F, hidden, hidden_color)");
   return -2;
+}
+
+// multi-sub-field gated inference forward: sorted layout (n_slots, perm, field_start), `packed` = K blocks of the
+// ps_main_field_gated_sizes layout back to back; gate_a / gate_b / sigma / sem in the CALLER's point order
+extern "C" int ps_main_field_fwd_gated_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                          const float* sel, const float* packed, int64_t n_slots, const float* gate_a, const float* gate_b,
+                                          float gate_threshold, float* sigma, float* sem, const int32_t* perm, const int32_t* field_start,
+                                          int K, void* stream) {
+  PS_REQUIRE(gate_a != nullptr && gate_b != nullptr && sigma != nullptr && sem != nullptr, "ps_main_field_fwd_gated_ms: null argument");
+  PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_fwd_gated_ms: need the sorted layout");
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.S = 1; a.A = 0;
+  a.packed = packed; a.N = n_slots; a.sigma = sigma; a.sem = sem; a.perm = perm; a.field_start = field_start; a.K = K;
+  a.gate_a = gate_a; a.gate_b = gate_b; a.gate_thr = gate_threshold;
+  return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream, false, true);
+}
+
+// The MERGED network as a TRAINING path for routed tiles (K >= 1 sub-fields in the sorted layout; DESIGN.md 4.5 rewrite 1 per
+// sub-field): packed block per sub-field = [base (L*F -> hidden -> 16) | semantic head with the merged first layer (hidden -> 64 -> 64
+// -> 64) | colour head]; same arguments as ps_main_field_fwd_ms / ps_main_field_bwd_ms, kept activations `acts`
+// [n_slots, act_width] and the three-kernel backward's workspace `dzb_scratch` [n_slots, dzb_width] with the widths of
+// ps_main_field_m_sizes.  The semantic kernel returns d(W'), d(b') of the merged layer in the semantic stack's first gradient slot
+// (-> ps_merge_linear_bwd_batch) and the base kernel the 16-row output layer's.
+extern "C" int ps_main_field_m_sizes(int LF, int hidden, int hidden_color, int64_t* packed_floats, int64_t* grad_floats,
+                                     int64_t* offsets /*[6]: P_BASE,P_SEM,P_RGB,G_BASE,G_SEM,G_RGB*/, int* act_width, int* dzb_width) {
+#define X(lf, h, hc)                                               \
+  if (LF == lf && hidden == h && hidden_color == hc) {             \
+    using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>; \
+    *packed_floats = C::PACKED;                                    \
+    *grad_floats = C::GPACKED;                                     \
+    if (offsets) {                                                 \
+      offsets[0] = C::P_BASE;                                      \
+      offsets[1] = C::P_SEM;                                       \
+      offsets[2] = C::P_RGB;                                       \
+      offsets[3] = C::G_BASE;                                      \
+      offsets[4] = C::G_SEM;                                       \
+      offsets[5] = C::G_RGB;                                       \
+    }                                                              \
+    if (act_width) *act_width = C::ACT_W;                          \
+    if (dzb_width) *dzb_width = C::DZB_W;                          \
+    return 0;                                                      \
+  }
+  PS_MAIN_CFGS(X)
+#undef X
+  ps_set_error("ps_main_field_m: unsupported (L*F, hidden, hidden_color)");
+  return -2;
+}
+
+extern "C" int ps_main_field_m_fwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                      const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                      int64_t n_slots, float* sigma, float* rgb, float* sem, float* acts, const int32_t* perm,
+                                      const int32_t* field_start, int K, void* stream) {
+  PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_m_fwd_ms: need the sorted layout");
+  MainArgs a{};
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = n_slots; a.sigma = sigma; a.rgb = rgb; a.sem = sem; a.acts = acts; a.perm = perm; a.field_start = field_start; a.K = K;
+  return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream, false, true);
+}
+
+extern "C" int ps_main_field_m_bwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
+                                      const float* sel, const float* dirs, const float* app, int S, int A, const float* packed,
+                                      const float* dsigma, const float* drgb, const float* dsem, const float* weights, int64_t n_slots,
+                                      float* dfeat, float* dapp, float* gpart, const float* acts, float* dzb_scratch, float* dapp_points,
+                                      const int32_t* perm, const int32_t* field_start, int K, int stages, void* stream) {
+  PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_m_bwd_ms: need the sorted layout");
+  MainArgs a{};
+  a.dzb = dzb_scratch;
+  a.dapp_pt = dapp_points;
+  a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.dirs = dirs; a.app = app; a.S = S; a.A = A;
+  a.packed = packed; a.N = n_slots; a.dsigma = dsigma; a.drgb = drgb; a.dsem = dsem; a.w = weights; a.dfeat = dfeat; a.dapp = dapp; a.gpart = gpart; a.acts = const_cast<float*>(acts);
+  a.perm = perm; a.field_start = field_start; a.K = K;
+  return main_bwd_impl(a, hidden, hidden_color, stages, (hipStream_t)stream, false, true);
 }
 
 extern "C" int ps_main_field_bwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,

@@ -749,6 +749,32 @@ def main_field_gated(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g:
     return sigma, semantics
 
 
+def ms_main_field_gated(lay: "MsLayout", u: Tensor, sel: Tensor, tables: Sequence[Tensor], scalings: Tensor, g: GridCfg, base, sem, rgb,
+                        gate_a: Tensor, gate_b: Tensor, threshold: float):
+    """main_field_gated for the K routed sub-fields of a tile (no autograd): -> (density [N], semantics [N,64]) in the caller's point
+    order; base / sem / rgb: per sub-field layer lists; gate_a / gate_b [N] in the caller's order."""
+    K = lay.K
+    layers = [list(base[k]) + list(sem[k]) + list(rgb[k]) for k in range(K)]
+    hidden, hidden_color = base[0][0][0].shape[0], rgb[0][0][0].shape[0]
+    A = rgb[0][0][0].shape[1] - 16 - GEO_DIM
+    spec = _main_spec_m(g.out_dim, hidden, hidden_color, A)
+    dev = u.device
+    with torch.no_grad():
+        feat, _ = _ms_encode(lay, u, [_f32(t, "hash table") for t in tables], scalings, g, count=False)
+        mm = _MsMerged.get(layers)
+        mm.merge()
+        st = _MsStacks.get("main_m", [spec.base, spec.sem, spec.rgb], (spec.p_off, spec.g_off), spec.packed, spec.g_total, mm.klayers,
+                           lib().ps_main_field_parts_ms(1 << 40, K))
+        st.pack()
+        sigma, semantics = torch.empty(lay.N, device=dev), torch.empty(lay.N, SEM_DIM, device=dev)
+        with prof.region("main_field_fwd"):
+            check(lib().ps_main_field_fwd_gated_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden,
+                                                   hidden_color, _p(sel), _p(st.packed), lay.n_slots, _p(_f32(gate_a).reshape(-1)),
+                                                   _p(_f32(gate_b).reshape(-1)), float(threshold), _p(sigma), _p(semantics), _p(lay.perm),
+                                                   lay.field_start, K, _stream()), "ps_main_field_fwd_gated_ms")
+    return sigma, semantics
+
+
 def main_field(u: Tensor, sel: Tensor, dirs: Optional[Tensor], app: Optional[Tensor], S: int, table: Tensor, scalings: Tensor,
                g: GridCfg, base: Sequence[Tuple[Tensor, Tensor]], sem: Sequence[Tuple[Tensor, Tensor]],
                rgb: Sequence[Tuple[Tensor, Tensor]], want_rgb: bool = True, want_sem: bool = True):
@@ -1017,6 +1043,112 @@ def ms_prop_field(lay: MsLayout, u: Tensor, sel: Tensor, tables: Sequence[Tensor
     return _apply(_PropFieldMS, lay, u, sel, scalings, g, *tables, *flat)
 
 
+# ---- routed tiles on the MERGED network (DESIGN.md 4.5 rewrite 1 per sub-field; csrc/field.hip MainCfg MERGE_): base output rows 16..79
+# folded into the semantic head's first layer, W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0.  Training (three-kernel
+# backward on kept activations) and the gated inference query of the prior extraction.  PRESIGHT_MERGED_MS=0: the unmerged kernels.
+MERGED_MS = os.environ.get("PRESIGHT_MERGED_MS", "1") != "0"
+
+
+class MainSpecM:
+    def __init__(self, LF: int, hidden: int, hidden_color: int, app_dim: int):
+        self.base = MlpSpec([LF, hidden, 16])
+        self.sem = MlpSpec([hidden, 64, 64, SEM_DIM], first_colmap=chain_colmap(hidden // 4, hidden), ks0=hidden // 4)
+        self.rgb = MlpSpec([16 + GEO_DIM + app_dim, hidden_color, hidden_color, 3], first_colmap=colour_colmap(app_dim), ks0=12)
+        self.p_off = [0, self.base.packed, self.base.packed + self.sem.packed]
+        self.packed = self.p_off[2] + self.rgb.packed
+        self.g_off = [0, self.base.g_total, self.base.g_total + self.sem.g_total]
+        self.g_total = self.g_off[2] + self.rgb.g_total
+        pf, gf, aw, dw = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
+        offs = (ctypes.c_int64 * 6)()
+        check(lib().ps_main_field_m_sizes(LF, hidden, hidden_color, ctypes.byref(pf), ctypes.byref(gf), offs, ctypes.byref(aw), ctypes.byref(dw)),
+              "ps_main_field_m_sizes")
+        assert pf.value == self.packed and gf.value == self.g_total and list(offs) == self.p_off + self.g_off, (pf.value, self.packed, list(offs))
+        self.act_width, self.dzb_width = aw.value, dw.value
+
+
+_MAIN_SPECS_M: dict = {}
+
+
+def _main_spec_m(LF, hidden, hidden_color, app_dim) -> MainSpecM:
+    key = (LF, hidden, hidden_color, app_dim)
+    if key not in _MAIN_SPECS_M:
+        _MAIN_SPECS_M[key] = MainSpecM(*key)
+    return _MAIN_SPECS_M[key]
+
+
+def merged_supported(base, sem, rgb) -> bool:
+    """the PreSight layout: 2-layer base MLP ending in 1 + 15 + 64 outputs, 3-layer 64-wide semantic head, 3-layer colour head"""
+    return (len(base) == 2 and len(sem) == 3 and len(rgb) == 3 and base[1][0].shape[0] == BASE_OUT and sem[0][0].shape == (64, SEM_DIM)
+            and sem[2][0].shape[0] == SEM_DIM and base[0][0].shape[0] % 16 == 0
+            and all(t.dtype == torch.float32 and t.is_contiguous() for W, b in list(base) + list(sem) for t in (W, b)))
+
+
+class _MsMerged:
+    """K merged first semantic layers of a routed tile: persistent W' / b' (and d(W') / d(b')) buffers at fixed addresses, the device
+    pointer table of ps_merge_linear_fwd_batch, and the kernel-side layer lists [base0, base1[:16], merged, sem1, sem2, rgb0..2]."""
+
+    _cache: dict = {}
+
+    @classmethod
+    def get(cls, layers: List[List[Tuple[Tensor, Tensor]]]):
+        key = tuple(t.data_ptr() for f in layers for W, b in f for t in (W, b))
+        obj = cls._cache.get(key)
+        if obj is None:
+            if len(cls._cache) > 8:
+                cls._cache.clear()
+            obj = cls(layers)
+            cls._cache[key] = obj
+        return obj
+
+    def __init__(self, layers):
+        self.K = len(layers)
+        hidden = layers[0][0][0].shape[0]
+        dev = layers[0][0][0].device
+        self.hidden = hidden
+        self.Wm, self.bm = torch.empty(self.K, 64, hidden, device=dev), torch.empty(self.K, 64, device=dev)
+        self.dWm, self.dbm = torch.zeros_like(self.Wm), torch.zeros_like(self.bm)
+        rows, self.klayers = [], []
+        for k, f in enumerate(layers):
+            (Wb0, bb0), (Wb1, bb1), (Ws0, bs0), (Ws1, bs1), (Ws2, bs2) = f[:5]
+            rows += [Ws0.data_ptr(), bs0.data_ptr(), Wb1.data_ptr() + 4 * 16 * hidden, bb1.data_ptr() + 4 * 16]
+            self.klayers.append([(Wb0, bb0), (Wb1[:16], bb1[:16]), (self.Wm[k], self.bm[k]), (Ws1, bs1), (Ws2, bs2)] + list(f[5:]))
+        self.fwd_ptrs = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._bwd_cache: dict = {}
+
+    def merge(self):
+        check(lib().ps_merge_linear_fwd_batch(_p(self.fwd_ptrs), self.K, 64, SEM_DIM, self.hidden, _p(self.Wm), _p(self.bm), _stream()),
+              "ps_merge_linear_fwd_batch")
+
+    def kernel_dsts(self, dsts: List[Tuple[Tensor, Tensor]], per: int):
+        """dsts: (dW, db) of every ORIGINAL layer (field-major) -> destinations of the kernels' layers (base layer 1: its first 16
+        rows; merged layer: this object's zeroed d(W') / d(b')) + the pointer table of ps_merge_linear_bwd_batch"""
+        self.dWm.zero_()
+        self.dbm.zero_()
+        out = []
+        for k in range(self.K):
+            d = dsts[k * per:(k + 1) * per]
+            out += [d[0], (d[1][0][:16], d[1][1][:16]), (self.dWm[k], self.dbm[k])] + list(d[3:])
+        return out
+
+    def merge_backward(self, layers, dsts, per: int):
+        key = tuple(t.data_ptr() for d in dsts for t in d)
+        tab = self._bwd_cache.get(key)
+        if tab is None:
+            if len(self._bwd_cache) > 4:
+                self._bwd_cache.clear()
+            rows = []
+            h = self.hidden
+            for k, f in enumerate(layers):
+                (Wb1, bb1), (Ws0, _) = f[1], f[2]
+                (dWb1, dbb1), (dWs0, dbs0) = dsts[k * per + 1], dsts[k * per + 2]
+                rows += [Ws0.data_ptr(), Wb1.data_ptr() + 4 * 16 * h, bb1.data_ptr() + 4 * 16, dWs0.data_ptr(), dbs0.data_ptr(),
+                         dWb1.data_ptr() + 4 * 16 * h, dbb1.data_ptr() + 4 * 16]
+            tab = torch.tensor(rows, dtype=torch.int64, device=self.Wm.device)
+            self._bwd_cache[key] = tab
+        check(lib().ps_merge_linear_bwd_batch(_p(tab), self.K, _p(self.dWm), _p(self.dbm), 64, SEM_DIM, self.hidden, _stream()),
+              "ps_merge_linear_bwd_batch")
+
+
 def _ms_main_forward(ctx, train, lay: MsLayout, u, sel, dirs, app, S, scalings, g: GridCfg, want_rgb, want_sem, n_base, n_sem, params):
     K = lay.K
     tables = [_f32(t, "hash table") for t in params[:K]]
@@ -1029,11 +1161,24 @@ def _ms_main_forward(ctx, train, lay: MsLayout, u, sel, dirs, app, S, scalings, 
     if want_rgb and (0 if app is None else app.shape[1]) != A:
         raise ValueError(f"colour head expects SH16 + geo15 + app{A} inputs, got an appearance embedding of width "
                          f"{0 if app is None else app.shape[1]}")
-    spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+    # the merged network (rewrite 1): full evaluations -- training with kept activations, or inference
+    keep = KEEP_ACTIVATIONS and train and want_rgb and want_sem and lay.N > 0
+    merged = (MERGED_MS and want_sem and (keep or not train)
+              and merged_supported(layers[0][:n_base], layers[0][n_base:n_base + n_sem], layers[0][n_base + n_sem:])
+              and (not keep or os.environ.get("PRESIGHT_MAIN_BWD_SPLIT", "1") != "0"))
     dev = u.device
     feat, counts = _ms_encode(lay, u, tables, scalings, g, count=train)
-    st = _MsStacks.get("main", [spec.base, spec.sem, spec.rgb], (spec.p_off, spec.g_off), spec.packed, spec.g_total, layers,
-                       lib().ps_main_field_parts_ms(1 << 40, K))
+    mm = None
+    if merged:
+        spec = _main_spec_m(g.out_dim, hidden, hidden_color, A)
+        mm = _MsMerged.get(layers)
+        mm.merge()
+        st = _MsStacks.get("main_m", [spec.base, spec.sem, spec.rgb], (spec.p_off, spec.g_off), spec.packed, spec.g_total, mm.klayers,
+                           lib().ps_main_field_parts_ms(1 << 40, K))
+    else:
+        spec = _main_spec(g.out_dim, hidden, hidden_color, A)
+        st = _MsStacks.get("main", [spec.base, spec.sem, spec.rgb], (spec.p_off, spec.g_off), spec.packed, spec.g_total, layers,
+                           lib().ps_main_field_parts_ms(1 << 40, K))
     st.pack()
     N = lay.N
     sigma = torch.empty(N, device=dev)
@@ -1042,13 +1187,15 @@ def _ms_main_forward(ctx, train, lay: MsLayout, u, sel, dirs, app, S, scalings, 
     dirs = _f32(dirs) if dirs is not None else torch.zeros(1, 3, device=dev)
     app_c = _f32(app) if (app is not None and want_rgb) else None
     acts = None
-    if KEEP_ACTIVATIONS and train and want_rgb and want_sem and N > 0:
-        acts = torch.empty(lay.n_slots, lib().ps_main_field_act_width(g.out_dim, hidden, hidden_color), device=dev)
+    if keep:
+        acts = torch.empty(lay.n_slots, spec.act_width if merged else lib().ps_main_field_act_width(g.out_dim, hidden, hidden_color), device=dev)
+    fwd = lib().ps_main_field_m_fwd_ms if merged else lib().ps_main_field_fwd_ms
     with prof.region("main_field_fwd"):
-        check(lib().ps_main_field_fwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                         _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(st.packed), lay.n_slots, _p(sigma), _p(rgb), _p(sem),
-                                         _p(acts), _p(lay.perm), lay.field_start, K, _stream()), "ps_main_field_fwd_ms")
+        check(fwd(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                  _p(sel), _p(dirs), _p(app_c), max(S, 1), A, _p(st.packed), lay.n_slots, _p(sigma), _p(rgb), _p(sem),
+                  _p(acts), _p(lay.perm), lay.field_start, K, _stream()), "ps_main_field_fwd_ms")
     ctx.meta = (lay, g, hidden, hidden_color, A, S, st, tables, wb, want_rgb, want_sem)
+    ctx.merged = (mm, spec, layers) if merged else None
     ctx.direct = direct_params(*params)
     return (u, sel, dirs, app_c, scalings, feat, counts, acts), (sigma, rgb, sem)
 
@@ -1061,23 +1208,38 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
         acts = None
     dfeat = torch.empty_like(feat)
     nparts = lib().ps_main_field_parts_ms(lay.n_slots, K)
-    dzb = _dzb_scratch(lay.n_slots, u.device) if acts is not None else None
+    merged = getattr(ctx, "merged", None)
+    if merged is not None and acts is None:
+        raise RuntimeError("presight_amd: the merged routed network needs both head gradients in its backward")
+    if merged is not None:
+        dzb = torch.empty(lay.n_slots, merged[1].dzb_width, device=u.device)
+    else:
+        dzb = _dzb_scratch(lay.n_slots, u.device) if acts is not None else None
     # three-kernel backward: d(appearance) per point, summed over the samples of a ray below (no atomics)
     per_point = app is not None and dzb is not None and S > 0 and lay.N == app.shape[0] * S
     dapp_pt = torch.empty(lay.N, A, device=u.device) if per_point else None
     dapp = None if (app is None or per_point) else torch.zeros_like(app)
+    bwd = lib().ps_main_field_m_bwd_ms if merged is not None else lib().ps_main_field_bwd_ms
     with prof.region("main_field_bwd"):
         for stages in _bwd_stages(dzb):
-            check(lib().ps_main_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
-                                             _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(st.packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
-                                             _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(dzb), _p(dapp_pt), _p(lay.perm),
-                                             lay.field_start, K, stages, _stream()), "ps_main_field_bwd_ms")
+            check(bwd(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
+                      _p(sel), _p(dirs), _p(app), max(S, 1), A, _p(st.packed), _p(d_sigma), _p(d_rgb), _p(d_sem),
+                      _p(weights), lay.n_slots, _p(dfeat), _p(dapp), _p(st.gpart), _p(acts), _p(dzb), _p(dapp_pt), _p(lay.perm),
+                      lay.field_start, K, stages, _stream()), "ps_main_field_bwd_ms")
     if per_point:
         dapp = dapp_pt.view(app.shape[0], S, A).sum(1)
     ws = _ms_scatter_ws(lay, g, u.device)
     dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False)
     dsts, returned = _ms_layer_dsts(wb)
-    st.unpack(dsts, lay.field_start, nparts, 1)
+    if merged is not None:
+        # kernel layers -> [base0, base1 rows 0..15, merged layer, sem1, sem2, colour head]; the merged layer's gradient is carried
+        # back to semantic layer 0 and base layer 1 rows 16..79 of every sub-field by one launch (chain rule of W' = W_sem0 W_base1[16:])
+        mm, _, layers = merged
+        per = len(wb) // K // 2
+        st.unpack(mm.kernel_dsts(dsts, per), lay.field_start, nparts, 1)
+        mm.merge_backward(layers, dsts, per)
+    else:
+        st.unpack(dsts, lay.field_start, nparts, 1)
     mark_touched(ctx.direct, groups_on_device=True)
     mark_groups(lay, tables)
     return dapp, dtables, returned

@@ -316,7 +316,7 @@ class iNGPFieldMS(nn.Module):
         """(density [*bs,1], semantics [*bs,64]) from ONE evaluation of the field.  The reference's prior extraction calls
         density_fn and semantic_fn separately (ns/scripts/extract_priors.py:133-138) and semantic_fn re-runs density_fn
         (ingp_field.py:256): the hash encode and the base MLP run three times per point there, once here.
-        gate = (density_a, density_b, threshold) (one sub-field, inference): the semantic head is skipped for the 32-point tiles in
+        gate = (density_a, density_b, threshold) (inference; one sub-field or the routed tile): the semantic head is skipped for the 32-point tiles in
         which no point reaches mean(density_a, density_b, density) >= threshold -- those rows of the semantics are uninitialised
         (field_ops.main_field_gated)."""
         def run(f: iNGPField, pos):
@@ -331,6 +331,11 @@ class iNGPFieldMS(nn.Module):
 
         if len(self.fields) == 1:
             d, s = run(self.fields[0], positions.reshape(-1, 3))
+        elif gate is not None and not torch.is_grad_enabled() and F.MERGED_MS and F.merged_supported(*[self._ms()[n][0] for n in ("base", "sem", "rgb")]):
+            m = self._ms()
+            lay = F.MsLayout(self.centroids, pos=positions.reshape(-1, 3))
+            u, sel = lay.points(m["aabbs"], m["contract"])
+            d, s = F.ms_main_field_gated(lay, u, sel, m["tables"], m["scalings"], m["g"], m["base"], m["sem"], m["rgb"], gate[0], gate[1], gate[2])
         else:
             d, _, s = self._ms_points(positions)
         return d.view(*positions.shape[:-1], 1), s.view(*positions.shape[:-1], -1)

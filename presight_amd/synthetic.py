@@ -7,8 +7,8 @@ the ray, exactly what a camera log is to the reference's data manager (ns/data/P
 arrays of rgb / sky / features).  The teacher's samples are placed by its OWN density (its main field stands in for the
 proposal networks), so its renders are converged volume renderings of its field.
 
-Used by bench.py (`psnr_after_k_steps`), tools/soak.py and tests/test_hip_trainer.py; the CPU oracle has the same construction
-(oracle/nerf_oracle.py::teacher_params / teacher_targets) for the parity check at fixture size."""
+Used by bench.py (`psnr_after_k_steps`), tools/soak.py and tests/test_hip_trainer.py; the tests' CPU checker builds the same scene
+with its own code (draw order and constants below are the contract) for the parity check at fixture size."""
 from __future__ import annotations
 
 import math
@@ -37,7 +37,7 @@ def shape_teacher_(model, seed: int = 1234, max_res: float = TEACHER_MAX_RES, lo
       * colour and semantic output layers amplified (a default-initialised head renders a constant grey), semantic output bias
         0.5 (features spread around the middle of the [0, 1] range the loss clips its targets to).
     All random numbers come from one CPU generator in a fixed order (tables in sorted key order, then the probe points of
-    sub-field 0, 1, ...): oracle/nerf_oracle.py::teacher_params makes the same teacher for the CPU side."""
+    sub-field 0, 1, ...), so that the tests' CPU checker can make the same teacher."""
     sd = model.state_dict()  # tensors that alias the parameters
     g = torch.Generator().manual_seed(seed)
     dev = next(model.parameters()).device
