@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--fixed-batches", action="store_true", help="recycle 4 pre-made batches instead of the device chunk feed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg3 / cfg4 / extraction measurements of the default line")
+    ap.add_argument("--extract-model", choices=["cfg2", "cfg3"], default="cfg3",
+                    help="--config extract: the fields that are queried -- cfg3 = the production tile (K = 16 routed sub-fields, L10 F4 T2^20), cfg2 = one sub-field")
     ap.add_argument("--psnr-steps", type=int, default=300, help="iterations of the learnable-scene training run behind `psnr_after_k_steps` (0: skip)")
     return ap.parse_args(argv)
 
@@ -582,17 +584,60 @@ def secondary_training_lines(config, shapes, dev):
     return lines
 
 
-def secondary_extract_line(dev, res=512, passes=2):
+def extract_workload(model_cfg):
+    """per lattice point of the dense prior query (SURVEY.md 8d cfg 5: main field once + 2 proposal nets, no_grad), for the roofline rows:
+    algorithmic flops / hash bytes as SURVEY.md prices them; EXECUTED MACs of the kernels that run (merged network: base ending in 16
+    outputs for every point, the three 64 x 64 layers of the semantic head only for the 32-point tiles the gate lets through; the
+    proposal nets' 64 x 8 layer on the matrix cores) and the 64-byte lines their gathers touch (one line per x-pair, 4 per (point, level):
+    whatever the row width)."""
+    m = CONFIGS[model_cfg]["model"]
+    L, F = m["num_levels"], m["features_per_level"]
+    LF = L * F
+    alg_flop = 2 * (LF * 64 + 64 * 80 + 3 * 64 * 64) + 2 * 2 * 576
+    alg_byte = L * 8 * F * 4 + 2 * 8 * 8 * 4 + 64 * 2 + 4
+    ex_mac_always = (LF + 3) // 4 * 4 * 64 + 64 * 16 + 2 * 512
+    ex_mac_gated = 3 * 64 * 64
+    lines_byte = (L + 2 * 8) * 4 * 64 + 64 * 2 + 4
+    return dict(alg_flop=alg_flop, alg_byte=alg_byte, ex_mac_always=ex_mac_always, ex_mac_gated=ex_mac_gated, lines_byte=lines_byte)
+
+
+def extract_roofline(model_cfg, points_per_s_per_gpu, gated_frac):
+    """roofline object of an extraction line: `frac` on the work the kernels execute, against whichever ceiling binds"""
+    w = extract_workload(model_cfg)
+    ex_flop = 2 * (w["ex_mac_always"] + gated_frac * w["ex_mac_gated"])
+    t_mfma = ex_flop / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+    t_hbm = w["lines_byte"] / (HBM_PEAK_GBS * 1e9)
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    t = 1.0 / points_per_s_per_gpu
+    return {"bound": bound, "kernel": "whole pass (3 field queries per lattice point; executed work, DESIGN.md section 5)",
+            "achieved": (w["lines_byte"] / t / 1e9) if bound == "hbm" else (ex_flop / t / 1e12),
+            "peak": HBM_PEAK_GBS if bound == "hbm" else FP32_MFMA_PEAK_TFLOPS, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+            "frac": max(t_hbm, t_mfma) / t, "traffic": None,
+            "frac_mfma_executed": t_mfma / t, "frac_hbm_gathered_lines": t_hbm / t, "semantic_head_tiles_executed": gated_frac,
+            "executed_flop_per_point": ex_flop, "gathered_line_bytes_per_point": w["lines_byte"],
+            "frac_algorithmic_mfma": w["alg_flop"] / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, "frac_algorithmic_hbm": w["alg_byte"] / t / 1e9 / HBM_PEAK_GBS}
+
+
+def tile_aabb(scene):
+    """the box the dense lattice spans: the sub-field's AABB (K = 1) / the union of the K sub-field boxes (routed tile)"""
+    import torch
+
+    b = scene["aabbs"].reshape(-1, 2, 3)
+    return torch.stack([b[:, 0].min(0).values, b[:, 1].max(0).values])
+
+
+def secondary_extract_line(dev, res=512, passes=2, model_cfg="cfg2"):
     """BASELINE cfg 5 on one GPU, as `--config extract` measures it (see extract_main), for the `secondary` block"""
     import gc
 
     import torch
 
+    from presight_amd import field_ops as F
     from presight_amd.extract import dense_tile_query, voxelize
 
-    model, scene = build_model(dev, seed=42, config="cfg2")
+    model, scene = build_model(dev, seed=42, config=model_cfg)
     model.eval()
-    aabb = scene["aabbs"][0]
+    aabb = tile_aabb(scene)
     probe = dense_tile_query(model, aabb, res=64, density_threshold=-1.0)
     thr = float(torch.quantile(probe["densities"][:: max(1, probe["densities"].numel() // 100000)], 0.9))
     del probe
@@ -602,17 +647,22 @@ def secondary_extract_line(dev, res=512, passes=2):
         return out, voxelize(out["points"], out["features"], None, voxel=0.4, min_bound=out["min_bound"], points_max=out["points_max"])
 
     one_pass()
+    F.GATE_STATS = torch.zeros(2, device=dev, dtype=torch.int64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(passes):
         out, vox = one_pass()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / passes
-    flop_pt = 2 * (16 * 2 * 64 + 64 * 80 + 3 * 64 * 64) + 2 * 2 * 576
-    line = {"workload": f"BASELINE cfg 5: dense {res}^3 lattice of one tile (cfg-2 fields), 3 field queries + fp16 features + threshold + bit-exact "
-                        "voxel index + voxel down-sampling", "ms_per_step": dt * 1e3, "value": res ** 3 / dt, "unit": "points/s", "passes": passes,
+    st = F.GATE_STATS.tolist()
+    F.GATE_STATS = None
+    gated = st[0] / max(st[1], 1)
+    roof = extract_roofline(model_cfg, res ** 3 / dt, gated)
+    line = {"workload": f"BASELINE cfg 5: dense {res}^3 lattice of one tile ({CONFIGS[model_cfg]['workload'].split(':')[1].split(',')[0].strip()}; "
+                        f"K = {CONFIGS[model_cfg]['K']}), 3 field queries + fp16 features + threshold + bit-exact voxel index + voxel down-sampling",
+            "ms_per_step": dt * 1e3, "value": res ** 3 / dt, "unit": "points/s", "passes": passes,
             "kept_points": int(out["points"].shape[0]), "voxels": int(vox["key"].shape[0]),
-            "frac_of_binding": res ** 3 / dt * flop_pt / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+            "frac_of_binding": roof["frac"], "roofline": roof}
     del model, scene, out, vox
     gc.collect()
     torch.cuda.empty_cache()
@@ -651,9 +701,10 @@ def extract_main(args) -> int:
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     res = int(os.environ.get("PRESIGHT_EXTRACT_RES", "512"))
-    model, scene = build_model(dev, seed=42, config="cfg2")
+    mcfg = args.extract_model
+    model, scene = build_model(dev, seed=42, config=mcfg)
     model.eval()
-    aabb = scene["aabbs"][0]
+    aabb = tile_aabb(scene)
     total = res ** 3
     per = (total + world - 1) // world
     start, count = rank * per, max(0, min(per, total - rank * per))
@@ -673,6 +724,9 @@ def extract_main(args) -> int:
     for _ in range(max(0, args.warmup - 1)):
         one_pass()
     steps = max(1, min(args.steps, 5))
+    from presight_amd import field_ops as F
+
+    F.GATE_STATS = torch.zeros(2, device=dev, dtype=torch.int64)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -688,23 +742,21 @@ def extract_main(args) -> int:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     kept, nvox = int(out["points"].shape[0]), int(vox["key"].shape[0])
+    gst = F.GATE_STATS.tolist()
+    F.GATE_STATS = None
     if rank == 0:
         value = total * steps / dt
         per_gpu = value / world
-        # SURVEY.md 8d per query point: 1792 B of hash rows (main 16*8*2*4 + 2 proposal nets 8*8*1*4) + 2*(7680+12288) + 2*2*576 FLOP... cfg-2 fields
-        flop_pt, byte_pt = 2 * (16 * 2 * 64 + 64 * 80 + 3 * 64 * 64) + 2 * 2 * 576, 16 * 8 * 2 * 4 + 2 * 8 * 8 * 4 + 64 * 2 + 4
         line = {"metric": "prior-extraction lattice points/sec (whole node)", "value": value, "unit": "points/s", "n_gpus": world, "steps": steps,
                 "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"BASELINE cfg 5: dense {res}^3 lattice of one tile (cfg-2 fields): 3 field queries + fp16 features + density "
-                                       "threshold + bit-exact voxel index + voxel down-sampling of the kept points", "points_per_gpu": count,
-                           "parallelism": f"slabs{world}"},
-                "roofline": {"bound": "mfma", "kernel": "whole pass (per-point algorithmic work, SURVEY.md 8d)", "achieved": per_gpu * flop_pt / 1e12,
-                             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per_gpu * flop_pt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                             "traffic": None, "hbm_achieved_gbs": per_gpu * byte_pt / 1e9, "hbm_frac": per_gpu * byte_pt / 1e9 / HBM_PEAK_GBS},
+                "config": {"workload": f"BASELINE cfg 5: dense {res}^3 lattice of one tile ({mcfg} fields, K = {CONFIGS[mcfg]['K']} sub-fields): 3 field "
+                                       "queries + fp16 features + density threshold + bit-exact voxel index + voxel down-sampling of the kept points",
+                           "points_per_gpu": count, "parallelism": f"slabs{world}"},
+                "roofline": extract_roofline(mcfg, per_gpu, gst[0] / max(gst[1], 1)),
                 "density_threshold": thr, "kept_points_rank0": kept, "voxels_rank0": nvox}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_query_baseline()
+            line["cpu_baseline"] = cpu_query_baseline(mcfg)
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if world > 1:
@@ -713,20 +765,23 @@ def extract_main(args) -> int:
     return 0
 
 
-def cpu_query_baseline() -> dict:
-    """the CPU oracle's prior query (restatement of extract_priors.py:133-138, kind = "port") on a bounded sample of lattice points"""
+def cpu_query_baseline(model_cfg="cfg2") -> dict:
+    """the CPU oracle's prior query (restatement of extract_priors.py:133-138, kind = "port") on a bounded sample of lattice points;
+    model_cfg cfg3: the production tile (K = 16 routed sub-fields, L10 F4 T2^20 main tables)"""
     import statistics
 
     import torch
 
     from oracle import nerf_oracle as O
 
-    cfg = O.default_config()
+    cfg = O.default_config() if model_cfg == "cfg2" else O.prod_shaped_config(16, log2_hashmap_size=20)
+    if model_cfg != "cfg2":
+        cfg["num_cameras"], cfg["num_videos"] = 1440, 6
     scene = O.make_scene(cfg)
     P = O.make_params(cfg, seed=42)
     n = 1 << 18
     g = torch.Generator().manual_seed(0)
-    lo, hi = scene["aabbs"][0][0], scene["aabbs"][0][1]
+    lo, hi = scene["aabbs"][:, 0].min(0).values, scene["aabbs"][:, 1].max(0).values
     pts = lo + (hi - lo) * torch.rand(n, 3, generator=g)
     phys, model_name = host_cpu_info()
     maxt = torch.get_num_threads()
@@ -752,7 +807,7 @@ def cpu_query_baseline() -> dict:
     used = torch.get_num_threads()
     torch.set_num_threads(maxt)
     return dict(value=n / statistics.median(times), unit="points/s", cores=used, kind="port",
-                sample=f"median of {len(times)} passes over {n} lattice points (2 proposal fields + main field density and semantics, cfg-2 tables), "
+                sample=f"median of {len(times)} passes over {n} lattice points (2 proposal fields + main field density and semantics, {model_cfg} tables), "
                        f"torch-CPU oracle, {used} threads",
                 host=dict(cpu_model=model_name, physical_cores=phys, logical_cpus=os.cpu_count(), thread_probe_points_per_s=probe))
 
@@ -953,6 +1008,7 @@ def main():
             run_sec(["cfg3_65536", "cfg3_8192"], cfg3)
             run_sec(["cfg4_65536"], lambda: {"cfg4_65536": secondary_training_lines("cfg4", [(65536, 4, 2)], dev)[65536]})
             run_sec(["extract_512"], lambda: {"extract_512": secondary_extract_line(dev)})
+            run_sec(["extract_512_prod"], lambda: {"extract_512_prod": secondary_extract_line(dev, model_cfg="cfg3")})
             line["secondary"] = sec
         if world == 1 and args.config == "cfg2" and args.psnr_steps > 0:
             try:

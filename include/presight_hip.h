@@ -217,13 +217,16 @@ int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t N, int64_t
 int ps_main_field_gated_sizes(int LF, int hidden, int hidden_color, int64_t* packed_floats /*host*/, int64_t* offsets /*host [3]*/);
 int ps_main_field_fwd_gated(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
                             const float* packed, int64_t N, const float* gate_a, const float* gate_b, float gate_threshold,
-                            float* sigma, float* sem, void* stream);
+                            float* sigma, float* sem,
+                            unsigned long long* gate_stats /* nullable, device [2]: += (32-point tiles whose semantic head ran, tiles visited) */,
+                            void* stream);
 /* the same gated query for the K routed sub-fields of a production tile (ns/fields/PreSight/ingp_field_ms.py:97-126 evaluated by
  * ns/scripts/extract_priors.py:133-138): feat / sel in the sorted layout of ps_ms_route (n_slots), packed = K blocks of the
  * ps_main_field_gated_sizes layout back to back, gate_a / gate_b / sigma / sem in the CALLER's point order (reached through perm). */
 int ps_main_field_fwd_gated_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color, const float* sel,
                                const float* packed, int64_t n_slots, const float* gate_a, const float* gate_b, float gate_threshold,
-                               float* sigma, float* sem, const int32_t* perm, const int32_t* field_start, int K, void* stream);
+                               float* sigma, float* sem, unsigned long long* gate_stats /* as above */, const int32_t* perm,
+                               const int32_t* field_start, int K, void* stream);
 int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                       const float* sel, const float* dirs, const float* app, int S, int A, const float* packed, int64_t N,
                       float* sigma, float* rgb, float* sem, float* acts /* nullable: [ceil(N/16)*16, ps_main_field_act_width], register order */,

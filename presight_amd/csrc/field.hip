@@ -427,6 +427,7 @@ struct MainArgs {
   const float* gate_a;
   const float* gate_b;
   float gate_thr;
+  unsigned long long* gate_stats;  // nullable, device [2]: += (tiles whose semantic head ran, tiles visited) -- for the roofline row
 };
 
 // FACT (the factored semantic path of the training render node, one sub-field): the semantic head's input is a LINEAR function
@@ -642,6 +643,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   fetch(it1.first, nxt);
   float carry = 0.0f;                    // FACT: optical depth of the ray up to this tile
   float racc[C::FACT ? 16 : 1] = {0.f};  // FACT: this lane's part of sum_n w_n s_n (neurons 16nb + 4g + r, samples j, j + 16, ...)
+  unsigned n_tiles = 0, n_sem_tiles = 0;  // gated inference: tiles visited / tiles whose semantic head ran (uniform per wave)
   for (; it0.first < a.N; it0 = it1, it1 = it2, it2 = advance(it2)) {
     const int64_t first = it0.first;
     PS_STAMP(tm, 0)
@@ -721,6 +723,8 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
           }
         }
         run_sem = run_sem && __ballot(hit) != 0ull;
+        ++n_tiles;
+        n_sem_tiles += run_sem ? 1u : 0u;
       }
     }
     if (run_sem) {
@@ -849,6 +853,12 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   if (lane == 0)
     for (int i = 0; i < 16; ++i) atomicAdd(&g_ps_timing_fwd[i], tm_.acc[i]);
 #endif
+  if constexpr (!C::FACT) {
+    if (a.gate_stats != nullptr && lane == 0 && n_tiles != 0) {
+      atomicAdd(a.gate_stats, (unsigned long long)n_sem_tiles);
+      atomicAdd(a.gate_stats + 1, (unsigned long long)n_tiles);
+    }
+  }
 }
 
 // STORED: the hidden activations come from the training forward (a.acts) instead of being recomputed
@@ -1878,12 +1888,12 @@ extern "C" int ps_main_field_fwd(const float* feat, int64_t plane_stride, int LF
 // ps_main_field_gated_sizes.  Densities are bit-identical to ps_main_field_fwd, semantics agree to fp32 rounding.
 extern "C" int ps_main_field_fwd_gated(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                        const float* sel, const float* packed, int64_t N, const float* gate_a, const float* gate_b,
-                                       float gate_threshold, float* sigma, float* sem, void* stream) {
+                                       float gate_threshold, float* sigma, float* sem, unsigned long long* gate_stats, void* stream) {
   PS_REQUIRE(gate_a != nullptr && gate_b != nullptr && sigma != nullptr && sem != nullptr, "ps_main_field_fwd_gated: null argument");
   MainArgs a{};
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.S = 1; a.A = 0;
   a.packed = packed; a.N = N; a.sigma = sigma; a.sem = sem; a.K = 1;
-  a.gate_a = gate_a; a.gate_b = gate_b; a.gate_thr = gate_threshold;
+  a.gate_a = gate_a; a.gate_b = gate_b; a.gate_thr = gate_threshold; a.gate_stats = gate_stats;
   return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream, false, true);
 }
 
@@ -1911,14 +1921,14 @@ extern "C" int ps_main_field_gated_sizes(int LF, int hidden, int hidden_color, i
 // ps_main_field_gated_sizes layout back to back; gate_a / gate_b / sigma / sem in the CALLER's point order
 extern "C" int ps_main_field_fwd_gated_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, int hidden_color,
                                           const float* sel, const float* packed, int64_t n_slots, const float* gate_a, const float* gate_b,
-                                          float gate_threshold, float* sigma, float* sem, const int32_t* perm, const int32_t* field_start,
-                                          int K, void* stream) {
+                                          float gate_threshold, float* sigma, float* sem, unsigned long long* gate_stats, const int32_t* perm,
+                                          const int32_t* field_start, int K, void* stream) {
   PS_REQUIRE(gate_a != nullptr && gate_b != nullptr && sigma != nullptr && sem != nullptr, "ps_main_field_fwd_gated_ms: null argument");
   PS_REQUIRE(perm != nullptr && field_start != nullptr && K >= 1, "ps_main_field_fwd_gated_ms: need the sorted layout");
   MainArgs a{};
   a.feat = feat; a.plane_stride = plane_stride; a.LF = LF; a.F = F; a.sel = sel; a.S = 1; a.A = 0;
   a.packed = packed; a.N = n_slots; a.sigma = sigma; a.sem = sem; a.perm = perm; a.field_start = field_start; a.K = K;
-  a.gate_a = gate_a; a.gate_b = gate_b; a.gate_thr = gate_threshold;
+  a.gate_a = gate_a; a.gate_b = gate_b; a.gate_thr = gate_threshold; a.gate_stats = gate_stats;
   return main_fwd_impl(a, hidden, hidden_color, (hipStream_t)stream, false, true);
 }
 

@@ -712,6 +712,7 @@ class MainSpecGated:
 
 
 _MAIN_SPECS_G: dict = {}
+GATE_STATS: Optional[Tensor] = None  # int64 device tensor [2] while a caller (bench.py) counts executed / visited tiles of the gated query
 
 
 def main_field_gated(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g: GridCfg, base, sem, rgb, gate_a: Tensor, gate_b: Tensor,
@@ -745,7 +746,7 @@ def main_field_gated(u: Tensor, sel: Tensor, table: Tensor, scalings: Tensor, g:
         with prof.region("main_field_fwd"):
             check(lib().ps_main_field_fwd_gated(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color,
                                                 _p(sel), _p(packed), N, _p(_f32(gate_a).reshape(-1)), _p(_f32(gate_b).reshape(-1)),
-                                                float(threshold), _p(sigma), _p(semantics), _stream()), "ps_main_field_fwd_gated")
+                                                float(threshold), _p(sigma), _p(semantics), _p(GATE_STATS), _stream()), "ps_main_field_fwd_gated")
     return sigma, semantics
 
 
@@ -770,8 +771,8 @@ def ms_main_field_gated(lay: "MsLayout", u: Tensor, sel: Tensor, tables: Sequenc
         with prof.region("main_field_fwd"):
             check(lib().ps_main_field_fwd_gated_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden,
                                                    hidden_color, _p(sel), _p(st.packed), lay.n_slots, _p(_f32(gate_a).reshape(-1)),
-                                                   _p(_f32(gate_b).reshape(-1)), float(threshold), _p(sigma), _p(semantics), _p(lay.perm),
-                                                   lay.field_start, K, _stream()), "ps_main_field_fwd_gated_ms")
+                                                   _p(_f32(gate_b).reshape(-1)), float(threshold), _p(sigma), _p(semantics), _p(GATE_STATS),
+                                                   _p(lay.perm), lay.field_start, K, _stream()), "ps_main_field_fwd_gated_ms")
     return sigma, semantics
 
 

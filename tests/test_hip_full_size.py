@@ -189,3 +189,52 @@ def test_dense_lattice_512_cubed_index_and_slab_merge(dev):
     assert torch.equal(m["features"].cpu(), one["features"].cpu())  # fp64 sums of fp16 members -> fp16: exact
     assert int(one["hits"].sum()) == one["index"].shape[0] * 0 + int(m["hits"].sum())
     torch.testing.assert_close(m["points"].cpu(), one["points"].cpu(), rtol=0, atol=1e-5)
+
+
+def test_dense_lattice_512_cubed_production_tile(dev, monkeypatch):
+    """BASELINE cfg 5 on the PRODUCTION tile (K = 16 routed sub-fields, L10 F4 T2^20 main tables; ns/scripts/extract_priors.py:133-138
+    on ns/fields/PreSight/ingp_field_ms.py:97-126): the 512^3 lattice over the union of the sub-field boxes through the gated + merged
+    routed kernels.  Properties that hold at full size: the query of two odd slabs equals the one-pass query point for point (no
+    exchange between slabs: the router, the gate and the voxel origin do not depend on the slab); the integer-key merge of the slabs'
+    voxel sums equals the one-pass down-sampling; and on one 8 M-point chunk the kept points, their densities (bit for bit) and fp16
+    features (one fp16 ulp) equal the UNGATED, UNMERGED routed query."""
+    import bench
+    from presight_amd import extract
+    from presight_amd import field_ops as F
+
+    res, voxel = 512, 0.4
+    model, scene = bench.build_model(dev, seed=3, config="cfg3")
+    model.eval()
+    assert len(model.field.fields) == 16
+    aabb = bench.tile_aabb(scene)
+    chunk = 1 << 23
+    probe = extract.dense_tile_query(model, aabb, res=64, density_threshold=-1.0)
+    thr = float(torch.quantile(probe["densities"][:: max(1, probe["densities"].numel() // 100000)], 0.9))
+    del probe
+    F.GATE_STATS = torch.zeros(2, device=dev, dtype=torch.int64)
+    full = extract.dense_tile_query(model, aabb, res=res, chunk=chunk, density_threshold=thr)
+    ran, seen = F.GATE_STATS.tolist()
+    F.GATE_STATS = None
+    assert seen >= res ** 3 // 32 and 0 < ran < seen  # the gate skipped semantic-head tiles (routed layout: padded chunks add tiles)
+    half = (res ** 3) // 2 + 54321
+    a = extract.dense_tile_query(model, aabb, res=res, chunk=chunk, start=0, count=half, density_threshold=thr)
+    b = extract.dense_tile_query(model, aabb, res=res, chunk=chunk, start=half, count=res ** 3 - half, density_threshold=thr)
+    assert full["points"].shape[0] > 1_000_000
+    for k in ("points", "features", "densities", "voxel_index"):
+        assert torch.equal(torch.cat([a[k], b[k]]), full[k]), k
+    kw = dict(voxel=voxel, min_bound=full["min_bound"], points_max=full["points_max"], want_sums=True)
+    one = extract.voxelize(full["points"], full["features"], None, **kw)
+    va, vb = extract.voxelize(a["points"], a["features"], None, **kw), extract.voxelize(b["points"], b["features"], None, **kw)
+    del full, a, b
+    m = extract.merge_voxels([va, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in vb.items()}])
+    assert torch.equal(m["key"].cpu(), one["key"].cpu()) and torch.equal(m["hits"].cpu(), one["hits"].cpu())
+    assert torch.equal(m["features"].cpu(), one["features"].cpu())
+    # one chunk against the ungated query on the unmerged routed kernels
+    s0 = 7 * chunk
+    pts = extract.lattice_points(aabb, res, s0, chunk, dev)
+    dens_g, keep_g, feat_g = extract.query_priors(model, pts, thr)
+    monkeypatch.setattr(F, "MERGED_MS", False)
+    dens_u, feat_u = extract.query_priors(model, pts)
+    assert torch.equal(dens_g, dens_u) and torch.equal(keep_g, dens_u > thr)
+    diff = (feat_g.float() - feat_u[keep_g].float()).abs()
+    assert float(diff.max()) <= 2.0 ** -10 and float((diff > 0).float().mean()) < 1e-3
