@@ -601,21 +601,29 @@ def extract_workload(model_cfg):
     return dict(alg_flop=alg_flop, alg_byte=alg_byte, ex_mac_always=ex_mac_always, ex_mac_gated=ex_mac_gated, lines_byte=lines_byte)
 
 
+GATHER_LINES_L2_RESIDENT = 267e9  # measured: distinct 64-B lines/s of random gathers into an L2-resident 4 MiB table (profiles/r02_microbench_random_gather.txt)
+GATHER_LINES_HBM_RESIDENT = 54e9  # measured: the same into a 2 GiB table (every line from HBM = 3.5 TB/s of 64-B lines)
+
+
 def extract_roofline(model_cfg, points_per_s_per_gpu, gated_frac):
-    """roofline object of an extraction line: `frac` on the work the kernels execute, against whichever ceiling binds"""
+    """roofline object of an extraction line, on the work the kernels EXECUTE.  The pass is neither HBM-stream- nor MFMA-bound: its
+    compulsory HBM traffic is the tables once + the kept outputs (a few hundred MB per 134 M points), its time goes into gathers that
+    the caches serve.  The contract row is therefore the matrix-core one (executed flops / time / peak, small and honest); the gather
+    side is reported as 64-byte lines per second next to the two MEASURED gather ceilings of this part (an L2-resident table and an
+    HBM-resident one): lattice points are spatially coherent, so the rate lies between them."""
     w = extract_workload(model_cfg)
     ex_flop = 2 * (w["ex_mac_always"] + gated_frac * w["ex_mac_gated"])
-    t_mfma = ex_flop / (FP32_MFMA_PEAK_TFLOPS * 1e12)
-    t_hbm = w["lines_byte"] / (HBM_PEAK_GBS * 1e9)
-    bound = "hbm" if t_hbm >= t_mfma else "mfma"
     t = 1.0 / points_per_s_per_gpu
-    return {"bound": bound, "kernel": "whole pass (3 field queries per lattice point; executed work, DESIGN.md section 5)",
-            "achieved": (w["lines_byte"] / t / 1e9) if bound == "hbm" else (ex_flop / t / 1e12),
-            "peak": HBM_PEAK_GBS if bound == "hbm" else FP32_MFMA_PEAK_TFLOPS, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-            "frac": max(t_hbm, t_mfma) / t, "traffic": None,
-            "frac_mfma_executed": t_mfma / t, "frac_hbm_gathered_lines": t_hbm / t, "semantic_head_tiles_executed": gated_frac,
-            "executed_flop_per_point": ex_flop, "gathered_line_bytes_per_point": w["lines_byte"],
-            "frac_algorithmic_mfma": w["alg_flop"] / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, "frac_algorithmic_hbm": w["alg_byte"] / t / 1e9 / HBM_PEAK_GBS}
+    lines = w["lines_byte"] // 64
+    return {"bound": "mfma", "kernel": "whole pass (3 field queries per lattice point; executed matrix-core work)",
+            "achieved": ex_flop / t / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex_flop / t / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": None, "semantic_head_tiles_executed": gated_frac, "executed_flop_per_point": ex_flop,
+            "frac_algorithmic": w["alg_flop"] / t / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "gather": {"lines_per_point": lines, "lines_per_s": lines / t, "measured_ceiling_l2_resident_lines_per_s": GATHER_LINES_L2_RESIDENT,
+                       "measured_ceiling_hbm_resident_lines_per_s": GATHER_LINES_HBM_RESIDENT,
+                       "frac_of_l2_resident_ceiling": lines / t / GATHER_LINES_L2_RESIDENT,
+                       "frac_of_hbm_resident_ceiling": lines / t / GATHER_LINES_HBM_RESIDENT},
+            "frac_algorithmic_hbm": w["alg_byte"] / t / 1e9 / HBM_PEAK_GBS}
 
 
 def tile_aabb(scene):
@@ -662,7 +670,8 @@ def secondary_extract_line(dev, res=512, passes=2, model_cfg="cfg2"):
                         f"K = {CONFIGS[model_cfg]['K']}), 3 field queries + fp16 features + threshold + bit-exact voxel index + voxel down-sampling",
             "ms_per_step": dt * 1e3, "value": res ** 3 / dt, "unit": "points/s", "passes": passes,
             "kept_points": int(out["points"].shape[0]), "voxels": int(vox["key"].shape[0]),
-            "frac_of_binding": roof["frac"], "roofline": roof}
+            "frac_of_binding": roof["frac"], "frac_of_binding_note": "executed matrix-core flops / time / fp32 MFMA peak; gather rates in roofline.gather",
+            "roofline": roof}
     del model, scene, out, vox
     gc.collect()
     torch.cuda.empty_cache()
