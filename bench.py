@@ -82,6 +82,9 @@ def parse_args(argv=None):
     ap.add_argument("--fixed-batches", action="store_true", help="recycle 4 pre-made batches instead of the device chunk feed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg3 / cfg4 / extraction measurements of the default line")
+    ap.add_argument("--parallelism", choices=["dp", "tiles"], default="dp",
+                    help="dp: data-parallel training of ONE tile over the ranks (gradient exchange every step); tiles: one independent tile "
+                         "per rank, no exchange at all -- how the reference builds a city (docs/building_priors.md:7-44: one ns-train per tile)")
     ap.add_argument("--extract-model", choices=["cfg2", "cfg3"], default="cfg3",
                     help="--config extract: the fields that are queried -- cfg3 = the production tile (K = 16 routed sub-fields, L10 F4 T2^20), cfg2 = one sub-field")
     ap.add_argument("--psnr-steps", type=int, default=300, help="iterations of the learnable-scene training run behind `psnr_after_k_steps` (0: skip)")
@@ -578,6 +581,18 @@ def secondary_training_lines(config, shapes, dev):
                        "value": rays / dt, "unit": "rays/s", "parameters": n_params,
                        "top3_regions_ms_per_step": {k: round(v, 3) for k, v in top}, "frac_of_binding": rays / dt / ceil}
         del batches
+    if config == "cfg3" and os.environ.get("PRESIGHT_NO_DRY_OVERLAP") != "1":
+        # strong scaling of the production tile: the exchange schedule by construction from a dry run of the bucketed, sharded exchange
+        # at the per-rank shapes (65 536 rays = N 1, 8192 rays = one of 8 ranks)
+        for rays, _, _ in shapes:
+            try:
+                dry = dry_overlap_timeline(model, scene, rays, dev, steps=3, exchange="sharded")
+                n = max(1, 65536 // rays)
+                dry["predicted"] = {f"N{n}": exchange_schedule(dry["buckets"], n, "sharded")} if n > 1 else {
+                    f"N{m}_upper_bound_full_batch_compute": exchange_schedule(dry["buckets"], m, "sharded") for m in (2, 4)}
+                lines[rays]["exchange_overlap_dry_run"] = dry
+            except Exception as e:
+                lines[rays]["exchange_overlap_dry_run"] = {"error": f"{type(e).__name__}: {e}"}
     del trainer, model, scene
     gc.collect()
     torch.cuda.empty_cache()
@@ -679,17 +694,77 @@ def secondary_extract_line(dev, res=512, passes=2, model_cfg="cfg2"):
 
 
 def exchange_model(bytes_on_link_per_rank: float, world: int, step_ms_single: float = None) -> dict:
-    """The scaling model of DESIGN.md section 6, evaluated for this run: a rank sends (and receives) `bytes_on_link_per_rank` per
-    step -- (N-1)/N of every reduce-scattered / all-gathered byte, twice that for an all-reduce.  xGMI is point-to-point: with the
-    direct (all-to-all) algorithm every peer link carries 1/(N-1) of it concurrently -> t = bytes / ((N-1) * link rate); a ring
-    moves everything over ONE link per direction -> t = bytes / link rate.  RCCL picks between them; both bounds are printed next
-    to the measured exposed time, which is what is left after the overlap with backward / the next step's sampling."""
+    """The link-time bounds of DESIGN.md section 6 for this run: a rank sends (and receives) `bytes_on_link_per_rank` per step --
+    (N-1)/N of every reduce-scattered / all-gathered byte, twice that for an all-reduce.  xGMI is point-to-point, ~153 GB/s per link and
+    direction, 7 links per GPU.  ASSUMPTION (never measured here: no multi-GPU node was available to the builder): RCCL's direct
+    (all-to-all) algorithms keep all N-1 peer links busy at once -> t = bytes / ((N-1) * link rate); a ring moves everything over ONE
+    link per direction -> t = bytes / link rate.  Which one RCCL picks for these message sizes is not known; both are printed next to
+    the measured exposed time, which is what is left after the overlap with backward / the next step's sampling."""
     if world <= 1:
         return None
     direct = bytes_on_link_per_rank / ((world - 1) * XGMI_LINK_GBS * 1e9) * 1e3
     ring = bytes_on_link_per_rank / (XGMI_LINK_GBS * 1e9) * 1e3
-    return {"link_GBps_per_direction": XGMI_LINK_GBS, "peer_links_used": world - 1, "predicted_ms_all_links": direct,
-            "predicted_ms_ring_one_link": ring}
+    return {"link_GBps_per_direction": XGMI_LINK_GBS, "peer_links_used_ASSUMED": world - 1, "predicted_ms_all_links": direct,
+            "predicted_ms_ring_one_link": ring,
+            "assumption": "all N-1 peer links concurrently (direct algorithm) vs one link (ring): RCCL's choice is not known, no multi-GPU run exists"}
+
+
+def exchange_schedule(timeline, world: int, mode: str, compute_scale: float = 1.0) -> dict:
+    """Exposed vs hidden exchange time BY CONSTRUCTION, from a measured bucket timeline (FlatGrads.timeline_summary: for every
+    exchange bucket its bytes and how long before the end of backward its gradient was complete on this GPU).  The communication
+    stream runs the buckets in order: start_b = max(ready_b, end_{b-1}), end_b = start_b + t_b with t_b = the bucket's bytes on the
+    links / link rate (exchange_model's two bounds); what is left after the end of backward is EXPOSED, the rest is hidden under
+    kernels that are still running.  compute_scale: the per-rank backward of a strong-scaled run is shorter than the measured one."""
+    if not timeline:
+        return None
+    out = {}
+    for label, links in (("all_links_ASSUMED", world - 1), ("ring_one_link", 1)):
+        t_end, rows, total = None, [], 0.0
+        for b in timeline:
+            if b["steps_exchanged"] == 0:
+                continue
+            on_link = b["bytes"] * (world - 1) / world * (2.0 if mode == "allreduce" else 1.0)
+            t_b = on_link / (links * XGMI_LINK_GBS * 1e9) * 1e3
+            ready = -b["ms_before_backward_end"] * compute_scale
+            start = ready if t_end is None else max(ready, t_end)
+            t_end = start + t_b
+            total += t_b
+            rows.append({"bucket": b["bucket"], "MB": round(b["bytes"] / 1e6, 2), "ready_ms_before_backward_end": round(-ready, 3),
+                         "link_ms": round(t_b, 3), "exposed_ms": round(max(0.0, t_end) - max(0.0, start), 3) if t_end > 0 else 0.0,
+                         "hidden_ms": round(t_b - (max(0.0, t_end) - max(0.0, start)), 3) if t_end > 0 else round(t_b, 3)})
+        out[label] = {"link_ms_total": round(total, 3), "exposed_ms": round(max(0.0, t_end or 0.0), 3),
+                      "hidden_ms": round(total - max(0.0, t_end or 0.0), 3), "buckets": rows}
+    return out
+
+
+def dry_overlap_timeline(model, scene, rays, dev, steps=5, exchange="allreduce"):
+    """bucket timeline of the overlapped exchange measured on ONE GPU: a second trainer on the same model with the bucketed exchange
+    armed but no process group (PRESIGHT_DRY_OVERLAP: split accumulate launches, hand-over bookkeeping and stream events run as they
+    would with N ranks; no collective is issued)"""
+    import torch
+
+    old = os.environ.get("PRESIGHT_DRY_OVERLAP")
+    os.environ["PRESIGHT_DRY_OVERLAP"] = "1"
+    try:
+        tr = Trainer(model, scene, 1, exchange=exchange)
+    finally:
+        if old is None:
+            os.environ.pop("PRESIGHT_DRY_OVERLAP", None)
+        else:
+            os.environ["PRESIGHT_DRY_OVERLAP"] = old
+    batches = make_batches(scene, dev, 2, 0, rays=rays)
+    for i in range(3):
+        tr.step(batches[i % 2])
+    tr.grads.record_timeline = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(batches[i % 2])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    tl = tr.grads.timeline_summary()
+    return {"ms_per_step_with_split_launches": ms, "buckets": tl,
+            "handed_over_in_backward": sum(1 for t in tl if t["handed_over_in_backward"] == t["steps_exchanged"] > 0), "n_buckets": len(tl)}
 
 
 # --------------------------------------------------------------------------------------------------------- extraction bench
@@ -850,11 +925,14 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = CONFIGS[args.config]
-    scaling = args.scaling or cfg["scaling"]
+    tiles = args.parallelism == "tiles"
+    scaling = "weak" if tiles else (args.scaling or cfg["scaling"])
     exchange = args.exchange or cfg["exchange"]
     rays = args.rays if scaling == "weak" else args.rays // world  # ns/data/PreSight/my_datamanager.py:203-212: R // world
-    model, scene = build_model(dev, seed=42, config=args.config)  # same init on every rank (DDP broadcast equivalent)
-    trainer = Trainer(model, scene, world, exchange=exchange, global_depth_clip=args.global_depth_clip)
+    # dp: same init on every rank (DDP broadcast equivalent).  tiles: every rank owns a DIFFERENT tile -- its own parameters, its own
+    # rays, no collective in the step (the process group only brackets the timed region)
+    model, scene = build_model(dev, seed=42 + (rank if tiles else 0), config=args.config)
+    trainer = Trainer(model, scene, 1 if tiles else world, exchange=exchange, global_depth_clip=args.global_depth_clip and not tiles)
     # data: the device-resident chunk feed (one gather launch per batch, next chunk prefetched on a side stream; the reference's
     # loader semantics: shuffled pass over the chunk, rank r takes every world-th slot) or 4 recycled pre-made batches
     feed, batches = None, None
@@ -863,7 +941,7 @@ def main():
     else:
         from presight_amd.datafeed import ChunkFeed
 
-        feed = ChunkFeed(lambda i: synthetic_chunk(scene, dev, i), batch_size=rays, device=dev, world=world, rank=rank)
+        feed = ChunkFeed(lambda i: synthetic_chunk(scene, dev, i), batch_size=rays, device=dev, world=1 if tiles else world, rank=0 if tiles else rank)
     last_batch = [None]
 
     def run(n):
@@ -901,13 +979,19 @@ def main():
     # itself; in the timed steps the proposal backward overlaps the main field's)
     from presight_amd import ops as _ops
 
+    comm = dict(trainer.grads.stats)
     side_was, _ops.SIDE_STREAM = _ops.SIDE_STREAM, False
     prof.enable(True)
     run(min(args.steps, 8))
     kern = {**prof.summary(), **kern}  # live figures win
     prof.enable(False)
     _ops.SIDE_STREAM = side_was
-    comm = dict(trainer.grads.stats)
+    timeline = None
+    if world > 1 and not tiles:  # when every bucket became ready relative to the end of backward (normal schedule: proposal side stream on)
+        trainer.grads.record_timeline = True
+        run(4)
+        timeline = trainer.grads.timeline_summary()
+        trainer.grads.record_timeline = False
     # secondary figure (NOT `value`): the reference's own steady-state proposal-update schedule after warm-up
     # (ray_samplers.py:586 + nerfacto_nusc_ms.py:300-305: gradients reach the proposal nets every 6th step)
     trainer.update_props_every_step = False
@@ -918,7 +1002,7 @@ def main():
     dt_sched, _ = timed(n_sched)
     # secondary figure: the other scaling mode on the same ranks (strong: args.rays over all ranks; weak: args.rays per rank)
     other = None
-    if world > 1:
+    if world > 1 and not tiles:
         trainer.update_props_every_step = True
         o_rays = args.rays // world if scaling == "weak" else args.rays
         keep = (feed, batches)
@@ -929,7 +1013,7 @@ def main():
         other = dict(scaling="strong" if scaling == "weak" else "weak", rays_per_gpu=o_rays, value=world * o_rays * 8 / dt_o,
                      ms_per_step=dt_o / 8 * 1e3)
     replica_diff = None
-    if world > 1:
+    if world > 1 and not tiles:
         # data-parallel consistency: every rank applied the same averaged gradients, so the replicas must still be identical
         trainer.grads.wait_params()
         mine = trainer.opt.flat[0]
@@ -958,8 +1042,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "data_feed": "4 recycled batches" if feed is None else f"device chunk feed ({feed.chunks_loaded} chunk(s) of {1 << 22} pixels loaded)",
-            "config": {"workload": cfg["workload"], "rays_per_gpu": rays, "rays_per_step_global": rays * world, "parallelism": f"dp{world}",
-                       "exchange": trainer.exchange if world > 1 else None},
+            "config": {"workload": cfg["workload"], "rays_per_gpu": rays, "rays_per_step_global": rays * world,
+                       "parallelism": f"tiles{world} (one independent tile per GPU, no exchange)" if tiles else f"dp{world}",
+                       "exchange": trainer.exchange if (world > 1 and not tiles) else None},
             "roofline": None if dom is None else {
                 "bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
                 "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC)",
@@ -979,15 +1064,32 @@ def main():
                                "the proposal networks' backward with the main field's" if side_was else "single stream",
             "value_reference_schedule": world * rays * n_sched / dt_sched,
             "other_scaling": other,
-            "comm": None if world == 1 else {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+            "comm": None if (world == 1 or tiles) else {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                                              "collectives_per_step": comm["collectives"] / args.steps,
+                                             "gradient_buckets_issued_during_backward_per_step": comm.get("in_backward", 0) / args.steps,
                                              "bytes_on_link_per_rank_per_step": comm["bytes"] / args.steps,
+                                             "bucket_timeline": timeline,
+                                             "schedule_by_construction": exchange_schedule(timeline, world, trainer.exchange),
                                              "exchange_exposed_ms": kern.get("exchange_exposed", (0, None))[1],
                                              "model": exchange_model(comm["bytes"] / args.steps, world)},
             "replicas_max_abs_diff": replica_diff,
             "psnr_vs_random_targets": psnr,
             "loss": float(sum(v.detach() for v in loss_dict.values())),
         }
+        if world == 1 and rays == RAYS and os.environ.get("PRESIGHT_NO_DRY_OVERLAP") != "1" and "dynamic" not in cfg:
+            # the overlapped exchange, measured as far as ONE GPU can: bucket hand-over times from a dry run of the bucketed exchange
+            # (split accumulate launches, no collectives) -> exposed / hidden link time per bucket for N = 2, 4, 8 by construction
+            try:
+                if feed is not None:
+                    feed.close()
+                    feed = None
+                dry = dry_overlap_timeline(model, scene, rays, dev, exchange=exchange)
+                dry["predicted"] = {f"N{n}": exchange_schedule(dry["buckets"], n, exchange) for n in (2, 4, 8)}
+                dry["note"] = ("weak scaling (every rank runs this step): per-bucket link time from the xGMI bounds of exchange_model, hidden "
+                               "under the kernels still running after the bucket's hand-over; no multi-GPU run exists")
+                line["exchange_overlap_dry_run"] = dry
+            except Exception as e:
+                line["exchange_overlap_dry_run"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.config == "cfg2" and not args.no_secondary and rays == RAYS:
             # the other single-GPU BASELINE shapes, a few steps each (cfg 2 is the line itself; their own full runs: --config ...)
             if feed is not None:
@@ -1028,7 +1130,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
             line["psnr_vs_oracle"] = _PSNR_VS_ORACLE
-        if world > 1:
+        if world > 1 and not tiles:
             mdl = line["comm"]["model"]
             print(f"bench.py: gradient exchange per step and rank: {line['comm']['bytes_on_link_per_rank_per_step'] / 1e6:.1f} MB on the links; "
                   f"predicted {mdl['predicted_ms_all_links']:.2f} ms over all {world - 1} peer links ({mdl['predicted_ms_ring_one_link']:.2f} ms as a "

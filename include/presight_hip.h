@@ -282,8 +282,21 @@ int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, const float* s
                               int64_t plane_stride, float* const* dtables, int K, const int32_t* chunk_field,
                               const uint32_t* slice_counts, int absmax_ready, void* workspace,
                               int dst_is_zero /* the caller guarantees dtables[*] hold zeros (first contribution of the step): the
-                                                 flush then writes instead of read-modify-writing; slices without records stay untouched */,
+                                                 flush then writes instead of read-modify-writing;
+                                                 slices without records stay untouched */,
                               void* stream);
+/* The binned table backward in PIECES, for a gradient that is exchanged bucket by bucket while the backward is still running
+ * (the reference's DDP overlaps its bucketed all-reduce with backward: ns/pipelines/PreSight/my_pipeline.py:121-124): phase 1 = prepare
+ * (counts, stream offsets, record write pass), phase 2 = accumulate the items [item_begin, item_end) of ps_grid_scatter_items()
+ * = K * L * slices, ordered (sub-field, level, slice) like the gradient in memory; the same arguments in every call of one scatter. */
+int ps_grid_scatter_items(int L, int F, int log2T, int K);
+int ps_grid_scatter_binned_part(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
+                                int64_t plane_stride, float* dtable, int accumulate, const uint32_t* slice_counts, int absmax_ready,
+                                void* workspace, int phase, int item_begin, int item_end, void* stream);
+int ps_grid_scatter_binned_ms_part(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t n_slots,
+                                   int64_t plane_stride, float* const* dtables, int K, const int32_t* chunk_field,
+                                   const uint32_t* slice_counts, int absmax_ready, void* workspace, int dst_is_zero, int phase,
+                                   int item_begin, int item_end, void* stream);
 /* fused fields: packed = K packed parameter blocks back to back (ps_*_field_sizes packed_floats each); gpart receives
  * ps_*_field_parts_ms(n_slots, K) partial gradient blocks, reduced per sub-field by ps_mlp_unpack_table_ms */
 int ps_prop_field_parts_ms(int64_t n_slots, int K);

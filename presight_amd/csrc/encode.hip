@@ -737,11 +737,12 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
                                                           const float* __restrict__ rec_val, const unsigned* __restrict__ gmax_bits,
                                                           int L, int log2T, int log2_slice, int64_t n_rec_max, int headroom_log2,
                                                           int accumulate, float* __restrict__ dtable, float* const* __restrict__ dtables,
-                                                          float out_scale /* the gradient is multiplied by this (1: exactly the plain result) */) {
+                                                          float out_scale /* the gradient is multiplied by this (1: exactly the plain result) */,
+                                                          int item0 /* first item of this launch (the items may be dealt to several launches) */) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F]
   const int entries = 1 << log2_slice;
   const int n_slices = 1 << (log2T - log2_slice);
-  const int item = blockIdx.x;  // (sub-field * L + level) * n_slices + slice
+  const int item = item0 + blockIdx.x;  // (sub-field * L + level) * n_slices + slice
   const int vlevel = item / n_slices, sl = item % n_slices;
   const int level = vlevel % L;
   const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
@@ -902,7 +903,10 @@ int64_t binned_workspace(int L, int F, int log2T, int64_t N, int K, int D = 3) {
 int scatter_binned_impl(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                         int64_t plane_stride, float* dtable, float* const* dtables, int K, const int* chunk_field, int accumulate,
                         const uint32_t* slice_counts, int absmax_ready, void* workspace, hipStream_t s, int D = 3, int64_t period = 0,
-                        float out_scale = 1.0f, const float* dfeat_b = nullptr) {
+                        float out_scale = 1.0f, const float* dfeat_b = nullptr, int phase = 3, int item_begin = 0, int item_end = -1) {
+  // phase bit 0: prepare (counts, stream offsets, record write pass); bit 1: accumulate the items [item_begin, item_end) (item_end < 0:
+  // all).  A caller that exchanges the gradient in pieces launches the accumulate pass once per piece (items are ordered
+  // (sub-field, level, slice) = the order of the gradient in memory) and hands every piece over as soon as its launch is enqueued.
   PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_scatter_binned: features_per_level must be 1, 2 or 4");
   PS_REQUIRE(D == 3 || (D == 4 && K == 1 && chunk_field == nullptr), "ps_grid_scatter_binned: 3-D grids, or one 4-D grid");
   PS_REQUIRE(period == 0 || (period > 0 && N <= 3 * period), "ps_grid_scatter_binned: at most three position sets");
@@ -923,11 +927,16 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
   float* rec_val = (float*)(rec_idx + n_rec_max); // [F+1][n_rec_max] (plane F = ox)
   // absmax_ready: the first K*L words of the workspace already hold the per-level max |d(feature)| bits (written by the
   // field backward kernel that produced dfeat) -> keep them and skip the absmax pass
-  hipError_t e = absmax_ready ? hipMemsetAsync(ws + 4096, 0, (int64_t)n_items * 4, s) : hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
-  if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
-  if (slice_counts != nullptr && N > 0) {  // record counts (upper bounds) from the forward pass: ps_grid_encode
-    e = hipMemcpyAsync(cursors, slice_counts, (size_t)n_items * 4, hipMemcpyDeviceToDevice, s);
+  if (item_end < 0 || item_end > n_items) item_end = n_items;
+  PS_REQUIRE(item_begin >= 0 && item_begin <= item_end, "ps_grid_scatter_binned: bad item range");
+  hipError_t e = hipSuccess;
+  if (phase & 1) {
+    e = absmax_ready ? hipMemsetAsync(ws + 4096, 0, (int64_t)n_items * 4, s) : hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
     if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
+    if (slice_counts != nullptr && N > 0) {  // record counts (upper bounds) from the forward pass: ps_grid_encode
+      e = hipMemcpyAsync(cursors, slice_counts, (size_t)n_items * 4, hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
+    }
   }
   int headroom = 62 - 26;  // 8N <= 2^26 contributions per row
   {
@@ -945,18 +954,21 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
     const int64_t chunks = (N + bin_points(DD) - 1) / bin_points(DD);                                                     \
-    if (N > 0) {                                                                                                          \
-      if (slice_counts == nullptr)                                                                                        \
-        bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,      \
-                                                                            plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period, dfeat_b); \
+    if (phase & 1) {                                                                                                      \
+      if (N > 0) {                                                                                                        \
+        if (slice_counts == nullptr)                                                                                      \
+          bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,    \
+                                                                              plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period, dfeat_b); \
+      }                                                                                                                   \
+      stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                         \
+      if (N > 0)                                                                                                          \
+        bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,     \
+                                                                             plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
+                                                                             absmax_ready ? nullptr : gmax_bits, period, dfeat_b); \
     }                                                                                                                     \
-    stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                           \
-    if (N > 0)                                                                                                            \
-      bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,       \
-                                                                           plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
-                                                                           absmax_ready ? nullptr : gmax_bits, period, dfeat_b); \
-    accumulate_kernel<FF><<<(unsigned)n_items, 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
-                                                               n_rec_max, headroom, accumulate, dtable, dtables, out_scale); \
+    if ((phase & 2) && item_end > item_begin)                                                                             \
+      accumulate_kernel<FF><<<(unsigned)(item_end - item_begin), 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
+                                                                                 n_rec_max, headroom, accumulate, dtable, dtables, out_scale, item_begin); \
   }
   if (D == 3) {
     if (F == 1) PS_LAUNCH_BINNED(1)
@@ -992,6 +1004,30 @@ extern "C" int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, con
   PS_REQUIRE(n_slots % ps::kMsChunk == 0, "ps_grid_scatter_binned_ms: the sorted layout is a whole number of chunks");
   return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, n_slots, plane_stride, nullptr, dtables, K, chunk_field, /*accumulate=*/dst_is_zero ? 2 : 1,
                              slice_counts, absmax_ready, workspace, (hipStream_t)stream);
+}
+
+// The same two scatters in PIECES, for a gradient that is exchanged bucket by bucket while the backward is still running
+// (presight_amd/dist.py): phase 1 = prepare (count, stream offsets, record write pass), phase 2 = accumulate the items
+// [item_begin, item_end) of ps_grid_scatter_items() = K * L * slices, ordered (sub-field, level, slice) like the gradient in memory;
+// phase 3 with the full range = the one-call functions above.  Every accumulate call needs the same arguments as the prepare call.
+extern "C" int ps_grid_scatter_items(int L, int F, int log2T, int K) { return K * L * (1 << (log2T - binned_log2_slice(F, log2T))); }
+
+extern "C" int ps_grid_scatter_binned_part(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
+                                           int64_t N, int64_t plane_stride, float* dtable, int accumulate,
+                                           const uint32_t* slice_counts, int absmax_ready, void* workspace, int phase, int item_begin,
+                                           int item_end, void* stream) {
+  return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, N, plane_stride, dtable, nullptr, 1, nullptr, accumulate, slice_counts,
+                             absmax_ready, workspace, (hipStream_t)stream, 3, 0, 1.0f, nullptr, phase, item_begin, item_end);
+}
+
+extern "C" int ps_grid_scatter_binned_ms_part(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
+                                              int64_t n_slots, int64_t plane_stride, float* const* dtables, int K,
+                                              const int32_t* chunk_field, const uint32_t* slice_counts, int absmax_ready, void* workspace,
+                                              int dst_is_zero, int phase, int item_begin, int item_end, void* stream) {
+  PS_REQUIRE(dtables != nullptr && chunk_field != nullptr && K >= 1, "ps_grid_scatter_binned_ms_part: need the gradient pointers and the chunk map");
+  PS_REQUIRE(n_slots % ps::kMsChunk == 0, "ps_grid_scatter_binned_ms_part: the sorted layout is a whole number of chunks");
+  return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, n_slots, plane_stride, nullptr, dtables, K, chunk_field, /*accumulate=*/dst_is_zero ? 2 : 1,
+                             slice_counts, absmax_ready, workspace, (hipStream_t)stream, 3, 0, 1.0f, nullptr, phase, item_begin, item_end);
 }
 
 // ---- 4-D grid of the dynamic field (csrc/dynamic.hip; BASELINE cfg 4): same record streams and accumulate kernel, 8 x-pairs

@@ -45,9 +45,11 @@ class CommLog:
         if path:
             self.file = open(path.replace("{rank}", os.environ.get("RANK", "0")), "a", buffering=1)
 
-    def issue(self, kind: str, bucket, nbytes: int, stream: str, step=None):
+    def issue(self, kind: str, bucket, nbytes: int, stream: str, step=None, phase: Optional[str] = None):
+        """phase: "backward" = issued from a gradient hook while the backward pass is still being enqueued, "finish" = issued from
+        finish_exchange after it (bucketed gradient collectives only)"""
         self.seq += 1
-        line = f"{self.seq} {kind} bucket={bucket} bytes={nbytes} stream={stream} step={step}"
+        line = f"{self.seq} {kind} bucket={bucket} bytes={nbytes} stream={stream} step={step}" + (f" phase={phase}" if phase else "")
         self.ring.append(line)
         if self.file is not None:
             self.file.write(line + "\n")
@@ -97,10 +99,15 @@ def intersect_ranges(xs: Sequence[Tuple[int, int]], ys: Sequence[Tuple[int, int]
 
 
 class FlatGrads:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_sizes: Optional[Sequence[int]] = None, shard_world: int = 1):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_sizes: Optional[Sequence[int]] = None, shard_world: int = 1,
+                 splits: Optional[Dict[int, int]] = None):
         """bucket_sizes: number of consecutive parameters per exchange bucket (bucket-major parameter order); with
         shard_world = W every bucket's range is padded to a multiple of 4*W floats so that it splits into W equal,
-        16-byte-aligned shards (mode "sharded")."""
+        16-byte-aligned shards (mode "sharded").
+        splits: {bucket index: G} -- a ONE-parameter bucket (a hash table) is exchanged as G equal consecutive pieces, each its own
+        collective, handed over by the producer piece by piece (part_done): the table backward accumulates level group after level
+        group, so the reduce-scatter of group g runs underneath the accumulate launch of group g + 1.  G is lowered until the pieces
+        are equal and shard-aligned."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and p.numel() > 0]
         pad = lambda n: (n + 3) // 4 * 4  # noqa: E731  keep every view 16-byte aligned (vectorised optimizer kernels)
         if bucket_sizes is None:
@@ -111,8 +118,9 @@ class FlatGrads:
         self.offsets: List[int] = []
         self.bucket_ranges: List[Tuple[int, int]] = []
         self.bucket_params: List[Tuple[int, int]] = []  # (first parameter index, one past the last)
+        self.bucket_parts: Dict[int, List[Tuple[int, int]]] = {}  # declared bucket -> ranges of its pieces (split buckets only)
         off, i = 0, 0
-        for nb in bucket_sizes:
+        for bi, nb in enumerate(bucket_sizes):
             start = off
             for p in self.params[i:i + nb]:
                 self.offsets.append(off)
@@ -120,6 +128,15 @@ class FlatGrads:
             off = (off + align - 1) // align * align
             self.bucket_ranges.append((start, off))
             self.bucket_params.append((i, i + nb))
+            G = int((splits or {}).get(bi, 1))
+            if G > 1:
+                if nb != 1:
+                    raise ValueError("FlatGrads: only a one-parameter bucket can be split into pieces")
+                n = off - start
+                while G > 1 and (n % G or (n // G) % align):
+                    G -= 1
+                if G > 1:
+                    self.bucket_parts[bi] = [(start + g * (n // G), start + (g + 1) * (n // G)) for g in range(G)]
             i += nb
         self.total = off
         dev = self.params[0].device
@@ -148,6 +165,10 @@ class FlatGrads:
         self.group_steps: Optional[Tensor] = None   # int32 [n_groups], torch.optim.Adam's state["step"] of the group
         self.n_groups = 0
         self.step_no = 0  # zero_() calls so far (only labels the lines of COMM_LOG)
+        self._in_finish = False
+        self.dry = False            # bucket bookkeeping and timeline without a process group (enable_overlap(dry=True))
+        self.record_timeline = False  # record, per step, when every bucket became ready relative to the end of backward
+        self._timeline: List[dict] = []
 
     def define_groups(self, groups: Sequence[Sequence[torch.nn.Parameter]]):
         """Parameters whose "received a gradient this step" is only known ON THE DEVICE: the sub-fields of a routed tile (the
@@ -201,7 +222,7 @@ class FlatGrads:
         for p in self.params:
             p._ps_touched = False
         for b in self._buckets:
-            b["seen"], b["launched"], b["work"], b["ready"] = 0, False, None, None
+            b["seen"], b["launched"], b["work"], b["ready"], b["ready_t"], b["phase"] = 0, False, None, None, None, None
         self._next_launch = 0
 
     def touched(self, group: Optional[dist.ProcessGroup] = None) -> List[bool]:
@@ -229,15 +250,18 @@ class FlatGrads:
 
     # ------------------------------------------------------------------ overlapped, bucketed exchange
     def enable_overlap(self, buckets: List[List[torch.nn.Parameter]], group: Optional[dist.ProcessGroup] = None,
-                       mode: str = "allreduce"):
+                       mode: str = "allreduce", dry: bool = False):
         """Exchange the gradient buffer in buckets, each as soon as it is complete, on a side stream, while the backward of the
         remaining parameters is still running (the reference's DDP overlaps its bucketed all-reduce with backward the same
-        way).  A bucket = parameters that are contiguous in the flat buffer (e.g. one optimizer group); it becomes READY when
-        every one of its parameters has received its gradient of this step.  Buckets are launched strictly in the order of
-        `buckets` (pass them in the order backward completes them): a ready bucket waits for its predecessors, and whatever
-        has not been launched by the end of backward goes out in finish_exchange() — in the same order on every rank, which
-        is what keeps the collectives of ranks whose routing left different sub-fields without samples paired correctly.
-        A parameter must receive at most ONE gradient contribution per step (checked: a second one after the launch raises)."""
+        way).  A bucket = parameters that are contiguous in the flat buffer (e.g. one optimizer group), or one of the G pieces
+        of a split one-parameter bucket (`splits` of the constructor); it becomes READY when every one of its parameters has
+        received its gradient of this step / when its producer reports the piece (part_done).  Buckets are launched strictly in
+        the order of `buckets` (pass them in the order backward completes them): a ready bucket waits for its predecessors, and
+        whatever has not been launched by the end of backward goes out in finish_exchange() -- in the same order on every rank,
+        which is what keeps the collectives of ranks whose routing left different sub-fields without samples paired correctly.
+        A parameter must receive at most ONE gradient contribution per step (checked: a second one after the launch raises).
+        dry: no process group is involved -- the bookkeeping, the stream events and the timeline run as they would (one GPU:
+        measures when every bucket becomes ready relative to the end of backward, the input of the scaling model)."""
         if mode not in ("allreduce", "sharded"):
             raise ValueError(mode)
         index = {id(p): i for i, p in enumerate(self.params)}
@@ -249,18 +273,31 @@ class FlatGrads:
             if ids != list(range(ids[0], ids[-1] + 1)):
                 raise ValueError("FlatGrads.enable_overlap: the parameters of a bucket must be contiguous in the flat buffer")
             a, b = self.offsets[ids[0]], self.offsets[ids[-1]] + self._pad(self.params[ids[-1]].numel())
+            declared = [bi for bi, pr in enumerate(self.bucket_params) if pr == (ids[0], ids[-1] + 1)]
             if mode == "sharded":
-                match = [r for r, pr in zip(self.bucket_ranges, self.bucket_params) if pr == (ids[0], ids[-1] + 1)]
-                if not match or (match[0][1] - match[0][0]) % (4 * self.shard_world):
+                if not declared or (self.bucket_ranges[declared[0]][1] - self.bucket_ranges[declared[0]][0]) % (4 * self.shard_world):
                     raise ValueError("FlatGrads: sharded exchange needs the buckets declared at construction (bucket_sizes=, "
                                      "shard_world=) so that their ranges split into equal aligned shards")
-                a, b = match[0]
-            self._buckets.append(dict(range=(a, b), n=len(ids), seen=0, launched=False, work=None, index=len(self._buckets)))
+                a, b = self.bucket_ranges[declared[0]]
+            parts = self.bucket_parts.get(declared[0]) if declared else None
+            if parts:
+                p = self.params[ids[0]]
+                p._ps_parts = len(parts)
+                p._ps_part_done = self._on_part
+                p._ps_part_buckets = []
+                for g, rng in enumerate(parts):
+                    self._buckets.append(dict(range=rng, n=1, seen=0, launched=False, work=None, index=len(self._buckets), part=(g, len(parts))))
+                    p._ps_part_buckets.append(len(self._buckets) - 1)
+                p._ps_bucket = p._ps_part_buckets[0]
+                p._ps_on_touch = self._on_touch
+                continue
+            self._buckets.append(dict(range=(a, b), n=len(ids), seen=0, launched=False, work=None, index=len(self._buckets), part=None))
             for i in ids:
                 self.params[i]._ps_bucket = len(self._buckets) - 1
                 self.params[i]._ps_on_touch = self._on_touch
         self._group = group
         self.mode = mode
+        self.dry = bool(dry)
         self._next_launch = 0
         if mode == "sharded" and self._distributed() and dist.get_world_size(group) != self.shard_world:
             raise ValueError(f"FlatGrads: built for shard_world={self.shard_world}, process group has {dist.get_world_size(group)} ranks")
@@ -270,7 +307,32 @@ class FlatGrads:
     def _distributed(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
 
+    def _mark_ready(self, b):
+        """the bucket's gradients are complete on the streams as they stand NOW (the proposal networks' backward runs on side
+        streams, ops.side_stream); the launch may happen later, from another stream's context"""
+        if self._comm_stream is not None:
+            from .ops import side_streams
+
+            b["ready"] = []
+            for st in [torch.cuda.current_stream(self.flat.device)] + side_streams(self.flat.device):
+                ev = torch.cuda.Event(enable_timing=self.record_timeline)
+                ev.record(st)
+                b["ready"].append(ev)
+
     def _on_touch(self, p):
+        parts = getattr(p, "_ps_part_buckets", None)
+        if parts is not None:
+            # a split parameter: its pieces are reported one by one (part_done); a whole-parameter report (a producer that does not
+            # work in pieces, or the closing mark of one that does) completes whatever piece is still open
+            for bi in parts:
+                b = self._buckets[bi]
+                if b["seen"] < b["n"]:
+                    if b["launched"]:
+                        raise RuntimeError("FlatGrads: a piece of a split parameter was exchanged before its gradient was complete")
+                    b["seen"] = b["n"]
+                    self._mark_ready(b)
+            self._launch_ready()
+            return
         b = self._buckets[p._ps_bucket]
         if b["launched"]:
             i = next(k for k, q in enumerate(self.params) if q is p)
@@ -279,17 +341,18 @@ class FlatGrads:
         if not p._ps_touched:
             b["seen"] += 1
             if b["seen"] == b["n"]:
-                if self._comm_stream is not None:
-                    # the bucket's gradients are complete on the streams as they stand NOW (the proposal networks' backward runs
-                    # on side streams, ops.side_stream); the launch may happen later, from another stream's context
-                    from .ops import side_streams
-
-                    b["ready"] = []
-                    for st in [torch.cuda.current_stream(self.flat.device)] + side_streams(self.flat.device):
-                        ev = torch.cuda.Event()
-                        ev.record(st)
-                        b["ready"].append(ev)
+                self._mark_ready(b)
                 self._launch_ready()
+
+    def _on_part(self, p, g: int):
+        """piece g of the split parameter p holds its complete gradient (everything that produces it is enqueued on the current
+        stream): called by the producer (field_ops._scatter) right after the launch that wrote the piece"""
+        b = self._buckets[p._ps_part_buckets[g]]
+        if b["launched"] or b["seen"]:
+            raise RuntimeError(f"FlatGrads: piece {g} of a split parameter {tuple(p.shape)} was reported twice in one step")
+        b["seen"] = 1
+        self._mark_ready(b)
+        self._launch_ready()
 
     def _launch_ready(self):
         """launch, in bucket order, every bucket whose predecessors have gone out and whose gradients are complete"""
@@ -305,6 +368,7 @@ class FlatGrads:
 
     def _launch(self, b):
         b["launched"] = True
+        b["phase"] = "finish" if self._in_finish else "backward"
         if not self._distributed():
             return
         rank, world = self._rank_world()
@@ -314,7 +378,7 @@ class FlatGrads:
         def issue():
             seg.div_(world)
             COMM_LOG.issue("reduce_scatter" if self.mode == "sharded" else "all_reduce", b["index"], 4 * (e - a),
-                           "side" if self._comm_stream is not None else "current", self.step_no)
+                           "side" if self._comm_stream is not None else "current", self.step_no, phase=b["phase"])
             if self.mode == "sharded":
                 n = (e - a) // world
                 b["work"] = dist.reduce_scatter_tensor(seg[rank * n:(rank + 1) * n], seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
@@ -323,6 +387,7 @@ class FlatGrads:
                 b["work"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
                 self.stats["bytes"] += 2 * 4 * (e - a) * (world - 1) // world
             self.stats["collectives"] += 1
+            self.stats["in_backward"] = self.stats.get("in_backward", 0) + (b["phase"] == "backward")
 
         if self._comm_stream is not None:
             ev = torch.cuda.Event()
@@ -351,17 +416,54 @@ class FlatGrads:
             dist.all_reduce(self.group_flags, op=dist.ReduceOp.MAX, group=self._group)  # device tensor, stream-ordered: no host sync
         if not self._buckets:
             return self.all_reduce_mean(self._group)
-        for b in self._buckets[self._next_launch:]:
-            if b["seen"] == 0 and not self.flags_may_differ_across_ranks:
-                b["launched"] = True  # no parameter of the bucket got a gradient on any rank (schedule-driven): nothing to exchange
-            else:
-                self._launch(b)
+        end_ev = None
+        if self.record_timeline and self.flat.is_cuda:
+            end_ev = torch.cuda.Event(enable_timing=True)
+            end_ev.record()  # the end of backward on the compute stream (the side streams have been joined)
+        self._in_finish = True
+        try:
+            for b in self._buckets[self._next_launch:]:
+                if b["seen"] == 0 and not self.flags_may_differ_across_ranks:
+                    b["launched"] = True  # no parameter of the bucket got a gradient on any rank (schedule-driven): nothing to exchange
+                else:
+                    self._launch(b)
+        finally:
+            self._in_finish = False
         self._next_launch = len(self._buckets)
         for b in self._buckets:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
+        if end_ev is not None:
+            self._timeline.append(dict(end=end_ev, buckets=[(b["index"], b["range"][1] - b["range"][0], b.get("ready"), b.get("phase"), b["seen"])
+                                                           for b in self._buckets]))
         return None
+
+    def timeline_summary(self) -> List[dict]:
+        """per bucket, averaged over the recorded steps: floats, the phase it was handed over in, and `ms_before_backward_end` = how
+        long before the end of backward its gradient was complete on every stream that produced it (0 for a bucket that was only
+        complete at the end) -- the window its collective can hide in.  Synchronises."""
+        if not self._timeline:
+            return []
+        torch.cuda.synchronize()
+        acc: Dict[int, dict] = {}
+        for rec in self._timeline:
+            for idx, n, ready, phase, seen in rec["buckets"]:
+                d = acc.setdefault(idx, dict(bucket=idx, floats=n, steps=0, ms=0.0, in_backward=0, exchanged=0))
+                if seen == 0:
+                    continue  # no gradient this step (proposal networks off schedule)
+                d["exchanged"] += 1
+                if ready:
+                    d["ms"] += min(max(0.0, ev.elapsed_time(rec["end"])) for ev in ready)
+                    d["steps"] += 1
+                d["in_backward"] += int(phase == "backward")
+        out = []
+        for idx in sorted(acc):
+            d = acc[idx]
+            out.append(dict(bucket=idx, bytes=4 * d["floats"], steps_exchanged=d["exchanged"], handed_over_in_backward=d["in_backward"],
+                            ms_before_backward_end=d["ms"] / d["steps"] if d["steps"] else 0.0))
+        self._timeline = []
+        return out
 
     # ------------------------------------------------------------------ sharded mode: who owns what, parameters back
     def owned_ranges(self) -> List[Tuple[int, int]]:

@@ -135,8 +135,21 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
         acc = 2  # first contribution of the step into the zeroed flat gradient buffer: written, not read-modify-written
     dtable = sink if sink is not None else torch.empty(table_shape, device=u.device, dtype=torch.float32)
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
+    pieces = getattr(sink_owner, "_ps_parts", 1) if (sink is not None and sink_owner is not None) else 1
     with prof.region(f"grid_scatter_L{L}F{F}"):
-        if _binned(N, L):
+        if _binned(N, L) and pieces > 1:
+            # the gradient is exchanged in `pieces` level groups (presight_amd.dist.FlatGrads splits): one accumulate launch per group,
+            # every group handed to the exchange as soon as its launch is enqueued -- its reduce-scatter runs under the next launches
+            ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
+            items = lib().ps_grid_scatter_items(L, F, l2t, 1)
+            per_level = items // L
+            args = (_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts), int(ws_with_absmax is not None), _p(ws))
+            check(lib().ps_grid_scatter_binned_part(*args, 1, 0, 0, _stream()), "ps_grid_scatter_binned_part")
+            for gi in range(pieces):
+                l0, l1 = L * gi // pieces, L * (gi + 1) // pieces
+                check(lib().ps_grid_scatter_binned_part(*args, 2, l0 * per_level, l1 * per_level, _stream()), "ps_grid_scatter_binned_part")
+                sink_owner._ps_part_done(sink_owner, gi)
+        elif _binned(N, L):
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
             check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
                                                int(ws_with_absmax is not None), _p(ws), _stream()), "ps_grid_scatter_binned")
@@ -372,8 +385,11 @@ def _main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     u, sel, dirs, app, scalings, feat, packed, counts, acts = saved
     g, tshape, _, _ = ctx.meta
     dapp, dfeat, flat = _stack_backward(ctx, sel, dirs, app, feat, packed, acts, d_sigma, d_rgb, d_sem, weights)
+    # the MLP gradients are complete (unpacked): their bucket may leave while the table backward runs; the table follows (in pieces
+    # when its bucket is split, _scatter reports them one by one)
+    mark_touched([t for t in ctx.direct if t is not ctx.table_ref])
     dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.table_sink, counts, sink_owner=ctx.table_ref)
-    mark_touched(ctx.direct)
+    mark_touched([t for t in ctx.direct if t is ctx.table_ref])
     return dapp, dtable, flat
 
 
@@ -663,7 +679,6 @@ class _MainFieldRenderF(torch.autograd.Function):
         with prof.region("ray_colour_bwd"):
             check(lib().ps_ray_colour_bwd(_p(dray), _p(dirs), _p(app), _p(_f32(r0[0])), R, S, A, hidden_color, _p(dWr0), _p(dapp), _stream()),
                   "ps_ray_colour_bwd")
-        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.table_sink, counts, sink_owner=ctx.table_ref)
         # weight gradients: partial blocks -> torch layout.  Base layer 1: rows 0..15 (sigma_raw | geo15) directly, rows 16..79
         # through the merged layer (chain rule of W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0)
         dWm, dbm = torch.zeros_like(Wm), torch.zeros_like(bm)
@@ -677,7 +692,10 @@ class _MainFieldRenderF(torch.autograd.Function):
             check(lib().ps_merge_linear_bwd(_p(dWm), _p(dbm), _p(_f32(Ws0)), Wb1c.data_ptr() + 4 * 16 * hidden, bb1c.data_ptr() + 4 * 16, 64, SEM_DIM,
                                             hidden, _p(dWs0), _p(dbs0), dWb1.data_ptr() + 4 * 16 * hidden, dbb1.data_ptr() + 4 * 16, _stream()),
                   "ps_merge_linear_bwd")
-        mark_touched(ctx.direct)
+        # the MLP gradients are complete: their bucket may leave while the table backward runs; then the table (in pieces when split)
+        mark_touched([t for t in ctx.direct if t is not ctx.table_ref])
+        dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.table_sink, counts, sink_owner=ctx.table_ref)
+        mark_touched([t for t in ctx.direct if t is ctx.table_ref])
         return (None, None, None, dapp, None, None, None, dtable, None, None, *ret)
 
 
@@ -958,18 +976,34 @@ def _ms_scatter_ws(lay: MsLayout, g: GridCfg, device) -> Tensor:
                       device)
 
 
-def _ms_scatter(lay: MsLayout, u, dfeat, scalings, g: GridCfg, tables: Sequence[Tensor], counts, ws, absmax_ready: bool):
+def _ms_scatter(lay: MsLayout, u, dfeat, scalings, g: GridCfg, tables: Sequence[Tensor], counts, ws, absmax_ready: bool, mark: bool = False):
     """table gradients of all sub-fields; -> list of returned gradients (None where the gradient went into the parameter's
-    pre-allocated .grad in place)"""
+    pre-allocated .grad in place).  mark: report the tables to the owner of the flat gradient buffer (mark_touched) from here --
+    in sub-field GROUPS when the owner exchanges them group by group (tables[0]._ps_ms_parts, set by the trainer): one accumulate
+    launch per group, every group's tables handed over as soon as its launch is enqueued."""
     sinks = [grad_sink(t) for t in tables]
     fresh = [None if s is not None else torch.zeros_like(t) for s, t in zip(sinks, tables)]
     dst = [s if s is not None else f for s, f in zip(sinks, fresh)]
     zero_dst = all(s is None or _sink_is_zero(t) for s, t in zip(sinks, tables))  # fresh zeros / untouched, cleared sinks
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
+    K = lay.K
+    groups = getattr(tables[0], "_ps_ms_parts", 1) if mark else 1
     with prof.region(f"grid_scatter_L{L}F{F}"):
+        if groups > 1 and K % groups == 0:
+            per_field = lib().ps_grid_scatter_items(L, F, l2t, 1)
+            args = (_p(u), _p(dfeat), _p(scalings), L, F, l2t, lay.n_slots, lay.n_slots * F, _p(_ptr_table(dst)), K, lay.chunk_field, _p(counts),
+                    int(absmax_ready), _p(ws), int(zero_dst))
+            check(lib().ps_grid_scatter_binned_ms_part(*args, 1, 0, 0, _stream()), "ps_grid_scatter_binned_ms_part")
+            for gi in range(groups):
+                k0, k1 = K * gi // groups, K * (gi + 1) // groups
+                check(lib().ps_grid_scatter_binned_ms_part(*args, 2, k0 * per_field, k1 * per_field, _stream()), "ps_grid_scatter_binned_ms_part")
+                mark_touched(direct_params(*tables[k0:k1]), groups_on_device=True)
+            return fresh
         check(lib().ps_grid_scatter_binned_ms(_p(u), _p(dfeat), _p(scalings), L, F, l2t, lay.n_slots, lay.n_slots * F, _p(_ptr_table(dst)),
-                                              lay.K, lay.chunk_field, _p(counts), int(absmax_ready), _p(ws), int(zero_dst), _stream()),
+                                              K, lay.chunk_field, _p(counts), int(absmax_ready), _p(ws), int(zero_dst), _stream()),
               "ps_grid_scatter_binned_ms")
+    if mark:
+        mark_touched(direct_params(*tables), groups_on_device=True)
     return fresh
 
 
@@ -1229,8 +1263,6 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
                       lay.field_start, K, stages, _stream()), "ps_main_field_bwd_ms")
     if per_point:
         dapp = dapp_pt.view(app.shape[0], S, A).sum(1)
-    ws = _ms_scatter_ws(lay, g, u.device)
-    dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False)
     dsts, returned = _ms_layer_dsts(wb)
     if merged is not None:
         # kernel layers -> [base0, base1 rows 0..15, merged layer, sem1, sem2, colour head]; the merged layer's gradient is carried
@@ -1241,7 +1273,10 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
         mm.merge_backward(layers, dsts, per)
     else:
         st.unpack(dsts, lay.field_start, nparts, 1)
-    mark_touched(ctx.direct, groups_on_device=True)
+    # the MLP gradients are complete: their bucket may leave while the table backward runs; the tables follow (group by group)
+    mark_touched(direct_params(*wb), groups_on_device=True)
+    ws = _ms_scatter_ws(lay, g, u.device)
+    dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False, mark=True)
     mark_groups(lay, tables)
     return dapp, dtables, returned
 

@@ -60,39 +60,87 @@ class Trainer:
         neither: constant learning rate."""
         self.model, self.scene, self.world = model, scene, world
         groups = model.get_param_groups()
-        # bucket-major order, in the order backward COMPLETES the groups on the GPU (buckets are exchanged strictly in this order).
-        # With the proposal networks on their side stream (ops.side_stream, DESIGN.md 4.6) their chain ends ~0.5 ms before the main
-        # chain writes its last gradient (the main hash table's), so "proposal_networks" goes first and its all-reduce runs under
-        # the main chain's tail; on one stream "fields" (main field, sky, embeddings) are finished before the proposal backward
-        # starts and travel underneath it.  A group that receives no gradient in a step (proposal nets off-schedule) is one
-        # contiguous range to skip.
-        first = ("proposal_networks", "fields") if (ops.SIDE_STREAM and torch.cuda.is_available()) else ("fields", "proposal_networks")
-        order = [k for k in first if k in groups] + sorted(k for k in groups if k not in first)
-        seen, uniq, sizes = set(), [], []
-        for k in order:
+        # Flat order = the order in which backward COMPLETES the gradients on the GPU; exchange buckets are consecutive runs of it and
+        # go out strictly in this order, each as soon as it is complete (the reference's DDP overlaps its bucketed all-reduce with
+        # backward the same way, ns/pipelines/PreSight/my_pipeline.py:121-124):
+        #   proposal network n-1 .. 0   one bucket each.  Their backward depends on the interlevel loss only and runs on a side stream
+        #                               (ops.side_stream, DESIGN.md 4.6): it ends long before the main chain does;
+        #   "fields" small parameters   MLPs of the main field, sky model, embeddings: complete when the main MLP backward kernels and
+        #                               the gradient unpack are done, i.e. BEFORE the main table backward starts;
+        #   main hash tables            last.  One sub-field: the table is exchanged as level groups, one accumulate launch per group
+        #                               (FlatGrads splits); routed tile: the K tables in sub-field groups, one accumulate launch per
+        #                               group -- the reduce-scatter of group g runs underneath the accumulate launch of group g + 1.
+        # Only the LAST piece is complete at the end of backward: everything else is handed over while kernels are still running.
+        # A group that receives no gradient in a step (proposal nets off-schedule) is one contiguous range to skip.
+        names = {id(p): n for n, p in model.named_parameters(remove_duplicate=False)}
+        is_table = lambda p: names.get(id(p), "").endswith("hash_table")  # noqa: E731
+        seen, uniq, sizes, kinds = set(), [], [], []
+
+        def add_bucket(plist, kind):
             n0 = len(uniq)
-            for p in groups[k]:  # the reference registers mlp_base = Sequential(grid, mlp): the same tensors appear twice -> dedup
+            for p in plist:  # the reference registers mlp_base = Sequential(grid, mlp): the same tensors appear twice -> dedup
                 if p.requires_grad and p.numel() > 0 and id(p) not in seen:
                     seen.add(id(p))
                     uniq.append(p)
-            sizes.append(len(uniq) - n0)
+            if len(uniq) > n0:
+                sizes.append(len(uniq) - n0)
+                kinds.append(kind)
+
+        prop_nets = list(getattr(model, "proposal_networks", []))
+        prop_ids = {id(p) for p in groups.get("proposal_networks", [])}
+        if model.config.use_same_proposal_network or not prop_nets:
+            add_bucket(groups.get("proposal_networks", []), "proposal_networks")
+        else:
+            for i in reversed(range(len(prop_nets))):
+                add_bucket([p for p in prop_nets[i].parameters() if id(p) in prop_ids], "proposal_networks")
+            add_bucket(groups.get("proposal_networks", []), "proposal_networks")  # (anything the loop did not reach)
+        fields = list(groups.get("fields", []))
+        add_bucket([p for p in fields if not is_table(p)], "fields")
+        main_tables = [p for p in fields if is_table(p) and id(p) not in seen]
+        split_pieces = int(os.environ.get("PRESIGHT_TABLE_PIECES", "4"))
+        n_table_buckets, table_split = 0, None
+        if len(main_tables) == 1:
+            add_bucket(main_tables, "fields")
+            table_split = len(sizes) - 1
+            n_table_buckets = 1
+        elif main_tables:
+            G = max(1, min(split_pieces, len(main_tables)))
+            while len(main_tables) % G:
+                G -= 1
+            per = len(main_tables) // G
+            for gi in range(G):
+                add_bucket(main_tables[gi * per:(gi + 1) * per], "fields")
+            n_table_buckets = G
+        for k in sorted(groups):
+            if k not in ("proposal_networks", "fields"):
+                add_bucket(groups[k], k)
         assert seen == {id(p) for p in model.parameters() if p.requires_grad and p.numel() > 0}
-        self.group_names = order
+        self.group_names = kinds  # bucket -> optimizer group name
         sharded = exchange == "sharded" and world > 1
-        self.grads = FlatGrads(uniq, bucket_sizes=sizes, shard_world=world if sharded else 1)
+        overlap = ((world > 1 or os.environ.get("PRESIGHT_DRY_OVERLAP") == "1") and not model.config.use_same_proposal_network
+                   and os.environ.get("PRESIGHT_NO_OVERLAP") != "1")
+        splits = {table_split: split_pieces} if (overlap and table_split is not None and split_pieces > 1) else None
+        self.grads = FlatGrads(uniq, bucket_sizes=sizes, shard_world=world if sharded else 1, splits=splits)
         # K > 1: whether a sub-field got samples is decided on the device; the optimizer kernel skips the ones that did not
         # (torch.optim.Adam with grad None), and under data parallelism the decision is agreed across ranks on the device
         rg = routed_groups(model)
         if rg:
             self.grads.define_groups(rg)
-        if world > 1 and not model.config.use_same_proposal_network and os.environ.get("PRESIGHT_NO_OVERLAP") != "1":
+        if overlap:
             buckets, i = [], 0
             for n in sizes:
                 buckets.append(uniq[i:i + n])
                 i += n
-            self.grads.enable_overlap(buckets, mode="sharded" if sharded else "allreduce")
+            if len(main_tables) > 1 and n_table_buckets > 1:
+                main_tables[0]._ps_ms_parts = n_table_buckets  # field_ops._ms_scatter: one accumulate launch per sub-field group
+            self.grads.enable_overlap(buckets, mode="sharded" if sharded else "allreduce", dry=world == 1)
             if sharded:
-                model.param_gate = lambda name: self.grads.wait_params(self.group_names.index(name))
+                # (a declared bucket may have become several exchange buckets: the pieces of the split table)
+                gate: Dict[str, list] = {}
+                for b in self.grads._buckets:
+                    pi = next(j for j, (a0, a1) in enumerate(self.grads.bucket_ranges) if a0 <= b["range"][0] < a1)
+                    gate.setdefault(kinds[pi], []).append(b["index"])
+                model.param_gate = lambda name: [self.grads.wait_params(j) for j in gate.get(name, ())]
         self.exchange = "sharded" if sharded else "allreduce"
         if global_depth_clip and world > 1:
             ops.set_depth_clip_hook(_depth_hook())

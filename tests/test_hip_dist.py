@@ -180,40 +180,52 @@ def _tiny_model(dev, K=1):
     return model, scene
 
 
-def test_trainer_buckets_on_gpu_single_rank(dev):
-    """bench.Trainer with the bucketed exchange armed (no process group: launches are bookkeeping only): both buckets are
-    handed over DURING backward, strictly in the trainer's bucket order (the order the GPU completes them: proposal networks on
-    their side stream first, then fields), every parameter receives exactly one contribution, and a second in-place contribution
-    after the hand-over raises."""
+@pytest.mark.parametrize("K", [1, 4])
+def test_trainer_buckets_on_gpu_single_rank(dev, K, monkeypatch):
+    """The trainer's bucketed exchange armed without a process group (PRESIGHT_DRY_OVERLAP: launches are bookkeeping only).  Flat
+    order = completion order: proposal network 1, proposal network 0 (side stream), the fields' small parameters (complete before
+    the main table backward starts), then the main hash table as 2 level-group pieces (K = 1) / the K tables in sub-field groups
+    (routed tile), one accumulate launch per piece.  EVERY bucket is handed over during backward, strictly in bucket order; every
+    parameter receives exactly one contribution, and a second in-place contribution after the hand-over raises."""
     import bench
     from presight_amd.ops import mark_touched
 
-    model, scene = _tiny_model(dev)
+    monkeypatch.setenv("PRESIGHT_DRY_OVERLAP", "1")
+    model, scene = _tiny_model(dev, K=K)
     tr = bench.Trainer(model, scene, 1)
-    groups = model.get_param_groups()
-    uid = {id(p) for p in tr.grads.params}
+    fg = tr.grads
+    n_table = 2 if K == 1 else 4  # tiny model: 2 levels -> 2 pieces; K = 4 tables -> 4 groups of one
+    assert tr.group_names == ["proposal_networks", "proposal_networks", "fields"] + ["fields"] * (1 if K == 1 else n_table)
+    assert len(fg._buckets) == 3 + n_table and fg.dry
+    if K == 1:
+        assert [b["part"] for b in fg._buckets[3:]] == [(0, 2), (1, 2)]
     order = []
-    assert tr.group_names == ["proposal_networks", "fields"]
-    tr.grads.enable_overlap([[p for p in groups[k] if id(p) in uid] for k in tr.group_names])
-    launch = tr.grads._launch
-    tr.grads._launch = lambda b: (order.append(b["index"]), launch(b))[1]
+    launch = fg._launch
+    fg._launch = lambda b: (order.append((b["index"], fg._in_finish)), launch(b))[1]
     batches = bench.make_batches(scene, dev, 2, 0, rays=512)
+    fg.record_timeline = True
     for i in range(2):
         order.clear()
         tr.step(batches[i])
-        assert order == [0, 1], order  # bucket order, although the host finishes enqueueing the fields' backward first
-    assert all(b["launched"] for b in tr.grads._buckets)
+        assert order == [(j, False) for j in range(3 + n_table)], order  # bucket order, all of them BEFORE finish_exchange
+    assert all(b["launched"] and b["phase"] == "backward" for b in fg._buckets)
+    tl = fg.timeline_summary()
+    assert len(tl) == 3 + n_table and all(t["handed_over_in_backward"] == 2 for t in tl)
+    assert tl[0]["ms_before_backward_end"] >= tl[-1]["ms_before_backward_end"] >= 0.0
     with pytest.raises(RuntimeError, match="second gradient"):
-        mark_touched([tr.grads.params[0]])
-    assert all(s == 2 for s in tr.opt.steps)
-    # off-schedule step: proposal networks get no gradient -> their bucket is skipped, their Adam step count stays
+        mark_touched([fg.params[0]])
+    assert all(s == 2 for s in tr.opt.param_steps())
+    # off-schedule step: proposal networks get no gradient -> their buckets are skipped, their Adam step count stays
     tr.update_props_every_step = False
     tr.step_idx = 50000
     model.proposal_sampler.step_cb(50000)  # past the "first 10 steps always update" rule of ray_samplers.py:586
     model.proposal_sampler._steps_since_update = 0
+    order.clear()
     tr.step(batches[0])
-    n_prop = tr.grads.bucket_params[0][1]
-    assert all(s == 2 for s in tr.opt.steps[:n_prop]) and all(s == 3 for s in tr.opt.steps[n_prop:])
+    assert [j for j, _ in order] == list(range(2, 3 + n_table))
+    n_prop = fg.bucket_params[1][1]
+    steps = tr.opt.param_steps()
+    assert all(s == 2 for s in steps[:n_prop]) and all(s == 3 for s in steps[n_prop:])
 
 
 def _run_bench_two_ranks(extra, timeout=300, attempts=2):
@@ -264,6 +276,12 @@ def _run_bench_two_ranks(extra, timeout=300, attempts=2):
     assert line["comm"]["backend"] == ("nccl" if two_gpus else "gloo")
     logs = read_logs()
     assert logs[0] == logs[1] and len(logs[0]) > 10, "the ranks issued different collective sequences"
+    # overlap by construction: of the gradient buckets of a step, all but (at most) the last leave while backward is still running
+    grad = [ln for ln in logs[0] if (" all_reduce " in ln or " reduce_scatter " in ln) and "bucket=" in ln and "bucket=-" not in ln]
+    steps_seen = sorted({ln.split("step=")[1].split()[0] for ln in grad})
+    for st in steps_seen[1:-1]:
+        mine = [ln for ln in grad if f"step={st} " in ln + " "]
+        assert len(mine) >= 4 and sum("phase=backward" in ln for ln in mine) >= len(mine) - 1, mine
     for r in (0, 1):
         os.remove(path(comm, r))
     line["_hang_retries"] = len(failures)

@@ -299,6 +299,111 @@ _WORKER_SHARDED = textwrap.dedent("""
 """)
 
 
+_WORKER_PIECES = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from presight_amd.dist import FlatGrads, init_from_env, intersect_ranges, COMM_LOG
+    from presight_amd.ops import mark_touched
+    rank, local, world = init_from_env("cpu")
+    mode = {mode!r}
+    torch.manual_seed(0)
+    small, table = torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(32, 2))
+    fg = FlatGrads([small, table], bucket_sizes=[1, 1], shard_world=world if mode == "sharded" else 1, splits={{1: 4}})
+    t0 = fg.offsets[1]  # (the small bucket is padded to a whole number of shards in sharded mode)
+    assert fg.bucket_parts == {{1: [(t0 + 16 * g, t0 + 16 * (g + 1)) for g in range(4)]}}, fg.bucket_parts
+    fg.enable_overlap([[small], [table]], mode=mode)
+    assert len(fg._buckets) == 5 and table._ps_parts == 4
+    flat_p = torch.zeros(fg.total)
+    for p, off in zip([small, table], fg.offsets):
+        flat_p[off:off + p.numel()] = p.data.reshape(-1)
+        p.data = flat_p[off:off + p.numel()].view_as(p)
+    before = flat_p.clone()
+
+    def update():
+        fg.finish_exchange()
+        owned, touched = fg.owned_ranges(), fg.touched_ranges()
+        for a, b in intersect_ranges(touched, owned):
+            flat_p[a:b] -= 0.1 * fg.flat[a:b]
+        fg.gather_params(flat_p, touched)
+        fg.wait_params()
+
+    # step 1: a piece-aware producer (field_ops._scatter): MLP-like parameter first, then the table level group by level group
+    fg.zero_()
+    small.grad.add_(rank + 1.0)
+    mark_touched([small])
+    assert [b["launched"] for b in fg._buckets] == [True, False, False, False, False]
+    for g in range(4):
+        table.grad.view(-1)[16 * g:16 * (g + 1)].add_((rank + 1.0) * (g + 1))
+        table._ps_part_done(table, g)
+        assert [b["launched"] for b in fg._buckets] == [True] + [True] * (g + 1) + [False] * (3 - g)
+    mark_touched([table])  # the closing whole-parameter mark of the backward node: nothing left to hand over, no error
+    assert all(b["phase"] == "backward" for b in fg._buckets)  # EVERY bucket left before finish_exchange
+    update()
+    exp = before.clone()
+    exp[0:12] -= 0.1 * 1.5
+    for g in range(4):
+        exp[t0 + 16 * g:t0 + 16 * (g + 1)] -= 0.1 * 1.5 * (g + 1)
+    assert torch.allclose(flat_p, exp, atol=1e-6), (rank, (flat_p - exp).abs().max())
+    # step 2: a producer that does not work in pieces reports the whole parameter: all pieces go out at once, in order
+    fg.zero_()
+    table.grad.add_(rank + 1.0)
+    small.grad.add_(2.0 * (rank + 1.0))
+    mark_touched([table])
+    assert [b["launched"] for b in fg._buckets] == [False] * 5  # bucket order: the small bucket goes first
+    mark_touched([small])
+    assert [b["launched"] for b in fg._buckets] == [True] * 5
+    update()
+    exp[0:12] -= 0.1 * 3.0
+    exp[t0:t0 + 64] -= 0.1 * 1.5
+    assert torch.allclose(flat_p, exp, atol=1e-6)
+    # step 3: the table receives nothing on any rank (off-schedule): its pieces are skipped, only the small bucket is exchanged
+    fg.zero_()
+    small.grad.add_(rank + 1.0)
+    mark_touched([small])
+    n_before = COMM_LOG.seq
+    update()
+    exp[0:12] -= 0.1 * 1.5
+    assert torch.allclose(flat_p, exp, atol=1e-6) and COMM_LOG.seq - n_before == (1 if mode == "sharded" else 0)
+    # a piece reported twice is an error
+    fg.zero_()
+    table._ps_part_done(table, 0)
+    try:
+        table._ps_part_done(table, 0)
+        raise SystemExit("a piece reported twice must raise")
+    except RuntimeError as e:
+        assert "twice" in str(e)
+    for g in range(1, 4):
+        table._ps_part_done(table, g)
+    mark_touched([small, table])
+    fg.finish_exchange()
+    ref = flat_p.clone(); dist.broadcast(ref, src=0)
+    assert torch.equal(ref, flat_p)
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
+def test_split_table_buckets_gloo_world2(tmp_path, mode):
+    """A hash table exchanged as level-group PIECES (FlatGrads splits): every piece is its own collective, handed over by the producer
+    as soon as the accumulate launch of that level group is enqueued -- before backward ends -- strictly in bucket order on every
+    rank; a producer that reports the whole parameter, an off-schedule step and the sharded update work as before."""
+    script = tmp_path / "worker_pieces.py"
+    script.write_text(_WORKER_PIECES.format(root=ROOT, mode=mode))
+    port = "29741" if mode == "allreduce" else "29743"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PRESIGHT_COMM_LOG=str(tmp_path / "comm_{rank}.log"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
+    logs = [(tmp_path / f"comm_{r_}.log").read_text().splitlines() for r_ in range(2)]
+    assert logs[0] == logs[1]
+    kind = "reduce_scatter" if mode == "sharded" else "all_reduce"
+    step1 = [ln for ln in logs[0] if f" {kind} " in ln and "step=1" in ln]
+    assert len(step1) == 5 and all("phase=backward" in ln for ln in step1)  # all 5 buckets of the first step left during backward
+    assert [ln.split("bucket=")[1].split()[0] for ln in step1] == ["0", "1", "2", "3", "4"]
+
+
 def test_sharded_exchange_gloo_world2(tmp_path):
     """reduce-scatter -> update of the owned shard -> all-gather (presight_amd.dist mode "sharded"): bit-equal replicas"""
     script = tmp_path / "worker_sharded.py"
