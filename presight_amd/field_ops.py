@@ -143,6 +143,8 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
             items = lib().ps_grid_scatter_items(L, F, l2t, 1)
             per_level = items // L
+            if L % pieces:
+                raise RuntimeError(f"presight_amd: a table of {L} levels cannot be exchanged in {pieces} equal level groups")
             args = (_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts), int(ws_with_absmax is not None), _p(ws))
             check(lib().ps_grid_scatter_binned_part(*args, 1, 0, 0, _stream()), "ps_grid_scatter_binned_part")
             for gi in range(pieces):

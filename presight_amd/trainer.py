@@ -65,12 +65,15 @@ class Trainer:
         # backward the same way, ns/pipelines/PreSight/my_pipeline.py:121-124):
         #   proposal network n-1 .. 0   one bucket each.  Their backward depends on the interlevel loss only and runs on a side stream
         #                               (ops.side_stream): it ends long before the main chain does;
-        #   "fields" small parameters   MLPs of the main field, sky model, embeddings: complete when the main MLP backward kernels and
-        #                               the gradient unpack are done, i.e. BEFORE the main table backward starts;
+        #   main field MLPs             complete when the main MLP backward kernels and the gradient unpack are done, i.e. BEFORE the
+        #                               main table backward starts;
         #   main hash tables            last.  One sub-field: the table is exchanged as level groups, one accumulate launch per group
         #                               (FlatGrads splits); routed tile: the K tables in sub-field groups, one accumulate launch per
         #                               group -- the reduce-scatter of group g runs underneath the accumulate launch of group g + 1.
-        # Only the LAST piece is complete at the end of backward: everything else is handed over while kernels are still running.
+        #   tail                        sky model + embeddings (the embeddings' gradient is an output of the main field's backward node):
+        #                               ~0.1 MB, complete at the very end.
+        # Only the last table piece and the tiny tail are complete at the end of backward: everything else is handed over while kernels
+        # are still running.
         # A group that receives no gradient in a step (proposal nets off-schedule) is one contiguous range to skip.
         names = {id(p): n for n, p in model.named_parameters(remove_duplicate=False)}
         is_table = lambda p: names.get(id(p), "").endswith("hash_table")  # noqa: E731
@@ -95,7 +98,9 @@ class Trainer:
                 add_bucket([p for p in prop_nets[i].parameters() if id(p) in prop_ids], "proposal_networks")
             add_bucket(groups.get("proposal_networks", []), "proposal_networks")  # (anything the loop did not reach)
         fields = list(groups.get("fields", []))
-        add_bucket([p for p in fields if not is_table(p)], "fields")
+        # the main field's MLPs are complete after its backward kernels + the gradient unpack, BEFORE its table backward starts; the
+        # embeddings (their gradient is an OUTPUT of the main field's backward node) and the sky model close the step: tail bucket
+        add_bucket([p for p in fields if not is_table(p) and names.get(id(p), "").startswith("field.")], "fields")
         main_tables = [p for p in fields if is_table(p) and id(p) not in seen]
         split_pieces = int(os.environ.get("PRESIGHT_TABLE_PIECES", "4"))
         n_table_buckets, table_split = 0, None
@@ -103,6 +108,9 @@ class Trainer:
             add_bucket(main_tables, "fields")
             table_split = len(sizes) - 1
             n_table_buckets = 1
+            # pieces = whole level groups (field_ops._scatter launches the accumulate pass per group): the largest divisor of L
+            L = int(model.field.fields[0].mlp_base_grid.num_levels)
+            split_pieces = max(d for d in range(1, max(1, split_pieces) + 1) if L % d == 0)
         elif main_tables:
             G = max(1, min(split_pieces, len(main_tables)))
             while len(main_tables) % G:
@@ -111,6 +119,7 @@ class Trainer:
             for gi in range(G):
                 add_bucket(main_tables[gi * per:(gi + 1) * per], "fields")
             n_table_buckets = G
+        add_bucket(fields, "fields")  # tail: sky model, appearance / video embeddings (small)
         for k in sorted(groups):
             if k not in ("proposal_networks", "fields"):
                 add_bucket(groups[k], k)

@@ -195,10 +195,10 @@ def test_trainer_buckets_on_gpu_single_rank(dev, K, monkeypatch):
     tr = bench.Trainer(model, scene, 1)
     fg = tr.grads
     n_table = 2 if K == 1 else 4  # tiny model: 2 levels -> 2 pieces; K = 4 tables -> 4 groups of one
-    assert tr.group_names == ["proposal_networks", "proposal_networks", "fields"] + ["fields"] * (1 if K == 1 else n_table)
-    assert len(fg._buckets) == 3 + n_table and fg.dry
+    assert tr.group_names == ["proposal_networks", "proposal_networks", "fields"] + ["fields"] * (1 if K == 1 else n_table) + ["fields"]
+    assert len(fg._buckets) == 4 + n_table and fg.dry
     if K == 1:
-        assert [b["part"] for b in fg._buckets[3:]] == [(0, 2), (1, 2)]
+        assert [b["part"] for b in fg._buckets[3:5]] == [(0, 2), (1, 2)]
     order = []
     launch = fg._launch
     fg._launch = lambda b: (order.append((b["index"], fg._in_finish)), launch(b))[1]
@@ -207,11 +207,12 @@ def test_trainer_buckets_on_gpu_single_rank(dev, K, monkeypatch):
     for i in range(2):
         order.clear()
         tr.step(batches[i])
-        assert order == [(j, False) for j in range(3 + n_table)], order  # bucket order, all of them BEFORE finish_exchange
+        assert order == [(j, False) for j in range(4 + n_table)], order  # bucket order, all of them BEFORE finish_exchange
     assert all(b["launched"] and b["phase"] == "backward" for b in fg._buckets)
     tl = fg.timeline_summary()
-    assert len(tl) == 3 + n_table and all(t["handed_over_in_backward"] == 2 for t in tl)
+    assert len(tl) == 4 + n_table and all(t["handed_over_in_backward"] == 2 for t in tl)
     assert tl[0]["ms_before_backward_end"] >= tl[-1]["ms_before_backward_end"] >= 0.0
+    assert tl[2]["ms_before_backward_end"] > tl[2 + n_table]["ms_before_backward_end"]  # the MLP bucket is ready before the last table piece
     with pytest.raises(RuntimeError, match="second gradient"):
         mark_touched([fg.params[0]])
     assert all(s == 2 for s in tr.opt.param_steps())
@@ -222,7 +223,7 @@ def test_trainer_buckets_on_gpu_single_rank(dev, K, monkeypatch):
     model.proposal_sampler._steps_since_update = 0
     order.clear()
     tr.step(batches[0])
-    assert [j for j, _ in order] == list(range(2, 3 + n_table))
+    assert [j for j, _ in order] == list(range(2, 4 + n_table))
     n_prop = fg.bucket_params[1][1]
     steps = tr.opt.param_steps()
     assert all(s == 2 for s in steps[:n_prop]) and all(s == 3 for s in steps[n_prop:])
