@@ -222,7 +222,7 @@ class FlatGrads:
         for p in self.params:
             p._ps_touched = False
         for b in self._buckets:
-            b["seen"], b["launched"], b["work"], b["ready"], b["ready_t"], b["phase"] = 0, False, None, None, None, None
+            b["seen"], b["launched"], b["work"], b["ready"], b["ready_t"], b["phase"], b["skipped"] = 0, False, None, None, None, None, False
         self._next_launch = 0
 
     def touched(self, group: Optional[dist.ProcessGroup] = None) -> List[bool]:
@@ -354,10 +354,23 @@ class FlatGrads:
         self._mark_ready(b)
         self._launch_ready()
 
+    def skip_buckets(self, indices: Sequence[int]):
+        """These buckets receive NO gradient in this step on ANY rank, and every rank knows it before backward starts (the proposal
+        networks on an off-schedule step: the update schedule is a function of the step count, ns/model_components/ray_samplers.py:586).
+        They are taken out of the launch order at once, so that the buckets behind them do not wait for the end of backward; a
+        gradient that reaches one of them after all raises (second-contribution guard).  Call after zero_()."""
+        for i in indices:
+            b = self._buckets[i]
+            b["launched"], b["skipped"] = True, True
+        self._launch_ready()
+
     def _launch_ready(self):
         """launch, in bucket order, every bucket whose predecessors have gone out and whose gradients are complete"""
         while self._next_launch < len(self._buckets):
             b = self._buckets[self._next_launch]
+            if b.get("skipped"):
+                self._next_launch += 1
+                continue
             if b["seen"] < b["n"]:
                 return
             self._launch(b)

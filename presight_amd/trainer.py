@@ -150,6 +150,8 @@ class Trainer:
                     pi = next(j for j, (a0, a1) in enumerate(self.grads.bucket_ranges) if a0 <= b["range"][0] < a1)
                     gate.setdefault(kinds[pi], []).append(b["index"])
                 model.param_gate = lambda name: [self.grads.wait_params(j) for j in gate.get(name, ())]
+        self._prop_buckets = [b["index"] for b in self.grads._buckets
+                              if kinds[next(j for j, (a0, a1) in enumerate(self.grads.bucket_ranges) if a0 <= b["range"][0] < a1)] == "proposal_networks"]
         self.exchange = "sharded" if sharded else "allreduce"
         if global_depth_clip and world > 1:
             ops.set_depth_clip_hook(_depth_hook())
@@ -217,6 +219,12 @@ class Trainer:
         rb = RayBundle(o, d, pa, camera_indices=batch["ray_indices"][:, 0:1], metadata=meta, times=None if times is None else times.view(-1, 1))
         if self.update_props_every_step:
             m.proposal_sampler._steps_since_update = 1 << 30  # proposal nets receive gradients EVERY step (upper bound of the schedule)
+        if self._prop_buckets:
+            # off-schedule step (the same decision on every rank: it is a function of the step count, ray_samplers.py:586): the
+            # proposal buckets leave the launch order now, the buckets behind them are handed over during backward as usual
+            ps = m.proposal_sampler
+            if not (ps._steps_since_update > ps.update_sched(ps._step) or ps._step < 10):
+                self.grads.skip_buckets(self._prop_buckets)
         out = m(rb, jitters=list(batch["jitter"])) if "jitter" in batch else m(rb)  # stored draws: parity runs only
         loss_dict = m.get_loss_dict(out, batch)
         # one concat + one reduction instead of a chain of scalar adds; the loss scale enters as the seed of the backward pass

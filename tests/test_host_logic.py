@@ -364,6 +364,25 @@ _WORKER_PIECES = textwrap.dedent("""
     update()
     exp[0:12] -= 0.1 * 1.5
     assert torch.allclose(flat_p, exp, atol=1e-6) and COMM_LOG.seq - n_before == (1 if mode == "sharded" else 0)
+    # step 4: the FIRST bucket is known to receive nothing on any rank (schedule-driven, e.g. proposal networks off schedule):
+    # skip_buckets takes it out of the launch order, the pieces behind it still leave during backward
+    fg.zero_()
+    fg.skip_buckets([0])
+    for g in range(4):
+        table.grad.view(-1)[16 * g:16 * (g + 1)].add_(rank + 1.0)
+        table._ps_part_done(table, g)
+    assert [b["launched"] for b in fg._buckets] == [True] * 5 and [b["phase"] for b in fg._buckets[1:]] == ["backward"] * 4
+    mark_touched([table])
+    update()
+    exp[t0:t0 + 64] -= 0.1 * 1.5
+    assert torch.allclose(flat_p, exp, atol=1e-6)
+    try:
+        fg.zero_()
+        fg.skip_buckets([0])
+        mark_touched([small])  # a gradient for a bucket that was declared empty
+        raise SystemExit("a contribution to a skipped bucket must raise")
+    except RuntimeError as e:
+        assert "second gradient" in str(e)
     # a piece reported twice is an error
     fg.zero_()
     table._ps_part_done(table, 0)
