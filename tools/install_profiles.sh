@@ -6,7 +6,11 @@ cp $G/bench_${T}_cfg2.json profiles/${T}_bench_line_under_rocprofv3_cfg2.json
 cp $G/bench_${T}_cfg3.json profiles/${T}_bench_line_cfg3_65536rays.json
 cp $G/bench_${T}_cfg3_8192.json profiles/${T}_bench_line_cfg3_8192rays.json
 cp $G/bench_${T}_cfg4.json profiles/${T}_bench_line_cfg4.json
-cp $G/bench_${T}_extract.json profiles/${T}_bench_line_extract_512cubed.json
+cp $G/bench_${T}_extract.json profiles/${T}_bench_line_extract_512cubed_production_tile.json
+cp $G/bench_${T}_extract_cfg2.json profiles/${T}_bench_line_extract_512cubed_cfg2_fields.json
+cp $G/kernel_stats_${T}_cfg3_8192.txt profiles/${T}_kernel_stats_cfg3_8192rays_bench_steps5_warmup2.txt
+cp $G/pmc_summary_${T}_cfg3.txt profiles/${T}_pmc_summary_cfg3.txt
+cp $G/pmc_summary_${T}_cfg4.txt profiles/${T}_pmc_summary_cfg4.txt
 cp $G/kernel_stats_${T}_cfg2.txt profiles/${T}_kernel_stats_cfg2_bench_steps10_warmup3.txt
 cp $G/kernel_stats_${T}_cfg3.txt profiles/${T}_kernel_stats_cfg3_bench_steps4_warmup2.txt
 cp $G/kernel_stats_${T}_cfg4.txt profiles/${T}_kernel_stats_cfg4_bench_steps4_warmup2.txt

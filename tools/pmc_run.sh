@@ -4,11 +4,15 @@
 TAG=${1:-dev}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out /tmp/pmc
-KERN="main_bwd,main_fwd,accumulate_kernel,bin_kernel,grid_encode,prop_bwd_kernel,prop_fwd_kernel,composite,absmax,adam"
+KERN="main_bwd,main_fwd,accumulate_kernel,bin_kernel,grid_encode,prop_bwd_kernel,prop_fwd_kernel,composite,absmax,adam,grid4,flow_,blend_"
 OUT=gpurun_out/pmc_summary_$TAG.txt
 : > $OUT
-i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" \
+# PMC_BASIC=1: the four groups that price a kernel against its roofline (HBM bytes, matrix-pipe busy, L2 hit rate) -- used for the
+# secondary configurations (cfg 3 / cfg 4), whose steps are long
+if [ "${PMC_BASIC:-0}" = "1" ]; then
+  GROUPS_LIST=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum")
+else
+  GROUPS_LIST=("FETCH_SIZE" "WRITE_SIZE" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" \
            "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" \
@@ -16,10 +20,13 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
            "TA_BUSY_avr TA_TA_BUSY_sum" \
            "TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
-           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"; do
+           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM")
+fi
+i=0
+for grp in "${GROUPS_LIST[@]}"; do
   i=$((i+1))
   rm -rf /tmp/pmc/p$i
-  timeout -k 5 240 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc/p$i -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > /tmp/pmc/p$i.log 2>&1
+  timeout -k 5 240 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc/p$i -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --psnr-steps 0 "$@" > /tmp/pmc/p$i.log 2>&1
   echo "== pass $i: --pmc $grp (rc=$?)" >> $OUT
   python3 tools/rocpd_pmc.py $KERN /tmp/pmc/p$i/pmc_results.db >> $OUT 2>&1
   tail -n 3 /tmp/pmc/p$i.log | cut -c1-300 >> $OUT
