@@ -468,6 +468,11 @@ int ps_grid4_encode(const float* x, const float* table, const float* scalings, i
  * x [M,4], M <= 2 * period when period > 0 (two position sets share one gradient plane), dx [M,3]. */
 int ps_grid4_input_grad(const float* x, const float* dfeat, const float* table, const float* scalings, int L, int F, int log2T,
                         int64_t M, int64_t period, int64_t plane_stride, float g_scale, float* dx, void* stream);
+/* the same gradient, level-parallel (a workgroup = 2048 positions of ONE level, dealt to the XCDs like the encode, + an ordered sum
+ * over the levels): bit-identical result, workspace = ps_grid4_input_grad_workspace(L, M) bytes */
+int64_t ps_grid4_input_grad_workspace(int L, int64_t M);
+int ps_grid4_input_grad_levels(const float* x, const float* dfeat, const float* table, const float* scalings, int L, int F, int log2T,
+                               int64_t M, int64_t period, int64_t plane_stride, float g_scale, float* dx, float* workspace, void* stream);
 /* table gradient of the 4-D grid: the binned fixed-point scatter of ps_grid_scatter_binned with 8 x-pair records per (point,
  * level); dtable (+)= out_scale * scatter(d(features)); accumulate as ps_grid_scatter_binned; workspace of
  * ps_grid4_scatter_workspace.  x [M,4].  period > 0: up to three position sets of `period` points in ONE launch -- point m < period

@@ -227,6 +227,67 @@ __global__ __launch_bounds__(256) void grid4_input_grad_kernel(const float* __re
   dx[m * 3 + 2] = g_scale * az;
 }
 
+// The same gradient, LEVEL-PARALLEL (round 4): a workgroup takes 2048 positions of ONE level, dealt like the encode (enc_item: every
+// XCD's L2 holds one level's table at a time; the one-thread-walks-all-levels kernel above has all L tables in flight at once and
+// thrashes the L2s: 4.8 ms at cfg 4), and writes the level's unscaled partial sums part[l][m] = (sx, sy, sz); a second pass adds the
+// levels in order with the same fmaf chain as above, so the result is bit-identical.
+template <int F>
+__global__ __launch_bounds__(256) void grid4_input_grad_level_kernel(const float* __restrict__ x, const float* __restrict__ dfeat,
+                                                                     const float* __restrict__ table, const float* __restrict__ scalings,
+                                                                     int L, int log2T, int64_t M, int64_t period, int64_t plane_stride,
+                                                                     int group, int parts, float* __restrict__ part) {
+  const int64_t chunks = (M + 255) / 256;
+  const int64_t groups = (chunks + group - 1) / group;
+  int level;
+  int64_t my_group;
+  bool valid;
+  enc_item(groups, L, parts, level, my_group, valid);
+  if (!valid) return;
+  const uint32_t mask = (1u << log2T) - 1u;
+  const float scale = scalings[level];
+  const float* tl = table + ((int64_t)level << log2T) * F;
+  for (int64_t chunk = my_group * group, end = min(chunks, chunk + group); chunk < end; ++chunk) {
+    const int64_t m = chunk * 256 + threadIdx.x;
+    if (m >= M) continue;
+    const int64_t n = (period > 0 && m >= period) ? m - period : m;
+    const Cell4 c = make_cell4(*reinterpret_cast<const f32x4*>(x + m * 4), scale);
+    float g[F];
+    load_row<F>(dfeat + level * plane_stride + n * F, g);
+    const uint32_t hx[2] = {(uint32_t)c.fx, (uint32_t)c.cx};  // index 1 = ceil
+    const uint32_t hy[2] = {(uint32_t)c.fy * kPrimeY, (uint32_t)c.cy * kPrimeY};
+    const uint32_t hz[2] = {(uint32_t)c.fz * kPrimeZ, (uint32_t)c.cz * kPrimeZ};
+    const uint32_t ht[2] = {(uint32_t)c.ft * kPrimeT, (uint32_t)c.ct * kPrimeT};
+    const float wx[2] = {1.0f - c.ox, c.ox}, wy[2] = {1.0f - c.oy, c.oy}, wz[2] = {1.0f - c.oz, c.oz}, wt[2] = {1.0f - c.ot, c.ot};
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int ix = k & 1, iy = (k >> 1) & 1, iz = (k >> 2) & 1, it = (k >> 3) & 1;
+      Row<F> r;
+      r.load(tl + (size_t)((hx[ix] ^ hy[iy] ^ hz[iz] ^ ht[it]) & mask) * F);
+      float dot = 0.f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) dot = fmaf(r.v[f], g[f], dot);
+      const float sgx = ix ? 1.0f : -1.0f, sgy = iy ? 1.0f : -1.0f, sgz = iz ? 1.0f : -1.0f;
+      sx = fmaf(dot * sgx, wy[iy] * wz[iz] * wt[it], sx);
+      sy = fmaf(dot * sgy, wx[ix] * wz[iz] * wt[it], sy);
+      sz = fmaf(dot * sgz, wx[ix] * wy[iy] * wt[it], sz);
+    }
+    float* o = part + ((int64_t)level * M + m) * 3;
+    o[0] = sx;
+    o[1] = sy;
+    o[2] = sz;
+  }
+}
+
+__global__ __launch_bounds__(256) void grid4_input_grad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ scalings,
+                                                                      int L, int64_t M, float g_scale, float* __restrict__ dx) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // (position, axis)
+  if (i >= M * 3) return;
+  float a = 0.f;
+  for (int l = 0; l < L; ++l) a = fmaf(scalings[l], part[(int64_t)l * M * 3 + i], a);
+  dx[i] = g_scale * a;
+}
+
 // ------------------------------------------------------------------------------------------ flow MLP
 // flow = flow_scale * MLP(e0) with MLP = Linear(LF, H) ReLU Linear(H, H) ReLU Linear(H, 6); outputs 0..2 = forward flow,
 // 3..5 = backward flow.  In the MFMA D layout lane (point j, group g) holds outputs 4g..4g+3 of its point: group 0 owns
@@ -482,6 +543,29 @@ extern "C" int ps_grid4_input_grad(const float* x, const float* dfeat, const flo
   if (F == FF) grid4_input_grad_kernel<FF><<<grid, 256, 0, s>>>(x, dfeat, table, scalings, L, log2T, M, period, plane_stride, g_scale, dx);
   X(1) X(2) X(4)
 #undef X
+  PS_CHECK_LAUNCH();
+}
+
+// level-parallel version: workspace [L, M, 3] floats (ps_grid4_input_grad_workspace bytes); bit-identical to ps_grid4_input_grad
+extern "C" int64_t ps_grid4_input_grad_workspace(int L, int64_t M) { return (int64_t)L * M * 3 * 4; }
+
+extern "C" int ps_grid4_input_grad_levels(const float* x, const float* dfeat, const float* table, const float* scalings, int L, int F,
+                                          int log2T, int64_t M, int64_t period, int64_t plane_stride, float g_scale, float* dx,
+                                          float* workspace, void* stream) {
+  PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid4_input_grad_levels: features_per_level must be 1, 2 or 4");
+  PS_REQUIRE(period == 0 || M <= 2 * period, "ps_grid4_input_grad_levels: at most two position sets per gradient plane");
+  PS_REQUIRE(workspace != nullptr, "ps_grid4_input_grad_levels: workspace required");
+  if (M == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int group = 8;  // 2048 positions of one level per workgroup
+  const int64_t chunks = (M + 255) / 256, groups = (chunks + group - 1) / group;
+  const int P = enc_parts(L);
+  const dim3 grid((unsigned)(8 * (int64_t)(L * P / 8) * ((groups + P - 1) / P)));
+#define X(FF) \
+  if (F == FF) grid4_input_grad_level_kernel<FF><<<grid, 256, 0, s>>>(x, dfeat, table, scalings, L, log2T, M, period, plane_stride, group, P, workspace);
+  X(1) X(2) X(4)
+#undef X
+  grid4_input_grad_reduce_kernel<<<(unsigned)((M * 3 + 255) / 256), 256, 0, s>>>(workspace, scalings, L, M, g_scale, dx);
   PS_CHECK_LAUNCH();
 }
 

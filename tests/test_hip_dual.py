@@ -115,6 +115,12 @@ def test_grid4_table_and_position_gradients(dev, L, F, log2T):
     ok = ((frac > 1e-3) & (frac < 1 - 1e-3)).all(-1).all(-1)
     errx = float((dx.cpu() - refx)[ok].abs().max()) / float(refx.abs().max())
     assert errx < 2e-5 and int(ok.sum()) > N, (errx, int(ok.sum()))
+    # the level-parallel version (the product path): same per-level sums, added in level order with the same fmaf chain -> bit-identical
+    dx2 = torch.empty_like(dx)
+    wsp = torch.empty(lib().ps_grid4_input_grad_workspace(L, 2 * N) // 4, device=dev)
+    check(lib().ps_grid4_input_grad_levels(_p(xwd), _p(dwp), _p(tabd), _p(scd), L, F, log2T, 2 * N, N, N * F, 1.0 / 3.0, _p(dx2), _p(wsp),
+                                           _stream()), "input_grad_levels")
+    assert torch.equal(dx2, dx)
 
 
 def _dual_setup(dev, levels=2, feats=2, seed=3, rays=96):
