@@ -406,8 +406,13 @@ constexpr int kBinThreads = 256;
 #ifndef PS_BIN_PPT
 #define PS_BIN_PPT 2
 #endif
-constexpr int bin_points_per_thread(int D) { return D == 4 ? 1 : PS_BIN_PPT; }
-constexpr int bin_points(int D) { return kBinThreads * bin_points_per_thread(D); }  // points per workgroup
+// points per thread of the bin kernel.  A workgroup's records leave as one run per slice: 4 F-byte-wide planes of (points x 4 / slices)
+// records.  F = 4 tables have 256 slices per level (4096 rows of int64 accumulators fill the LDS), so 512 points give runs of 8
+// records = 32 bytes per plane -- partial cache lines (PMC, production tile: 6.6 GB written for 4.0 GB of records); 1024 points double
+// the runs (cfg 3 main table backward 4.97 -> 4.34 ms) at one workgroup per CU.  F = 1 / 2 (16 / 64 slices) are best at 512 points
+// (cfg 2 main 2.55 vs 2.70 ms, proposal 1.05 vs 1.22 ms at 1024; 256 points: 1.36 ms).
+constexpr int bin_points_per_thread(int D, int F) { return D == 4 ? 1 : (F == 4 ? 2 * PS_BIN_PPT : PS_BIN_PPT); }
+constexpr int bin_points(int D, int F) { return kBinThreads * bin_points_per_thread(D, F); }  // points per workgroup
 constexpr int kMaxSlices = 256;
 constexpr int kAccBytes = 128 * 1024;
 
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
                                                           float* __restrict__ rec_val, const int* __restrict__ chunk_field,
                                                           unsigned* __restrict__ gmax_track /* nullable: per-level max |dfeat| bits */,
                                                           int64_t period, const float* __restrict__ dfeat_b) {
-  constexpr int kBinPointsPerThread = bin_points_per_thread(D);
+  constexpr int kBinPointsPerThread = bin_points_per_thread(D, F);
   constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
   constexpr int NP = D == 4 ? 8 : 4;  // x-pairs per (point, level)
   // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record.
@@ -953,7 +958,7 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
       hipFuncSetAttribute((const void*)accumulate_kernel<FF>, hipFuncAttributeMaxDynamicSharedMemorySize, kAccBytes);     \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    const int64_t chunks = (N + bin_points(DD) - 1) / bin_points(DD);                                                     \
+    const int64_t chunks = (N + bin_points(DD, FF) - 1) / bin_points(DD, FF);                                                   \
     if (phase & 1) {                                                                                                      \
       if (N > 0) {                                                                                                        \
         if (slice_counts == nullptr)                                                                                      \
