@@ -164,14 +164,20 @@ def blend(sigma_s, rgb_s, sem_s, sigma_d, rgb_d, sem_d, eps: float = 1e-6) -> Tu
     return sigma, rgb_s + wd * (rgb_d - rgb_s), sem_s + wd * (sem_d - sem_s)
 
 
+def dynamic_aabb(scene: dict) -> Tensor:
+    """the box the dynamic field is normalised by: the sub-field's AABB (K = 1) / the union of the K sub-field boxes of a routed tile
+    (the static branch is routed like the reference's iNGPFieldMS, the dynamic branch is ONE field over the whole tile)"""
+    b = scene["aabbs"]
+    return b[0] if b.shape[0] == 1 else torch.stack([b[:, 0].min(0).values, b[:, 1].max(0).values])
+
+
 def dual_model_forward(P, cfg, scene, batch, training: bool = True, anneal: float = 1.0):
-    assert cfg["num_fields"] == 1, "the dual model is defined for one sub-field"
     times = batch["times"] if "times" in batch else ray_times(scene, batch["ray_indices"])
 
     def override(static_eval, pos, dir_s, app_s, R, S):
         sigma_s, rgb_s, sem_s = static_eval()
         t_s = times[:, None].expand(R, S).reshape(-1)
-        sigma_d, rgb_d, sem_d = dynamic_eval(P, cfg, pos, t_s, dir_s, app_s, scene["aabbs"][0])
+        sigma_d, rgb_d, sem_d = dynamic_eval(P, cfg, pos, t_s, dir_s, app_s, dynamic_aabb(scene))
         sigma, rgb, sem = blend(sigma_s.view(-1), rgb_s, sem_s, sigma_d, rgb_d, sem_d)
         return sigma, rgb, sem, dict(dynamic_density=sigma_d, static_density=sigma_s.view(-1))
 

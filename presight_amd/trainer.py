@@ -75,7 +75,9 @@ class Trainer:
         # Only the last table piece and the tiny tail are complete at the end of backward: everything else is handed over while kernels
         # are still running.
         # A group that receives no gradient in a step (proposal nets off-schedule) is one contiguous range to skip.
-        names = {id(p): n for n, p in model.named_parameters(remove_duplicate=False)}
+        names: Dict[int, str] = {}
+        for n, p in model.named_parameters(remove_duplicate=False):
+            names.setdefault(id(p), n)  # (aliases -- mlp_base = Sequential(grid, mlp), dual_field.static_field -- keep the first name)
         is_table = lambda p: names.get(id(p), "").endswith("hash_table")  # noqa: E731
         seen, uniq, sizes, kinds = set(), [], [], []
 
@@ -101,7 +103,7 @@ class Trainer:
         # the main field's MLPs are complete after its backward kernels + the gradient unpack, BEFORE its table backward starts; the
         # embeddings (their gradient is an OUTPUT of the main field's backward node) and the sky model close the step: tail bucket
         add_bucket([p for p in fields if not is_table(p) and names.get(id(p), "").startswith("field.")], "fields")
-        main_tables = [p for p in fields if is_table(p) and id(p) not in seen]
+        main_tables = [p for p in fields if is_table(p) and id(p) not in seen and names.get(id(p), "").startswith("field.")]
         split_pieces = int(os.environ.get("PRESIGHT_TABLE_PIECES", "4"))
         n_table_buckets, table_split = 0, None
         if len(main_tables) == 1:

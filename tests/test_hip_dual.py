@@ -123,7 +123,7 @@ def test_grid4_table_and_position_gradients(dev, L, F, log2T):
     assert torch.equal(dx2, dx)
 
 
-def _dual_setup(dev, levels=2, feats=2, seed=3, rays=96):
+def _dual_setup(dev, levels=2, feats=2, seed=3, rays=96, K=1):
     from oracle import dual_oracle as D
     from oracle import nerf_oracle as O
     from presight_amd import ops
@@ -131,14 +131,18 @@ def _dual_setup(dev, levels=2, feats=2, seed=3, rays=96):
     from presight_amd.rays import RayBundle
 
     cfg = D.dual_config(tiny=True, levels=levels, feats=feats)
+    cfg["num_fields"] = K
+    if K > 1:
+        cfg["num_cameras"] = 48  # 8 frames: K distinct centroids on the polyline
     for p in [cfg["main"]] + cfg["props"]:
         p["log2_hashmap_size"] = 10
     scene = O.make_scene(cfg)
     P = D.make_dual_params(cfg, seed=seed, table_scale=0.3)
-    P["field.fields.0.mlp_base_mlp.layers.1.bias"][0] = -3.5  # keep the rays unsaturated: (1 - accumulation) carries the sky gradients
     P["dynamic_field.mlp_base_mlp.layers.1.bias"][0] = -4.0
-    for i in range(2):
-        P[f"proposal_networks.{i}.fields.0.mlp_base.1.layers.1.bias"][0] = -2.0
+    for k in range(K):
+        P[f"field.fields.{k}.mlp_base_mlp.layers.1.bias"][0] = -3.5  # keep the rays unsaturated: (1 - accumulation) carries the sky gradients
+        for i in range(2):
+            P[f"proposal_networks.{i}.fields.{k}.mlp_base.1.layers.1.bias"][0] = -2.0
     batch = O.make_batch(cfg, scene, rays, step=0)
     batch["times"] = D.ray_times(scene, batch["ray_indices"])
     m, d = cfg["main"], cfg["dynamic"]
@@ -161,7 +165,8 @@ def _dual_setup(dev, levels=2, feats=2, seed=3, rays=96):
         for k, v in params.items():
             for name in (k, k.replace("mlp_base_grid.", "mlp_base.0.").replace("mlp_base_mlp.", "mlp_base.1."),
                          k.replace("encoding.hash_table", "mlp_base.0.hash_table"), "dual_field." + k,
-                         k.replace("field.fields.0.", "dual_field.static_field.")):
+                         k.replace("field.fields.0.", "dual_field.static_field.") if K == 1 else k.replace("field.fields.", "dual_field.static_field.fields."),
+                         (k.replace("field.fields.", "dual_field.static_field.fields.").replace("mlp_base_grid.", "mlp_base.0.").replace("mlp_base_mlp.", "mlp_base.1."))):
                 if name in sd:
                     sd[name] = v
         model.load_state_dict(sd)
@@ -228,11 +233,15 @@ def test_blend_forward_backward_incl_clamped_branch(dev):
         torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-5, atol=1e-5 * float(b.grad.abs().max()))
 
 
-def test_dual_training_step_matches_oracle(dev):
-    """whole cfg-4 step: forward, the six losses, backward; every parameter gradient against the oracle"""
+@pytest.mark.parametrize("K", [1, 3])
+def test_dual_training_step_matches_oracle(dev, K):
+    """whole cfg-4 step: forward, the six losses, backward; every parameter gradient against the oracle.  K = 3: the SG-Onenorth
+    shape in small -- the static branch routed over K sub-fields (all K in one launch per kernel, merged network), the dynamic branch one
+    field over the union of their boxes."""
     from oracle import dual_oracle as D
 
-    model, cfg, scene, P, batch, bundle, _ = _dual_setup(dev)
+    model, cfg, scene, P, batch, bundle, _ = _dual_setup(dev, K=K, rays=96 if K == 1 else 160)
+    assert len(model.field.fields) == K and model.dual_field.routed == (K > 1)
     out = model(bundle(), jitters=[j.to(dev) for j in batch["jitter"]])
     gt = {k: batch[k].to(dev) for k in ("rgb", "features", "sky")}
     losses = model.get_loss_dict(out, gt)
@@ -255,7 +264,7 @@ def test_dual_training_step_matches_oracle(dev):
     _, _, g64 = D.dual_train_step(to_double(P), cfg, to_double(scene), to_double(batch))
     errs, names, bounds = assert_grads_within_oracle_noise({n: p.grad for n, p in model.named_parameters()}, g_ref, g64, what="dual step")
     print(f"dual step vs oracle: {len(errs)} gradients: median {errs[len(errs) // 2]:.1e}, max {errs[-1]:.1e} ({names[-1]}, bound {bounds[-1]:.1e})")
-    assert len(errs) == len(P) and errs[len(errs) // 2] < 2e-5
+    assert errs[len(errs) // 2] < 2e-5 and len(errs) + sum(1 for v in g_ref.values() if float(v.abs().max()) == 0) == len(P)
 
 
 def test_zero_dynamic_density_is_the_static_model_bitwise(dev):
