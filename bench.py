@@ -65,6 +65,16 @@ CONFIGS = {
                  workload="BASELINE cfg 4: static (cfg-2 field) + dynamic (4-D hash grid L=8,F=4,T=2^19 + flow MLP 32-64-64-6 + MLP stack, "
                           "3-position temporal aggregation) dual field, density-weighted blend, 2 static proposal nets, 128/64/64 samples, "
                           "fwd+6 losses+bwd+Adam"),
+    # the same dual field on the SG-Onenorth tile shape (ns/configs/method_configs.py:271-367: num_aabbs = 16, production grids): the
+    # static branch is the routed K = 16 production field of cfg 3, the dynamic branch one field over the union of the sub-field boxes
+    "cfg4prod": dict(K=16, model=dict(num_levels=10, features_per_level=4, log2_hashmap_size=20, base_res=16, max_res=16384, hidden_dim=64,
+                                      hidden_dim_color=64),
+                     dynamic=dict(dynamic_num_levels=8, dynamic_features_per_level=4, dynamic_log2_hashmap_size=19, dynamic_base_res=16,
+                                  dynamic_max_res=512, dynamic_hidden_dim=64, dynamic_hidden_dim_color=64, flow_hidden_dim=64),
+                     scaling="strong", exchange="sharded",
+                     workload="BASELINE cfg 4 on the SG-Onenorth tile shape: static branch = K=16 routed production field (L=10,F=4,T=2^20), dynamic "
+                              "branch = 4-D hash grid L=8,F=4,T=2^19 + flow MLP + MLP stack over the tile, 2 routed proposal nets, 128/64/64 samples, "
+                              "fwd+6 losses+bwd+Adam"),
 }
 
 
@@ -74,7 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "extract"], default="cfg2")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg4prod", "extract"], default="cfg2")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
     ap.add_argument("--exchange", choices=["allreduce", "sharded"], default=None)
     ap.add_argument("--rays", type=int, default=RAYS, help="rays per step: per GPU (weak) / over all GPUs (strong)")
@@ -1118,6 +1128,7 @@ def main():
 
             run_sec(["cfg3_65536", "cfg3_8192"], cfg3)
             run_sec(["cfg4_65536"], lambda: {"cfg4_65536": secondary_training_lines("cfg4", [(65536, 4, 2)], dev)[65536]})
+            run_sec(["cfg4prod_65536"], lambda: {"cfg4prod_65536": secondary_training_lines("cfg4prod", [(65536, 3, 2)], dev)[65536]})
             run_sec(["extract_512"], lambda: {"extract_512": secondary_extract_line(dev)})
             run_sec(["extract_512_prod"], lambda: {"extract_512_prod": secondary_extract_line(dev, model_cfg="cfg3")})
             line["secondary"] = sec
