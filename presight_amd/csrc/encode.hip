@@ -411,7 +411,10 @@ constexpr int kBinThreads = 256;
 // records = 32 bytes per plane -- partial cache lines (PMC, production tile: 6.6 GB written for 4.0 GB of records); 1024 points double
 // the runs (cfg 3 main table backward 4.97 -> 4.34 ms) at one workgroup per CU.  F = 1 / 2 (16 / 64 slices) are best at 512 points
 // (cfg 2 main 2.55 vs 2.70 ms, proposal 1.05 vs 1.22 ms at 1024; 256 points: 1.36 ms).
-constexpr int bin_points_per_thread(int D, int F) { return D == 4 ? 1 : (F == 4 ? 2 * PS_BIN_PPT : PS_BIN_PPT); }
+#ifndef PS_BIN_PPT_4D
+#define PS_BIN_PPT_4D 1
+#endif
+constexpr int bin_points_per_thread(int D, int F) { return D == 4 ? PS_BIN_PPT_4D : (F == 4 ? 2 * PS_BIN_PPT : PS_BIN_PPT); }
 constexpr int bin_points(int D, int F) { return kBinThreads * bin_points_per_thread(D, F); }  // points per workgroup
 constexpr int kMaxSlices = 256;
 constexpr int kAccBytes = 128 * 1024;
