@@ -227,6 +227,9 @@ def Trainer(model, scene, world, exchange="allreduce", global_depth_clip=False):
 
     t = _Trainer(model, scene, world, exchange=exchange, global_depth_clip=global_depth_clip)
     t.update_props_every_step = True
+    # single process: the fields' Adam runs on a second stream underneath the next step's proposal sampling (presight_amd/trainer.py;
+    # the end of a timed region synchronises every stream)
+    t.pipeline_adam = world == 1 and os.environ.get("PRESIGHT_PIPELINE_ADAM", "1") != "0"
     return t
 
 
@@ -578,12 +581,14 @@ def secondary_training_lines(config, shapes, dev):
         from presight_amd import ops as _ops
 
         side_was, _ops.SIDE_STREAM = _ops.SIDE_STREAM, False  # per-region times with the chip to themselves
+        pipe_was, trainer.pipeline_adam = trainer.pipeline_adam, False
         prof.enable(True)
         for i in range(2):
             trainer.step(batches[i % 2])
         kern = prof.summary()
         prof.enable(False)
         _ops.SIDE_STREAM = side_was
+        trainer.pipeline_adam = pipe_was
         # ("main_field_bwd" is the sum of the three stage regions when those are timed)
         per_step = {k: n * ms / 2 for k, (n, ms) in kern.items() if k != "main_field_bwd" or "main_bwd_sem_kernel" not in kern}
         top = sorted(per_step.items(), key=lambda kv: -kv[1])[:3]
@@ -980,7 +985,7 @@ def main():
     trainer.grads.stats = {"collectives": 0, "bytes": 0}
     # the longest kernels are timed live inside the timed steps (one HIP-event pair each); every other region -- two dozen
     # event pairs per step and the three-call split of the backward cost the timeline 1 % -- in a separate pass behind it
-    live = ("main_field_fwd", "adam")
+    live = ("main_field_fwd",) if trainer.pipeline_adam else ("main_field_fwd", "adam")
     prof.enable(True, only=live)
     dt, (loss_dict, out) = timed(args.steps)
     psnr = float(model.get_metrics_dict(out, last_batch[0])["psnr"].detach())
@@ -991,11 +996,14 @@ def main():
 
     comm = dict(trainer.grads.stats)
     side_was, _ops.SIDE_STREAM = _ops.SIDE_STREAM, False
+    pipe_was, trainer.pipeline_adam = trainer.pipeline_adam, False
+    live_adam = kern.pop("adam", None) if pipe_was else None  # (pipelined: the live region only brackets the proposal networks' piece)
     prof.enable(True)
     run(min(args.steps, 8))
     kern = {**prof.summary(), **kern}  # live figures win
     prof.enable(False)
     _ops.SIDE_STREAM = side_was
+    trainer.pipeline_adam = pipe_was
     timeline = None
     if world > 1 and not tiles:  # when every bucket became ready relative to the end of backward (normal schedule: proposal side stream on)
         trainer.grads.record_timeline = True

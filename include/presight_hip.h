@@ -399,8 +399,9 @@ int ps_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
  * group (nullable) / group[i] >= 0: whether range i received a gradient this step is decided ON THE DEVICE --
  * group_flags[group[i]] != 0 (device int32 [n_groups], set by ps_ms_mark_groups for the routed sub-fields that received
  * samples: ingp_field_ms.py:97-126 never calls an empty sub-field, so its gradients stay None and Adam skips it); its step
- * count lives in group_steps[group[i]] (device int32) and is advanced after the update.  A range whose flag is 0 is left
- * untouched: parameters, both moments and the step count keep their bits. */
+ * count lives in group_steps[group[i]] (device int32) and is advanced after the update (the groups this call references: one
+ * optimizer step may be issued as several calls over disjoint ranges, on different streams).  A range whose flag is 0 is left
+ * untouched: parameters, both moments and the step count keep their bits.  n_groups <= 256. */
 int ps_adam_step_ranges(float* p, const float* g, float* m, float* v, int n_ranges, const int64_t* start /*host*/,
                         const int64_t* count /*host*/, const int* step /*host*/, const int* group /*host, nullable*/,
                         const int32_t* group_flags /*device, nullable*/, int32_t* group_steps /*device, nullable*/, int n_groups,

@@ -114,9 +114,14 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p,
   }
 }
 
-__global__ void adam_commit_kernel(const int* __restrict__ flags, int* __restrict__ steps, int n_groups) {
+// groups referenced by one ps_adam_step_ranges call (an optimizer step may be issued in several calls -- e.g. the proposal networks'
+// ranges first and the fields' on another stream -- and every group's count must advance exactly once)
+struct GroupMask {
+  unsigned long long w[4];
+};
+__global__ void adam_commit_kernel(const int* __restrict__ flags, int* __restrict__ steps, int n_groups, GroupMask mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_groups && flags[i] != 0) steps[i] += 1;
+  if (i < n_groups && ((mask.w[i >> 6] >> (i & 63)) & 1ull) && flags[i] != 0) steps[i] += 1;
 }
 
 }  // namespace
@@ -142,14 +147,18 @@ extern "C" int ps_adam_step(float* p, const float* g, float* m, float* v, int64_
 // n_ranges disjoint, non-empty ranges [start[i], start[i]+count[i]) (floats, start a multiple of 4) of the flat buffers;
 // start / count / step / group are HOST arrays.  group == NULL or group[i] < 0: range i is updated at the host-side step count
 // step[i] >= 1.  group[i] >= 0: the device decides (see adam_ranges_kernel) from group_flags[group[i]] / group_steps[group[i]]
-// (device int32 arrays of n_groups entries); after the last launch the step counts of the flagged groups are advanced by one.
+// (device int32 arrays of n_groups entries); after the last launch the step counts of the flagged groups THIS CALL REFERENCES are
+// advanced by one (an optimizer step may be issued as several calls over disjoint ranges).
 // ceil(n_ranges / 32) launches (+ 1 when groups are given).
 extern "C" int ps_adam_step_ranges(float* p, const float* g, float* m, float* v, int n_ranges, const int64_t* start,
                                    const int64_t* count, const int* step, const int* group, const int32_t* group_flags,
                                    int32_t* group_steps, int n_groups, float lr, float beta1, float beta2, float eps,
                                    float weight_decay, float grad_scale, void* stream) {
   PS_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "ps_adam_step_ranges: buffers must be 16-byte aligned");
+  PS_REQUIRE(n_groups <= 256, "ps_adam_step_ranges: at most 256 device-decided groups");
+  GroupMask mask{{0ull, 0ull, 0ull, 0ull}};
   for (int i = 0; i < n_ranges; ++i) {
+    if (group != nullptr && group[i] >= 0 && group[i] < 256) mask.w[group[i] >> 6] |= 1ull << (group[i] & 63);
     PS_REQUIRE(count[i] > 0, "ps_adam_step_ranges: empty range");
     PS_REQUIRE((start[i] & 3) == 0, "ps_adam_step_ranges: range starts must be multiples of 4 floats");
     const int grp = group != nullptr ? group[i] : -1;
@@ -179,7 +188,7 @@ extern "C" int ps_adam_step_ranges(float* p, const float* g, float* m, float* v,
     if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
   }
   if (group != nullptr && n_groups > 0 && group_flags != nullptr)
-    adam_commit_kernel<<<(unsigned)((n_groups + 255) / 256), 256, 0, (hipStream_t)stream>>>(group_flags, group_steps, n_groups);
+    adam_commit_kernel<<<(unsigned)((n_groups + 255) / 256), 256, 0, (hipStream_t)stream>>>(group_flags, group_steps, n_groups, mask);
   PS_CHECK_LAUNCH();
 }
 

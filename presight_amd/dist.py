@@ -200,24 +200,43 @@ class FlatGrads:
         field_ops._GROUP_TABLES.clear()  # mark_groups' cached group-id tables are keyed by the owner: drop the previous owner's
         self.n_groups = n
         dev = self.flat.device
-        self.group_flags = torch.zeros(max(n, 1), device=dev, dtype=torch.int32)
+        self._group_flag_bufs = [torch.zeros(max(n, 1), device=dev, dtype=torch.int32) for _ in range(2)]
+        self.group_flags = self._group_flag_bufs[0]
         self.group_steps = torch.zeros(max(n, 1), device=dev, dtype=torch.int32)
         self.flags_may_differ_across_ranks = False
 
     # ------------------------------------------------------------------ per-step bookkeeping
-    def zero_(self):
+    def zero_(self, already_zeroed: Optional[Sequence[Tuple[int, int]]] = None):
         """Start of a step: gradients to zero, "received a gradient this step" flags cleared (torch's zero_grad(set_to_none=True)
         + "grad is None -> the optimizer skips the parameter" semantics, without freeing the flat buffer).  Only the ranges
         that received a gradient in the previous step (as agreed across ranks: touched_ranges) are written; everything else
-        is still zero (a production tile's 3.5 GiB buffer is mostly untouched when a sub-field gets no samples)."""
+        is still zero (a production tile's 3.5 GiB buffer is mostly untouched when a sub-field gets no samples).
+        already_zeroed: ranges somebody else has cleared (or will have cleared, in stream order, before anything writes them):
+        the pipelined optimizer step clears the fields' gradients on its own stream right behind their Adam update."""
         if self._dirty is None:
             self.flat.zero_()
         else:
-            for a, b in self._dirty:
+            todo = self._dirty
+            if already_zeroed:
+                keep, cur = [], list(todo)
+                for a, b in cur:  # subtract the sorted, disjoint ranges of already_zeroed
+                    x = a
+                    for c, d in already_zeroed:
+                        if d <= x or c >= b:
+                            continue
+                        if c > x:
+                            keep.append((x, c))
+                        x = max(x, d)
+                    if x < b:
+                        keep.append((x, b))
+                todo = keep
+            for a, b in todo:
                 self.flat[a:b].zero_()
         self._dirty = None
         self.step_no += 1
         if self.n_groups:
+            # two flag arrays, alternating: the previous step's flags may still be read by an optimizer piece running on another stream
+            self.group_flags = self._group_flag_bufs[self.step_no & 1]
             self.group_flags.zero_()
         for p in self.params:
             p._ps_touched = False

@@ -54,19 +54,22 @@ class HipAdam:
             self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
 
     @torch.no_grad()
-    def step(self, skip=()):
+    def step(self, skip=(), subset=None):
         """skip: indices of parameters whose update is withheld this step although they received a gradient (GradScaler.step
         found an inf / nan in their group): treated like parameters without a gradient.
+        subset: only these parameter indices are updated by this call (the step is issued in pieces: presight_amd.trainer.Trainer
+        runs the fields' piece on a second stream underneath the next step's proposal sampling); launches go to the current stream.
         torch.optim.Adam semantics per PARAMETER: state["step"] (the bias-correction exponent) advances only for parameters
         that received a gradient this step; the others are skipped entirely (no decay, no moment update), like torch with
         grad None after zero_grad(set_to_none=True).  Proposal networks (a gradient every ~6th step after warm-up) and
         sub-fields that saw no sample therefore keep their own, smaller step counts."""
-        self.step_count += 1
+        if subset is None or 0 in subset or not self.params:
+            self.step_count += 1  # (a step issued in pieces counts once: with the piece that holds parameter 0)
         s = _stream()
         if self.flat is not None:
             fg = self.flat_grads
             fg._join_side_streams()
-            idx = [i for i in fg.touched_params() if i not in skip]
+            idx = [i for i in fg.touched_params() if i not in skip and (subset is None or i in subset)]
             if skip and fg.n_groups:  # device-decided groups of withheld parameters: lower their flags
                 for g_ in {getattr(self.params[i], "_ps_group", None) for i in skip} - {None}:
                     fg.group_flags[g_] = 0
@@ -103,7 +106,7 @@ class HipAdam:
             return
         for i, (p, m, v) in enumerate(zip(self.params, self.exp_avg, self.exp_avg_sq)):
             g = p.grad
-            if g is None or i in skip:
+            if g is None or i in skip or (subset is not None and i not in subset):
                 continue
             if not g.is_contiguous():
                 g = g.contiguous()

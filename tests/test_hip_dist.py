@@ -229,6 +229,37 @@ def test_trainer_buckets_on_gpu_single_rank(dev, K, monkeypatch):
     assert all(s == 2 for s in steps[:n_prop]) and all(s == 3 for s in steps[n_prop:])
 
 
+@pytest.mark.parametrize("K", [1, 4])
+def test_pipelined_adam_is_bitwise_the_plain_step(dev, K):
+    """Trainer.pipeline_adam (single process): the proposal networks' Adam right behind backward, the fields' Adam + the clearing of
+    their gradients on a second stream underneath the next iteration's proposal sampling, the compute stream waiting for it at
+    model.param_gate("fields").  Same arithmetic in the same order: after 6 iterations -- with an off-schedule proposal step and, for
+    the routed tile, device-decided sub-field groups -- parameters, both moments and every step count are BIT-identical to the
+    plain trainer's."""
+    import bench
+
+    states = []
+    for pipelined in (False, True):
+        model, scene = _tiny_model(dev, K=K)
+        tr = bench.Trainer(model, scene, 1)
+        tr.pipeline_adam = pipelined
+        tr.update_props_every_step = False
+        batches = bench.make_batches(scene, dev, 3, 0, rays=512)
+        for i in range(6):
+            if i == 3:
+                tr.step_idx = 50000
+                model.proposal_sampler.step_cb(50000)
+                model.proposal_sampler._steps_since_update = 0  # -> the next two steps are off schedule
+            tr.step(batches[i % 3])
+        tr.join()
+        torch.cuda.synchronize()
+        states.append((tr.opt.flat[0].clone(), tr.opt.flat[2].clone(), tr.opt.flat[3].clone(), tr.opt.param_steps(), tr.grads.flat.clone()))
+        assert (tr._pipe is not None) == pipelined
+    a, b = states
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
+    assert len(set(a[3])) > 1  # (proposal parameters took fewer steps than the fields')
+
+
 def _run_bench_two_ranks(extra, timeout=300, attempts=2):
     """bench.py --gpus 2 in a fresh child process.  A run that hangs or times out is NEVER a skip: the per-rank collective logs
     (presight_amd.dist.CommLog) are compared first -- different issued sequences = an ordering bug in the exchange = failure at
