@@ -227,9 +227,11 @@ def Trainer(model, scene, world, exchange="allreduce", global_depth_clip=False):
 
     t = _Trainer(model, scene, world, exchange=exchange, global_depth_clip=global_depth_clip)
     t.update_props_every_step = True
-    # single process: the fields' Adam runs on a second stream underneath the next step's proposal sampling (presight_amd/trainer.py;
-    # the end of a timed region synchronises every stream)
-    t.pipeline_adam = world == 1 and os.environ.get("PRESIGHT_PIPELINE_ADAM", "1") != "0"
+    # PRESIGHT_PIPELINE_ADAM=1 (single process): the fields' Adam on a second stream underneath the next step's proposal sampling
+    # (presight_amd/trainer.py).  Measured and left OFF: on the production tile the sampling front is HBM-bound itself (512 MB of
+    # proposal tables per net) and shares the memory system with the 26 GB Adam stream -- cfg 3 26.3 -> 27.2 ms at 65 536 rays,
+    # 10.5 -> 10.2 ms at 8192; cfg 2 (0.15 ms of Adam) unchanged
+    t.pipeline_adam = world == 1 and os.environ.get("PRESIGHT_PIPELINE_ADAM", "0") == "1"
     return t
 
 
