@@ -243,6 +243,39 @@ class Trainer:
             torch.cuda.current_stream().wait_event(self._pipe["event"])
             self._pipe["event"] = None
 
+    def _begin_step(self):
+        """clear the gradients of the previous step; -> the pipeline state when this step's optimizer runs pipelined"""
+        pipe = self._pipe_state() if (self.pipeline_adam and self.world == 1 and not self.update_grad_scaler and torch.cuda.is_available()) else None
+        if pipe is None:
+            self.join()
+        # (pipelined: the fields' gradients were cleared on the pipeline stream right behind their Adam update)
+        self.grads.zero_(already_zeroed=pipe["ranges"] if (pipe is not None and pipe["zeroed"]) else None)
+        if pipe is not None:
+            pipe["zeroed"] = False
+        return pipe
+
+    def _optimizer_step(self, pipe) -> bool:
+        """-> whether the schedulers may step (the loss scale did not decrease)"""
+        if self.update_grad_scaler:
+            return self._scaler_step()
+        if pipe is None:
+            self.opt.step()  # on the scaled gradients (optimizer_step_all, optimizers.py:133-140)
+            return True
+        from .dist import intersect_ranges
+
+        self.opt.step(subset=pipe["others"])  # proposal networks: the next iteration needs them first
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(pipe["stream"]):
+            pipe["stream"].wait_event(ev)
+            self.opt.step(subset=pipe["fields"])
+            for a, b in intersect_ranges(self.grads._dirty or [], pipe["ranges"]):
+                self.grads.flat[a:b].zero_()
+            done = torch.cuda.Event()
+            done.record(pipe["stream"])
+        pipe["event"], pipe["zeroed"] = done, self.grads._dirty is not None
+        return True
+
     def _run_callbacks(self, where: TrainingCallbackLocation):
         for cb in self.callbacks:
             cb.run_callback_at_location(self.step_idx, where)
@@ -251,13 +284,7 @@ class Trainer:
         m, s = self.model, self.scene
         m.train()
         self._run_callbacks(TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
-        pipe = self._pipe_state() if (self.pipeline_adam and self.world == 1 and not self.update_grad_scaler and torch.cuda.is_available()) else None
-        if pipe is None:
-            self.join()
-        # (pipelined: the fields' gradients were cleared on the pipeline stream right behind their Adam update)
-        self.grads.zero_(already_zeroed=pipe["ranges"] if (pipe is not None and pipe["zeroed"]) else None)
-        if pipe is not None:
-            pipe["zeroed"] = False
+        pipe = self._begin_step()
         o, d, pa, dn = ops.generate_rays(batch["ray_indices"], s["c2w"], s["fx"], s["fy"], s["cx"], s["cy"])
         vid = batch["video_ids"] if "video_ids" in batch else batch["video_id"]  # synthetic batches / the reference's collated key
         meta = {"video_id": vid.view(-1, 1), "directions_norm": dn}
@@ -285,26 +312,7 @@ class Trainer:
         with prof.region("exchange_exposed"):
             self.grads.finish_exchange()
         with prof.region("adam"):
-            if self.update_grad_scaler:
-                scale_kept = self._scaler_step()
-            elif pipe is not None:
-                from .dist import intersect_ranges
-
-                self.opt.step(subset=pipe["others"])  # proposal networks: the next iteration needs them first
-                ev = torch.cuda.Event()
-                ev.record()
-                with torch.cuda.stream(pipe["stream"]):
-                    pipe["stream"].wait_event(ev)
-                    self.opt.step(subset=pipe["fields"])
-                    for a, b in intersect_ranges(self.grads._dirty or [], pipe["ranges"]):
-                        self.grads.flat[a:b].zero_()
-                    done = torch.cuda.Event()
-                    done.record(pipe["stream"])
-                pipe["event"], pipe["zeroed"] = done, self.grads._dirty is not None
-                scale_kept = True
-            else:
-                self.opt.step()  # on the scaled gradients (optimizer_step_all, optimizers.py:133-140)
-                scale_kept = True
+            scale_kept = self._optimizer_step(pipe)
         if self.scheduler is not None and scale_kept:  # trainer.py:499-505
             self.scheduler.step()
         self._run_callbacks(TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
