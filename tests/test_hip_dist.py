@@ -250,8 +250,9 @@ def test_pipelined_adam_equals_the_plain_step(dev, K):
             pipe = tr._begin_step()
             torch.cuda.synchronize()
             assert float(fg.flat.abs().max()) == 0.0  # whoever was responsible has cleared every gradient
-            fg.flat.copy_((torch.randn(fg.total, generator=g) * 1e-3).to(dev))
             touched = [p for i, p in enumerate(fg.params) if not (it == 1 and tr.group_names[_bucket_of(fg, i)] == "proposal_networks")]
+            for p in touched:  # (the padding between parameters is never written, as in training)
+                p.grad.copy_((torch.randn(p.shape, generator=g) * 1e-3).to(dev))
             mark_touched(touched, groups_on_device=True)  # (second step: proposal networks off schedule)
             if fg.n_groups:
                 flags = torch.zeros(fg.n_groups, dtype=torch.int32)
