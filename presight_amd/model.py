@@ -8,7 +8,7 @@ from __future__ import annotations
 import functools
 from collections import defaultdict
 from dataclasses import dataclass, field
-from typing import Dict, List, Literal, Optional, Tuple, Type
+from typing import Callable, Dict, List, Literal, Optional, Tuple, Type
 
 import numpy as np
 import torch
@@ -99,6 +99,58 @@ class NerfactoNuscMSModelConfig:
 
     def setup(self, **kwargs):
         return self._target(self, **kwargs)
+
+
+class LazyOutputs(dict):
+    """The model's output dict with entries that are evaluated on first access.  The reference renders the proposal levels'
+    threshold depths in every forward (`prop_depth_i`, ns/models/PreSight/nerfacto_nusc_ms.py:543-544) although only the viewer and
+    the evaluation images read them; in a training step they are two compositing launches nobody looks at.  Membership, iteration
+    and item access behave like the plain dict's: a lazy key is present from the start, reading it (or iterating over values /
+    items) evaluates it once."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy: Dict[str, Callable] = {}
+
+    def lazy(self, key: str, fn: Callable):
+        self._lazy[key] = fn
+        dict.__setitem__(self, key, None)  # (keeps the key's position and membership)
+
+    def _force(self, key):
+        fn = self._lazy.pop(key, None)
+        if fn is not None:
+            dict.__setitem__(self, key, fn())
+
+    def __getitem__(self, key):
+        self._force(key)
+        return dict.__getitem__(self, key)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def pop(self, key, *default):
+        self._force(key)
+        return dict.pop(self, key, *default)
+
+    def _force_all(self):
+        for k in list(self._lazy):
+            self._force(k)
+
+    def items(self):
+        self._force_all()
+        return dict.items(self)
+
+    def values(self):
+        self._force_all()
+        return dict.values(self)
+
+    def copy(self):
+        self._force_all()
+        return dict(self)
 
 
 class _PropDensityFn:
@@ -305,7 +357,7 @@ class NerfactoNuscMSModel(nn.Module):
         # accumulation = clamp(acc, 0, 1); rgb/semantics += (1 - accumulation) * sky   (nerfacto_nusc_ms.py:512-533)
         rgb, accumulation, semantics = ops.sky_blend(rgb, acc_raw, semantics if c.use_semantics else None,
                                                      sky_outputs.get(FieldHeadNames.RGB), sky_outputs.get(FieldHeadNames.SEMANTICS))
-        outputs = {"rgb": rgb, "accumulation": accumulation, "depth": depth.detach(), "expected_depth": expected_depth}
+        outputs = LazyOutputs({"rgb": rgb, "accumulation": accumulation, "depth": depth.detach(), "expected_depth": expected_depth})
         if c.use_semantics:
             outputs["semantics"] = semantics
             if not self.training and self.dino_to_rgb is not None:
@@ -313,9 +365,16 @@ class NerfactoNuscMSModel(nn.Module):
         if self.training:
             outputs["weights_list"] = weights_list
             outputs["ray_samples_list"] = ray_samples_list
-        with torch.no_grad():
-            for i in range(c.num_proposal_iterations):
-                outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
+
+        def prop_depth(i):
+            with torch.no_grad():
+                return self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
+
+        for i in range(c.num_proposal_iterations):
+            if self.training:  # evaluated when somebody reads it (nothing in a training step does)
+                outputs.lazy(f"prop_depth_{i}", functools.partial(prop_depth, i))
+            else:
+                outputs[f"prop_depth_{i}"] = prop_depth(i)
         return outputs
 
     def get_metrics_dict(self, outputs, batch):

@@ -539,3 +539,22 @@ def test_epoch_order_is_the_reference_loader_order():
         assert torch.equal(epoch_order(P, world, rank, seed=0), torch.from_numpy(G[f"order_w{world}r{rank}"]))
     # padding by wrap-around keeps every rank's share equal; an unshuffled pass is the identity
     assert epoch_order(10, 4, 3).shape[0] == 3 and epoch_order(10, 1, 0, shuffle=False).tolist() == list(range(10))
+
+
+def test_lazy_outputs_behave_like_a_dict():
+    """presight_amd.model.LazyOutputs: `prop_depth_i` of a training forward is evaluated on first access (the reference renders it
+    in every forward, ns/models/PreSight/nerfacto_nusc_ms.py:543-544); membership, order, get / items / values are the plain dict's"""
+    from presight_amd.model import LazyOutputs
+
+    calls = []
+    o = LazyOutputs({"rgb": 1})
+    o.lazy("prop_depth_0", lambda: (calls.append(0), "d0")[1])
+    o.lazy("prop_depth_1", lambda: (calls.append(1), "d1")[1])
+    assert "prop_depth_0" in o and list(o.keys()) == ["rgb", "prop_depth_0", "prop_depth_1"] and not calls
+    assert o["prop_depth_1"] == "d1" and calls == [1] and o["prop_depth_1"] == "d1" and calls == [1]
+    assert o.get("prop_depth_0") == "d0" and o.get("missing", 3) == 3 and calls == [1, 0]
+    o.lazy("x", lambda: 7)
+    assert dict(o.items()) == {"rgb": 1, "prop_depth_0": "d0", "prop_depth_1": "d1", "x": 7} and list(o.values())[-1] == 7
+    o.lazy("y", lambda: 8)
+    o["y"] = 9  # an explicit assignment wins
+    assert o["y"] == 9 and o.pop("x") == 7 and "x" not in o
