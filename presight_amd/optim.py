@@ -187,3 +187,11 @@ class WarmupMultiStepSchedule:
 
     def get_last_lr(self) -> List[float]:
         return [self.opt.lr]
+
+    def state_dict(self):
+        return {"t": self.t, "lr_init": self.lr_init}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        self.lr_init = float(sd.get("lr_init", self.lr_init))
+        self.opt.lr = self.lr_at(self.t)

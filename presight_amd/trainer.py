@@ -276,6 +276,33 @@ class Trainer:
         pipe["event"], pipe["zeroed"] = done, self.grads._dirty is not None
         return True
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> Dict:
+        """what ns/engine/trainer.py:432-460 saves next to the pipeline's state_dict -- step, optimizers, schedulers, scalers -- for this
+        trainer: the Adam state (moments, per-parameter step counts incl. the device-decided sub-field groups), the schedule position,
+        the loss scale, and the proposal sampler's update-schedule counters (the reference keeps those on the sampler object, so a
+        resumed run restarts them at 0: here they are saved, see load_state_dict)"""
+        self.join()
+        ps = self.model.proposal_sampler
+        return {"step": self.step_idx, "optimizer": self.opt.state_dict(), "scheduler": None if self.scheduler is None else self.scheduler.state_dict(),
+                "scalers": {"scale": self.loss_scale, "growth_tracker": self._growth_tracker},
+                "proposal_sampler": {"steps_since_update": ps._steps_since_update, "step": ps._step, "anneal": ps._anneal}}
+
+    def load_state_dict(self, sd: Dict, restore_sampler: bool = True):
+        """restore_sampler=False reproduces the reference's resume exactly (its sampler counters restart; ns/engine/trainer.py:396-429
+        loads step / pipeline / optimizers / schedulers / scalers only)"""
+        self.join()
+        self.step_idx = int(sd["step"])
+        self.opt.load_state_dict(sd["optimizer"])
+        if self.scheduler is not None and sd.get("scheduler") is not None:
+            self.scheduler.load_state_dict(sd["scheduler"])
+        self.loss_scale = float(sd["scalers"]["scale"])
+        self._growth_tracker = int(sd["scalers"]["growth_tracker"])
+        if restore_sampler and "proposal_sampler" in sd:
+            ps = self.model.proposal_sampler
+            ps._steps_since_update, ps._step = int(sd["proposal_sampler"]["steps_since_update"]), int(sd["proposal_sampler"]["step"])
+            ps.set_anneal(float(sd["proposal_sampler"]["anneal"]))
+
     def _run_callbacks(self, where: TrainingCallbackLocation):
         for cb in self.callbacks:
             cb.run_callback_at_location(self.step_idx, where)

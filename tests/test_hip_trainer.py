@@ -134,3 +134,47 @@ def test_update_grad_scaler_branch_skips_the_group_with_an_inf(gold_model_traj):
     assert tr.loss_scale == 512.0 and tr.opt.lr == lr1  # scale decreased -> scheduler_step_all is not called
     tr.step(_dev_batch(batches[2], dev))
     assert tr.opt.lr > lr1 and all(torch.isfinite(v).all() for v in model.state_dict().values())
+
+
+def test_checkpoint_resume_continues_the_run(gold_model_traj):
+    """Trainer.state_dict / load_state_dict (what ns/engine/trainer.py:432-460 saves: step, optimizers, schedulers, scalers): a run that is
+    saved after 12 iterations (an off-schedule proposal step, a sub-field that has been skipped: uneven Adam step counts) and resumed in a
+    FRESH model + trainer continues like the uninterrupted one -- same learning rates, same pattern of stepped parameters, losses within
+    the run-to-run noise of the step, final parameters within the trimmed 2-norm bound of the trajectory test."""
+    import copy
+
+    from presight_amd.trainer import Trainer
+
+    G = gold_model_traj
+    dev = torch.device("cuda:0")
+    cfg, scene, P, batches = model_traj_setup(G)
+    M = int(G["max_iterations"])
+
+    def fresh():
+        model = build_hip_model(cfg, scene, P, dev, proposal_weights_anneal_max_num_iters=M // 10, proposal_warmup=M // 10)
+        return model, Trainer(model, _scene_dev(scene, dev), loss_scale=float(G["loss_scale"]), max_num_iterations=M)
+
+    model_a, tr_a = fresh()
+    for s in range(12):
+        tr_a.step(_dev_batch(batches[s], dev))
+    ckpt = {"pipeline": copy.deepcopy(model_a.state_dict()), "trainer": copy.deepcopy(tr_a.state_dict())}  # (what torch.save would hold)
+    model_b, tr_b = fresh()
+    model_b.load_state_dict(ckpt["pipeline"])
+    tr_b.load_state_dict(ckpt["trainer"])
+    assert tr_b.step_idx == 12 and tr_b.opt.lr == tr_a.opt.lr and tr_b.opt.param_steps() == tr_a.opt.param_steps()
+    assert len(set(tr_b.opt.param_steps())) > 1
+    for k in P:
+        assert torch.equal(model_a.state_dict()[k], model_b.state_dict()[k]), k
+    la, lb = [], []
+    for s in range(12, 24):
+        a, _ = tr_a.step(_dev_batch(batches[s], dev))
+        b, _ = tr_b.step(_dev_batch(batches[s], dev))
+        assert tr_a.opt.lr == tr_b.opt.lr and abs(tr_a.opt.lr - float(G["lr"][s + 1] if s + 1 < 24 else tr_a.opt.lr)) < 1e-12
+        la.append([float(v.detach()) for v in a.values()])
+        lb.append([float(v.detach()) for v in b.values()])
+    assert tr_a.opt.param_steps() == tr_b.opt.param_steps()
+    np.testing.assert_allclose(np.array(lb), np.array(la), rtol=2e-4, atol=1e-7)
+    fa = {k: model_a.state_dict()[k].detach().cpu() for k in P}
+    fb = {k: model_b.state_dict()[k].detach().cpu() for k in P}
+    err = traj_param_error(fb, fa, P)
+    assert max(err.values()) < 1e-4 and traj_param_max_diff(fb, fa) <= 4 * float(G["lr"].max()), sorted(err.items(), key=lambda kv: -kv[1])[:3]
