@@ -7,6 +7,8 @@ mkdir -p gpurun_out /tmp/pmc
 KERN="main_bwd,main_fwd,accumulate_kernel,bin_kernel,grid_encode,prop_bwd_kernel,prop_fwd_kernel,composite,absmax,adam,grid4,flow_,blend_"
 OUT=gpurun_out/pmc_summary_$TAG.txt
 : > $OUT
+# the hash of the kernel sources THESE counters are collected on (tools/pmc_traffic.py stamps profiles/traffic.json with it)
+echo "src_sha16=$(python3 -c 'import bench; print(bench.kernel_sources_sha())')" >> $OUT
 # PMC_BASIC=1: the four groups that price a kernel against its roofline (HBM bytes, matrix-pipe busy, L2 hit rate) -- used for the
 # secondary configurations (cfg 3 / cfg 4), whose steps are long
 if [ "${PMC_BASIC:-0}" = "1" ]; then

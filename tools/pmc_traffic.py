@@ -11,8 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 src, dst = sys.argv[1], sys.argv[2]
-cur, data = None, {}
+cur, data, sha = None, {}, None
 for line in open(src):
+    if line.startswith("src_sha16="):
+        sha = line.strip().split("=", 1)[1]
+        continue
     m = re.match(r"\s+(\S+)\s+launches\s+(\d+)\s+avg\s+([\d.]+)", line)
     if m and cur:
         data.setdefault(cur, {})[m.group(1)] = float(m.group(3))
@@ -26,5 +29,7 @@ for key, pat in (("main_fwd_kernel", "main_fwd_kernel"), ("main_bwd_sem_kernel",
             out[key] = dict(hbm_bytes_per_launch=(2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024, fetch_kb=d["FETCH_SIZE"], write_kb=d["WRITE_SIZE"],
                             source=f"profiles/{os.path.basename(src)} (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)")
             break
-json.dump(dict(src_sha16=bench.kernel_sources_sha(), kernels=out), open(dst, "w"), indent=1)
+if sha is None:  # summaries of earlier rounds carry no stamp: the figure cannot be tied to a source state
+    sha = "unstamped"
+json.dump(dict(src_sha16=sha, kernels=out), open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
