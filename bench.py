@@ -220,18 +220,21 @@ def synthetic_chunk(scene, dev, chunk_index, pixels=1 << 22):
                 depths=None, features=torch.rand(pixels, 64, device=dev, generator=g))
 
 
-def Trainer(model, scene, world, exchange="allreduce", global_depth_clip=False):
+def Trainer(model, scene, world, exchange="allreduce", global_depth_clip=False, **kw):
     """presight_amd.trainer.Trainer (the timed region) with the bench's setting: proposal networks receive gradients EVERY step
     (the upper bound of the reference's update schedule; its steady state is reported as `value_reference_schedule`)"""
     from presight_amd.trainer import Trainer as _Trainer
 
-    t = _Trainer(model, scene, world, exchange=exchange, global_depth_clip=global_depth_clip)
+    pipelined = world == 1 and os.environ.get("PRESIGHT_PIPELINE_ADAM", "0") == "1"
+    if pipelined:
+        kw.setdefault("fused_table_adam", False)  # (the pipelined optimizer step is the alternative to the fused table update)
+    t = _Trainer(model, scene, world, exchange=exchange, global_depth_clip=global_depth_clip, **kw)
     t.update_props_every_step = True
     # PRESIGHT_PIPELINE_ADAM=1 (single process): the fields' Adam on a second stream underneath the next step's proposal sampling
     # (presight_amd/trainer.py).  Measured and left OFF: on the production tile the sampling front is HBM-bound itself (512 MB of
     # proposal tables per net) and shares the memory system with the 26 GB Adam stream -- cfg 3 26.3 -> 27.2 ms at 65 536 rays,
     # 10.5 -> 10.2 ms at 8192; cfg 2 (0.15 ms of Adam) unchanged
-    t.pipeline_adam = world == 1 and os.environ.get("PRESIGHT_PIPELINE_ADAM", "0") == "1"
+    t.pipeline_adam = pipelined
     return t
 
 
@@ -463,13 +466,17 @@ def kernel_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def roofline_entries(kern, cfg, rays, n_params=0, live=()):
+def roofline_entries(kern, cfg, rays, n_params=0, live=(), fused_tables=None):
     """per-kernel roofline rows from the HIP-event regions of presight_amd.prof (mean ms per launch over the timed steps).
     Algorithmic work: MLP flops = 2 x MACs (backward = 2 x forward: dX + dW); hash bytes = one
-    F*4-byte row per corner, 8 corners per (point, level), gathered once forward, read + written once backward."""
+    F*4-byte row per corner, 8 corners per (point, level), gathered once forward, read + written once backward.
+    fused_tables = (main table entries, mean entries of one proposal net's tables) when the tables' Adam step runs inside their table
+    backward (Trainer.fused_table_adam): those launches also stream p, m, v in and out (24 bytes per entry) and the optimizer kernel
+    covers the remaining parameters only."""
     m = cfg["model"]
     L, F = m["num_levels"], m["features_per_level"]
     n_main, n_p0, n_p1 = rays * 64, rays * 128, rays * 64
+    ft_main, ft_prop = fused_tables if fused_tables else (0, 0)
     mac_main = (L * F) * 64 + 64 * 80 + 3 * 64 * 64 + (47 * 64 + 64 * 64 + 64 * 3)  # base + semantic head + colour head
     mac_prop = 8 * 64 + 64
     rows = []
@@ -515,8 +522,9 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=()):
     ex = lambda macs, k: 2 * k * macs * n_main  # noqa: E731
     add("main_fwd_kernel", "main_field_fwd", "mfma", 2 * mac_main * n_main, "TFLOP/s", ex(ex_base + ex_sem + ex_rgb, 1),
         extra_regions=("sem_out_fwd", "ray_colour_fwd", "merge_linear_fwd") if fact else ())
-    if n_params:  # dense Adam: p, m, v read + written, g read = 28 bytes per parameter
-        add("adam_ranges_kernel", "adam", "hbm", 28.0 * n_params, "GB/s")
+    n_adam = n_params - (ft_main + 2 * ft_prop)
+    if n_params and (not fused_tables or n_adam > 20e6):  # dense Adam: p, m, v read + written, g read = 28 bytes per parameter
+        add("adam_ranges_kernel" + (" (all parameters but the hash tables)" if fused_tables else ""), "adam", "hbm", 28.0 * n_adam, "GB/s")
     # the main backward is three kernels (semantic head, colour head, base MLP), timed one by one
     # (the merged layer's own rows of base layer 1 are priced with the semantic head in the factored split, as the kernels run them)
     add("main_bwd_sem_kernel", "main_bwd_sem_kernel", "mfma", 2 * 2 * mac_sem * n_main, "TFLOP/s", ex(ex_sem, 2),
@@ -531,8 +539,11 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=()):
     add("prop_fwd_kernel (both fields)", "prop_field_fwd", "mfma", 2 * mac_prop * (n_p0 + n_p1) / 2, "TFLOP/s", 2 * 512 * (n_p0 + n_p1) / 2)
     add(f"grid_encode main (L{L} F{F})", f"grid_encode_L{L}F{F}", "hbm", n_main * L * 8 * F * 4, "GB/s")
     add("grid_encode proposal (L8 F1, mean of both)", "grid_encode_L8F1", "hbm", (n_p0 + n_p1) / 2 * 8 * 8 * 4, "GB/s")
-    add(f"table backward main (absmax+bin+accumulate, L{L} F{F})", f"grid_scatter_L{L}F{F}", "hbm", 2 * n_main * L * 8 * F * 4, "GB/s")
-    add("table backward proposal (bin+accumulate, L8 F1, mean of both)", "grid_scatter_L8F1", "hbm", 2 * (n_p0 + n_p1) / 2 * 8 * 8 * 4, "GB/s")
+    tag = " + Adam of the table" if fused_tables else ""
+    add(f"table backward main (absmax+bin+accumulate{tag}, L{L} F{F})", f"grid_scatter_L{L}F{F}", "hbm",
+        2 * n_main * L * 8 * F * 4 + 24.0 * ft_main, "GB/s")
+    add(f"table backward proposal (bin+accumulate{tag}, L8 F1, mean of both)", "grid_scatter_L8F1", "hbm",
+        2 * (n_p0 + n_p1) / 2 * 8 * 8 * 4 + 24.0 * ft_prop, "GB/s")
     return rows
 
 
@@ -1046,7 +1057,12 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * rays * args.steps / dt
-        rows = roofline_entries(kern, cfg, rays, n_params=sum(p.numel() for p in trainer.grads.params), live=live)
+        fused_tables = None
+        if getattr(trainer, "fused_table_adam", False):
+            main_t = sum(p.numel() for f_ in model.field.fields for n_, p in f_.named_parameters() if n_.endswith("hash_table"))
+            prop_t = sum(p.numel() for net in model.proposal_networks for n_, p in net.named_parameters() if n_.endswith("hash_table"))
+            fused_tables = (main_t, prop_t / max(1, len(model.proposal_networks)))
+        rows = roofline_entries(kern, cfg, rays, n_params=sum(p.numel() for p in trainer.grads.params), live=live, fused_tables=fused_tables)
         # the dominant kernel: the single kernel with the longest average launch
         single = [r for r in rows if "summed" not in r["kernel"] and "mean of both" not in r["kernel"] and "absmax+bin" not in r["kernel"]]
         dom = max(single, key=lambda r: r["avg_launch_ms"]) if single else None

@@ -297,6 +297,30 @@ int ps_grid_scatter_binned_ms_part(const float* u, const float* dfeat, const flo
                                    int64_t plane_stride, float* const* dtables, int K, const int32_t* chunk_field,
                                    const uint32_t* slice_counts, int absmax_ready, void* workspace, int dst_is_zero, int phase,
                                    int item_begin, int item_end, void* stream);
+/* Table backward + Adam in ONE pass, for training that exchanges no gradients (a single process, or one tile per GPU:
+ * docs/building_priors.md:7-44).  The reference runs loss.backward() and then torch.optim.Adam over every table
+ * (ns/engine/trainer.py:470-486, ns/engine/optimizers.py:133-140): the table gradient is written, read back by the optimizer and zeroed
+ * at the next step.  A hash table receives exactly one gradient contribution per step, so here the accumulate pass applies the SAME
+ * element update as ps_adam_step_ranges (one shared device function: equal bits) to every slice it finishes and the gradient never
+ * reaches memory.  dtable / dtables[k] point INTO the flat gradient buffer grad_base and only locate the entries (element offset
+ * dtable - grad_base into param_base / exp_avg_base / exp_avg_sq_base, all of one layout); they must hold zeros and stay zero.
+ * Every slice of the items [item_begin, item_end) is updated, records or not (weight decay and moment decay reach every entry, as in
+ * torch).  phase / items as in ps_grid_scatter_binned_part.  step >= 1: the tables' torch-style step count for this update.
+ * Routed tile: group_of_field [K] (device int32, nullable) names the device-decided group of every sub-field (>= 0: group_flags /
+ * group_steps as in ps_adam_step_ranges -- a sub-field whose flag is down is left untouched; its step count is advanced by the
+ * ps_adam_step_ranges call that updates the group's other parameters, after this one in stream order); < 0: updated at `step`. */
+int ps_grid_scatter_binned_adam(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
+                                int64_t plane_stride, float* dtable, const uint32_t* slice_counts, int absmax_ready, void* workspace,
+                                int phase, int item_begin, int item_end, const float* grad_base, float* param_base,
+                                float* exp_avg_base, float* exp_avg_sq_base, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, float grad_scale, int step, void* stream);
+int ps_grid_scatter_binned_ms_adam(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t n_slots,
+                                   int64_t plane_stride, float* const* dtables, int K, const int32_t* chunk_field,
+                                   const uint32_t* slice_counts, int absmax_ready, void* workspace, int phase, int item_begin,
+                                   int item_end, const float* grad_base, float* param_base, float* exp_avg_base,
+                                   float* exp_avg_sq_base, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                   float grad_scale, int step, const int32_t* group_of_field, const int32_t* group_flags,
+                                   const int32_t* group_steps, void* stream);
 /* fused fields: packed = K packed parameter blocks back to back (ps_*_field_sizes packed_floats each); gpart receives
  * ps_*_field_parts_ms(n_slots, K) partial gradient blocks, reduced per sub-field by ps_mlp_unpack_table_ms */
 int ps_prop_field_parts_ms(int64_t n_slots, int K);

@@ -2,6 +2,7 @@
 // reference: ns/engine/optimizers.py:133-140, ns/configs/method_configs.py:158-168 — lr 1e-2, betas (0.9, 0.999),
 // eps 1e-15, L2 weight decay 1e-5 added to the gradient, no amsgrad).  One pass: 4 streams in (p, g, m, v), 3 out.
 #include "common.hpp"
+#include "adam_core.hpp"
 
 namespace {
 
@@ -9,28 +10,23 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gs) {
   const int64_t i0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
   if (i0 >= n) return;
+  const ps::AdamHyper h{lr, b1, b2, eps, wd, gs};
   if (i0 + 3 < n) {
     f32x4 P = *reinterpret_cast<f32x4*>(p + i0), G = *reinterpret_cast<const f32x4*>(g + i0);
     f32x4 M = *reinterpret_cast<f32x4*>(m + i0), V = *reinterpret_cast<f32x4*>(v + i0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gk = G[k] * gs + wd * P[k];
-      M[k] = b1 * M[k] + (1.0f - b1) * gk;
-      V[k] = b2 * V[k] + (1.0f - b2) * gk * gk;
-      const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
-      P[k] = P[k] - (lr / bc1) * (M[k] / denom);
+      float pk = P[k], mk = M[k], vk = V[k];
+      ps::adam_update(pk, G[k], mk, vk, h, bc1, bc2_sqrt);
+      P[k] = pk;
+      M[k] = mk;
+      V[k] = vk;
     }
     *reinterpret_cast<f32x4*>(p + i0) = P;
     *reinterpret_cast<f32x4*>(m + i0) = M;
     *reinterpret_cast<f32x4*>(v + i0) = V;
   } else {
-    for (int64_t i = i0; i < n; ++i) {
-      const float gk = g[i] * gs + wd * p[i];
-      m[i] = b1 * m[i] + (1.0f - b1) * gk;
-      v[i] = b2 * v[i] + (1.0f - b2) * gk * gk;
-      const float denom = sqrtf(v[i]) / bc2_sqrt + eps;
-      p[i] = p[i] - (lr / bc1) * (m[i] / denom);
-    }
+    for (int64_t i = i0; i < n; ++i) ps::adam_update(p[i], g[i], m[i], v[i], h, bc1, bc2_sqrt);
   }
 }
 
@@ -68,15 +64,13 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p,
     if (flags[grp] == 0) return;
     // two double-precision pow() per THREAD cost more than the block's 114 KB of traffic: one lane evaluates them
     __shared__ float s_bc[2];
-    if (threadIdx.x == 0) {
-      const double st = (double)(steps[grp] + 1);
-      s_bc[0] = (float)(1.0 - pow((double)b1, st));
-      s_bc[1] = (float)sqrt(1.0 - pow((double)b2, st));
-    }
+    if (threadIdx.x == 0)
+      ps::adam_bias_corrections(b1, b2, steps[grp] + 1, s_bc[0], s_bc[1]);
     __syncthreads();
     bc1 = s_bc[0];
     bc2_sqrt = s_bc[1];
   }
+  const ps::AdamHyper h{lr, b1, b2, eps, wd, gs};
   const int64_t first = (int64_t)(blockIdx.x - R.blk0[r]) * kRangeBlockElems;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -93,23 +87,17 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p,
       f32x4 M = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mm)), V = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vv));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float gk = G[k] * gs + wd * P[k];
-        M[k] = b1 * M[k] + (1.0f - b1) * gk;
-        V[k] = b2 * V[k] + (1.0f - b2) * gk * gk;
-        const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
-        P[k] = P[k] - (lr / bc1) * (M[k] / denom);
-      }
+      float pk = P[k], mk = M[k], vk = V[k];
+      ps::adam_update(pk, G[k], mk, vk, h, bc1, bc2_sqrt);
+      P[k] = pk;
+      M[k] = mk;
+      V[k] = vk;
+    }
       __builtin_nontemporal_store(P, reinterpret_cast<f32x4*>(pp));
       __builtin_nontemporal_store(M, reinterpret_cast<f32x4*>(mm));
       __builtin_nontemporal_store(V, reinterpret_cast<f32x4*>(vv));
     } else {
-      for (int64_t i = 0; i0 + i < n; ++i) {
-        const float gk = gg[i] * gs + wd * pp[i];
-        mm[i] = b1 * mm[i] + (1.0f - b1) * gk;
-        vv[i] = b2 * vv[i] + (1.0f - b2) * gk * gk;
-        const float denom = sqrtf(vv[i]) / bc2_sqrt + eps;
-        pp[i] = pp[i] - (lr / bc1) * (mm[i] / denom);
-      }
+      for (int64_t i = 0; i0 + i < n; ++i) ps::adam_update(pp[i], gg[i], mm[i], vv[i], h, bc1, bc2_sqrt);
     }
   }
 }

@@ -19,6 +19,7 @@
 // Reference semantics: ns/cameras/rays.py:49-58, ns/fields/PreSight/ingp_field.py:169-177,
 // ns/field_components/encodings.py:343-384 (forward) and its autograd (index_put_ scatter-add).
 #include "common.hpp"
+#include "adam_core.hpp"
 #include "encode_core.hpp"
 #include "hashgrid_core.hpp"
 #include "ms_core.hpp"
@@ -739,6 +740,21 @@ __global__ __launch_bounds__(1024) void stream_offsets_kernel(unsigned* __restri
     }
 }
 
+// Adam applied in the accumulate kernel's flush (ps_grid_scatter_binned_adam): single-process training exchanges no gradients, and a
+// hash table receives exactly one gradient contribution per step, so the finished gradient of a slice never has to leave the chip --
+// the flush reads the slice's parameters and moments, applies ps::adam_update (the optimizer kernels' own function: same bits) and
+// writes them back.  Per parameter and step that removes the gradient's store, its load by the optimizer kernel and next step's
+// zero fill: 12 of the 40 bytes a table entry moves per step (a production tile: 940 M entries).  g_base == null: not fused.
+struct AdamFuse {
+  const float* g_base;  // the flat gradient buffer the destination pointers point into: element offset = out - g_base
+  float *p_base, *m_base, *v_base;  // flat parameters / first / second moments, same layout
+  ps::AdamHyper h;
+  float bc1, bc2_sqrt;            // bias corrections at the host-side step count (tables without a device-decided group)
+  const int* group_of_field;      // [K] device-decided group of every sub-field (routed tiles; < 0 / null: host-decided), see adam.hip
+  const int* flags;
+  const int* steps;
+};
+
 template <int F>
 __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __restrict__ cursors, const unsigned* __restrict__ starts,
                                                           const unsigned* __restrict__ rec_idx,
@@ -746,7 +762,8 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
                                                           int L, int log2T, int log2_slice, int64_t n_rec_max, int headroom_log2,
                                                           int accumulate, float* __restrict__ dtable, float* const* __restrict__ dtables,
                                                           float out_scale /* the gradient is multiplied by this (1: exactly the plain result) */,
-                                                          int item0 /* first item of this launch (the items may be dealt to several launches) */) {
+                                                          int item0 /* first item of this launch (the items may be dealt to several launches) */,
+                                                          AdamFuse A) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F]
   const int entries = 1 << log2_slice;
   const int n_slices = 1 << (log2T - log2_slice);
@@ -755,7 +772,20 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   const int level = vlevel % L;
   const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
   const int64_t n = cursors[item] - base;  // the write pass advanced the cursor from the stream start to its end
-  if (n == 0 && accumulate) return;  // nothing to add (a sub-field without points: most slices of a multi-sub-field launch)
+  const bool fused = A.g_base != nullptr;
+  if (n == 0 && accumulate && !fused) return;  // nothing to add (a sub-field without points: most slices of a multi-sub-field launch)
+  float bc1 = A.bc1, bc2_sqrt = A.bc2_sqrt;
+  if (fused && A.group_of_field != nullptr) {
+    const int grp = A.group_of_field[vlevel / L];
+    if (grp >= 0) {  // workgroup-uniform.  A sub-field that received no samples is not updated at all (adam.hip: torch with grad None)
+      if (A.flags[grp] == 0) return;
+      __shared__ float s_bc[2];
+      if (threadIdx.x == 0) ps::adam_bias_corrections(A.h.b1, A.h.b2, A.steps[grp] + 1, s_bc[0], s_bc[1]);
+      __syncthreads();
+      bc1 = s_bc[0];
+      bc2_sqrt = s_bc[1];
+    }
+  }
   if (dtables != nullptr) dtable = dtables[vlevel / L];
   const unsigned gbits = gmax_bits[vlevel];
   float* out = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
@@ -792,7 +822,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   // (production shape: ~4 k records per slice, the kernel is a chain of latencies: 3.2 ms for 41 k workgroups)
   const int64_t first_i0 = (int64_t)threadIdx.x * kChunk;
   if (first_i0 < n) load_batch(first_i0);
-  const bool dense = !(accumulate && n * 4 < entries);
+  const bool dense = fused || !(accumulate && n * 4 < entries);  // (fused: every entry of the slice is updated, gradient or not)
   constexpr int kOutPerThread = kAccBytes / 8 / 1024;  // 16 values of the slice per thread
   float prev[kOutPerThread];
 #pragma unroll
@@ -802,13 +832,14 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   }
   for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
   __syncthreads();
-  if (gbits >= 0x7f800000u) {  // a non-finite d(feature) on this level: the gradient is NaN, like torch's index_add of a NaN
+  const bool nan_level = gbits >= 0x7f800000u;  // a non-finite d(feature) on this level: the gradient is NaN, like torch's index_add of a NaN
+  if (nan_level && !fused) {
     for (int i = threadIdx.x; i < entries * F; i += 1024) out[i] = __builtin_nanf("");
     return;
   }
   const float scale = fixed_scale(gbits, headroom_log2);
   const unsigned low = (unsigned)entries - 1u;
-  for (int64_t i0 = first_i0; i0 < n; i0 += 1024 * kChunk) {
+  for (int64_t i0 = first_i0; i0 < n && !nan_level; i0 += 1024 * kChunk) {
     if (i0 != first_i0) load_batch(i0);
     unsigned p_row = 0xffffffffu, p_rowc = 0xffffffffu;
     long long p_f[F], p_c[F];
@@ -872,6 +903,33 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
     }
     return;
   }
+  if (fused) {
+    // the slice's Adam step: parameters and both moments in (requested together: one round trip), updated, out; the gradient itself
+    // is never written (its buffer keeps the zeros the step started with)
+    const int64_t off = out - A.g_base;
+    float *pp = A.p_base + off, *mm = A.m_base + off, *vv = A.v_base + off;
+    float P[kOutPerThread], M[kOutPerThread], V[kOutPerThread];
+#pragma unroll
+    for (int k = 0; k < kOutPerThread; ++k) {
+      const int i = threadIdx.x + k * 1024;
+      const bool ok = i < entries * F;
+      P[k] = ok ? __builtin_nontemporal_load(pp + i) : 0.0f;
+      M[k] = ok ? __builtin_nontemporal_load(mm + i) : 0.0f;
+      V[k] = ok ? __builtin_nontemporal_load(vv + i) : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kOutPerThread; ++k) {
+      const int i = threadIdx.x + k * 1024;
+      if (i < entries * F) {
+        const float val = nan_level ? __builtin_nanf("") : (float)((double)acc[i] * (double)inv * (double)out_scale);
+        ps::adam_update(P[k], val, M[k], V[k], A.h, bc1, bc2_sqrt);
+        __builtin_nontemporal_store(P[k], pp + i);
+        __builtin_nontemporal_store(M[k], mm + i);
+        __builtin_nontemporal_store(V[k], vv + i);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < kOutPerThread; ++k) {
     const int i = threadIdx.x + k * 1024;
@@ -911,7 +969,8 @@ int64_t binned_workspace(int L, int F, int log2T, int64_t N, int K, int D = 3) {
 int scatter_binned_impl(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                         int64_t plane_stride, float* dtable, float* const* dtables, int K, const int* chunk_field, int accumulate,
                         const uint32_t* slice_counts, int absmax_ready, void* workspace, hipStream_t s, int D = 3, int64_t period = 0,
-                        float out_scale = 1.0f, const float* dfeat_b = nullptr, int phase = 3, int item_begin = 0, int item_end = -1) {
+                        float out_scale = 1.0f, const float* dfeat_b = nullptr, int phase = 3, int item_begin = 0, int item_end = -1,
+                        const AdamFuse* adam = nullptr) {
   // phase bit 0: prepare (counts, stream offsets, record write pass); bit 1: accumulate the items [item_begin, item_end) (item_end < 0:
   // all).  A caller that exchanges the gradient in pieces launches the accumulate pass once per piece (items are ordered
   // (sub-field, level, slice) = the order of the gradient in memory) and hands every piece over as soon as its launch is enqueued.
@@ -920,6 +979,9 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
   PS_REQUIRE(period == 0 || (period > 0 && N <= 3 * period), "ps_grid_scatter_binned: at most three position sets");
   PS_REQUIRE(N * L * (D == 4 ? 16 : 8) + 4096 + 4 * (int64_t)K * L * 256 < ((int64_t)1 << 32), "ps_grid_scatter_binned: too many contributions for 32-bit stream offsets");
   PS_REQUIRE(K * L <= 1024, "ps_grid_scatter_binned: at most 1024 (sub-field, level) pairs");
+  PS_REQUIRE(adam == nullptr || (accumulate == 2 && D == 3 && out_scale == 1.0f),
+             "ps_grid_scatter_binned_adam: the fused update needs a zeroed destination it is the only contribution to");
+  const AdamFuse fuse = adam != nullptr ? *adam : AdamFuse{nullptr, nullptr, nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 1.f, 1.f, nullptr, nullptr, nullptr};
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
   PS_REQUIRE(n_slices <= kMaxSlices, "ps_grid_scatter_binned: too many slices");
@@ -976,7 +1038,7 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
     }                                                                                                                     \
     if ((phase & 2) && item_end > item_begin)                                                                             \
       accumulate_kernel<FF><<<(unsigned)(item_end - item_begin), 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
-                                                                                 n_rec_max, headroom, accumulate, dtable, dtables, out_scale, item_begin); \
+                                                                                 n_rec_max, headroom, accumulate, dtable, dtables, out_scale, item_begin, fuse); \
   }
   if (D == 3) {
     if (F == 1) PS_LAUNCH_BINNED(1)
@@ -1036,6 +1098,57 @@ extern "C" int ps_grid_scatter_binned_ms_part(const float* u, const float* dfeat
   PS_REQUIRE(n_slots % ps::kMsChunk == 0, "ps_grid_scatter_binned_ms_part: the sorted layout is a whole number of chunks");
   return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, n_slots, plane_stride, nullptr, dtables, K, chunk_field, /*accumulate=*/dst_is_zero ? 2 : 1,
                              slice_counts, absmax_ready, workspace, (hipStream_t)stream, 3, 0, 1.0f, nullptr, phase, item_begin, item_end);
+}
+
+// ---- table backward + Adam in one pass (AdamFuse above).  dtable / dtables[*] point into the flat gradient buffer grad_base (they
+// locate the parameters: element offset = dtable - grad_base into param_base / exp_avg_base / exp_avg_sq_base, all of one layout) and
+// must hold zeros; nothing is written there.  Every slice of the items [item_begin, item_end) is updated, records or not.  One table
+// (K = 1): at the host-side step count `step` >= 1.  Routed tile: sub-field k belongs to the device-decided group group_of_field[k]
+// (>= 0; flags / steps as in ps_adam_step_ranges: a sub-field whose flag is down is left untouched, the step counts are advanced by
+// the optimizer call that updates the group's other parameters) or, < 0, is updated at `step`.
+namespace {
+int make_fuse(AdamFuse& A, const float* grad_base, float* param_base, float* exp_avg_base, float* exp_avg_sq_base, float lr, float beta1,
+              float beta2, float eps, float weight_decay, float grad_scale, int step, const int32_t* group_of_field,
+              const int32_t* group_flags, const int32_t* group_steps) {
+  PS_REQUIRE(grad_base && param_base && exp_avg_base && exp_avg_sq_base, "ps_grid_scatter_binned_adam: null flat buffer");
+  PS_REQUIRE(step >= 1 || group_of_field != nullptr, "ps_grid_scatter_binned_adam: step counts from 1");
+  PS_REQUIRE(group_of_field == nullptr || (group_flags != nullptr && group_steps != nullptr), "ps_grid_scatter_binned_adam: groups need flags and steps");
+  const double st = step >= 1 ? (double)step : 1.0;
+  A = AdamFuse{grad_base, param_base, exp_avg_base, exp_avg_sq_base, {lr, beta1, beta2, eps, weight_decay, grad_scale},
+               (float)(1.0 - pow((double)beta1, st)), (float)sqrt(1.0 - pow((double)beta2, st)), group_of_field, group_flags, group_steps};
+  return 0;
+}
+}  // namespace
+
+extern "C" int ps_grid_scatter_binned_adam(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
+                                           int64_t plane_stride, float* dtable, const uint32_t* slice_counts, int absmax_ready,
+                                           void* workspace, int phase, int item_begin, int item_end, const float* grad_base,
+                                           float* param_base, float* exp_avg_base, float* exp_avg_sq_base, float lr, float beta1, float beta2,
+                                           float eps, float weight_decay, float grad_scale, int step, void* stream) {
+  AdamFuse A;
+  if (int rc = make_fuse(A, grad_base, param_base, exp_avg_base, exp_avg_sq_base, lr, beta1, beta2, eps, weight_decay, grad_scale, step,
+                         nullptr, nullptr, nullptr))
+    return rc;
+  PS_REQUIRE(dtable != nullptr && dtable >= grad_base, "ps_grid_scatter_binned_adam: the destination must lie in the flat gradient buffer");
+  return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, N, plane_stride, dtable, nullptr, 1, nullptr, /*accumulate=*/2, slice_counts,
+                             absmax_ready, workspace, (hipStream_t)stream, 3, 0, 1.0f, nullptr, phase, item_begin, item_end, &A);
+}
+
+extern "C" int ps_grid_scatter_binned_ms_adam(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T,
+                                              int64_t n_slots, int64_t plane_stride, float* const* dtables, int K,
+                                              const int32_t* chunk_field, const uint32_t* slice_counts, int absmax_ready, void* workspace,
+                                              int phase, int item_begin, int item_end, const float* grad_base, float* param_base,
+                                              float* exp_avg_base, float* exp_avg_sq_base, float lr, float beta1, float beta2, float eps,
+                                              float weight_decay, float grad_scale, int step, const int32_t* group_of_field,
+                                              const int32_t* group_flags, const int32_t* group_steps, void* stream) {
+  PS_REQUIRE(dtables != nullptr && chunk_field != nullptr && K >= 1, "ps_grid_scatter_binned_ms_adam: need the gradient pointers and the chunk map");
+  PS_REQUIRE(n_slots % ps::kMsChunk == 0, "ps_grid_scatter_binned_ms_adam: the sorted layout is a whole number of chunks");
+  AdamFuse A;
+  if (int rc = make_fuse(A, grad_base, param_base, exp_avg_base, exp_avg_sq_base, lr, beta1, beta2, eps, weight_decay, grad_scale, step,
+                         group_of_field, group_flags, group_steps))
+    return rc;
+  return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, n_slots, plane_stride, nullptr, dtables, K, chunk_field, /*accumulate=*/2,
+                             slice_counts, absmax_ready, workspace, (hipStream_t)stream, 3, 0, 1.0f, nullptr, phase, item_begin, item_end, &A);
 }
 
 // ---- 4-D grid of the dynamic field (csrc/dynamic.hip; BASELINE cfg 4): same record streams and accumulate kernel, 8 x-pairs

@@ -240,6 +240,7 @@ class FlatGrads:
             self.group_flags.zero_()
         for p in self.params:
             p._ps_touched = False
+            p._ps_fused_done = False  # (HipAdam.enable_fused_tables: "updated inside the table backward this step")
         for b in self._buckets:
             b["seen"], b["launched"], b["work"], b["ready"], b["ready_t"], b["phase"], b["skipped"] = 0, False, None, None, None, None, False
         self._next_launch = 0
@@ -258,7 +259,9 @@ class FlatGrads:
         records their ranges as the only part of the buffer the next zero_() has to clear"""
         flags = self.touched(group)
         idx = [i for i, t in enumerate(flags) if t]
-        self._dirty = _merge([(self.offsets[i], self.offsets[i] + self._pad(self.params[i].numel())) for i in idx])
+        # (a table whose Adam update ran inside its backward never had its gradient written: its range still holds zeros)
+        self._dirty = _merge([(self.offsets[i], self.offsets[i] + self._pad(self.params[i].numel())) for i in idx
+                              if not getattr(self.params[i], "_ps_fused_done", False)])
         return idx
 
     def touched_ranges(self, group: Optional[dist.ProcessGroup] = None) -> List[tuple]:

@@ -125,6 +125,22 @@ def _sink_is_zero(param: Optional[Tensor]) -> bool:
     return param is not None and getattr(param, "_ps_touched", True) is False
 
 
+def _refuse_second_contribution(tables: Sequence[Optional[Tensor]]) -> None:
+    for t in tables:
+        if t is not None and getattr(t, "_ps_fused_done", False):
+            raise RuntimeError("presight_amd: a hash table whose Adam update is fused into its backward received a second gradient "
+                               "contribution in one step (HipAdam.enable_fused_tables needs exactly one; PRESIGHT_FUSED_TABLE_ADAM=0)")
+
+
+def _fused_adam(tables: Sequence[Optional[Tensor]], routed: bool):
+    """the Adam arguments for a table backward that also applies the optimizer step (HipAdam.enable_fused_tables), or None: every
+    table must be owned by the same optimizer and its gradient sink must still hold the zeros the step started with"""
+    opt = getattr(tables[0], "_ps_fused_adam", None) if tables and tables[0] is not None else None
+    if opt is None or any(t is None or getattr(t, "_ps_fused_adam", None) is not opt or not _sink_is_zero(t) for t in tables):
+        return None
+    return opt.fused_table_args(list(tables), routed)
+
+
 def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape, sink: Optional[Tensor] = None,
              counts: Optional[Tensor] = None, ws_with_absmax: Optional[Tensor] = None, sink_owner: Optional[Tensor] = None) -> Optional[Tensor]:
     """table gradient; with `sink` (the parameter's pre-allocated .grad, ops.grad_sink) it is ADDED there and None is returned.
@@ -136,8 +152,16 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
     dtable = sink if sink is not None else torch.empty(table_shape, device=u.device, dtype=torch.float32)
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
     pieces = getattr(sink_owner, "_ps_parts", 1) if (sink is not None and sink_owner is not None) else 1
+    _refuse_second_contribution([sink_owner])
+    fused = _fused_adam([sink_owner], routed=False) if (acc == 2 and pieces == 1) else None
     with prof.region(f"grid_scatter_L{L}F{F}"):
-        if _binned(N, L) and pieces > 1:
+        if fused is not None:
+            # single-process training: the accumulate pass applies the table's Adam step itself, the gradient is never written
+            ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
+            check(lib().ps_grid_scatter_binned_adam(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), _p(counts),
+                                                    int(ws_with_absmax is not None), _p(ws), 3, 0, -1, *fused, _stream()),
+                  "ps_grid_scatter_binned_adam")
+        elif _binned(N, L) and pieces > 1:
             # the gradient is exchanged in `pieces` level groups (presight_amd.dist.FlatGrads splits): one accumulate launch per group,
             # every group handed to the exchange as soon as its launch is enqueued -- its reduce-scatter runs under the next launches
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
@@ -990,7 +1014,16 @@ def _ms_scatter(lay: MsLayout, u, dfeat, scalings, g: GridCfg, tables: Sequence[
     L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
     K = lay.K
     groups = getattr(tables[0], "_ps_ms_parts", 1) if mark else 1
+    _refuse_second_contribution(tables)
+    fused = _fused_adam(list(tables), routed=True) if (zero_dst and groups == 1 and all(s is not None for s in sinks)) else None
     with prof.region(f"grid_scatter_L{L}F{F}"):
+        if fused is not None:
+            check(lib().ps_grid_scatter_binned_ms_adam(_p(u), _p(dfeat), _p(scalings), L, F, l2t, lay.n_slots, lay.n_slots * F,
+                                                       _p(_ptr_table(dst)), K, lay.chunk_field, _p(counts), int(absmax_ready), _p(ws), 3, 0, -1,
+                                                       *fused, _stream()), "ps_grid_scatter_binned_ms_adam")
+            if mark:
+                mark_touched(direct_params(*tables), groups_on_device=True)
+            return fresh
         if groups > 1 and K % groups == 0:
             per_field = lib().ps_grid_scatter_items(L, F, l2t, 1)
             args = (_p(u), _p(dfeat), _p(scalings), L, F, l2t, lay.n_slots, lay.n_slots * F, _p(_ptr_table(dst)), K, lay.chunk_field, _p(counts),
@@ -1062,11 +1095,11 @@ class _PropFieldMS(torch.autograd.Function):
             check(lib().ps_prop_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
                                              _p(st.packed), _p(_f32(dsigma)), lay.n_slots, _p(dfeat), _p(st.gpart), _p(ws), _p(lay.perm),
                                              lay.field_start, K, _stream()), "ps_prop_field_bwd_ms")
+        mark_groups(lay, tables)  # (before the table backward: with the tables' Adam step fused into it, it reads the flags)
         dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=True)
         dsts, returned = _ms_layer_dsts(wb)
         st.unpack(dsts, lay.field_start, nparts // 4, 4)
         mark_touched(ctx.direct, groups_on_device=True)
-        mark_groups(lay, tables)
         return (None, None, None, None, None, *dtables, *returned)
 
 
@@ -1278,8 +1311,8 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
     # the MLP gradients are complete: their bucket may leave while the table backward runs; the tables follow (group by group)
     mark_touched(direct_params(*wb), groups_on_device=True)
     ws = _ms_scatter_ws(lay, g, u.device)
+    mark_groups(lay, tables)  # (before the table backward: with the tables' Adam step fused into it, it reads the flags)
     dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False, mark=True)
-    mark_groups(lay, tables)
     return dapp, dtables, returned
 
 

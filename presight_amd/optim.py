@@ -29,6 +29,7 @@ class HipAdam:
                 raise RuntimeError("HipAdam: parameters must be contiguous fp32 CUDA tensors")
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.grad_scale = float(grad_scale)
+        self.fused_armed = False  # enable_fused_tables: only a backward pass the trainer has armed applies the tables' update
         self.step_count = 0  # optimizer steps taken (informational; the bias corrections use the per-parameter counts)
         self.steps: List[int] = [0] * len(self.params)  # torch's state[p]["step"]
         self.flat = None
@@ -53,6 +54,63 @@ class HipAdam:
             self.exp_avg = [torch.zeros_like(p) for p in self.params]
             self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
 
+    # ------------------------------------------------------------------ Adam inside the table backward (single-process training)
+    def enable_fused_tables(self, indices: Sequence[int]) -> None:
+        """The hash tables self.params[i], i in indices, are updated INSIDE their table backward (ps_grid_scatter_binned_adam: the
+        accumulate pass applies this optimizer's element update to every slice it finishes, the gradient never reaches memory) instead
+        of by step().  Valid when nobody needs the gradient itself: no exchange (one process / one tile per GPU), no found-inf check
+        (update_grad_scaler=False), and one gradient contribution per table and step (a second one raises).  Same bits as step():
+        both run csrc/adam_core.hpp::adam_update on the same fp32 gradient."""
+        if self.flat is None:
+            raise RuntimeError("HipAdam.enable_fused_tables: needs the flat buffers (flat_grads=...)")
+        for i in indices:
+            p = self.params[i]
+            p._ps_fused_adam, p._ps_fused_index, p._ps_fused_done = self, i, False
+
+    def disable_fused_tables(self) -> None:
+        for p in self.params:
+            if getattr(p, "_ps_fused_adam", None) is self:
+                p._ps_fused_adam = None
+
+    def fused_table_args(self, tables: Sequence[torch.nn.Parameter], routed: bool):
+        """Called by the table backward (field_ops._scatter / _ms_scatter) right before its launch: -> the Adam arguments of
+        ps_grid_scatter_binned_adam (routed: of ps_grid_scatter_binned_ms_adam) for THIS step's update of `tables`, or None when it has
+        to go through step() after all.  Advances the host-side step counts and marks the tables as updated: step() skips them and
+        FlatGrads.zero_ leaves their (still zero) gradient ranges alone."""
+        if not self.fused_armed:
+            return None  # a backward pass outside Trainer.step (gradient inspection, tests): plain gradients, step() does the update
+        fg = self.flat_grads
+        for t in tables:
+            if getattr(t, "_ps_fused_done", False):
+                raise RuntimeError("presight_amd: a hash table whose Adam update is fused into its backward received a second gradient "
+                                   "contribution in one step (HipAdam.enable_fused_tables needs exactly one)")
+        gids = [getattr(t, "_ps_group", None) if fg.n_groups else None for t in tables]
+        if not routed and gids[0] is not None:
+            return None  # a routed sub-field called on its own: whether it counts as updated is the device's decision
+        idx = [t._ps_fused_index for t in tables]
+        host = [i for i, g_ in zip(idx, gids) if g_ is None]
+        if host and len({self.steps[i] for i in host}) != 1:
+            return None
+        step = self.steps[host[0]] + 1 if host else 0
+        for i in host:
+            self.steps[i] += 1
+        for t in tables:
+            t._ps_fused_done = True
+        fp, fgr, fm, fv = self.flat
+        args = (_p(fgr), _p(fp), _p(fm), _p(fv), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.grad_scale, step)
+        if not routed:
+            return args
+        if all(g_ is None for g_ in gids):
+            return args + (None, None, None)
+        key = tuple(-1 if g_ is None else g_ for g_ in gids)
+        tbl = self._fused_gid_tables.get(key) if hasattr(self, "_fused_gid_tables") else None
+        if tbl is None:
+            if not hasattr(self, "_fused_gid_tables"):
+                self._fused_gid_tables = {}
+            tbl = torch.tensor(key, dtype=torch.int32, device=fp.device)
+            self._fused_gid_tables[key] = tbl
+        return args + (_p(tbl), _p(fg.group_flags), _p(fg.group_steps))
+
     @torch.no_grad()
     def step(self, skip=(), subset=None):
         """skip: indices of parameters whose update is withheld this step although they received a gradient (GradScaler.step
@@ -69,7 +127,8 @@ class HipAdam:
         if self.flat is not None:
             fg = self.flat_grads
             fg._join_side_streams()
-            idx = [i for i in fg.touched_params() if i not in skip and (subset is None or i in subset)]
+            idx = [i for i in fg.touched_params() if i not in skip and (subset is None or i in subset)
+                   and not getattr(self.params[i], "_ps_fused_done", False)]  # (updated inside their table backward already)
             if skip and fg.n_groups:  # device-decided groups of withheld parameters: lower their flags
                 for g_ in {getattr(self.params[i], "_ps_group", None) for i in skip} - {None}:
                     fg.group_flags[g_] = 0

@@ -53,7 +53,8 @@ class Trainer:
 
     def __init__(self, model, scene: Dict, world: int = 1, exchange: str = "allreduce", global_depth_clip: bool = False,
                  lr: float = 1e-2, eps: float = 1e-15, weight_decay: float = 1e-5, loss_scale: float = 2.0 ** 10,
-                 update_grad_scaler: bool = False, max_num_iterations: Optional[int] = None, schedule: Optional[Dict] = None):
+                 update_grad_scaler: bool = False, max_num_iterations: Optional[int] = None, schedule: Optional[Dict] = None,
+                 fused_table_adam: Optional[bool] = None):
         """loss_scale = TrainerConfig.init_grad_scale, update_grad_scaler = TrainerConfig.update_grad_scaler (trainer.py:70-73).
         max_num_iterations: builds the learning-rate schedule of the PreSight method configs (method_configs.py:158-168: warm-up over
         max // 10 steps, x0.33 at max // 4, max // 2, 3 max // 4); `schedule` = explicit WarmupMultiStepSchedule keyword arguments;
@@ -167,6 +168,18 @@ class Trainer:
         if schedule is None and max_num_iterations is not None:
             schedule = dict(max_steps=max_num_iterations, warmup_steps=max_num_iterations // 10,
                             milestones=[max_num_iterations // 4, max_num_iterations // 2, max_num_iterations * 3 // 4])
+        # Single-process training (world == 1: also one tile per GPU, docs/building_priors.md:7-44) exchanges no gradients, so the hash
+        # tables' Adam step runs INSIDE their table backward (HipAdam.enable_fused_tables / ps_grid_scatter_binned_adam): the gradient of
+        # a table is never written, read back or zeroed -- 12 of the 40 bytes a table entry moves per step, 940 M entries on a production
+        # tile.  Same bits as the separate step (one shared element update).  Off: PRESIGHT_FUSED_TABLE_ADAM=0, any exchange, the
+        # found-inf check of update_grad_scaler (it needs the gradients).  The dual field's static and proposal tables qualify (one
+        # evaluation per step); its 4-D table (three position sets, its own scatter entry point) keeps the separate update.
+        can_fuse = world == 1 and not overlap and not self.update_grad_scaler
+        if fused_table_adam and not can_fuse:
+            raise ValueError("Trainer(fused_table_adam=True) needs world == 1, no exchange overlap and update_grad_scaler=False")
+        self.fused_table_adam = can_fuse and (os.environ.get("PRESIGHT_FUSED_TABLE_ADAM", "1") != "0" if fused_table_adam is None else bool(fused_table_adam))
+        if self.fused_table_adam:
+            self.opt.enable_fused_tables([i for i, p in enumerate(uniq) if is_table(p)])
         self.scheduler = WarmupMultiStepSchedule(self.opt, lr_init=lr, **schedule) if schedule is not None else None
         self.callbacks = model.get_training_callbacks(TrainingCallbackAttributes(optimizers=self.opt, grad_scaler=None, pipeline=None))
         self.step_idx = 0
@@ -245,7 +258,8 @@ class Trainer:
 
     def _begin_step(self):
         """clear the gradients of the previous step; -> the pipeline state when this step's optimizer runs pipelined"""
-        pipe = self._pipe_state() if (self.pipeline_adam and self.world == 1 and not self.update_grad_scaler and torch.cuda.is_available()) else None
+        pipe = self._pipe_state() if (self.pipeline_adam and self.world == 1 and not self.update_grad_scaler and not self.fused_table_adam
+                                      and torch.cuda.is_available()) else None
         if pipe is None:
             self.join()
         # (pipelined: the fields' gradients were cleared on the pipeline stream right behind their Adam update)
@@ -327,6 +341,7 @@ class Trainer:
             ps = m.proposal_sampler
             if not (ps._steps_since_update > ps.update_sched(ps._step) or ps._step < 10):
                 self.grads.skip_buckets(self._prop_buckets)
+        self.opt.fused_armed = self.fused_table_adam  # table backward nodes of THIS backward pass apply their tables' Adam step
         out = m(rb, jitters=list(batch["jitter"])) if "jitter" in batch else m(rb)  # stored draws: parity runs only
         loss_dict = m.get_loss_dict(out, batch)
         # one concat + one reduction instead of a chain of scalar adds; the loss scale enters as the seed of the backward pass
@@ -335,6 +350,7 @@ class Trainer:
             self._seed = torch.full((), self.loss_scale, device=loss.device)
             self._seed_value = self.loss_scale
         loss.backward(gradient=self._seed)
+        self.opt.fused_armed = False
         ops.join_side_streams()  # the proposal networks' backward ran on their side stream: the exchange / optimizer wait for it
         with prof.region("exchange_exposed"):
             self.grads.finish_exchange()

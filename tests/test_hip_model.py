@@ -352,7 +352,7 @@ def test_proposal_side_stream_changes_nothing_but_the_schedule():
             batch = bench.make_batches(scene, dev, 1, 0, rays=2048)[0]
             torch.manual_seed(3)
             if flat:
-                tr = Trainer(model, scene, 1, exchange="allreduce")
+                tr = Trainer(model, scene, 1, exchange="allreduce", fused_table_adam=False)  # (this test reads the table gradients)
                 ld, _ = tr.step(batch)
                 torch.cuda.synchronize()
                 # (the trainer's bucket order, hence the layout of its flat buffers, follows the stream setting: compare by name;

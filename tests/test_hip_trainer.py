@@ -178,3 +178,40 @@ def test_checkpoint_resume_continues_the_run(gold_model_traj):
     fb = {k: model_b.state_dict()[k].detach().cpu() for k in P}
     err = traj_param_error(fb, fa, P)
     assert max(err.values()) < 1e-4 and traj_param_max_diff(fb, fa) <= 4 * float(G["lr"].max()), sorted(err.items(), key=lambda kv: -kv[1])[:3]
+
+
+def test_fused_table_adam_equals_the_separate_optimizer_step(gold_model_traj):
+    """Single-process training applies the hash tables' Adam step inside their table backward (ps_grid_scatter_binned_adam /
+    ps_grid_scatter_binned_ms_adam: the gradient is never written) -- the default of Trainer(world=1).  It must be the SAME update as
+    backward -> optimizer.step() (ns/engine/trainer.py:470-486): the first iteration from equal parameters leaves bit-equal tables and
+    moments (the table gradient is integer-accumulated = deterministic, and both paths run one shared element update); over the 24
+    reference iterations (K = 3 routed tile, off-schedule proposal steps, a sub-field without samples: device-decided skips) the step
+    counts agree exactly and the parameters stay within the run-to-run noise of the loop (the MLP gradients use float atomics)."""
+    from presight_amd.trainer import Trainer
+
+    G = gold_model_traj
+    dev = torch.device("cuda:0")
+    cfg, scene, P, batches = model_traj_setup(G)
+    M, N = int(G["max_iterations"]), int(G["n_steps"])
+    runs = []
+    for fused in (True, False):
+        model = build_hip_model(cfg, scene, P, dev, proposal_weights_anneal_max_num_iters=M // 10, proposal_warmup=M // 10)
+        tr = Trainer(model, _scene_dev(scene, dev), loss_scale=float(G["loss_scale"]), max_num_iterations=M, fused_table_adam=fused)
+        assert tr.fused_table_adam == fused
+        runs.append((model, tr))
+    (ma, ta), (mb, tb) = runs
+    tables = [i for i, p in enumerate(ta.opt.params) if getattr(p, "_ps_fused_adam", None) is ta.opt]
+    assert len(tables) == 9  # 3 sub-fields x (main table + 2 proposal tables)
+    for s in range(N):
+        ta.step(_dev_batch(batches[s], dev))
+        tb.step(_dev_batch(batches[s], dev))
+        if s == 0:
+            for i in tables:
+                assert torch.equal(ta.opt.params[i], tb.opt.params[i]), i
+                assert torch.equal(ta.opt.exp_avg[i], tb.opt.exp_avg[i]) and torch.equal(ta.opt.exp_avg_sq[i], tb.opt.exp_avg_sq[i]), i
+                assert float(ta.opt.params[i].grad.abs().max()) == 0.0  # the fused path never writes the gradient
+        assert ta.opt.param_steps() == tb.opt.param_steps(), s
+    fa = {k: ma.state_dict()[k].detach().cpu() for k in P}
+    fb = {k: mb.state_dict()[k].detach().cpu() for k in P}
+    err = traj_param_error(fa, fb, P)
+    assert max(err.values()) < 1e-4 and traj_param_max_diff(fa, fb) <= 4 * float(G["lr"].max()), sorted(err.items(), key=lambda kv: -kv[1])[:3]

@@ -20,22 +20,17 @@ def main():
     batches = bench.make_batches(scene, dev, 4, 0)
     for i in range(steps_before):
         tr.step(batches[i % 4])
-    cap = {}
+    caps = []
     orig = FO._scatter
 
-    def spy(u, dfeat, scalings, g, tshape, sink=None):
-        if g.features_per_level == 2:
-            cap.update(u=u.clone(), dfeat=dfeat.clone(), scalings=scalings.clone(), g=g)
-        return orig(u, dfeat, scalings, g, tshape, sink)
+    def spy(u, dfeat, scalings, g, tshape, sink=None, counts=None, ws_with_absmax=None, sink_owner=None):
+        caps.append(dict(u=u.clone(), dfeat=dfeat.clone(), scalings=scalings.clone(), g=g,
+                         counts=None if counts is None else counts.clone(), absmax=ws_with_absmax is not None))
+        return orig(u, dfeat, scalings, g, tshape, sink, counts, ws_with_absmax, sink_owner)
 
     FO._scatter = spy
     tr.step(batches[0])
     FO._scatter = orig
-    u, dfeat, sc, g = cap["u"], cap["dfeat"], cap["scalings"], cap["g"]
-    N = u.shape[0]
-    L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
-    ws = torch.empty(lib().ps_grid_scatter_workspace(L, F, l2t, N) + 4096, dtype=torch.uint8, device=dev)
-    out = torch.empty((1 << l2t) * L, F, device=dev)
     s = torch.cuda.current_stream().cuda_stream
 
     def timed(fn, n=5):
@@ -49,18 +44,34 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n
 
-    t_all = timed(lambda: check(lib().ps_grid_scatter_binned(u.data_ptr(), dfeat.data_ptr(), sc.data_ptr(), L, F, l2t, N, N * F,
-                                                             out.data_ptr(), 0, ws.data_ptr(), s), "scatter"))
-    print(f"after {steps_before} steps: all {L} levels together {t_all:.3f} ms (N={N})")
-    tot = 0.0
-    for l in range(L):
-        sl = sc[l:l + 1].contiguous()
-        plane = dfeat[l].contiguous()
-        t = timed(lambda: check(lib().ps_grid_scatter_binned(u.data_ptr(), plane.data_ptr(), sl.data_ptr(), 1, F, l2t, N, N * F,
-                                                             out.data_ptr(), 0, ws.data_ptr(), s), "scatter"))
-        tot += t
-        print(f"  level {l:2d} res {int(sl[0]):5d}: {t:.3f} ms")
-    print(f"  sum of single-level runs {tot:.3f} ms")
+    for cap in caps:
+        u, dfeat, sc, g = cap["u"], cap["dfeat"], cap["scalings"], cap["g"]
+        N = u.shape[0]
+        L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
+        ws = torch.empty(lib().ps_grid_scatter_workspace(L, F, l2t, N) + 4096, dtype=torch.uint8, device=dev)
+        out = torch.empty((1 << l2t) * L, F, device=dev)
+        items = lib().ps_grid_scatter_items(L, F, l2t, 1)
+        cnt = cap["counts"]
+
+        def run(uu, df, scl, LL, phase, i0=0, i1=-1, c=None):
+            check(lib().ps_grid_scatter_binned_part(uu.data_ptr(), df.data_ptr(), scl.data_ptr(), LL, F, l2t, N, N * F, out.data_ptr(), 0,
+                                                    0 if c is None else c.data_ptr(), 0, ws.data_ptr(), phase, i0, i1, s), "scatter")
+
+        t_all = timed(lambda: run(u, dfeat, sc, L, 3, c=cnt))
+        t_prep = timed(lambda: run(u, dfeat, sc, L, 1, c=cnt))
+        t_acc = timed(lambda: run(u, dfeat, sc, L, 2))
+        print(f"after {steps_before} steps: L{L} F{F} T2^{l2t} N={N} counts_from_fwd={cnt is not None}: all {t_all:.3f} ms = prepare {t_prep:.3f} + accumulate {t_acc:.3f}")
+        per = items // L
+        tot = 0.0
+        for l in range(L):
+            sl = sc[l:l + 1].contiguous()
+            plane = dfeat[l].contiguous()
+            tp = timed(lambda: run(u, plane, sl, 1, 1))
+            ta = timed(lambda: run(u, plane, sl, 1, 2))
+            t1 = timed(lambda: run(u, plane, sl, 1, 2, 0, 1))  # slice 0 of the level alone (dense levels: all of it)
+            tot += tp + ta
+            print(f"  level {l:2d} res {int(sl[0]):5d}: prepare (count+write) {tp:.3f}  accumulate {ta:.3f} ms (slice 0 alone {t1:.3f}; {per} slices)")
+        print(f"  sum of single-level runs {tot:.3f} ms")
 
 
 if __name__ == "__main__":
