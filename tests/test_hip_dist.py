@@ -385,3 +385,55 @@ def test_chunk_feed_yields_the_reference_loader_batches(dev):
         assert torch.equal(first_of_next["rgb"].cpu(), t(G[f"b_rgb_w{world}r{rank}"])[0])
         feed.close()
         assert calls[:2] == [0, 1]
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_fused_table_adam_is_the_separate_step_bit_for_bit(dev, K):
+    """Trainer(world=1) applies the hash tables' Adam step inside their table backward (ps_grid_scatter_binned_adam, routed tile:
+    ps_grid_scatter_binned_ms_adam): from equal parameters, ONE iteration leaves every table, both its moments and its step count
+    bit-equal to backward -> optimizer.step() (the table gradient is integer-accumulated, both paths run csrc/adam_core.hpp), the
+    fused path never writes the tables' gradients, a backward pass outside Trainer.step is left alone (plain gradients), and a second
+    gradient contribution to an already-updated table raises instead of being lost."""
+    import bench
+    from presight_amd import field_ops as FO
+
+    runs = []
+    for fused in (True, False):
+        model, scene = _tiny_model(dev, K=K)
+        tr = bench.Trainer(model, scene, 1, fused_table_adam=fused)
+        assert tr.fused_table_adam == fused
+        batches = bench.make_batches(scene, dev, 2, 0, rays=512)
+        torch.manual_seed(11)
+        tr.step(batches[0])
+        runs.append((model, tr, batches))
+    (ma, ta, batches), (mb, tb, _) = runs
+    names = {id(p): n for n, p in ma.named_parameters()}
+    tables = [i for i, p in enumerate(ta.opt.params) if names[id(p)].endswith("hash_table")]
+    assert len(tables) == 3 * K and all(getattr(ta.opt.params[i], "_ps_fused_adam", None) is ta.opt for i in tables)
+    assert ta.opt.param_steps() == tb.opt.param_steps()
+    moved = 0
+    for i in tables:
+        assert torch.equal(ta.opt.params[i], tb.opt.params[i]), names[id(ta.opt.params[i])]
+        assert torch.equal(ta.opt.exp_avg[i], tb.opt.exp_avg[i]) and torch.equal(ta.opt.exp_avg_sq[i], tb.opt.exp_avg_sq[i])
+        assert float(ta.opt.params[i].grad.abs().max()) == 0.0
+        moved += int(float(ta.opt.exp_avg_sq[i].abs().max()) > 0)
+    assert moved >= 3  # (K = 4: a sub-field the 512 rays never reach stays untouched on both sides)
+    # a backward pass the trainer has not armed: plain table gradients, nothing is updated
+    from presight_amd import ops
+    from presight_amd.rays import RayBundle
+
+    b = batches[1]
+    ta.grads.zero_()
+    before = [ta.opt.params[i].detach().clone() for i in tables]
+    o, d, pa, dn = ops.generate_rays(b["ray_indices"], ta.scene["c2w"], ta.scene["fx"], ta.scene["fy"], ta.scene["cx"], ta.scene["cy"])
+    rb = RayBundle(o, d, pa, camera_indices=b["ray_indices"][:, 0:1], metadata={"video_id": b["video_ids"][:, None], "directions_norm": dn})
+    ma.train()
+    sum(ma.get_loss_dict(ma(rb), b).values()).backward()
+    assert all(torch.equal(x, ta.opt.params[i]) for x, i in zip(before, tables))
+    assert sum(float(ta.opt.params[i].grad.abs().max()) > 0 for i in tables) >= 3
+    # a table that has been updated inside its backward cannot take another contribution in the same step
+    ta.opt.params[tables[0]]._ps_fused_done = True
+    with pytest.raises(RuntimeError, match="second gradient contribution"):
+        FO._refuse_second_contribution([ta.opt.params[tables[0]]])
+    ta.grads.zero_()
+    assert ta.opt.params[tables[0]]._ps_fused_done is False
