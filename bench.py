@@ -1098,6 +1098,12 @@ def main():
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
             "kernels_ms_note": "per-kernel pass without the proposal side stream (each kernel alone on the chip); the timed steps overlap "
                                "the proposal networks' backward with the main field's" if side_was else "single stream",
+            "optimizer": {"adam": "every step, inside the timed region",
+                          "hash_tables": ("updated INSIDE their table backward (ps_grid_scatter_binned_adam: the accumulate pass applies the "
+                                          "optimizer kernel's own element update to every slice, bit-equal to the separate step; the "
+                                          "`adam` region below covers the remaining parameters only)") if getattr(trainer, "fused_table_adam", False)
+                          else "updated by adam_ranges_kernel like every other parameter (a gradient exchange needs the gradients)",
+                          "fused_table_adam": bool(getattr(trainer, "fused_table_adam", False))},
             "value_reference_schedule": world * rays * n_sched / dt_sched,
             "other_scaling": other,
             "comm": None if (world == 1 or tiles) else {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
