@@ -908,24 +908,35 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
     // is never written (its buffer keeps the zeros the step started with)
     const int64_t off = out - A.g_base;
     float *pp = A.p_base + off, *mm = A.m_base + off, *vv = A.v_base + off;
-    float P[kOutPerThread], M[kOutPerThread], V[kOutPerThread];
+    // 16-byte accesses: a thread owns 4 consecutive entries in each of kOutPerThread / 4 rounds (the flat buffers and every slice
+    // start on 16-byte boundaries: presight_amd.dist.FlatGrads pads its views, a slice holds a power of two >= 4 of values)
+    constexpr int kVec = kOutPerThread / 4;
+    f32x4 P[kVec], M[kVec], V[kVec];
 #pragma unroll
-    for (int k = 0; k < kOutPerThread; ++k) {
-      const int i = threadIdx.x + k * 1024;
-      const bool ok = i < entries * F;
-      P[k] = ok ? __builtin_nontemporal_load(pp + i) : 0.0f;
-      M[k] = ok ? __builtin_nontemporal_load(mm + i) : 0.0f;
-      V[k] = ok ? __builtin_nontemporal_load(vv + i) : 0.0f;
+    for (int k = 0; k < kVec; ++k) {
+      const int i = (threadIdx.x + k * 1024) * 4;
+      if (i < entries * F) {
+        P[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pp + i));
+        M[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mm + i));
+        V[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vv + i));
+      }
     }
 #pragma unroll
-    for (int k = 0; k < kOutPerThread; ++k) {
-      const int i = threadIdx.x + k * 1024;
+    for (int k = 0; k < kVec; ++k) {
+      const int i = (threadIdx.x + k * 1024) * 4;
       if (i < entries * F) {
-        const float val = nan_level ? __builtin_nanf("") : (float)((double)acc[i] * (double)inv * (double)out_scale);
-        ps::adam_update(P[k], val, M[k], V[k], A.h, bc1, bc2_sqrt);
-        __builtin_nontemporal_store(P[k], pp + i);
-        __builtin_nontemporal_store(M[k], mm + i);
-        __builtin_nontemporal_store(V[k], vv + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float val = nan_level ? __builtin_nanf("") : (float)((double)acc[i + j] * (double)inv * (double)out_scale);
+          float pk = P[k][j], mk = M[k][j], vk = V[k][j];
+          ps::adam_update(pk, val, mk, vk, A.h, bc1, bc2_sqrt);
+          P[k][j] = pk;
+          M[k][j] = mk;
+          V[k][j] = vk;
+        }
+        __builtin_nontemporal_store(P[k], reinterpret_cast<f32x4*>(pp + i));
+        __builtin_nontemporal_store(M[k], reinterpret_cast<f32x4*>(mm + i));
+        __builtin_nontemporal_store(V[k], reinterpret_cast<f32x4*>(vv + i));
       }
     }
     return;
@@ -1130,6 +1141,8 @@ extern "C" int ps_grid_scatter_binned_adam(const float* u, const float* dfeat, c
                          nullptr, nullptr, nullptr))
     return rc;
   PS_REQUIRE(dtable != nullptr && dtable >= grad_base, "ps_grid_scatter_binned_adam: the destination must lie in the flat gradient buffer");
+  PS_REQUIRE((((uintptr_t)dtable | (uintptr_t)grad_base | (uintptr_t)param_base | (uintptr_t)exp_avg_base | (uintptr_t)exp_avg_sq_base) & 15) == 0,
+             "ps_grid_scatter_binned_adam: the flat buffers and the table's view must be 16-byte aligned");
   return scatter_binned_impl(u, dfeat, scalings, L, F, log2T, N, plane_stride, dtable, nullptr, 1, nullptr, /*accumulate=*/2, slice_counts,
                              absmax_ready, workspace, (hipStream_t)stream, 3, 0, 1.0f, nullptr, phase, item_begin, item_end, &A);
 }
