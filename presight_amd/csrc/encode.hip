@@ -403,20 +403,37 @@ extern "C" int ps_grid_scatter(const float* u, const float* dfeat, const float* 
 // =================================================================================================
 namespace {
 
-constexpr int kBinThreads = 256;
-#ifndef PS_BIN_PPT
-#define PS_BIN_PPT 2
+// Workgroup shape of the bin kernel: threads x points per thread.  A workgroup's records leave as one run per slice: (F + 2) 4-byte
+// planes of (points x 4 / slices) records, so the POINTS per workgroup set the run length (partial cache lines below ~32 records) and
+// the LDS staging area, hence how many workgroups share a CU; the THREADS set how many waves work on it.  The kernel is a chain of
+// latencies (point loads -> hashes -> LDS counting sort -> one global reservation per slice -> stores), so more waves per staged
+// record help: 512 threads instead of 256 at the same points per workgroup, measured on one box in alternation --
+//   cfg 2 14.16 -> 13.90 ms per step (main table backward 2.67 -> 2.58 with 1024 points, proposal 1.08 -> 1.04 with 512),
+//   cfg 3 24.5 -> 24.2 ms, cfg 4 (4-D table, 512 instead of 256 points) 50.6 -> 49.0 ms.
+// History of the points: F = 4 tables have 256 slices per level, 512 points gave runs of 8 records = 32 bytes per plane (PMC,
+// production tile: 6.6 GB written for 4.0 GB of records), 1024 points double them (4.97 -> 4.34 ms).  1024 points x 1024 threads does
+// not fit F = 2 (staging area > 64 KiB static LDS).
+#ifndef PS_BIN_THREADS
+#define PS_BIN_THREADS 512
 #endif
-// points per thread of the bin kernel.  A workgroup's records leave as one run per slice: 4 F-byte-wide planes of (points x 4 / slices)
-// records.  F = 4 tables have 256 slices per level (4096 rows of int64 accumulators fill the LDS), so 512 points give runs of 8
-// records = 32 bytes per plane -- partial cache lines (PMC, production tile: 6.6 GB written for 4.0 GB of records); 1024 points double
-// the runs (cfg 3 main table backward 4.97 -> 4.34 ms) at one workgroup per CU.  F = 1 / 2 (16 / 64 slices) are best at 512 points
-// (cfg 2 main 2.55 vs 2.70 ms, proposal 1.05 vs 1.22 ms at 1024; 256 points: 1.36 ms).
+#ifndef PS_BIN_THREADS_F4
+#define PS_BIN_THREADS_F4 PS_BIN_THREADS
+#endif
+constexpr int bin_threads(int D, int F) { return (D == 3 && F == 4) ? PS_BIN_THREADS_F4 : PS_BIN_THREADS; }
+#ifndef PS_BIN_PPT
+#define PS_BIN_PPT 2  // F = 2
+#endif
+#ifndef PS_BIN_PPT_F1
+#define PS_BIN_PPT_F1 1
+#endif
+#ifndef PS_BIN_PPT_F4
+#define PS_BIN_PPT_F4 2
+#endif
 #ifndef PS_BIN_PPT_4D
 #define PS_BIN_PPT_4D 1
 #endif
-constexpr int bin_points_per_thread(int D, int F) { return D == 4 ? PS_BIN_PPT_4D : (F == 4 ? 2 * PS_BIN_PPT : PS_BIN_PPT); }
-constexpr int bin_points(int D, int F) { return kBinThreads * bin_points_per_thread(D, F); }  // points per workgroup
+constexpr int bin_points_per_thread(int D, int F) { return D == 4 ? PS_BIN_PPT_4D : (F == 4 ? PS_BIN_PPT_F4 : (F == 1 ? PS_BIN_PPT_F1 : PS_BIN_PPT)); }
+constexpr int bin_points(int D, int F) { return bin_threads(D, F) * bin_points_per_thread(D, F); }  // points per workgroup
 constexpr int kMaxSlices = 256;
 constexpr int kAccBytes = 128 * 1024;
 
@@ -435,7 +452,7 @@ __device__ __forceinline__ float fixed_scale(unsigned gmax_bits, int headroom_lo
 // period > 0 (up to three position sets of `period` points each, dynamic.hip): point n < period takes row n of dfeat, a point
 // n >= period takes row (n - period) mod period of dfeat_b (dfeat itself when dfeat_b is null).
 template <int F, bool COUNT_ONLY, int D = 3>
-__global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restrict__ u, const float* __restrict__ dfeat,
+__global__ __launch_bounds__(bin_threads(D, F)) void bin_kernel(const float* __restrict__ u, const float* __restrict__ dfeat,
                                                           const float* __restrict__ scalings, int L, int log2T,
                                                           int log2_slice, int64_t N, int64_t plane_stride, int64_t n_rec_max,
                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
@@ -443,6 +460,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float* __restric
                                                           unsigned* __restrict__ gmax_track /* nullable: per-level max |dfeat| bits */,
                                                           int64_t period, const float* __restrict__ dfeat_b) {
   constexpr int kBinPointsPerThread = bin_points_per_thread(D, F);
+  constexpr int kBinThreads = bin_threads(D, F);
   constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
   constexpr int NP = D == 4 ? 8 : 4;  // x-pairs per (point, level)
   // LDS: per-slice counters / offsets / global bases + staged records (idx + F values) + slice id per staged record.
@@ -1038,12 +1056,12 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
     if (phase & 1) {                                                                                                      \
       if (N > 0) {                                                                                                        \
         if (slice_counts == nullptr)                                                                                      \
-          bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,    \
+          bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), bin_threads(DD, FF), 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,    \
                                                                               plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period, dfeat_b); \
       }                                                                                                                   \
       stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                         \
       if (N > 0)                                                                                                          \
-        bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), kBinThreads, 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,     \
+        bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), bin_threads(DD, FF), 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,     \
                                                                              plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
                                                                              absmax_ready ? nullptr : gmax_bits, period, dfeat_b); \
     }                                                                                                                     \
