@@ -1557,7 +1557,10 @@ int ms_grid(int64_t n_slots, int pts_per_tile, int waves, int max_blocks, int K)
 #ifndef PS_PROP_BWD_BLOCKS
 #define PS_PROP_BWD_BLOCKS 512
 #endif
-constexpr int kPropFwdPB = PS_PROP_FWD_PB, kPropBwdPB = 2, kMainFwdPB = 2, kMainFwdWaves = 4, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
+#ifndef PS_PROP_BWD_PB
+#define PS_PROP_BWD_PB 2
+#endif
+constexpr int kPropFwdPB = PS_PROP_FWD_PB, kPropBwdPB = PS_PROP_BWD_PB, kMainFwdPB = 2, kMainFwdWaves = 4, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
 constexpr int kPropBwdBlocks = PS_PROP_BWD_BLOCKS;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
 
 // (L*F, hidden) of the proposal nets

@@ -1,11 +1,18 @@
 #!/bin/bash
 # A/B of library variants copied to tools/_vlib (tools/build_variant.sh builds them under presight_amd/_variants, which does not travel):
-#   gpurun -- 'bash tools/ab_variants.sh "<bench args>" <rounds> <variant> ...'   ("" = the product library, always first)
+#   gpurun -- 'bash tools/ab_variants.sh "<bench args>" <rounds> <variant> ...'   (the product library always runs first in a round)
 cd $GRAFT_REPO_ROOT
 args=$1; rounds=$2; shift; shift
+cat > /tmp/ab_fmt.py <<'PY'
+import json, sys
+d = json.loads(sys.stdin.read())
+k = d["kernels_ms"]
+keep = {a: round(b, 3) for a, b in k.items() if any(t in a for t in ("scatter", "adam", "prop", "encode", "main_field"))}
+print(sys.argv[1], round(d["ms_per_step"], 2), keep)
+PY
 for r in $(seq $rounds); do
   for v in "" "$@"; do
     if [ -z "$v" ]; then unset PRESIGHT_HIP_LIB; name=product; else export PRESIGHT_HIP_LIB=$PWD/tools/_vlib/lib_$v.so; name=$v; fi
-    PRESIGHT_NO_DRY_OVERLAP=1 timeout 400 python bench.py $args --no-cpu-baseline --psnr-steps 0 --no-secondary 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms']; print('$name', round(d['ms_per_step'],2), {a:round(b,2) for a,b in k.items() if 'scatter' in a or a=='adam'})"
+    PRESIGHT_NO_DRY_OVERLAP=1 timeout 400 python bench.py $args --no-cpu-baseline --psnr-steps 0 --no-secondary 2>/dev/null | tail -1 | python /tmp/ab_fmt.py $name
   done
 done
