@@ -17,6 +17,9 @@
 // for ps_grid_scatter.
 #include "common.hpp"
 #include "field_io.hpp"
+// the only one-point-block forward of this file is the factored training node in its two-workgroups-per-CU shape (MainFwdShape):
+// its layers keep ONE accumulator chain per output block, i.e. the summation order of the two-block kernels (same bits)
+#define PS_FWD_PB1_SPLIT 0
 #include "mlp_core.hpp"
 #include "ms_core.hpp"
 #include "pointwise_core.hpp"
@@ -1561,6 +1564,22 @@ int ms_grid(int64_t n_slots, int pts_per_tile, int waves, int max_blocks, int K)
 #define PS_PROP_BWD_PB 2
 #endif
 constexpr int kPropFwdPB = PS_PROP_FWD_PB, kPropBwdPB = PS_PROP_BWD_PB, kMainFwdPB = 2, kMainFwdWaves = 4, kMainBwdPB = PS_MAIN_BWD_PB, kMainBwdWaves = PS_MAIN_BWD_WAVES;
+// Shape of the main forward launch.  The kernel holds a wave's activations in registers: with two 16-point blocks per wave it needs
+// > 256 registers (one wave per SIMD, one workgroup per CU) and every LDS operand read, activation store and non-matrix instruction
+// of that wave stalls the matrix pipe of its SIMD.  Where TWO workgroups fit a CU's 160 KiB of LDS (the factored / merged one-sub-field
+// stacks: 69-73 KiB each) the kernel runs ONE point block per wave (184-194 registers) in twice as many workgroups: two waves per SIMD
+// cover each other's stalls -- cfg 2 main_fwd_kernel 1.76 -> 1.59 ms.  (The three backward kernels need >= 2 point blocks for their
+// pipelined operand staging and their weight-gradient accumulators, and stay at one wave per SIMD.)
+#ifndef PS_MAIN_FWD_TWO_WG
+#define PS_MAIN_FWD_TWO_WG 1
+#endif
+template <class C>
+struct MainFwdShape {
+  // (the training node of one sub-field only: the gated inference forward counts and skips tiles of 2 x 16 points)
+  static constexpr bool kTwo = PS_MAIN_FWD_TWO_WG && C::FACT && 2 * (C::FW * 4 + 2048) <= 160 * 1024;
+  static constexpr int kPB = kTwo ? 1 : kMainFwdPB;
+  static constexpr int kBlocks = kTwo ? 512 : 256;
+};
 constexpr int kPropBwdBlocks = PS_PROP_BWD_BLOCKS;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
 
 // (L*F, hidden) of the proposal nets
@@ -1743,9 +1762,9 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>;                                                    \
     if (a.perm != nullptr) {                                                                                          \
       a.packed_stride = C::PACKED;                                                                                    \
-      main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, true><<<ms_grid(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256, a.K), kMainFwdWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, true><<<ms_grid(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks, a.K), kMainFwdWaves * 64, 0, s>>>(a); \
     } else {                                                                                                          \
-      main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks), kMainFwdWaves * 64, 0, s>>>(a); \
     }                                                                                                                 \
     PS_CHECK_LAUNCH();                                                                                                \
   }
@@ -1760,7 +1779,7 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;                                                           \
-    main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+    main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks), kMainFwdWaves * 64, 0, s>>>(a); \
     PS_CHECK_LAUNCH();                                                                                                \
   }
     PS_MAIN_CFGS(X)
@@ -1776,9 +1795,9 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
     if (a.perm != nullptr) {                                                                                          \
       a.packed_stride = C::PACKED;                                                                                    \
-      main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, true><<<ms_grid(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256, a.K), kMainFwdWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, true><<<ms_grid(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks, a.K), kMainFwdWaves * 64, 0, s>>>(a); \
     } else {                                                                                                          \
-      main_fwd_kernel<C, kMainFwdPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * kMainFwdPB, kMainFwdWaves, 256), kMainFwdWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks), kMainFwdWaves * 64, 0, s>>>(a); \
     }                                                                                                                 \
     PS_CHECK_LAUNCH();                                                                                                \
   }

@@ -27,6 +27,10 @@
 #include <type_traits>
 #include "common.hpp"
 
+#ifndef PS_FWD_PB1_SPLIT
+#define PS_FWD_PB1_SPLIT 1
+#endif
+
 namespace ps {
 
 // ---- compile-time description of one layer -------------------------------------------------
@@ -171,8 +175,10 @@ __device__ __forceinline__ void layer_fwd_pf(const W& params, const FwdFrags<LT>
     else
       next();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PB == 1) {
+    if constexpr (PB == 1 && PS_FWD_PB1_SPLIT) {
       // a single accumulator would serialise on the 40-cycle MFMA dependency: split the k-steps over two
+      // (PS_FWD_PB1_SPLIT = 0, set by a translation unit whose one-block kernels run two waves per SIMD: the other wave fills the
+      //  dependency gap, and the sums keep the order of the two-block kernels -- bit-identical outputs)
       f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc[0] = cur.b;
 #pragma unroll
