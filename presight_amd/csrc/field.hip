@@ -1575,9 +1575,11 @@ constexpr int kPropFwdPB = PS_PROP_FWD_PB, kPropBwdPB = PS_PROP_BWD_PB, kMainFwd
 #endif
 template <class C>
 struct MainFwdShape {
-  // (the training node of one sub-field only: the gated inference forward counts and skips tiles of 2 x 16 points)
+  // (two workgroups per CU: the training node of one sub-field only -- the other stacks' weight fragments fill > 80 KiB)
   static constexpr bool kTwo = PS_MAIN_FWD_TWO_WG && C::FACT && 2 * (C::FW * 4 + 2048) <= 160 * 1024;
-  static constexpr int kPB = kTwo ? 1 : kMainFwdPB;
+  // everything else: the same two waves per SIMD as ONE workgroup of eight one-block waves (PS_MAIN_FWD_TWO_WG = 0: the old shape)
+  static constexpr int kPB = PS_MAIN_FWD_TWO_WG ? 1 : kMainFwdPB;
+  static constexpr int kWaves = (PS_MAIN_FWD_TWO_WG && !kTwo) ? 8 : kMainFwdWaves;
   static constexpr int kBlocks = kTwo ? 512 : 256;
 };
 constexpr int kPropBwdBlocks = PS_PROP_BWD_BLOCKS;  // 2 workgroups per CU: the kernel is latency bound and its registers allow 2 waves/SIMD
@@ -1762,9 +1764,9 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>;                                                    \
     if (a.perm != nullptr) {                                                                                          \
       a.packed_stride = C::PACKED;                                                                                    \
-      main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, true><<<ms_grid(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks, a.K), kMainFwdWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, true><<<ms_grid(a.N, 16 * MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, MainFwdShape<C>::kBlocks, a.K), MainFwdShape<C>::kWaves * 64, 0, s>>>(a); \
     } else {                                                                                                          \
-      main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks), kMainFwdWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, MainFwdShape<C>::kBlocks), MainFwdShape<C>::kWaves * 64, 0, s>>>(a); \
     }                                                                                                                 \
     PS_CHECK_LAUNCH();                                                                                                \
   }
@@ -1779,7 +1781,7 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;                                                           \
-    main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks), kMainFwdWaves * 64, 0, s>>>(a); \
+    main_fwd_kernel<C, MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, MainFwdShape<C>::kBlocks), MainFwdShape<C>::kWaves * 64, 0, s>>>(a); \
     PS_CHECK_LAUNCH();                                                                                                \
   }
     PS_MAIN_CFGS(X)
@@ -1795,9 +1797,9 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
     if (a.perm != nullptr) {                                                                                          \
       a.packed_stride = C::PACKED;                                                                                    \
-      main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, true><<<ms_grid(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks, a.K), kMainFwdWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, true><<<ms_grid(a.N, 16 * MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, MainFwdShape<C>::kBlocks, a.K), MainFwdShape<C>::kWaves * 64, 0, s>>>(a); \
     } else {                                                                                                          \
-      main_fwd_kernel<C, MainFwdShape<C>::kPB, kMainFwdWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, kMainFwdWaves, MainFwdShape<C>::kBlocks), kMainFwdWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, MainFwdShape<C>::kBlocks), MainFwdShape<C>::kWaves * 64, 0, s>>>(a); \
     }                                                                                                                 \
     PS_CHECK_LAUNCH();                                                                                                \
   }
