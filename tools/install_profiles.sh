@@ -16,6 +16,7 @@ cp $G/kernel_stats_${T}_cfg3.txt profiles/${T}_kernel_stats_cfg3_bench_steps4_wa
 cp $G/kernel_stats_${T}_cfg4.txt profiles/${T}_kernel_stats_cfg4_bench_steps4_warmup2.txt
 cp $G/kernel_gaps_${T}_cfg2.txt profiles/${T}_kernel_gaps_cfg2.txt
 cp $G/pmc_summary_$T.txt profiles/${T}_pmc_summary.txt
+[ -f $G/soak_$T.txt ] && grep -v amdgpu.ids $G/soak_$T.txt > profiles/${T}_soak_1000_iterations.txt
 python tools/pmc_traffic.py profiles/${T}_pmc_summary.txt profiles/traffic.json > /dev/null
 python - <<PY
 import json
