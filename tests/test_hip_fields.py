@@ -401,3 +401,51 @@ def test_table_gradient_non_finite_input_gives_nan_not_garbage(F, dev):
         per_level = dt.view(4, 1 << 12, 2)
         assert bool(torch.isnan(per_level[2]).any())
         assert bool(torch.isfinite(per_level[[0, 1, 3]]).all())
+
+
+@pytest.mark.parametrize("L,nf,l2t,mx,N", [(16, 2, 19, 2048, 60001), (8, 1, 20, 4096, 30001), (10, 4, 14, 16384, 5000), (2, 2, 9, 64, 700)])
+def test_table_backward_with_the_adam_step_inside_equals_scatter_then_adam(F, dev, L, nf, l2t, mx, N):
+    """ps_grid_scatter_binned_adam (the table backward that applies the optimizer's element update to every slice it finishes: what
+    a single-process trainer runs) against the two-call sequence it replaces -- ps_grid_scatter_binned into a zeroed gradient, then
+    ps_adam_step_ranges over the table: parameters and both moments bit-equal, the gradient buffer untouched; every entry is updated
+    (weight decay / moment decay reach slices without records), and a level whose d(features) hold a NaN turns its entries NaN in
+    both paths (torch's index_add of a NaN followed by Adam)."""
+    import ctypes
+
+    from presight_amd._lib import check, lib
+
+    gen = torch.Generator().manual_seed(L * 11 + nf)
+    sc = O.hash_scalings(L, 16, mx).to(dev)
+    u = torch.rand(N, 3, generator=gen)
+    u[: N // 2] = u[:1] + torch.rand(N // 2, 3, generator=gen) * 0.05  # half of the points in one corner: most slices stay empty
+    u = u.clamp(0, 1).to(dev)
+    dfeat = (torch.randn(L, N, nf, generator=gen) * torch.logspace(-4, 1, L).view(L, 1, 1)).to(dev).contiguous()
+    dfeat[L - 1, 7, 0] = float("nan")
+    n = (1 << l2t) * L * nf
+    p0 = ((torch.rand(n, generator=gen) - 0.5) * 2e-4).to(dev)
+    m0 = (torch.randn(n, generator=gen) * 1e-3).to(dev)
+    v0 = (torch.rand(n, generator=gen) * 1e-6).to(dev)
+    ws = torch.empty(lib().ps_grid_scatter_workspace(L, nf, l2t, N) + 4096, dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    lr, b1, b2, eps, wd, gs, step = 3e-3, 0.9, 0.999, 1e-15, 1e-5, 1.0, 7
+    # the two-call sequence
+    pa, ma, va, ga = p0.clone(), m0.clone(), v0.clone(), torch.zeros(n, device=dev)
+    check(lib().ps_grid_scatter_binned(u.data_ptr(), dfeat.data_ptr(), sc.data_ptr(), L, nf, l2t, N, N * nf, ga.data_ptr(), 2, None, 0,
+                                       ws.data_ptr(), s), "scatter")
+    starts, counts = (ctypes.c_int64 * 1)(0), (ctypes.c_int64 * 1)(n)
+    steps, groups = (ctypes.c_int * 1)(step), (ctypes.c_int * 1)(-1)
+    check(lib().ps_adam_step_ranges(pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(), 1, starts, counts, steps, groups, None, None, 0,
+                                    lr, b1, b2, eps, wd, gs, s), "adam")
+    # the fused call
+    pb, mb, vb, gb = p0.clone(), m0.clone(), v0.clone(), torch.zeros(n, device=dev)
+    check(lib().ps_grid_scatter_binned_adam(u.data_ptr(), dfeat.data_ptr(), sc.data_ptr(), L, nf, l2t, N, N * nf, gb.data_ptr(), None, 0,
+                                            ws.data_ptr(), 3, 0, -1, gb.data_ptr(), pb.data_ptr(), mb.data_ptr(), vb.data_ptr(),
+                                            lr, b1, b2, eps, wd, gs, step, s), "scatter+adam")
+    torch.cuda.synchronize()
+    assert float(gb.abs().max()) == 0.0  # the gradient is never written
+    T = (1 << l2t) * nf
+    assert bool(torch.isnan(pa[(L - 1) * T:]).all()) and bool(torch.isfinite(pa[:(L - 1) * T]).all())
+    for a, b in ((pa, pb), (ma, mb), (va, vb)):
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+    assert not torch.equal(pa[:T], p0[:T]) and bool((ma[:(L - 1) * T] != m0[:(L - 1) * T]).all())  # every entry moved (decay), records or not
