@@ -62,23 +62,27 @@ __device__ __forceinline__ float nan_to_num0(float v) {
   return v;
 }
 
+__host__ __device__ constexpr int interlevel_floats_per_ray(int S, int Sp) { return 2 * (S + 1) + 4 * 2 * (S + 1) + Sp + 1; }
+
 __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict__ c_, const float* __restrict__ w_,
                                                          const float* __restrict__ cp_, const float* __restrict__ wp_,
                                                          int64_t R, int S, int Sp, float r, float* __restrict__ per_ray,
                                                          float* __restrict__ dwp) {
-  // per wave: A,B [n] | xr [m] | v2 [m] | yr [m] | cdf [m] | ret [Sp+1]
-  __shared__ float lds[4][2 * (kMaxS + 1) + 4 * kMaxM + kMaxSp + 1];
+  // per wave: A,B [n] | xr [m] | v2 [m] | yr [m] | cdf [m] | ret [Sp+1] -- sized for THIS call's S / Sp (dynamic LDS): the kernel is
+  // a chain of dependent LDS look-ups (binary searches, scans), so what it needs is resident waves, and at the maximal sizes
+  // (S 128, Sp 256: 6.2 KB per ray) a CU held 24 instead of 32
+  extern __shared__ float lds_dyn[];
   const int wv = threadIdx.x >> 6, lane = ps_lane();
   const int64_t ray = blockIdx.x * 4 + wv;
   if (ray >= R) return;
   const int n = S + 1, m = 2 * n;
-  float* A = lds[wv];
-  float* B = A + (kMaxS + 1);
-  float* xr = B + (kMaxS + 1);
-  float* v2 = xr + kMaxM;
-  float* yr = v2 + kMaxM;
-  float* cdf = yr + kMaxM;
-  float* ret = cdf + kMaxM;
+  float* A = lds_dyn + (size_t)wv * interlevel_floats_per_ray(S, Sp);
+  float* B = A + n;
+  float* xr = B + n;
+  float* v2 = xr + m;
+  float* yr = v2 + m;
+  float* cdf = yr + m;
+  float* ret = cdf + m;
   const float* c = c_ + ray * n;
   const float* w = w_ + ray * S;
   // a/b: shifted edges and the derivative pulses y1 (blur_stepfun, PreSight/losses.py:127-133)
@@ -257,7 +261,8 @@ extern "C" int ps_interlevel_loss(const float* c, const float* w, const float* c
                                   float pulse_width, float* per_ray, float* dwp, void* stream) {
   PS_REQUIRE(S <= kMaxS && Sp <= kMaxSp, "ps_interlevel_loss: S must be <= 128 and Sp <= 256");
   if (R == 0) return 0;
-  interlevel_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(c, w, cp, wp, R, S, Sp, pulse_width, per_ray, dwp);
+  interlevel_kernel<<<(unsigned)((R + 3) / 4), 256, 4 * interlevel_floats_per_ray(S, Sp) * sizeof(float), (hipStream_t)stream>>>(
+      c, w, cp, wp, R, S, Sp, pulse_width, per_ray, dwp);
   PS_CHECK_LAUNCH();
 }
 
