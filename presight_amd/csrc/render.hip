@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------ composite
 // One wave per ray.  Lane c accumulates channel c of the C-dim features (C <= 64); lanes 0..2 also
 // the rgb channels; sample-indexed scalars (acc, depths) are done with CH samples per lane + shuffles.
+// SEM = false / MAXCH = 1: the factored training node's call (no per-sample semantics, S <= 64) -- the same arithmetic without the
+// semantic branch's 16 row registers and with one sample per lane: 146 -> ~30 registers, 3 -> 8 resident waves per SIMD.
+template <bool SEM = true, int MAXCH = kMaxCh>
 __device__ __forceinline__ void composite_ray(const float* __restrict__ weights, const float* __restrict__ ebins,
                                               const float* __restrict__ rgb_s, const float* __restrict__ sem_s, int64_t ray, int S, int C,
                                               float threshold, float* __restrict__ rgb, float* __restrict__ acc,
@@ -245,7 +248,7 @@ __device__ __forceinline__ void composite_ray(const float* __restrict__ weights,
   const bool vec = (C & 3) == 0;  // 16 lanes x 4 channels cover a row with one 16-byte load per lane: four rows per load instruction
   if (vec && (sem_s != nullptr || rgb_s != nullptr)) {
     const int q = lane & 15, g = lane >> 4;
-    if (sem_s != nullptr) {
+    if (SEM && sem_s != nullptr) {
       const bool on = 4 * q < C;
       const float* ps = sem_s + ray * S * C + 4 * q;
       f32x4 a4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -298,7 +301,7 @@ __device__ __forceinline__ void composite_ray(const float* __restrict__ weights,
       if (rgb != nullptr && lane < 3) rgb[ray * 3 + lane] = lane == 0 ? c0 : (lane == 1 ? c1 : c2);
     }
   } else if (sem_s != nullptr || rgb_s != nullptr) {
-    const bool sem_on = sem_s != nullptr && lane < C, rgb_on = rgb_s != nullptr && lane < 3;
+    const bool sem_on = SEM && sem_s != nullptr && lane < C, rgb_on = rgb_s != nullptr && lane < 3;
     const float* ps = sem_s + ray * S * C + lane;
     const float* pr = rgb_s + ray * S * 3 + lane;
     // 8 sample rows in flight per lane (the rows are independent 256-byte streams; the FMA chain is the only dependency)
@@ -329,9 +332,9 @@ __device__ __forceinline__ void composite_ray(const float* __restrict__ weights,
   }
   // sample-parallel part
   const int CH = (S + 63) / 64;
-  float wl[kMaxCh], st[kMaxCh], local = 0.f, wt = 0.f;
+  float wl[MAXCH], st[MAXCH], local = 0.f, wt = 0.f;
 #pragma unroll
-  for (int c = 0; c < kMaxCh; ++c) {
+  for (int c = 0; c < MAXCH; ++c) {
     const int s = lane * CH + c;
     const bool ok = (c < CH && s < S);
     wl[c] = ok ? w[s] : 0.0f;
@@ -346,7 +349,7 @@ __device__ __forceinline__ void composite_ray(const float* __restrict__ weights,
   float run = incl - local;
   int first = S;  // sentinel
 #pragma unroll
-  for (int c = 0; c < kMaxCh; ++c) {
+  for (int c = 0; c < MAXCH; ++c) {
     const int s = lane * CH + c;
     run += wl[c];
     if (c < CH && s < S && run >= threshold && first == S) first = s;
@@ -361,13 +364,14 @@ __device__ __forceinline__ void composite_ray(const float* __restrict__ weights,
   }
 }
 
+template <bool SEM, int MAXCH>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ weights, const float* __restrict__ ebins,
                                                             const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
                                                             int64_t R, int S, int C, float threshold, float* __restrict__ rgb,
                                                             float* __restrict__ acc, float* __restrict__ depth,
                                                             float* __restrict__ exp_depth, float* __restrict__ sem) {
   const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray < R) composite_ray(weights, ebins, rgb_s, sem_s, ray, S, C, threshold, rgb, acc, depth, exp_depth, sem);
+  if (ray < R) composite_ray<SEM, MAXCH>(weights, ebins, rgb_s, sem_s, ray, S, C, threshold, rgb, acc, depth, exp_depth, sem);
 }
 
 // Extrema of the sample mid-points (e[s] + e[s+1]) / 2 over the whole batch = the clip range of the expected depth
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 // lane is the channel (coalesced 256-byte rows, 64 independent loads in flight), then a recursive-halving
 // transpose-reduction (63 cross-lane exchanges instead of 64 six-step wave sums) leaves lane s with the dot product of
 // sample s.
+template <bool SEM>
 __global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __restrict__ weights, const float* __restrict__ ebins,
                                                               const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
                                                               const float* __restrict__ d_rgb, const float* __restrict__ d_acc,
@@ -475,11 +480,13 @@ __global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __res
   const int lane = ps_lane();
   const float* w = weights + ray * S;
   const float* e = ebins + ray * (S + 1);
-  if ((C & 3) == 0) {
+  if (!SEM || (C & 3) == 0) {
     // 16 lanes x 4 channels per row, lane group g takes the rows 4u + g: 16 sixteen-byte loads per lane instead of 64 dword
     // loads, then a recursive halving over the 16 lanes of a row leaves lane (q, g) with the dot product of sample 4q + g
     const int q = lane & 15, g = lane >> 4;
-    float v[16];
+    float v[SEM ? 16 : 1];
+    v[0] = 0.0f;  // (SEM = false, the factored node's call: no semantic rows -- the sum of sixteen zeros)
+    if constexpr (SEM) {
     const bool on = sem_s != nullptr && d_sem != nullptr && 4 * q < C;
     const f32x4 gs = on ? *reinterpret_cast<const f32x4*>(d_sem + ray * C + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -498,6 +505,7 @@ __global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __res
   }
     PS_HALVE16(8) PS_HALVE16(4) PS_HALVE16(2) PS_HALVE16(1)
 #undef PS_HALVE16
+    }
     const int sr = 4 * q + g;
     const bool ok = sr < S;
     float gr = v[0];
@@ -515,11 +523,12 @@ __global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __res
     if (ok) d_weights[ray * S + sr] = gr;
     return;
   }
+  if constexpr (!SEM) return;  // (never reached: the branch above took every SEM = false call)
   const bool sem_on = sem_s != nullptr && d_sem != nullptr && lane < C;
   const bool rgb_on = rgb_s != nullptr && d_rgb != nullptr && lane < 3;
   const float gsem = sem_on ? d_sem[ray * C + lane] : 0.0f;
   const float grgb = rgb_on ? d_rgb[ray * 3 + lane] : 0.0f;
-  float v[64];
+  float v[SEM ? 64 : 1];
 #pragma unroll
   for (int s = 0; s < 64; ++s) {
     float part = 0.f;
@@ -621,8 +630,12 @@ extern "C" int ps_composite_fwd(const float* weights, const float* ebins, const 
     const unsigned grid = (unsigned)std::min<int64_t>((R * (S + 1) + 1023) / 1024, 256);
     midpoint_minmax_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(ebins, R, S, minmax);
   }
-  composite_fwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, R, S, C, threshold, rgb,
-                                                                                acc, depth, exp_depth, sem);
+  if (sem_s == nullptr && S <= 64)
+    composite_fwd_kernel<false, 1><<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, R, S, C, threshold,
+                                                                                            rgb, acc, depth, exp_depth, sem);
+  else
+    composite_fwd_kernel<true, kMaxCh><<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, R, S, C,
+                                                                                                threshold, rgb, acc, depth, exp_depth, sem);
   PS_CHECK_LAUNCH();
 }
 
@@ -638,8 +651,12 @@ extern "C" int ps_composite_bwd(const float* weights, const float* ebins, const 
   PS_REQUIRE(S <= kMaxCh * 64 && C <= 64, "ps_composite_bwd: S must be <= 256 and C <= 64");
   if (R == 0) return 0;
   if (d_rgb_s == nullptr && d_sem_s == nullptr && S <= 64) {
-    composite_bwd_w_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
-                                                                                    d_sem, d_exp, R, S, C, d_weights);
+    if (sem_s == nullptr || d_sem == nullptr)
+      composite_bwd_w_kernel<false><<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
+                                                                                             d_sem, d_exp, R, S, C, d_weights);
+    else
+      composite_bwd_w_kernel<true><<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
+                                                                                            d_sem, d_exp, R, S, C, d_weights);
     PS_CHECK_LAUNCH();
   }
   composite_bwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
