@@ -83,8 +83,9 @@ __global__ __launch_bounds__(256) void sem_out_fwd_kernel(const float* __restric
   for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < R; r += (int64_t)gridDim.x * 4) {
     const float h = H[r * kC + lane];
     float s = 0.f;
-#pragma unroll 16
-    for (int k = 0; k < kC; ++k) s = fmaf(__shfl(h, k, 64), Wt[k][lane], s);
+    // (fully unrolled: lane k of h is a compile-time lane -> v_readlane into a scalar register instead of a trip through the LDS crossbar)
+#pragma unroll
+    for (int k = 0; k < kC; ++k) s = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), k)), Wt[k][lane], s);
     sem[r * kC + lane] = s + bias * acc[r];
   }
 }
