@@ -105,7 +105,12 @@ int ps_composite_fwd(const float* weights, const float* ebins, const float* rgb_
 int ps_clip(float* v, int64_t n, const float* minmax, void* stream);
 int ps_composite_bwd(const float* weights, const float* ebins, const float* rgb_s, const float* sem_s, const float* d_rgb,
                      const float* d_acc, const float* d_sem, const float* d_exp, int64_t R, int S, int C,
-                     float* d_weights, float* d_rgb_s, float* d_sem_s, void* stream);
+                     float* d_weights, float* d_rgb_s, float* d_sem_s,
+                     const float* d_weights_add0 /* nullable [R,S]: gradients that reach the weights from elsewhere (the semantic
+                                                    branch of the factored node, losses that act on the weights: distortion, line of
+                                                    sight -- ns/models/PreSight/nerfacto_nusc_ms.py:586-612) are added to d_weights
+                                                    here, add0 first, instead of by two element-wise launches */,
+                     const float* d_weights_add1 /* nullable */, void* stream);
 
 /* ---- a16 per-ray losses: value per ray + gradient w.r.t. the weights in one pass ---------------------
  * distortion (ns/model_components/losses.py:130-149): sbins [R,S+1], w [R,S] -> per_ray [R], dw [R,S] */

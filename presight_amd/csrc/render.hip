@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
                                                             const float* __restrict__ d_rgb, const float* __restrict__ d_acc,
                                                             const float* __restrict__ d_sem, const float* __restrict__ d_exp,
                                                             int64_t R, int S, int C, float* __restrict__ d_weights,
-                                                            float* __restrict__ d_rgb_s, float* __restrict__ d_sem_s) {
+                                                            float* __restrict__ d_rgb_s, float* __restrict__ d_sem_s,
+                                                            const float* __restrict__ add0, const float* __restrict__ add1) {
   const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= R) return;
   const int lane = ps_lane();
@@ -474,6 +475,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     if (lane == 0) {
       float g = part + gacc;
       if (d_exp != nullptr) g += ge * (((e[s] + e[s + 1]) / 2.0f) / B - A / (B * B));
+      if (add0 != nullptr) g += add0[ray * S + s];
+      if (add1 != nullptr) g += add1[ray * S + s];
       d_weights[ray * S + s] = g;
     }
   }
@@ -489,7 +492,8 @@ __global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __res
                                                               const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
                                                               const float* __restrict__ d_rgb, const float* __restrict__ d_acc,
                                                               const float* __restrict__ d_sem, const float* __restrict__ d_exp,
-                                                              int64_t R, int S, int C, float* __restrict__ d_weights) {
+                                                              int64_t R, int S, int C, float* __restrict__ d_weights,
+                                                              const float* __restrict__ add0, const float* __restrict__ add1) {
   const int64_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= R) return;
   const int lane = ps_lane();
@@ -535,7 +539,11 @@ __global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __res
       const float A = ps_wave_sum(ws * mid), B = ps_wave_sum(ws) + 1e-10f;
       gr += d_exp[ray] * (mid / B - A / (B * B));
     }
-    if (ok) d_weights[ray * S + sr] = gr;
+    if (ok) {  // (+ the addends, in this order: what `dw += add0; dw += add1` launches used to do)
+      if (add0 != nullptr) gr += add0[ray * S + sr];
+      if (add1 != nullptr) gr += add1[ray * S + sr];
+      d_weights[ray * S + sr] = gr;
+    }
     return;
   }
   if constexpr (!SEM) return;  // (never reached: the branch above took every SEM = false call)
@@ -569,7 +577,11 @@ __global__ __launch_bounds__(256) void composite_bwd_w_kernel(const float* __res
     const float A = ps_wave_sum(ws * mid), B = ps_wave_sum(ws) + 1e-10f;
     g += d_exp[ray] * (mid / B - A / (B * B));
   }
-  if (lane < S) d_weights[ray * S + lane] = g;
+  if (lane < S) {
+    if (add0 != nullptr) g += add0[ray * S + lane];
+    if (add1 != nullptr) g += add1[ray * S + lane];
+    d_weights[ray * S + lane] = g;
+  }
 }
 
 template <class F>
@@ -662,20 +674,21 @@ extern "C" int ps_clip(float* v, int64_t n, const float* minmax, void* stream) {
 
 extern "C" int ps_composite_bwd(const float* weights, const float* ebins, const float* rgb_s, const float* sem_s,
                                 const float* d_rgb, const float* d_acc, const float* d_sem, const float* d_exp, int64_t R,
-                                int S, int C, float* d_weights, float* d_rgb_s, float* d_sem_s, void* stream) {
+                                int S, int C, float* d_weights, float* d_rgb_s, float* d_sem_s, const float* d_weights_add0,
+                                const float* d_weights_add1, void* stream) {
   PS_REQUIRE(S <= kMaxCh * 64 && C <= 64, "ps_composite_bwd: S must be <= 256 and C <= 64");
   if (R == 0) return 0;
   if (d_rgb_s == nullptr && d_sem_s == nullptr && S <= 64) {
     if (sem_s == nullptr || d_sem == nullptr)
       composite_bwd_w_kernel<false><<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
-                                                                                             d_sem, d_exp, R, S, C, d_weights);
+                                                                                             d_sem, d_exp, R, S, C, d_weights, d_weights_add0, d_weights_add1);
     else
       composite_bwd_w_kernel<true><<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
-                                                                                            d_sem, d_exp, R, S, C, d_weights);
+                                                                                            d_sem, d_exp, R, S, C, d_weights, d_weights_add0, d_weights_add1);
     PS_CHECK_LAUNCH();
   }
   composite_bwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, ebins, rgb_s, sem_s, d_rgb, d_acc,
                                                                                 d_sem, d_exp, R, S, C, d_weights, d_rgb_s,
-                                                                                d_sem_s);
+                                                                                d_sem_s, d_weights_add0, d_weights_add1);
   PS_CHECK_LAUNCH();
 }

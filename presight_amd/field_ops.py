@@ -516,11 +516,10 @@ class _MainFieldRender(torch.autograd.Function):
         if d_exp is not None:
             d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
         dw = torch.empty_like(w)
+        ext = _f32(d_w_ext).contiguous() if d_w_ext is not None else None  # losses that act on the weights directly (distortion, line of sight)
         check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s) if d_rgb is not None else None,
                                      _p(sem_s) if d_sem is not None else None, _p(d_rgb), _p(d_acc), _p(d_sem), _p(d_exp), R, S,
-                                     SEM_DIM, _p(dw), None, None, _stream()), "ps_composite_bwd")
-        if d_w_ext is not None:
-            dw.add_(_f32(d_w_ext))  # losses that act on the weights directly (distortion, line of sight)
+                                     SEM_DIM, _p(dw), None, None, _p(ext), None, _stream()), "ps_composite_bwd")
         dsig = torch.empty_like(sigma)
         check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
         dapp, dtable, flat = _main_backward(ctx, saved, dsig, d_rgb, d_sem, w)  # a missing head gradient skips that head
@@ -687,11 +686,10 @@ class _MainFieldRenderF(torch.autograd.Function):
             with prof.region("main_bwd_sem_kernel") if timed else contextlib.nullcontext():
                 field_bwd(1, None)
         dw = torch.empty_like(w)
+        # (+ the semantic branch's part and the losses that act on the weights directly -- distortion, line of sight -- added in the kernel)
+        ext = _f32(d_w_ext).contiguous() if d_w_ext is not None else None
         check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s), None, _p(d_rgb), _p(d_acc), None, _p(d_exp), R, S, SEM_DIM, _p(dw), None,
-                                     None, _stream()), "ps_composite_bwd")
-        dw.add_(dw_sem)
-        if d_w_ext is not None:
-            dw.add_(_f32(d_w_ext))  # losses that act on the weights directly (distortion, line of sight)
+                                     None, _p(dw_sem), _p(ext), _stream()), "ps_composite_bwd")
         dsig = torch.empty_like(sigma)
         check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
         with prof.region("main_field_bwd", extend=True):
@@ -1375,11 +1373,10 @@ class _MainFieldRenderMS(torch.autograd.Function):
         if d_exp is not None:
             d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
         dw = torch.empty_like(w)
+        ext = _f32(d_w_ext).contiguous() if d_w_ext is not None else None  # losses that act on the weights directly (distortion, line of sight)
         check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s) if d_rgb is not None else None,
                                      _p(sem_s) if d_sem is not None else None, _p(d_rgb), _p(d_acc), _p(d_sem), _p(d_exp), R, S,
-                                     SEM_DIM, _p(dw), None, None, _stream()), "ps_composite_bwd")
-        if d_w_ext is not None:
-            dw.add_(_f32(d_w_ext))
+                                     SEM_DIM, _p(dw), None, None, _p(ext), None, _stream()), "ps_composite_bwd")
         dsig = torch.empty_like(sigma)
         check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
         dapp, dtables, returned = _ms_main_backward(ctx, saved, dsig, d_rgb, d_sem, w)

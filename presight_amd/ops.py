@@ -509,7 +509,7 @@ class _Composite(torch.autograd.Function):
         check(lib().ps_composite_bwd(_p(weights), _p(ebins), _p(rgb_s) if d_rgb is not None else None,
                                      _p(sem_s) if d_sem is not None else None, _p(d_rgb), _p(d_acc), _p(d_sem), _p(d_exp), R, S,
                                      ctx.C, _p(dw), _p(d_rgb_s) if d_rgb is not None else None,
-                                     _p(d_sem_s) if d_sem is not None else None, _stream()), "ps_composite_bwd")
+                                     _p(d_sem_s) if d_sem is not None else None, None, None, _stream()), "ps_composite_bwd")
         if d_rgb is None and d_rgb_s is not None:
             d_rgb_s.zero_()
         if d_sem is None and d_sem_s is not None:
