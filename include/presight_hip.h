@@ -102,7 +102,8 @@ int ps_pdf_resample(const float* weights, const float* sbins, const float* jitte
 int ps_composite_fwd(const float* weights, const float* ebins, const float* rgb_s, const float* sem_s, int64_t R, int S,
                      int C, float threshold, float* rgb, float* acc, float* depth, float* exp_depth, float* sem,
                      float* minmax, void* stream);
-int ps_clip(float* v, int64_t n, const float* minmax, void* stream);
+int ps_clip(float* v, int64_t n, const float* minmax, float* keep /* nullable [n]: 1 where the value was inside the range, else 0 =
+                                                                     the clip's derivative for the backward */, void* stream);
 int ps_composite_bwd(const float* weights, const float* ebins, const float* rgb_s, const float* sem_s, const float* d_rgb,
                      const float* d_acc, const float* d_sem, const float* d_exp, int64_t R, int S, int C,
                      float* d_weights, float* d_rgb_s, float* d_sem_s,

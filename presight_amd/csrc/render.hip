@@ -427,9 +427,14 @@ __global__ __launch_bounds__(256) void midpoint_minmax_kernel(const float* __res
   }
 }
 
-__global__ void clip_kernel(float* __restrict__ v, int64_t n, const float* __restrict__ minmax) {
+__global__ void clip_kernel(float* __restrict__ v, int64_t n, const float* __restrict__ minmax, float* __restrict__ keep) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) v[i] = fminf(fmaxf(v[i], minmax[0]), minmax[1]);
+  if (i < n) {
+    const float x = v[i];
+    const float c = fminf(fmaxf(x, minmax[0]), minmax[1]);
+    v[i] = c;
+    if (keep != nullptr) keep[i] = (c == x) ? 1.0f : 0.0f;  // the clip's derivative (what `raw == clipped` gives)
+  }
 }
 
 // d_w[s] = sum_c rgb_s*d_rgb + sum_c sem_s*d_sem + d_acc + d_expdepth-terms ; d_rgb_s = w*d_rgb ; d_sem_s = w*d_sem
@@ -666,9 +671,9 @@ extern "C" int ps_composite_fwd(const float* weights, const float* ebins, const 
   PS_CHECK_LAUNCH();
 }
 
-extern "C" int ps_clip(float* v, int64_t n, const float* minmax, void* stream) {
+extern "C" int ps_clip(float* v, int64_t n, const float* minmax, float* keep, void* stream) {
   if (n == 0) return 0;
-  clip_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(v, n, minmax);
+  clip_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(v, n, minmax, keep);
   PS_CHECK_LAUNCH();
 }
 

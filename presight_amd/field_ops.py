@@ -498,8 +498,8 @@ class _MainFieldRender(torch.autograd.Function):
         check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), _p(sem_s), R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth),
                                      _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
         ops._apply_minmax_hook(minmax)
-        raw = expd.clone()
-        check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
+        raw = torch.empty_like(expd)  # 1 where the batch-global clip left the value alone (its derivative)
+        check(lib().ps_clip(_p(expd), R, _p(minmax), _p(raw), _stream()), "ps_clip")
         ctx.save_for_backward(*saved, ebins, sigma, w, rgb_s, sem_s, raw, expd)
         ctx.n_field_saved = len(saved)
         ctx.mark_non_differentiable(depth)
@@ -514,7 +514,7 @@ class _MainFieldRender(torch.autograd.Function):
         d_sem = _f32(d_sem) if d_sem is not None else None
         d_acc = _f32(d_acc) if d_acc is not None else None
         if d_exp is not None:
-            d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
+            d_exp = _f32(d_exp * raw)  # gradient of the batch-global clip
         dw = torch.empty_like(w)
         ext = _f32(d_w_ext).contiguous() if d_w_ext is not None else None  # losses that act on the weights directly (distortion, line of sight)
         check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s) if d_rgb is not None else None,
@@ -625,8 +625,8 @@ class _MainFieldRenderF(torch.autograd.Function):
         with prof.region("sem_out_fwd"):
             check(lib().ps_sem_out_fwd(_p(hid), _p(acc), _p(Ws2), _p(bs2), R, SEM_DIM, _p(sem), _stream()), "ps_sem_out_fwd")
         ops._apply_minmax_hook(minmax)
-        raw = expd.clone()
-        check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
+        raw = torch.empty_like(expd)  # 1 where the batch-global clip left the value alone (its derivative)
+        check(lib().ps_clip(_p(expd), R, _p(minmax), _p(raw), _stream()), "ps_clip")
         ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, raw, expd, hid, acc, Wm, bm)
         ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), spec)
         ctx.params = wb
@@ -664,7 +664,7 @@ class _MainFieldRenderF(torch.autograd.Function):
                                        _stream()), "ps_sem_out_bwd")
         d_acc = cray if d_acc is None else _f32(d_acc) + cray
         if d_exp is not None:
-            d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
+            d_exp = _f32(d_exp * raw)  # gradient of the batch-global clip
         pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
         check(lib().ps_main_field_f_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart), None,
                                           None, None), "ps_main_field_f_sizes")
@@ -1355,8 +1355,8 @@ class _MainFieldRenderMS(torch.autograd.Function):
         check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), _p(sem_s), R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth),
                                      _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
         ops._apply_minmax_hook(minmax)
-        raw = expd.clone()
-        check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
+        raw = torch.empty_like(expd)  # 1 where the batch-global clip left the value alone (its derivative)
+        check(lib().ps_clip(_p(expd), R, _p(minmax), _p(raw), _stream()), "ps_clip")
         ctx.save_for_backward(*saved, ebins, sigma, w, rgb_s, sem_s, raw, expd)
         ctx.n_field_saved = len(saved)
         ctx.mark_non_differentiable(depth)
@@ -1371,7 +1371,7 @@ class _MainFieldRenderMS(torch.autograd.Function):
         d_sem = _f32(d_sem) if d_sem is not None else None
         d_acc = _f32(d_acc) if d_acc is not None else None
         if d_exp is not None:
-            d_exp = _f32(d_exp * (raw == expd).float())  # gradient of the batch-global clip
+            d_exp = _f32(d_exp * raw)  # gradient of the batch-global clip
         dw = torch.empty_like(w)
         ext = _f32(d_w_ext).contiguous() if d_w_ext is not None else None  # losses that act on the weights directly (distortion, line of sight)
         check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s) if d_rgb is not None else None,

@@ -484,8 +484,8 @@ class _Composite(torch.autograd.Function):
         check(lib().ps_composite_fwd(_p(weights), _p(ebins), _p(rgb_s), _p(sem_s), R, S, C, threshold, _p(rgb), _p(acc), _p(depth),
                                      _p(expd), _p(sem), _p(minmax), _stream()), "ps_composite_fwd")
         _apply_minmax_hook(minmax)
-        raw = expd.clone()
-        check(lib().ps_clip(_p(expd), R, _p(minmax), _stream()), "ps_clip")
+        raw = torch.empty_like(expd)  # 1 where the batch-global clip left the value alone (its derivative)
+        check(lib().ps_clip(_p(expd), R, _p(minmax), _p(raw), _stream()), "ps_clip")
         ctx.save_for_backward(weights, ebins, rgb_s, sem_s, raw, expd)
         ctx.C = C
         ctx.mark_non_differentiable(depth)
@@ -502,7 +502,7 @@ class _Composite(torch.autograd.Function):
         d_sem = _f32(d_sem) if sem_s is not None and d_sem is not None else None
         d_acc = _f32(d_acc) if d_acc is not None else None
         if d_exp is not None:
-            d_exp = _f32(d_exp * (raw == expd).float())  # gradient of clip
+            d_exp = _f32(d_exp * raw)  # gradient of clip
         dw = torch.empty_like(weights)
         d_rgb_s = torch.empty_like(rgb_s) if (rgb_s is not None and ctx.needs_input_grad[2]) else None
         d_sem_s = torch.empty_like(sem_s) if (sem_s is not None and ctx.needs_input_grad[3]) else None
