@@ -24,19 +24,27 @@
 namespace {
 
 // W'[o][i] = sum_k W0[o][k] * We[k][i],  b'[o] = sum_k W0[o][k] * be[k] + b0[o];   W0 [O,K], We [K,I] (row stride we_ld), b' [O]
+// (both maps: every workgroup first copies the small matrices into LDS -- a thread per output walking 64 dependent global loads took
+//  24 / 44 us per launch for 64^3 MACs; the sums keep their order)
 __global__ __launch_bounds__(256) void merge_linear_fwd_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                                const float* __restrict__ We, const float* __restrict__ be, int O, int K,
                                                                int I, float* __restrict__ Wm, float* __restrict__ bm) {
+  extern __shared__ float ml_lds[];
+  float* sW0 = ml_lds;          // [O][K]
+  float* sWe = sW0 + O * K;     // [K][I]
+  for (int t = threadIdx.x; t < O * K; t += 256) sW0[t] = W0[t];
+  for (int t = threadIdx.x; t < K * I; t += 256) sWe[t] = We[t];
+  __syncthreads();
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < O * I) {
     const int o = idx / I, i = idx % I;
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s = fmaf(W0[o * K + k], We[k * I + i], s);
+    for (int k = 0; k < K; ++k) s = fmaf(sW0[o * K + k], sWe[k * I + i], s);
     Wm[idx] = s;
   } else if (idx < O * I + O) {
     const int o = idx - O * I;
     float s = b0[o];
-    for (int k = 0; k < K; ++k) s = fmaf(W0[o * K + k], be[k], s);
+    for (int k = 0; k < K; ++k) s = fmaf(sW0[o * K + k], be[k], s);
     bm[o] = s;
   }
 }
@@ -48,16 +56,24 @@ __global__ __launch_bounds__(256) void merge_linear_bwd_kernel(const float* __re
                                                                const float* __restrict__ be, int O, int K, int I,
                                                                float* __restrict__ dW0, float* __restrict__ db0,
                                                                float* __restrict__ dWe, float* __restrict__ dbe) {
+  extern __shared__ float ml_lds[];
+  float* sdWm = ml_lds;              // [O][I]
+  float* sW0 = sdWm + O * I;         // [O][K]
+  float* sWe = sW0 + O * K;          // [K][I + 1] (lanes walk k at a fixed i: the pad keeps them on different banks)
+  for (int t = threadIdx.x; t < O * I; t += 256) sdWm[t] = dWm[t];
+  for (int t = threadIdx.x; t < O * K; t += 256) sW0[t] = W0[t];
+  for (int t = threadIdx.x; t < K * I; t += 256) sWe[(t / I) * (I + 1) + t % I] = We[t];
+  __syncthreads();
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < O * K) {
     const int o = idx / K, k = idx % K;
     float s = dbm[o] * be[k];
-    for (int i = 0; i < I; ++i) s = fmaf(dWm[o * I + i], We[k * I + i], s);
+    for (int i = 0; i < I; ++i) s = fmaf(sdWm[o * I + i], sWe[k * (I + 1) + i], s);
     dW0[idx] += s;
   } else if (idx < O * K + K * I) {
     const int e = idx - O * K, k = e / I, i = e % I;
     float s = 0.f;
-    for (int o = 0; o < O; ++o) s = fmaf(W0[o * K + k], dWm[o * I + i], s);
+    for (int o = 0; o < O; ++o) s = fmaf(sW0[o * K + k], sdWm[o * I + i], s);
     dWe[e] += s;
   } else if (idx < O * K + K * I + O) {
     const int o = idx - O * K - K * I;
@@ -65,7 +81,7 @@ __global__ __launch_bounds__(256) void merge_linear_bwd_kernel(const float* __re
   } else if (idx < O * K + K * I + O + K) {
     const int k = idx - O * K - K * I - O;
     float s = 0.f;
-    for (int o = 0; o < O; ++o) s = fmaf(W0[o * K + k], dbm[o], s);
+    for (int o = 0; o < O; ++o) s = fmaf(sW0[o * K + k], dbm[o], s);
     dbe[k] += s;
   }
 }
@@ -307,15 +323,19 @@ extern "C" int ps_ray_colour_bwd(const float* dpart, const float* dirs, const fl
 extern "C" int ps_merge_linear_fwd(const float* W0, const float* b0, const float* We, const float* be, int O, int K, int I, float* Wm,
                                    float* bm, void* stream) {
   PS_REQUIRE(W0 && b0 && We && be && Wm && bm && O > 0 && K > 0 && I > 0, "ps_merge_linear_fwd: null argument");
-  merge_linear_fwd_kernel<<<(unsigned)((O * I + O + 255) / 256), 256, 0, (hipStream_t)stream>>>(W0, b0, We, be, O, K, I, Wm, bm);
+  PS_REQUIRE((size_t)(O * K + K * I) * 4 <= 60 * 1024, "ps_merge_linear_fwd: layers of at most ~85 x 85");
+  merge_linear_fwd_kernel<<<(unsigned)((O * I + O + 255) / 256), 256, (size_t)(O * K + K * I) * 4, (hipStream_t)stream>>>(W0, b0, We, be, O, K,
+                                                                                                                    I, Wm, bm);
   PS_CHECK_LAUNCH();
 }
 
 extern "C" int ps_merge_linear_bwd(const float* dWm, const float* dbm, const float* W0, const float* We, const float* be, int O, int K,
                                    int I, float* dW0, float* db0, float* dWe, float* dbe, void* stream) {
   PS_REQUIRE(dWm && dbm && W0 && We && be && dW0 && db0 && dWe && dbe, "ps_merge_linear_bwd: null argument");
-  merge_linear_bwd_kernel<<<(unsigned)((O * K + K * I + O + K + 255) / 256), 256, 0, (hipStream_t)stream>>>(dWm, dbm, W0, We, be, O, K, I, dW0,
-                                                                                                          db0, dWe, dbe);
+  const size_t lds = (size_t)(O * I + O * K + K * (I + 1)) * 4;
+  PS_REQUIRE(lds <= 60 * 1024, "ps_merge_linear_bwd: layers of at most ~70 x 70");
+  merge_linear_bwd_kernel<<<(unsigned)((O * K + K * I + O + K + 255) / 256), 256, lds, (hipStream_t)stream>>>(dWm, dbm, W0, We, be, O, K, I,
+                                                                                                           dW0, db0, dWe, dbe);
   PS_CHECK_LAUNCH();
 }
 
