@@ -26,9 +26,9 @@ namespace {
 // W'[o][i] = sum_k W0[o][k] * We[k][i],  b'[o] = sum_k W0[o][k] * be[k] + b0[o];   W0 [O,K], We [K,I] (row stride we_ld), b' [O]
 // (both maps: every workgroup first copies the small matrices into LDS -- a thread per output walking 64 dependent global loads took
 //  24 / 44 us per launch for 64^3 MACs; the sums keep their order)
-__global__ __launch_bounds__(256) void merge_linear_fwd_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
-                                                               const float* __restrict__ We, const float* __restrict__ be, int O, int K,
-                                                               int I, float* __restrict__ Wm, float* __restrict__ bm) {
+__device__ __forceinline__ void merge_linear_fwd_body(const float* __restrict__ W0, const float* __restrict__ b0,
+                                                      const float* __restrict__ We, const float* __restrict__ be, int O, int K, int I,
+                                                      float* __restrict__ Wm, float* __restrict__ bm) {
   extern __shared__ float ml_lds[];
   float* sW0 = ml_lds;          // [O][K]
   float* sWe = sW0 + O * K;     // [K][I]
@@ -51,11 +51,16 @@ __global__ __launch_bounds__(256) void merge_linear_fwd_kernel(const float* __re
 
 // dW0[o][k] += sum_i dWm[o][i] We[k][i] + dbm[o] be[k];  db0[o] += dbm[o];  dWe[k][i] += sum_o W0[o][k] dWm[o][i];
 // dbe[k] += sum_o W0[o][k] dbm[o]
-__global__ __launch_bounds__(256) void merge_linear_bwd_kernel(const float* __restrict__ dWm, const float* __restrict__ dbm,
-                                                               const float* __restrict__ W0, const float* __restrict__ We,
-                                                               const float* __restrict__ be, int O, int K, int I,
-                                                               float* __restrict__ dW0, float* __restrict__ db0,
-                                                               float* __restrict__ dWe, float* __restrict__ dbe) {
+__global__ __launch_bounds__(256) void merge_linear_fwd_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
+                                                               const float* __restrict__ We, const float* __restrict__ be, int O, int K,
+                                                               int I, float* __restrict__ Wm, float* __restrict__ bm) {
+  merge_linear_fwd_body(W0, b0, We, be, O, K, I, Wm, bm);
+}
+
+__device__ __forceinline__ void merge_linear_bwd_body(const float* __restrict__ dWm, const float* __restrict__ dbm,
+                                                      const float* __restrict__ W0, const float* __restrict__ We,
+                                                      const float* __restrict__ be, int O, int K, int I, float* __restrict__ dW0,
+                                                      float* __restrict__ db0, float* __restrict__ dWe, float* __restrict__ dbe) {
   extern __shared__ float ml_lds[];
   float* sdWm = ml_lds;              // [O][I]
   float* sW0 = sdWm + O * I;         // [O][K]
@@ -84,6 +89,14 @@ __global__ __launch_bounds__(256) void merge_linear_bwd_kernel(const float* __re
     for (int o = 0; o < O; ++o) s = fmaf(sW0[o * K + k], dbm[o], s);
     dbe[k] += s;
   }
+}
+
+__global__ __launch_bounds__(256) void merge_linear_bwd_kernel(const float* __restrict__ dWm, const float* __restrict__ dbm,
+                                                               const float* __restrict__ W0, const float* __restrict__ We,
+                                                               const float* __restrict__ be, int O, int K, int I,
+                                                               float* __restrict__ dW0, float* __restrict__ db0,
+                                                               float* __restrict__ dWe, float* __restrict__ dbe) {
+  merge_linear_bwd_body(dWm, dbm, W0, We, be, O, K, I, dW0, db0, dWe, dbe);
 }
 
 // sem[r][c] = sum_k H[r][k] W[c][k] + b[c] * acc[r]     (C = 64 outputs = one lane each, one wavefront per ray)
@@ -346,21 +359,8 @@ namespace {
 __global__ __launch_bounds__(256) void merge_linear_fwd_batch_kernel(const int64_t* __restrict__ ptrs, int O, int K, int I,
                                                                      float* __restrict__ Wm, float* __restrict__ bm) {
   const int64_t* row = ptrs + 4 * blockIdx.y;
-  const float *W0 = (const float*)row[0], *b0 = (const float*)row[1], *We = (const float*)row[2], *be = (const float*)row[3];
-  Wm += (size_t)blockIdx.y * O * I;
-  bm += (size_t)blockIdx.y * O;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < O * I) {
-    const int o = idx / I, i = idx % I;
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) s = fmaf(W0[o * K + k], We[k * I + i], s);
-    Wm[idx] = s;
-  } else if (idx < O * I + O) {
-    const int o = idx - O * I;
-    float s = b0[o];
-    for (int k = 0; k < K; ++k) s = fmaf(W0[o * K + k], be[k], s);
-    bm[o] = s;
-  }
+  merge_linear_fwd_body((const float*)row[0], (const float*)row[1], (const float*)row[2], (const float*)row[3], O, K, I,
+                        Wm + (size_t)blockIdx.y * O * I, bm + (size_t)blockIdx.y * O);
 }
 }  // namespace
 
@@ -368,44 +368,26 @@ namespace {
 __global__ __launch_bounds__(256) void merge_linear_bwd_batch_kernel(const int64_t* __restrict__ ptrs, const float* __restrict__ dWm,
                                                                      const float* __restrict__ dbm, int O, int K, int I) {
   const int64_t* row = ptrs + 7 * blockIdx.y;
-  const float *W0 = (const float*)row[0], *We = (const float*)row[1], *be = (const float*)row[2];
-  float *dW0 = (float*)row[3], *db0 = (float*)row[4], *dWe = (float*)row[5], *dbe = (float*)row[6];
-  dWm += (size_t)blockIdx.y * O * I;
-  dbm += (size_t)blockIdx.y * O;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < O * K) {
-    const int o = idx / K, k = idx % K;
-    float s = dbm[o] * be[k];
-    for (int i = 0; i < I; ++i) s = fmaf(dWm[o * I + i], We[k * I + i], s);
-    dW0[idx] += s;
-  } else if (idx < O * K + K * I) {
-    const int e = idx - O * K, k = e / I, i = e % I;
-    float s = 0.f;
-    for (int o = 0; o < O; ++o) s = fmaf(W0[o * K + k], dWm[o * I + i], s);
-    dWe[e] += s;
-  } else if (idx < O * K + K * I + O) {
-    const int o = idx - O * K - K * I;
-    db0[o] += dbm[o];
-  } else if (idx < O * K + K * I + O + K) {
-    const int k = idx - O * K - K * I - O;
-    float s = 0.f;
-    for (int o = 0; o < O; ++o) s = fmaf(W0[o * K + k], dbm[o], s);
-    dbe[k] += s;
-  }
+  merge_linear_bwd_body(dWm + (size_t)blockIdx.y * O * I, dbm + (size_t)blockIdx.y * O, (const float*)row[0], (const float*)row[1],
+                        (const float*)row[2], O, K, I, (float*)row[3], (float*)row[4], (float*)row[5], (float*)row[6]);
 }
 }  // namespace
 
 extern "C" int ps_merge_linear_bwd_batch(const int64_t* ptrs, int n_fields, const float* dWm, const float* dbm, int O, int K, int I,
                                          void* stream) {
   PS_REQUIRE(ptrs && dWm && dbm && n_fields > 0 && O > 0 && K > 0 && I > 0, "ps_merge_linear_bwd_batch: null argument");
-  merge_linear_bwd_batch_kernel<<<dim3((unsigned)((O * K + K * I + O + K + 255) / 256), (unsigned)n_fields), 256, 0, (hipStream_t)stream>>>(
+  const size_t lds = (size_t)(O * I + O * K + K * (I + 1)) * 4;
+  PS_REQUIRE(lds <= 60 * 1024, "ps_merge_linear_bwd_batch: layers of at most ~70 x 70");
+  merge_linear_bwd_batch_kernel<<<dim3((unsigned)((O * K + K * I + O + K + 255) / 256), (unsigned)n_fields), 256, lds, (hipStream_t)stream>>>(
       ptrs, dWm, dbm, O, K, I);
   PS_CHECK_LAUNCH();
 }
 
 extern "C" int ps_merge_linear_fwd_batch(const int64_t* ptrs, int n_fields, int O, int K, int I, float* Wm, float* bm, void* stream) {
   PS_REQUIRE(ptrs && Wm && bm && n_fields > 0 && O > 0 && K > 0 && I > 0, "ps_merge_linear_fwd_batch: null argument");
-  merge_linear_fwd_batch_kernel<<<dim3((unsigned)((O * I + O + 255) / 256), (unsigned)n_fields), 256, 0, (hipStream_t)stream>>>(ptrs, O, K, I, Wm, bm);
+  PS_REQUIRE((size_t)(O * K + K * I) * 4 <= 60 * 1024, "ps_merge_linear_fwd_batch: layers of at most ~85 x 85");
+  merge_linear_fwd_batch_kernel<<<dim3((unsigned)((O * I + O + 255) / 256), (unsigned)n_fields), 256, (size_t)(O * K + K * I) * 4,
+                                  (hipStream_t)stream>>>(ptrs, O, K, I, Wm, bm);
   PS_CHECK_LAUNCH();
 }
 
