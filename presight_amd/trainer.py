@@ -342,15 +342,17 @@ class Trainer:
             if not (ps._steps_since_update > ps.update_sched(ps._step) or ps._step < 10):
                 self.grads.skip_buckets(self._prop_buckets)
         self.opt.fused_armed = self.fused_table_adam  # table backward nodes of THIS backward pass apply their tables' Adam step
-        out = m(rb, jitters=list(batch["jitter"])) if "jitter" in batch else m(rb)  # stored draws: parity runs only
-        loss_dict = m.get_loss_dict(out, batch)
-        # one concat + one reduction instead of a chain of scalar adds; the loss scale enters as the seed of the backward pass
-        loss = torch.stack(list(loss_dict.values())).sum()
-        if self._seed is None or float(self._seed_value) != self.loss_scale:
-            self._seed = torch.full((), self.loss_scale, device=loss.device)
-            self._seed_value = self.loss_scale
-        loss.backward(gradient=self._seed)
-        self.opt.fused_armed = False
+        try:
+            out = m(rb, jitters=list(batch["jitter"])) if "jitter" in batch else m(rb)  # stored draws: parity runs only
+            loss_dict = m.get_loss_dict(out, batch)
+            # one concat + one reduction instead of a chain of scalar adds; the loss scale enters as the seed of the backward pass
+            loss = torch.stack(list(loss_dict.values())).sum()
+            if self._seed is None or float(self._seed_value) != self.loss_scale:
+                self._seed = torch.full((), self.loss_scale, device=loss.device)
+                self._seed_value = self.loss_scale
+            loss.backward(gradient=self._seed)
+        finally:
+            self.opt.fused_armed = False  # (also when the iteration raised: a later backward pass must not update anything)
         ops.join_side_streams()  # the proposal networks' backward ran on their side stream: the exchange / optimizer wait for it
         with prof.region("exchange_exposed"):
             self.grads.finish_exchange()
