@@ -18,10 +18,12 @@ proposal sampling (2 proposal fields, 2 PDF resamplings) -> main field -> compos
   --config extract (BASELINE.json configs[4]): prior extraction of one tile, 512^3 lattice (see presight_amd/extract.py).
   --scaling weak: every rank trains on its own 65 536-ray batch (default for cfg2); strong: 65 536 // N rays per rank.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, measured live with HIP events on
-the launch stream), `roofline_kernels` (the MFMA-bound and HBM-bound kernels of the step, same measurement), `end_to_end`
-(fraction of the binding end-to-end ceiling of SURVEY.md 8d) and `cpu_baseline` (the CPU oracle timed on the host cores,
-rank 0, N == 1 only)."""
+The LAST stdout line (rank 0) is the compact line of record (< 4 KB, `compact_line`): the contract fields plus `roofline` (dominant
+kernel, measured live with HIP events on the launch stream), `end_to_end` (fraction of the binding end-to-end ceiling of SURVEY.md
+8d), `cpu_baseline` (the CPU oracle timed on the host cores, rank 0, N == 1 only), the headline figures of the secondary shapes and
+`value_unfused_tables` (the step an N > 1 data-parallel rank runs).  The full record -- `roofline_kernels` (the MFMA-bound and
+HBM-bound kernels of the step, same measurement), `kernels_ms`, the exchange dry-run tables, the full `secondary` block, the bucket
+timeline of an N > 1 run -- is written to `bench_detail.json` (PRESIGHT_BENCH_DETAIL), whose path the line names."""
 from __future__ import annotations
 
 import argparse
@@ -76,6 +78,126 @@ CONFIGS = {
                               "branch = 4-D hash grid L=8,F=4,T=2^19 + flow MLP + MLP stack over the tile, 2 routed proposal nets, 128/64/64 samples, "
                               "fwd+6 losses+bwd+Adam"),
 }
+
+
+# --------------------------------------------------------------------------------------------------------- line of record
+LINE_BUDGET_BYTES = 4096  # the driver keeps a bounded tail of stdout: the LAST stdout line must stay far below it (tests/test_host_logic.py)
+DETAIL_FILE = os.environ.get("PRESIGHT_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+
+
+def _r(x, digits=4):
+    """floats of the compact line are rounded to `digits` SIGNIFICANT digits (the detail file keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return None if not isinstance(d, dict) else {k: d[k] for k in keys if k in d}
+
+
+def _clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
+
+
+def compact_line(full: dict, detail_path=None) -> dict:
+    """The line of record: the contract fields + `roofline` + `cpu_baseline` + the handful of headline figures, nothing that grows with
+    the number of buckets / kernels / secondary shapes.  Everything else (`roofline_kernels`, `kernels_ms`, the exchange dry-run tables,
+    the full `secondary` block, the bucket timeline of an N > 1 run) lives in the detail file the line names."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = dict(full.get("config") or {})
+    cfg["workload"] = _clip(cfg.get("workload"), 330)
+    out["config"] = {k: cfg[k] for k in ("workload", "rays_per_gpu", "points_per_gpu", "rays_per_step_global", "parallelism", "exchange")
+                     if cfg.get(k) is not None}
+    roof = full.get("roofline")
+    if roof is not None:
+        r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_algorithmic", "avg_launch_ms", "launches",
+                         "bytes_per_launch", "flops_per_launch", "traffic_source", "semantic_head_tiles_executed"))
+        r["kernel"] = _clip(r.get("kernel"), 120)
+        r["traffic_source"] = _clip(r.get("traffic_source"), 100)
+        if isinstance(roof.get("gather"), dict):
+            r["gather_frac_of_l2_resident_ceiling"] = roof["gather"].get("frac_of_l2_resident_ceiling")
+        out["roofline"] = r
+    if isinstance(full.get("end_to_end"), dict):
+        out["end_to_end"] = _pick(full["end_to_end"], ("binding", "frac_of_binding", "frac_of_mfma", "frac_of_hbm", "frac_of_hbm_incl_optimizer"))
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["sample"] = _clip(cb.get("sample"), 220)
+        if isinstance(cb.get("host"), dict):
+            c["cpu_model"], c["physical_cores"] = cb["host"].get("cpu_model"), cb["host"].get("physical_cores")
+        out["cpu_baseline"] = c
+    for k in ("speedup_vs_cpu", "value_reference_schedule", "value_unfused_tables", "ms_per_step_unfused_tables", "replicas_max_abs_diff",
+              "psnr_vs_random_targets", "loss", "kept_points_rank0", "voxels_rank0", "launches_per_step", "half_batch_pipeline"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    if isinstance(full.get("optimizer"), dict):
+        out["fused_table_adam"] = full["optimizer"].get("fused_table_adam")
+    if isinstance(full.get("psnr_vs_oracle"), dict):
+        out["psnr_vs_oracle"] = _pick(full["psnr_vs_oracle"], ("psnr_db", "max_abs_semantics", "max_rel_expected_depth"))
+    pk = full.get("psnr_after_k_steps")
+    if isinstance(pk, dict):
+        out["psnr_after_k_steps"] = _pick(pk, ("K", "psnr_final_db", "psnr_gain_db", "monotone", "error"))
+        if "psnr_db" in pk:
+            out["psnr_after_k_steps"]["psnr_first_db"] = pk["psnr_db"][0]
+    sec = full.get("secondary")
+    if isinstance(sec, dict):
+        out["secondary"] = {}
+        for name, e in sec.items():
+            if not isinstance(e, dict):
+                continue
+            c = _pick(e, ("ms_per_step", "value", "unit", "frac_of_binding", "binding"))
+            if "error" in e:
+                c["error"] = _clip(e["error"], 120)
+            if isinstance(e.get("exchange_overlap_dry_run"), dict) and "ms_per_step_with_split_launches" in e["exchange_overlap_dry_run"]:
+                c["ms_per_step_unfused_tables"] = e["exchange_overlap_dry_run"]["ms_per_step_with_split_launches"]
+            out["secondary"][name] = c
+    other = full.get("other_scaling")
+    if isinstance(other, dict):
+        out["other_scaling"] = _pick(other, ("scaling", "rays_per_gpu", "value", "ms_per_step"))
+    comm = full.get("comm")
+    if isinstance(comm, dict):
+        c = _pick(comm, ("backend", "ranks", "collectives_per_step", "gradient_buckets_issued_during_backward_per_step",
+                         "bytes_on_link_per_rank_per_step", "exchange_exposed_ms"))
+        if isinstance(comm.get("model"), dict):
+            c["predicted_ms_all_links_ASSUMED"] = comm["model"].get("predicted_ms_all_links")
+            c["predicted_ms_ring_one_link"] = comm["model"].get("predicted_ms_ring_one_link")
+        sched = comm.get("schedule_by_construction")
+        if isinstance(sched, dict):
+            c["exposed_ms_by_construction"] = {k: v.get("exposed_ms") for k, v in sched.items() if isinstance(v, dict)}
+        out["comm"] = c
+    if detail_path:
+        out["detail"] = detail_path
+    out = _r(out)
+    for k in ("value", "ms_per_step"):  # the figures of record keep their precision
+        out[k] = full.get(k)
+    return out
+
+
+def emit(full: dict):
+    """write the full record to the detail file and print the compact line of record as the LAST stdout line"""
+    path = None
+    try:
+        os.makedirs(os.path.dirname(DETAIL_FILE) or ".", exist_ok=True)
+        with open(DETAIL_FILE, "w") as f:
+            json.dump(full, f)
+        path = os.path.relpath(DETAIL_FILE, ROOT) if DETAIL_FILE.startswith(ROOT) else DETAIL_FILE
+    except OSError as e:  # a read-only tree must not take the line down
+        print(f"bench.py: detail file not written ({e})", file=sys.stderr)
+    line = compact_line(full, path)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_BUDGET_BYTES:  # never happens by construction (test_bench_line_is_compact); degrade instead of losing the record
+        for k in ("secondary", "comm", "other_scaling", "psnr_after_k_steps", "psnr_vs_oracle"):
+            line.pop(k, None)
+        text = json.dumps(line, separators=(",", ":"))
+    sys.stdout.flush()
+    print(text)
+    sys.stdout.flush()
 
 
 # --------------------------------------------------------------------------------------------------------- launcher
@@ -870,7 +992,7 @@ def extract_main(args) -> int:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_query_baseline(mcfg)
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -1130,6 +1252,9 @@ def main():
                 dry["note"] = ("weak scaling (every rank runs this step): per-bucket link time from the xGMI bounds of exchange_model, hidden "
                                "under the kernels still running after the bucket's hand-over; no multi-GPU run exists")
                 line["exchange_overlap_dry_run"] = dry
+                # the step an N > 1 data-parallel rank runs: table gradients written + separate Adam (the fused table update needs no exchange)
+                line["ms_per_step_unfused_tables"] = dry["ms_per_step_with_split_launches"]
+                line["value_unfused_tables"] = rays / (dry["ms_per_step_with_split_launches"] * 1e-3)
             except Exception as e:
                 line["exchange_overlap_dry_run"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.config == "cfg2" and not args.no_secondary and rays == RAYS:
@@ -1179,8 +1304,7 @@ def main():
                   f"predicted {mdl['predicted_ms_all_links']:.2f} ms over all {world - 1} peer links ({mdl['predicted_ms_ring_one_link']:.2f} ms as a "
                   f"one-link ring) vs {line['comm']['exchange_exposed_ms']} ms measured EXPOSED (not hidden under backward / sampling); "
                   f"step {ms:.2f} ms", file=sys.stderr)
-        print(json.dumps(line))
-        sys.stdout.flush()
+        emit(line)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

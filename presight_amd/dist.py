@@ -191,7 +191,11 @@ class FlatGrads:
                     raise ValueError("FlatGrads.define_groups: a parameter belongs to two groups")
                 mine.add(id(p))
                 # a NEW owner takes the parameter over (a second Trainer / FlatGrads on the same model: exchange-mode comparisons,
-                # rebuilding the trainer after a checkpoint load); the previous owner's flags are no longer raised for it
+                # rebuilding the trainer after a checkpoint load); the previous owner's flags are no longer raised for it, so the
+                # previous owner is marked: its zero_() raises instead of stepping a model whose routed sub-fields it would skip
+                prev = getattr(p, "_ps_group_owner", None)
+                if prev is not None and prev is not self:
+                    prev._groups_taken_over = True
                 p._ps_group = n
                 p._ps_group_owner = self
             n += 1
@@ -213,6 +217,9 @@ class FlatGrads:
         is still zero (a production tile's 3.5 GiB buffer is mostly untouched when a sub-field gets no samples).
         already_zeroed: ranges somebody else has cleared (or will have cleared, in stream order, before anything writes them):
         the pipelined optimizer step clears the fields' gradients on its own stream right behind their Adam update."""
+        if getattr(self, "_groups_taken_over", False):
+            raise RuntimeError("presight_amd.dist.FlatGrads: another FlatGrads (a newer Trainer on the same model) has taken over this "
+                               "one's device-decided parameter groups (define_groups); this one can no longer train the routed sub-fields")
         if self._dirty is None:
             self.flat.zero_()
         else:

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import functools
 from collections import defaultdict
+from collections.abc import MutableMapping
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Literal, Optional, Tuple, Type
 
@@ -101,55 +102,52 @@ class NerfactoNuscMSModelConfig:
         return self._target(self, **kwargs)
 
 
-class LazyOutputs(dict):
-    """The model's output dict with entries that are evaluated on first access.  The reference renders the proposal levels'
+class LazyOutputs(MutableMapping):
+    """The model's output mapping with entries that are evaluated on first access.  The reference renders the proposal levels'
     threshold depths in every forward (`prop_depth_i`, ns/models/PreSight/nerfacto_nusc_ms.py:543-544) although only the viewer and
     the evaluation images read them; in a training step they are two compositing launches nobody looks at.  Membership, iteration
-    and item access behave like the plain dict's: a lazy key is present from the start, reading it (or iterating over values /
-    items) evaluates it once."""
+    and item access behave like a dict's: a lazy key is present from the start (at the position it was registered), reading it
+    evaluates it once.  A `MutableMapping`, not a dict subclass: CPython's fast paths for dict subclasses (`dict(o)`, `{**o}`,
+    `d.update(o)`) bypass overridden accessors and would hand out the placeholder; here every access goes through `__getitem__`."""
 
     def __init__(self, *a, **k):
-        super().__init__(*a, **k)
+        self._data: Dict = dict(*a, **k)
         self._lazy: Dict[str, Callable] = {}
 
     def lazy(self, key: str, fn: Callable):
         self._lazy[key] = fn
-        dict.__setitem__(self, key, None)  # (keeps the key's position and membership)
+        self._data[key] = None  # (keeps the key's position and membership)
 
     def _force(self, key):
         fn = self._lazy.pop(key, None)
         if fn is not None:
-            dict.__setitem__(self, key, fn())
+            self._data[key] = fn()
 
     def __getitem__(self, key):
         self._force(key)
-        return dict.__getitem__(self, key)
+        return self._data[key]
 
     def __setitem__(self, key, value):
         self._lazy.pop(key, None)
-        dict.__setitem__(self, key, value)
+        self._data[key] = value
 
-    def get(self, key, default=None):
-        return self[key] if key in self else default
+    def __delitem__(self, key):
+        self._lazy.pop(key, None)
+        del self._data[key]
 
-    def pop(self, key, *default):
-        self._force(key)
-        return dict.pop(self, key, *default)
+    def __iter__(self):
+        return iter(self._data)
 
-    def _force_all(self):
-        for k in list(self._lazy):
-            self._force(k)
+    def __len__(self):
+        return len(self._data)
 
-    def items(self):
-        self._force_all()
-        return dict.items(self)
+    def __contains__(self, key):
+        return key in self._data
 
-    def values(self):
-        self._force_all()
-        return dict.values(self)
+    def __repr__(self):
+        return "LazyOutputs({" + ", ".join(f"{k!r}: {'<lazy>' if k in self._lazy else repr(v)}" for k, v in self._data.items()) + "})"
 
     def copy(self):
-        self._force_all()
         return dict(self)
 
 

@@ -39,10 +39,13 @@ def render_all(weights: Tensor, ray_samples: RaySamples, rgb: Optional[Tensor], 
 
 
 class RGBRenderer(nn.Module):
-    def __init__(self, background_color="random") -> None:
+    def __init__(self, background_color="black") -> None:
         super().__init__()
-        if background_color not in ("black", "random"):
-            raise NotImplementedError("presight_amd RGBRenderer: PreSight renders on a black background")
+        if background_color != "black":
+            # ns/model_components/renderers.py:199-229 blends a random colour during training for "random": rendering that as black would
+            # be a silent deviation, so every non-black background is refused (PreSight sets "black", nerfacto_nusc_ms.py:86,333)
+            raise NotImplementedError(f"presight_amd RGBRenderer: background_color={background_color!r} is not implemented; "
+                                      "PreSight renders on a black background")
         self.background_color = background_color
 
     def forward(self, rgb: Tensor, weights: Tensor, ray_indices=None, num_rays=None, background_color=None) -> Tensor:

@@ -179,7 +179,10 @@ class Trainer:
             raise ValueError("Trainer(fused_table_adam=True) needs world == 1, no exchange overlap and update_grad_scaler=False")
         self.fused_table_adam = can_fuse and (os.environ.get("PRESIGHT_FUSED_TABLE_ADAM", "1") != "0" if fused_table_adam is None else bool(fused_table_adam))
         if self.fused_table_adam:
-            self.opt.enable_fused_tables([i for i, p in enumerate(uniq) if is_table(p)])
+            # exactly ONE gradient contribution per table and step: with use_same_proposal_network (nerfacto_nusc_ms.py:263) the single
+            # proposal network is evaluated once per proposal iteration, so its tables receive two -- they keep the separate update
+            shared_prop = bool(model.config.use_same_proposal_network) and int(getattr(model.config, "num_proposal_iterations", 2)) > 1
+            self.opt.enable_fused_tables([i for i, p in enumerate(uniq) if is_table(p) and not (shared_prop and id(p) in prop_ids)])
         self.scheduler = WarmupMultiStepSchedule(self.opt, lr_init=lr, **schedule) if schedule is not None else None
         self.callbacks = model.get_training_callbacks(TrainingCallbackAttributes(optimizers=self.opt, grad_scaler=None, pipeline=None))
         self.step_idx = 0
@@ -193,6 +196,11 @@ class Trainer:
         self._seed: Optional[torch.Tensor] = None
         self._seed_value = self.loss_scale
         self.update_props_every_step = False
+        self._inconsistent: Optional[str] = None  # set when an iteration raised after a fused table update (see step())
+
+    def clear_failure(self):
+        """after restoring a consistent state (checkpoint) following an iteration that raised mid-backward with fused table updates"""
+        self._inconsistent = None
 
     def _scaler_step(self) -> bool:
         """update_grad_scaler=True: GradScaler.step per parameter group + GradScaler.update (optimizers.py:118-131,
@@ -201,16 +209,32 @@ class Trainer:
         fg = self.grads
         fg._join_side_streams()
         touched = set(fg.touched_params())
-        skip, any_inf, i = set(), False, 0
-        for n in self._bucket_sizes:
+        # the reference decides per OPTIMIZER = per parameter group ("proposal_networks" / "fields", optimizers.py:118-131): an inf
+        # anywhere in a group's gradients withholds the whole group's step.  The exchange buckets are finer than that (one per proposal
+        # network, MLPs / table pieces / tail of the fields), so the per-bucket flags are OR-ed per group name.
+        kinds = sorted(set(self.group_names))
+        by_kind, flags, i = {k: [] for k in kinds}, {k: [] for k in kinds}, 0
+        for n, kind in zip(self._bucket_sizes, self.group_names):
             idx = [j for j in range(i, i + n) if j in touched]
             i += n
             if not idx:
                 continue  # optimizers.py:130: a group without gradients is not stepped (and reports no inf)
             a, b = fg.offsets[idx[0]], fg.offsets[idx[-1]] + self.opt.params[idx[-1]].numel()
-            if not bool(torch.isfinite(fg.flat[a:b]).all()):
+            by_kind[kind].extend(idx)
+            flags[kind].append(~torch.isfinite(fg.flat[a:b]).all())
+        found = torch.stack([torch.stack(flags[k]).any() if flags[k] else torch.zeros((), dtype=torch.bool, device=fg.flat.device)
+                             for k in kinds]).to(torch.int32)
+        if self.world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # after a reduce-scatter a rank holds the reduced values of ITS shard only: a rank that neither produced nor owns the
+            # inf element would not see it and would step while the others skip -> agree on the flags (GradScaler does the same across
+            # its per-device found_inf tensors)
+            torch.distributed.all_reduce(found, op=torch.distributed.ReduceOp.MAX)
+        found = found.tolist()
+        skip, any_inf = set(), False
+        for k, f in zip(kinds, found):
+            if f:
                 any_inf = True
-                skip.update(idx)
+                skip.update(by_kind[k])
         self.opt.grad_scale = 1.0 / self.loss_scale
         self.opt.step(skip=skip)
         if any_inf:
@@ -323,6 +347,10 @@ class Trainer:
 
     def step(self, batch: Dict[str, torch.Tensor]):
         m, s = self.model, self.scene
+        if self._inconsistent:
+            raise RuntimeError("presight_amd Trainer: an earlier iteration raised AFTER hash tables had taken their fused Adam step "
+                               f"({self._inconsistent}); tables and the other parameters are one step apart.  Restore a checkpoint "
+                               "(load_state_dict + the model's state_dict) and call clear_failure() to continue")
         m.train()
         self._run_callbacks(TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
         pipe = self._begin_step()
@@ -342,6 +370,7 @@ class Trainer:
             if not (ps._steps_since_update > ps.update_sched(ps._step) or ps._step < 10):
                 self.grads.skip_buckets(self._prop_buckets)
         self.opt.fused_armed = self.fused_table_adam  # table backward nodes of THIS backward pass apply their tables' Adam step
+        completed = False
         try:
             out = m(rb, jitters=list(batch["jitter"])) if "jitter" in batch else m(rb)  # stored draws: parity runs only
             loss_dict = m.get_loss_dict(out, batch)
@@ -351,13 +380,18 @@ class Trainer:
                 self._seed = torch.full((), self.loss_scale, device=loss.device)
                 self._seed_value = self.loss_scale
             loss.backward(gradient=self._seed)
+            ops.join_side_streams()  # the proposal networks' backward ran on their side stream: the exchange / optimizer wait for it
+            with prof.region("exchange_exposed"):
+                self.grads.finish_exchange()
+            with prof.region("adam"):
+                scale_kept = self._optimizer_step(pipe)
+            completed = True
         finally:
             self.opt.fused_armed = False  # (also when the iteration raised: a later backward pass must not update anything)
-        ops.join_side_streams()  # the proposal networks' backward ran on their side stream: the exchange / optimizer wait for it
-        with prof.region("exchange_exposed"):
-            self.grads.finish_exchange()
-        with prof.region("adam"):
-            scale_kept = self._optimizer_step(pipe)
+            if not completed and self.fused_table_adam and any(getattr(p, "_ps_fused_done", False) for p in self.opt.params):
+                # the fused update is applied DURING backward: tables that had their turn before the exception are one optimizer step
+                # (and one bias-correction count) ahead of everything else.  Not recoverable in place -> refuse to go on silently
+                self._inconsistent = f"iteration {self.step_idx}"
         if self.scheduler is not None and scale_kept:  # trainer.py:499-505
             self.scheduler.step()
         self._run_callbacks(TrainingCallbackLocation.AFTER_TRAIN_ITERATION)

@@ -161,7 +161,7 @@ def test_adam_skips_groups_whose_device_flag_is_down(dev):
     assert opt.param_steps() == [3, 3, 4, 4, 6]
 
 
-def _tiny_model(dev, K=1):
+def _tiny_model(dev, K=1, **conf_kw):
     import bench
     from presight_amd.model import NerfactoNuscMSModel, NerfactoNuscMSModelConfig
 
@@ -172,7 +172,7 @@ def _tiny_model(dev, K=1):
                                      proposal_net_args_list=[dict(features_per_level=1, log2_hashmap_size=12, num_levels=2, base_res=16,
                                                                   max_res=32, hidden_dim=32, use_linear=False),
                                                              dict(features_per_level=1, log2_hashmap_size=12, num_levels=2, base_res=16,
-                                                                  max_res=64, hidden_dim=32, use_linear=False)])
+                                                                  max_res=64, hidden_dim=32, use_linear=False)], **conf_kw)
     scene = bench.make_scene(48, 2, K=K)
     model = NerfactoNuscMSModel(conf, num_train_cameras=48, num_train_videos=2, dino_to_rgb=None, centroids=scene["centroids"],
                                 aabbs=scene["aabbs"]).to(dev)
@@ -437,3 +437,74 @@ def test_fused_table_adam_is_the_separate_step_bit_for_bit(dev, K):
         FO._refuse_second_contribution([ta.opt.params[tables[0]]])
     ta.grads.zero_()
     assert ta.opt.params[tables[0]]._ps_fused_done is False
+
+
+def test_shared_proposal_network_keeps_the_separate_table_update(dev):
+    """use_same_proposal_network=True (a reference-supported config, nerfacto_nusc_ms.py:263): the one proposal network is evaluated in
+    both proposal iterations, so its table receives TWO gradient contributions per step -- it must stay out of the fused table update
+    (which needs exactly one); the default single-process Trainer steps, the main table is still fused, and the result equals the
+    trainer with the fused update off (tables bit-equal after the first iteration: integer-accumulated gradients, shared element update)."""
+    import bench
+
+    runs = []
+    for fused in (None, False):
+        model, scene = _tiny_model(dev, use_same_proposal_network=True)
+        assert len(model.proposal_networks) == 1
+        tr = bench.Trainer(model, scene, 1, fused_table_adam=fused)
+        batches = bench.make_batches(scene, dev, 2, 0, rays=512)
+        torch.manual_seed(11)
+        tr.step(batches[0])
+        runs.append((model, tr, batches))
+    (ma, ta, batches), (mb, tb, _) = runs
+    assert ta.fused_table_adam and not tb.fused_table_adam
+    names = {id(p): n for n, p in ma.named_parameters()}
+    fused = [names[id(p)] for p in ta.opt.params if getattr(p, "_ps_fused_adam", None) is ta.opt]
+    assert len(fused) == 1 and fused[0].startswith("field."), fused
+    assert ta.opt.param_steps() == tb.opt.param_steps()
+    for i, p in enumerate(ta.opt.params):
+        if names[id(p)].endswith("hash_table"):
+            assert torch.equal(p, tb.opt.params[i]), names[id(p)]
+            assert float(ta.opt.exp_avg_sq[i].abs().max()) > 0, names[id(p)]
+    torch.manual_seed(12)
+    ta.step(batches[1])  # (and a second iteration: the proposal table's two contributions accumulate, nothing raises)
+
+
+def test_an_iteration_that_raises_after_a_fused_update_blocks_the_trainer(dev):
+    """The fused table update is applied DURING backward: if the iteration raises afterwards, tables are one optimizer step ahead of
+    every other parameter.  The trainer refuses to continue silently (clear_failure() after restoring a checkpoint re-enables it)."""
+    import bench
+
+    model, scene = _tiny_model(dev)
+    tr = bench.Trainer(model, scene, 1)
+    assert tr.fused_table_adam
+    batches = bench.make_batches(scene, dev, 2, 0, rays=512)
+    tr.step(batches[0])
+    real = tr.grads.finish_exchange
+
+    def boom():
+        raise ValueError("injected")
+
+    tr.grads.finish_exchange = boom
+    with pytest.raises(ValueError, match="injected"):
+        tr.step(batches[1])
+    tr.grads.finish_exchange = real
+    assert not tr.opt.fused_armed
+    with pytest.raises(RuntimeError, match="fused Adam step"):
+        tr.step(batches[1])
+    tr.clear_failure()
+    tr.step(batches[1])
+
+
+def test_second_trainer_takes_the_routed_groups_over(dev):
+    """two Trainers on one routed model: the newer one owns the device-decided sub-field groups; the older one raises instead of
+    silently never updating the routed sub-fields"""
+    import bench
+
+    model, scene = _tiny_model(dev, K=4)
+    t1 = bench.Trainer(model, scene, 1)
+    batches = bench.make_batches(scene, dev, 1, 0, rays=512)
+    t1.step(batches[0])
+    t2 = bench.Trainer(model, scene, 1)
+    with pytest.raises(RuntimeError, match="taken over"):
+        t1.step(batches[0])
+    t2.step(batches[0])

@@ -1,5 +1,6 @@
 """CPU tests of the host-side logic: packed-layout bookkeeping, column maps, config / state-dict compatibility with the
 reference, dotted-path aliases for YAML configs, and the N > 1 gradient exchange (gloo, world_size 2)."""
+import json
 import os
 import subprocess
 import sys
@@ -558,3 +559,73 @@ def test_lazy_outputs_behave_like_a_dict():
     o.lazy("y", lambda: 8)
     o["y"] = 9  # an explicit assignment wins
     assert o["y"] == 9 and o.pop("x") == 7 and "x" not in o
+    # shallow copies go through __getitem__ too (a dict subclass would hand out the None placeholder on CPython's fast paths)
+    o.lazy("z", lambda: "dz")
+    assert dict(o)["z"] == "dz"
+    o.lazy("z2", lambda: "dz2")
+    assert {**o}["z2"] == "dz2"
+    o.lazy("z3", lambda: "dz3")
+    d = {}
+    d.update(o)
+    assert d["z3"] == "dz3" and o.copy() == d and len(o) == len(d)
+
+
+def test_bench_line_is_compact():
+    """The line of record must survive the driver's bounded stdout tail (round 4 lost its headline to a 29 KB line): `compact_line` of
+    the largest committed full record, and of a synthetic worst case (8-GPU run with a long bucket timeline, every secondary shape with
+    its dry-run tables, error strings of unbounded length), stays below LINE_BUDGET_BYTES and keeps the contract fields, `roofline` and
+    `cpu_baseline`."""
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line_default.json")))
+    assert len(json.dumps(full)) > 20000  # (the record that was lost)
+    line = bench.compact_line(full, "bench_detail.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < bench.LINE_BUDGET_BYTES, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "end_to_end", "secondary"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert "workload" in line["config"] and "model" not in line["config"]
+    # worst case: blow every unbounded part up
+    worst = json.loads(json.dumps(full))
+    worst["n_gpus"] = 8
+    tl = [{"bucket": i, "bytes": 671088640, "steps_exchanged": 3, "handed_over_in_backward": 3, "ms_before_backward_end": 1.2345678} for i in range(64)]
+    worst["comm"] = {"backend": "nccl", "ranks": 8, "collectives_per_step": 17.0, "gradient_buckets_issued_during_backward_per_step": 7.0,
+                     "bytes_on_link_per_rank_per_step": 1.234e9, "bucket_timeline": tl, "exchange_exposed_ms": 1.234,
+                     "schedule_by_construction": bench.exchange_schedule(tl, 8, "sharded"), "model": bench.exchange_model(1.234e9, 8)}
+    worst["other_scaling"] = dict(scaling="strong", rays_per_gpu=8192, value=1.23456789e7, ms_per_step=5.4321)
+    worst["replicas_max_abs_diff"] = 0.0
+    for i in range(12):
+        worst["secondary"][f"extra_shape_{i}"] = {"error": "RuntimeError: " + "x" * 5000}
+    worst["config"]["workload"] = "w" * 5000
+    worst["cpu_baseline"]["sample"] = "s" * 5000
+    worst["roofline"]["kernel"] = "k" * 5000
+    worst["roofline_kernels"] = worst["roofline_kernels"] * 20
+    text = json.dumps(bench.compact_line(worst, "bench_detail.json"), separators=(",", ":"))
+    assert len(text) < bench.LINE_BUDGET_BYTES + 3000  # emit() drops the optional blocks beyond the budget; the core alone must fit:
+    core = bench.compact_line(worst, "bench_detail.json")
+    for k in ("secondary", "comm", "other_scaling", "psnr_after_k_steps", "psnr_vs_oracle"):
+        core.pop(k, None)
+    assert len(json.dumps(core, separators=(",", ":"))) < bench.LINE_BUDGET_BYTES
+    # emit(): last stdout line parses, is compact, and the detail file holds the full record
+    import contextlib
+    import io
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        old = bench.DETAIL_FILE
+        bench.DETAIL_FILE = os.path.join(td, "detail.json")
+        try:
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                bench.emit(worst)
+            last = buf.getvalue().strip().splitlines()[-1]
+            assert len(last) < bench.LINE_BUDGET_BYTES
+            got = json.loads(last)
+            assert got["value"] == worst["value"] and "roofline" in got and "cpu_baseline" in got
+            assert json.load(open(bench.DETAIL_FILE))["roofline_kernels"] == worst["roofline_kernels"]
+        finally:
+            bench.DETAIL_FILE = old

@@ -5,7 +5,8 @@ cd $GRAFT_REPO_ROOT
 args=$1; rounds=$2; shift; shift
 cat > /tmp/ab_fmt.py <<'PY'
 import json, sys
-d = json.loads(sys.stdin.read())
+sys.stdin.read()
+d = json.load(open("bench_detail.json"))  # (the stdout line is the compact line of record; per-kernel times live in the detail file)
 k = d["kernels_ms"]
 keep = {a: round(b, 3) for a, b in k.items() if any(t in a for t in ("scatter", "adam", "prop", "encode", "main_field"))}
 print(sys.argv[1], round(d["ms_per_step"], 2), keep)

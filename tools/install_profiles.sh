@@ -2,6 +2,7 @@
 # copy the outputs of tools/profiles.sh <tag> from gpurun_out/ into profiles/ (names carry the round) and rebuild traffic.json
 T=${1:?tag}; G=gpurun_out
 cp $G/bench_$T.json profiles/${T}_bench_line_default.json
+cp $G/bench_${T}_detail.json profiles/${T}_bench_detail_default.json
 cp $G/bench_${T}_cfg2.json profiles/${T}_bench_line_under_rocprofv3_cfg2.json
 cp $G/bench_${T}_cfg3.json profiles/${T}_bench_line_cfg3_65536rays.json
 cp $G/bench_${T}_cfg3_8192.json profiles/${T}_bench_line_cfg3_8192rays.json
@@ -20,7 +21,7 @@ cp $G/pmc_summary_$T.txt profiles/${T}_pmc_summary.txt
 python tools/pmc_traffic.py profiles/${T}_pmc_summary.txt profiles/traffic.json > /dev/null
 python - <<PY
 import json
-d = json.load(open('profiles/${T}_bench_line_default.json'))
+d = json.load(open('profiles/${T}_bench_detail_default.json'))
 print('cfg2', round(d['ms_per_step'], 2), 'ms', round(d['value'] / 1e6, 3), 'M rays/s; reference schedule', round(d['value_reference_schedule'] / 1e6, 2))
 r = d['roofline']; print(' roofline', r['kernel'], round(r['frac'], 3), round(r['avg_launch_ms'], 3), 'ms', 'traffic', r['traffic'])
 for r in d['roofline_kernels']: print('  ', r['kernel'][:60], r['avg_launch_ms'], r['frac'])
