@@ -313,3 +313,33 @@ def learnable_scene_setup(rays: int = 192, steps: int = 40, test_rays: int = 384
         return b
 
     return cfg, scene, Pt, [batch(s, rays) for s in range(steps)], batch(9999, test_rays), O.make_params(cfg, seed=3)
+
+
+def checkpoint_from_fixture(G):
+    """tests/golden/checkpoint.npz -> the dict the REFERENCE's Trainer.save_checkpoint wrote (ns/engine/trainer.py:432-460): "step",
+    "pipeline" (`_model.`-prefixed tensors), "optimizers" (one torch.optim.Adam.state_dict per parameter group), "schedulers" (one
+    ChainedScheduler.state_dict per group), "scalers"; plus the fixture's meta record (parameter names per group, sampler counters)"""
+    import collections
+    import json
+
+    meta = json.loads(str(G["meta_json"]))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).reshape(a.shape)  # noqa: E731  (0-d buffers / step counts stay 0-d)
+
+    def unjson(x):
+        if isinstance(x, dict):
+            if set(x) == {"__counter__"}:
+                return collections.Counter({int(k): int(v) for k, v in x["__counter__"].items()})
+            return {k: unjson(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [unjson(v) for v in x]
+        return x
+
+    ckpt = {"step": int(meta["step"]), "pipeline": collections.OrderedDict((k, t(G["P::" + k])) for k in meta["pipeline_keys"]),
+            "optimizers": {}, "schedulers": unjson(meta["schedulers"]), "scalers": unjson(meta["scalers"])}
+    for g, rec in meta["optimizers"].items():
+        pgs = unjson(rec["param_groups"])
+        for pg in pgs:
+            pg["betas"] = tuple(pg["betas"])
+        ckpt["optimizers"][g] = {"state": {i: {k: t(G[f"O::{g}::{i}::{k}"]) for k in ("step", "exp_avg", "exp_avg_sq")} for i in rec["state_indices"]},
+                                 "param_groups": pgs}
+    return ckpt, meta

@@ -666,8 +666,10 @@ def traj_setup():
     return cfg, scene, P
 
 
-def gold_model_traj():
-    """N training iterations of the REFERENCE: its NerfactoNuscMSModel (K = 3), its own training callbacks (anneal + proposal
+def gold_model_traj(stop_after=None, on_stop=None):
+    """(stop_after / on_stop: gold_checkpoint re-runs the first iterations of this very loop and takes the reference's objects over
+    at the point where its Trainer would write a checkpoint; nothing is saved then.)
+    N training iterations of the REFERENCE: its NerfactoNuscMSModel (K = 3), its own training callbacks (anneal + proposal
     update schedule, nerfacto_nusc_ms.py:417-450), its Optimizers object (one torch.optim.Adam(lr 1e-2, eps 1e-15, wd 1e-5) and one
     WarmupMultiStepScheduler per parameter group, method_configs.py:158-168 with max_iterations = 60) driven exactly as
     Trainer.train_iteration does for PreSight's default update_grad_scaler=False (ns/engine/trainer.py:463-505):
@@ -736,6 +738,8 @@ def gold_model_traj():
         updated.append(int(any(named[k].grad is not None for k in keys if k.startswith("proposal_networks."))))
         if step in (11, N_STEPS - 1):
             snaps[step] = {k: v.detach().clone() for k, v in model.state_dict().items() if k in P}
+        if stop_after is not None and step == stop_after:
+            return on_stop(model=model, optimizers=optimizers, cfg=cfg, scene=scene, P=P, step=step, batches=batches, name_of=name_of)
     touched = np.array(touched, dtype=np.int8)
     updated = np.array(updated, dtype=np.int8)
     # what this fixture is for: off-schedule proposal steps and sub-fields without samples must actually occur
@@ -766,12 +770,135 @@ def gold_model_traj():
     save("model_traj", **arrs)
 
 
+def _jsonable(x):
+    """optimizer / scheduler state without tensors -> plain JSON (Counter and tuple become dict / list; integer keys become strings)"""
+    import collections
+
+    if isinstance(x, collections.Counter):
+        return {"__counter__": {str(k): int(v) for k, v in x.items()}}
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if isinstance(x, torch.Tensor):
+        return x.item() if x.numel() == 1 else x.tolist()
+    return x
+
+
+def gold_checkpoint():
+    """What the reference's Trainer.save_checkpoint (ns/engine/trainer.py:432-460) writes after iteration 11 of the trajectory run of
+    gold_model_traj -- {"step", "pipeline", "optimizers", "schedulers", "scalers"} with the pipeline's `_model.`-prefixed keys (a module
+    with the model as its `_model` child, like VanillaPipeline; the data manager's camera optimizer is "off" for PreSight and
+    contributes no key: checked below), one torch.optim.Adam state_dict and one ChainedScheduler state_dict per parameter group --
+    flattened into arrays + one JSON string, and the body of the extraction frame loop (ns/scripts/extract_priors.py:108-145) run on the
+    model AS RESTORED FROM THAT CHECKPOINT through the reference's own load path (Pipeline.load_pipeline,
+    ns/pipelines/base_pipeline.py:426-437).  model_traj.npz holds how the run continues (iterations 12..23)."""
+    import importlib
+    import json
+
+    from torch.cuda.amp import GradScaler
+
+    def on_stop(model, optimizers, cfg, scene, P, step, batches, name_of):
+        class _DataManager(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                co = importlib.import_module("nerfstudio.cameras.camera_optimizers")
+                self.train_camera_optimizer = co.CameraOptimizerConfig(mode="off").setup(num_cameras=cfg["num_cameras"], device="cpu")
+
+        class _Pipeline(torch.nn.Module):  # (VanillaPipeline's module tree: datamanager + _model; `model` is a property)
+            def __init__(self):
+                super().__init__()
+                self.datamanager = _DataManager()
+                self._model = model
+
+        pipe = _Pipeline()
+        ckpt = {"step": step, "pipeline": pipe.state_dict(),
+                "optimizers": {k: v.state_dict() for k, v in optimizers.optimizers.items()},
+                "schedulers": {k: v.state_dict() for k, v in optimizers.schedulers.items()},
+                "scalers": GradScaler(init_scale=2.0 ** 10).state_dict()}
+        assert all(k.startswith("_model.") for k in ckpt["pipeline"])
+        arrs, meta = {}, {"step": step, "pipeline_keys": list(ckpt["pipeline"].keys()), "optimizers": {}, "schedulers": _jsonable(ckpt["schedulers"]),
+                          "scalers": _jsonable(ckpt["scalers"]),
+                          "scalers_note": "torch's GradScaler is disabled on a CUDA-less host: its state_dict is {}; on a GPU the reference writes "
+                                          "{scale, growth_factor, backoff_factor, growth_interval, _growth_tracker}"}
+        ps = model.proposal_sampler  # NOT part of the reference's checkpoint (its resumed runs restart these); stored so that a test can
+        #                              continue the uninterrupted trajectory of model_traj.npz from this checkpoint
+        meta["sampler_not_in_checkpoint"] = {"steps_since_update": int(ps._steps_since_update), "step": int(ps._step), "anneal": float(ps._anneal)}
+        for k, v in ckpt["pipeline"].items():
+            arrs["P::" + k] = v
+        groups = model.get_param_groups()
+        for gname, osd in ckpt["optimizers"].items():
+            names = [name_of[id(p)] for p in groups[gname]]
+            assert osd["param_groups"][0]["params"] == list(range(len(names)))
+            meta["optimizers"][gname] = {"param_groups": _jsonable(osd["param_groups"]), "param_names": names,
+                                         "state_indices": sorted(int(i) for i in osd["state"])}
+            for i, st in osd["state"].items():
+                assert set(st) == {"step", "exp_avg", "exp_avg_sq"}, st.keys()
+                arrs[f"O::{gname}::{i}::step"] = st["step"]
+                arrs[f"O::{gname}::{i}::exp_avg"] = st["exp_avg"]
+                arrs[f"O::{gname}::{i}::exp_avg_sq"] = st["exp_avg_sq"]
+        # the reference's load path into a FRESH model (eval_setup -> eval_load_checkpoint -> load_pipeline): strict key match
+        cfg2, scene2, P2 = traj_setup()
+        fresh, _ = _build_ref_model(cfg2, scene2, {k: torch.zeros_like(v) for k, v in P2.items()},
+                                    proposal_weights_anneal_max_num_iters=6, proposal_warmup=6)
+        pipe2 = _Pipeline.__new__(_Pipeline)
+        torch.nn.Module.__init__(pipe2)
+        pipe2.datamanager, pipe2._model = _DataManager(), fresh
+        state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt["pipeline"].items()}
+        fresh.update_to_step(step)
+        pipe2.load_state_dict(state)
+        fresh.eval()
+        cm = importlib.import_module("nerfstudio.utils.colormaps")
+        psf = 1.0  # (after 12 iterations the fixture model is still nearly empty: depths sit near the far plane, and in the script's metre
+        #            units at the real pose scale 0.05 its fixed -3 < z < 6 height window would keep two dozen points)
+        cams = _cameras(scene)
+        cams.rescale_output_resolution(1.0 / 75.0)
+        coords = cams.get_image_coords()
+        frames = [0, 7]
+        arrs.update(scaling=np.array(1.0 / 75.0), H=np.array(int(cams.height[0])), W=np.array(int(cams.width[0])), pose_scale_factor=np.array(psf),
+                    frames=np.array(frames))
+        with torch.no_grad():
+            d_all = torch.cat([fresh.get_depth_for_camera_ray_bundle(cams.generate_rays(camera_indices=c, coords=coords, aabb_box=None))["depth"].flatten()
+                               for c in frames]) / psf
+            lo, hi = float(torch.quantile(d_all, 0.2)), float(torch.quantile(d_all, 0.85))
+            arrs.update(min_depth=np.array(lo), max_depth=np.array(hi))
+            n_sel = 0
+            for depth_type in ("depth", "expected_depth"):
+                for cam in frames:
+                    crb = cams.generate_rays(camera_indices=cam, coords=coords, aabb_box=None)
+                    outputs = fresh.get_depth_for_camera_ray_bundle(crb)
+                    depth = outputs[depth_type] / psf
+                    world = (crb.origins / psf + crb.directions * depth).view(-1, 3)
+                    depth = depth.flatten()
+                    sel = (depth < hi) & (depth > lo) & (world[:, 2] > -3.0) & (world[:, 2] < 6.0)
+                    world = world[sel]
+                    tag = f"{depth_type}_{cam}"
+                    arrs[f"raw_depth_{tag}"] = depth
+                    arrs[f"sel_{tag}"] = sel
+                    if len(world) == 0:
+                        continue
+                    n_sel += len(world)
+                    dl = [p.density_fn(world * psf).squeeze(-1) for p in fresh.proposal_networks]
+                    dl.append(fresh.field.density_fn(world * psf)[0].squeeze(-1))
+                    arrs[f"world_{tag}"] = world
+                    arrs[f"dens_{tag}"] = torch.stack(dl, dim=0).mean(dim=0)
+                    feats = fresh.field.semantic_fn(world * psf).clip(0.0, 1.0).to(torch.float16)
+                    arrs[f"feats_{tag}"] = feats
+                    arrs[f"colors_{tag}"] = cm.apply_feature_colormap(feats, scene["dino_to_rgb"])
+        print(f"checkpoint at step {step}: {len(ckpt['pipeline'])} pipeline keys, depth window {lo:.2f}..{hi:.2f}, {n_sel} hit points")
+        assert n_sel > 200
+        arrs["meta_json"] = np.array(json.dumps(meta))
+        save("checkpoint", **arrs)
+
+    gold_model_traj(stop_after=11, on_stop=on_stop)
+
+
 def _with_meta(rb, batch):
     rb.metadata["video_id"] = batch["video_ids"][:, None]
     return rb
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "model_k8", "model_traj", "extract", "datafeed"]
+    which = sys.argv[1:] or ["hashgrid", "ops", "sampling", "losses", "losses_real", "depth_losses", "model", "model_k8", "model_traj", "extract", "datafeed", "checkpoint"]
     for w in which:
         globals()["gold_" + w]()

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import build_hip_model, model_traj_setup, t, to_double, traj_param_error, traj_param_max_diff
+from conftest import (build_hip_model, checkpoint_from_fixture, load_golden, model_traj_setup, t, to_double, traj_param_error,
+                      traj_param_max_diff)
 
 pytestmark = pytest.mark.gpu
 
@@ -215,3 +216,147 @@ def test_fused_table_adam_equals_the_separate_optimizer_step(gold_model_traj):
     fb = {k: mb.state_dict()[k].detach().cpu() for k in P}
     err = traj_param_error(fa, fb, P)
     assert max(err.values()) < 1e-4 and traj_param_max_diff(fa, fb) <= 4 * float(G["lr"].max()), sorted(err.items(), key=lambda kv: -kv[1])[:3]
+
+
+def test_resume_from_a_reference_checkpoint_continues_the_reference_run(gold_model_traj, tmp_path):
+    """tests/golden/checkpoint.npz = the file the REFERENCE's Trainer.save_checkpoint objects wrote after iteration 11 of the trajectory
+    run (ns/engine/trainer.py:432-460: `_model.`-prefixed pipeline state, one torch Adam state_dict and one ChainedScheduler state_dict
+    per parameter group).  Written to `step-000000011.ckpt`, loaded through presight_amd.checkpoint.load_checkpoint into a ZERO-
+    initialised HIP model + a fresh trainer (trainer.py:396-429), the run continues like the reference's own iterations 12..23:
+    learning rates, which parameter is stepped when (uneven per-parameter Adam step counts: off-schedule proposal steps, sub-fields
+    without samples), losses and final parameters inside the trajectory test's computed bounds."""
+    from oracle import nerf_oracle as O
+    from presight_amd import checkpoint as C
+    from presight_amd.trainer import Trainer
+
+    G = gold_model_traj
+    ckpt, meta = checkpoint_from_fixture(load_golden("checkpoint"))
+    dev = torch.device("cuda:0")
+    cfg, scene, P, batches = model_traj_setup(G)
+    M, N = int(G["max_iterations"]), int(G["n_steps"])
+    model = build_hip_model(cfg, scene, {k: torch.zeros_like(v) for k, v in P.items()}, dev, proposal_weights_anneal_max_num_iters=M // 10,
+                            proposal_warmup=M // 10)
+    tr = Trainer(model, _scene_dev(scene, dev), loss_scale=float(G["loss_scale"]), max_num_iterations=M)
+    torch.save(ckpt, C.checkpoint_path(tmp_path, 11))
+    torch.save({**ckpt, "step": 5}, C.checkpoint_path(tmp_path, 5))  # (an older file in the directory: the newest step is taken)
+    assert C.load_checkpoint(str(tmp_path), model, tr) == 11
+    assert tr.step_idx == 12 and abs(tr.opt.lr - float(G["lr"][12])) < 1e-12
+    for k in P:
+        assert torch.equal(model.state_dict()[k].cpu(), t(G["S11_" + k])), k
+    # torch Adam's per-parameter step counts of the reference run = how often each parameter had a gradient in iterations 0..11
+    keys = [str(k) for k in G["keys"]]
+    pidx = {}
+    for i, p in enumerate(tr.opt.params):
+        for n, q in model.named_parameters(remove_duplicate=False):
+            if q is p and n in P:
+                pidx[n] = i
+    steps = tr.opt.param_steps()
+    for j, k in enumerate(keys):
+        assert steps[pidx[k]] == int(G["touched"][:12, j].sum()), k
+    assert len(set(steps)) > 2
+    # the sampler's update-schedule counters are not part of the reference's checkpoint (its resumed runs restart them); to continue
+    # the UNINTERRUPTED run of model_traj.npz they are taken from the fixture's side record
+    sm = meta["sampler_not_in_checkpoint"]
+    ps = model.proposal_sampler
+    ps._steps_since_update, ps._step = sm["steps_since_update"], sm["step"]
+    ps.set_anneal(sm["anneal"])
+    losses, before = [], steps
+    touched = {k: [] for k in P}
+    for s in range(12, N):
+        assert abs(tr.opt.lr - float(G["lr"][s])) < 1e-12
+        ld, _ = tr.step(_dev_batch(batches[s], dev))
+        assert abs(ps._anneal - float(G["anneal"][s])) < 1e-12
+        losses.append([float(ld[str(n)].detach()) for n in G["loss_names"]])
+        now = tr.opt.param_steps()
+        for k, i in pidx.items():
+            touched[k].append(now[i] - before[i])
+        before = now
+    for j, k in enumerate(keys):
+        assert touched[k] == G["touched"][12:, j].tolist(), k
+    r32 = O.train_trajectory(P, cfg, scene, batches, M, loss_scale=float(G["loss_scale"]))
+    r64 = O.train_trajectory(to_double(P), cfg, to_double(scene), to_double(batches), M, loss_scale=float(G["loss_scale"]))
+    l32, l64, ref, got = np.array(r32["losses"])[12:], np.array(r64["losses"])[12:], G["losses"][12:], np.array(losses)
+    bound = 2e-4 * np.abs(ref) + 4 * np.abs(l32 - l64) + 1e-8
+    assert (np.abs(got - ref) <= bound).all(), (np.argwhere(np.abs(got - ref) > bound), np.abs(got - ref).max())
+    final = {k: model.state_dict()[k].detach().cpu() for k in P}
+    want = {k: t(G[f"S23_{k}"]) for k in P}
+    err, noise = traj_param_error(final, want, P), traj_param_error(r32["params"], r64["params"], P)
+    bad = {k: (f"{e:.1e}", f"oracle noise {noise[k]:.1e}") for k, e in err.items() if e > max(5e-5, 4 * noise[k])}
+    assert not bad, bad
+    assert traj_param_max_diff(final, want) <= 4 * float(G["lr"].max())
+
+
+def test_written_checkpoint_has_the_reference_layout_and_resumes(gold_model_traj, tmp_path):
+    """presight_amd.checkpoint.save_checkpoint after the same 12 iterations: `step-000000011.ckpt` holds the reference checkpoint's
+    structure (tests/golden/checkpoint.npz) -- the five top-level keys, the same pipeline keys / shapes / dtypes in the same order, per
+    optimizer group the same parameters WITH state and the same step counts, the same hyper-parameters, the same scheduler state, a
+    GradScaler state -- with values inside the trajectory bounds; older files are removed (save_only_latest_checkpoint); a fresh model
+    + trainer resumed from the FILE continues like the uninterrupted run."""
+    from presight_amd import checkpoint as C
+    from presight_amd.trainer import Trainer
+
+    G = gold_model_traj
+    ref, meta = checkpoint_from_fixture(load_golden("checkpoint"))
+    dev = torch.device("cuda:0")
+    cfg, scene, P, batches = model_traj_setup(G)
+    M = int(G["max_iterations"])
+
+    def fresh(params):
+        model = build_hip_model(cfg, scene, params, dev, proposal_weights_anneal_max_num_iters=M // 10, proposal_warmup=M // 10)
+        return model, Trainer(model, _scene_dev(scene, dev), loss_scale=float(G["loss_scale"]), max_num_iterations=M)
+
+    model_a, tr_a = fresh(P)
+    for s in range(6):
+        tr_a.step(_dev_batch(batches[s], dev))
+    C.save_checkpoint(tr_a, tmp_path)
+    for s in range(6, 12):
+        tr_a.step(_dev_batch(batches[s], dev))
+    path = C.save_checkpoint(tr_a, tmp_path)
+    assert sorted(f.name for f in tmp_path.iterdir()) == ["step-000000011.ckpt"] and path.endswith("step-000000011.ckpt")
+    mine = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(mine) - {"presight_amd"} == set(ref) == {"step", "pipeline", "optimizers", "schedulers", "scalers"} and mine["step"] == ref["step"] == 11
+    assert list(mine["pipeline"]) == list(ref["pipeline"])
+    for k, v in mine["pipeline"].items():
+        assert v.shape == ref["pipeline"][k].shape and v.dtype == ref["pipeline"][k].dtype, k
+    init = {k: P[k[len("_model."):]] for k in ref["pipeline"] if k[len("_model."):] in P}
+    err = traj_param_error({k: mine["pipeline"][k] for k in init}, {k: ref["pipeline"][k] for k in init}, init)
+    assert max(err.values()) < 2e-3, sorted(err.items(), key=lambda kv: -kv[1])[:3]
+    assert set(mine["optimizers"]) == set(ref["optimizers"]) == {"proposal_networks", "fields"}
+    for g in ref["optimizers"]:
+        a, b = mine["optimizers"][g], ref["optimizers"][g]
+        assert sorted(a["state"]) == sorted(b["state"]), g  # the same parameters have been stepped at least once
+        ga, gb = a["param_groups"][0], b["param_groups"][0]
+        assert set(ga) <= set(gb) and set(gb) - set(ga) <= {"decoupled_weight_decay"} and ga["params"] == gb["params"]
+        for k in ("betas", "eps", "weight_decay", "amsgrad", "maximize", "initial_lr"):
+            assert ga[k] == gb[k], (g, k)
+        assert abs(ga["lr"] - gb["lr"]) < 1e-12
+        worst = 0.0
+        for j in a["state"]:
+            assert float(a["state"][j]["step"]) == float(b["state"][j]["step"]), (g, j)
+            for mom in ("exp_avg", "exp_avg_sq"):
+                x, y = a["state"][j][mom].double(), b["state"][j][mom].double()
+                assert x.shape == y.shape
+                worst = max(worst, float((x - y).norm() / y.norm().clamp_min(1e-30)))
+        assert worst < 2e-2, (g, worst)  # (moments of 12 fp32 iterations: ReLU flips move single networks by 1e-3)
+    assert set(mine["schedulers"]) == set(ref["schedulers"])
+    sa, sb = mine["schedulers"]["fields"], ref["schedulers"]["fields"]
+    assert sa["_schedulers"][0]["last_epoch"] == sb["_schedulers"][0]["last_epoch"] == 12
+    assert sa["_schedulers"][1]["milestones"] == sb["_schedulers"][1]["milestones"] and abs(sa["_last_lr"][0] - sb["_last_lr"][0]) < 1e-12
+    assert mine["scalers"]["scale"] == float(G["loss_scale"]) and set(mine["scalers"]) == {"scale", "growth_factor", "backoff_factor", "growth_interval",
+                                                                                          "_growth_tracker"}
+    # resume from the file (our own extra record restores the sampler counters) == the uninterrupted run
+    model_b, tr_b = fresh({k: torch.zeros_like(v) for k, v in P.items()})
+    assert C.load_checkpoint(path, model_b, tr_b) == 11
+    assert tr_b.step_idx == tr_a.step_idx == 12 and tr_b.opt.param_steps() == tr_a.opt.param_steps() and tr_b.opt.lr == tr_a.opt.lr
+    la, lb = [], []
+    for s in range(12, 24):
+        a, _ = tr_a.step(_dev_batch(batches[s], dev))
+        b, _ = tr_b.step(_dev_batch(batches[s], dev))
+        la.append([float(v.detach()) for v in a.values()])
+        lb.append([float(v.detach()) for v in b.values()])
+    assert tr_a.opt.param_steps() == tr_b.opt.param_steps() and tr_a.opt.lr == tr_b.opt.lr
+    np.testing.assert_allclose(np.array(lb), np.array(la), rtol=2e-4, atol=1e-7)
+    fa = {k: model_a.state_dict()[k].detach().cpu() for k in P}
+    fb = {k: model_b.state_dict()[k].detach().cpu() for k in P}
+    err = traj_param_error(fb, fa, P)
+    assert max(err.values()) < 1e-4 and traj_param_max_diff(fb, fa) <= 4 * float(G["lr"].max()), sorted(err.items(), key=lambda kv: -kv[1])[:3]
