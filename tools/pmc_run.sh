@@ -4,14 +4,18 @@
 TAG=${1:-dev}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out /tmp/pmc
-KERN="main_bwd,main_fwd,accumulate_kernel,bin_kernel,grid_encode,prop_bwd_kernel,prop_fwd_kernel,composite,absmax,adam,grid4,flow_,blend_"
+KERN="main_bwd,main_fwd,accumulate_kernel,bin_kernel,grid_encode,prop_bwd_kernel,prop_fwd_kernel,composite,absmax,adam,grid4,flow_,blend_,route,voxel,points,interlevel,per_ray"
 OUT=gpurun_out/pmc_summary_$TAG.txt
 : > $OUT
 # the hash of the kernel sources THESE counters are collected on (tools/pmc_traffic.py stamps profiles/traffic.json with it)
 echo "src_sha16=$(python3 -c 'import bench; print(bench.kernel_sources_sha())')" >> $OUT
 # PMC_BASIC=1: the four groups that price a kernel against its roofline (HBM bytes, matrix-pipe busy, L2 hit rate) -- used for the
 # secondary configurations (cfg 3 / cfg 4), whose steps are long
-if [ "${PMC_BASIC:-0}" = "1" ]; then
+# PMC_GATHER=1: the basic groups + the L1 / L2 request counters that price a gather-bound pass (prior extraction, cfg 5)
+if [ "${PMC_GATHER:-0}" = "1" ]; then
+  GROUPS_LIST=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" \
+               "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TA_BUSY_avr TA_TA_BUSY_sum")
+elif [ "${PMC_BASIC:-0}" = "1" ]; then
   GROUPS_LIST=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum")
 else
   GROUPS_LIST=("FETCH_SIZE" "WRITE_SIZE" \
