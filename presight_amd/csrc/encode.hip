@@ -969,6 +969,213 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   }
 }
 
+// ---- the fused update on tables of MANY SLICES WITH FEW RECORDS EACH (routed production tile: 16 sub-fields x 10 levels x 256
+// slices = 41 k items, ~4 k records per item at 65 536 rays, ~500 at 8192 -- half of the items receive none).  There the pass is a
+// stream of p / m / v (24 bytes per entry, 16 GB per launch) with a little LDS work in between, and accumulate_kernel above runs it as
+// a chain of latencies: its workgroup owns the CU (128 KiB of LDS), so nothing overlaps record loads -> zero fill -> accumulation ->
+// barrier -> p / m / v loads -> update -> stores (4.7 - 4.9 TB/s where a plain Adam stream sustains 6.4, tools/microbench/adam_stream.hip).
+//   accumulate_adam_kernel   the same arithmetic with every load of the item requested UP FRONT: the first record batch, then the
+//                            slice's parameters and moments (unconditional 16-byte loads: a conditional load makes hipcc merge the
+//                            loaded registers behind an s_waitcnt vmcnt(0)) -- the records return first and are
+//                            accumulated while p / m / v are still in flight; the first batch is peeled out of the record loop
+//                            so that nothing in flight is live across a branch.  The second moments are requested behind the
+//                            accumulation (PS_ACC_LATE_V: 16 registers less -- with all three arrays in flight the F = 4 kernel
+//                            spills 8 registers at its 128-register budget).  A slice WITHOUT records skips accumulators and
+//                            barriers.  Measured on one box, alternating (tools/ab_env.sh, table backward of the main tables =
+//                            record writer + this pass): production tile at 65 536 rays 6.61 - 6.90 -> 6.26 - 6.58 ms, at 8192 rays
+//                            3.93 - 3.97 -> 3.36 - 3.50 ms (16.1 GB of p / m / v: 2.5 ms at the 6.4 TB/s streaming ceiling).  Handing
+//                            the empty slices to a separate streaming launch (256-thread workgroups, the microbenchmark's shape) was
+//                            built and measured too: 3.69 - 3.76 ms with it, 3.65 - 3.66 without -- dropped.
+// Same element update (ps::adam_update) on the same fp32 gradient (integer sums are order-independent): bit-equal to the kernel above.
+#ifndef PS_ACC_LATE_V
+#define PS_ACC_LATE_V 1
+#endif
+template <int F, int CH>
+__device__ __forceinline__ void acc_consume_batch(long long* acc, const unsigned (&e)[CH], const float (&v)[F][CH], const float (&ox)[CH],
+                                                  int64_t i0, int64_t n, unsigned low, float scale) {
+  unsigned p_row = 0xffffffffu, p_rowc = 0xffffffffu;
+  long long p_f[F], p_c[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) p_f[f] = p_c[f] = 0;
+  auto flush = [&]() {
+    if (p_row != 0xffffffffu) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p_row * F + f]), (unsigned long long)p_f[f]);  // ds_add_u64
+        if (p_rowc != p_row) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p_rowc * F + f]), (unsigned long long)p_c[f]);
+      }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    if (i0 + k < n) {
+      const unsigned row = e[k] & 0xffffu, t = e[k] >> 16;
+      const bool pair = t < 30u;
+      const unsigned row_c = pair ? ((row ^ ((2u << t) - 1u)) & low) : row;
+      const float wf = pair ? 1.0f - ox[k] : 1.0f;
+      if (row != p_row || row_c != p_rowc) {
+        flush();
+        p_row = row;
+        p_rowc = row_c;
+#pragma unroll
+        for (int f = 0; f < F; ++f) p_f[f] = p_c[f] = 0;
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        p_f[f] += __float2ll_rn(v[f][k] * wf * scale);
+        if (pair) p_c[f] += __float2ll_rn(v[f][k] * ox[k] * scale);
+      }
+    }
+  }
+  flush();
+}
+
+// the workgroup-uniform preamble of the fused kernels: -> false when the item's sub-field belongs to a device-decided group whose
+// flag is down (not updated at all); bias corrections of such a group are evaluated here (one lane, broadcast through LDS)
+__device__ __forceinline__ bool fused_item_live(const AdamFuse& A, int field, float& bc1, float& bc2_sqrt) {
+  bc1 = A.bc1;
+  bc2_sqrt = A.bc2_sqrt;
+  if (A.group_of_field != nullptr) {
+    const int grp = A.group_of_field[field];
+    if (grp >= 0) {
+      if (A.flags[grp] == 0) return false;
+      __shared__ float s_bc[2];
+      if (threadIdx.x == 0) ps::adam_bias_corrections(A.h.b1, A.h.b2, A.steps[grp] + 1, s_bc[0], s_bc[1]);
+      __syncthreads();
+      bc1 = s_bc[0];
+      bc2_sqrt = s_bc[1];
+    }
+  }
+  return true;
+}
+
+template <int F>
+__global__ __launch_bounds__(1024) void accumulate_adam_kernel(const unsigned* __restrict__ cursors, const unsigned* __restrict__ starts,
+                                                               const unsigned* __restrict__ rec_idx, const float* __restrict__ rec_val,
+                                                               const unsigned* __restrict__ gmax_bits, int L, int log2T, int log2_slice,
+                                                               int64_t n_rec_max, int headroom_log2, float* __restrict__ dtable,
+                                                               float* const* __restrict__ dtables, int item0, AdamFuse A) {
+  extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F], entries * F == kAccBytes / 8 (host-checked)
+  constexpr int CH = F == 4 ? 4 : 8;                 // records per lane and batch
+  constexpr int kVec = kAccBytes / 8 / 1024 / 4;     // 16-byte vectors of the slice per thread and array
+  constexpr bool kLateV = PS_ACC_LATE_V != 0;        // the second moments requested behind the accumulation (16 registers less)
+  const int entries = 1 << log2_slice;
+  const int n_slices = 1 << (log2T - log2_slice);
+  const int item = item0 + blockIdx.x;
+  const int vlevel = item / n_slices, sl = item % n_slices;
+  const int level = vlevel % L;
+  const int64_t base = starts[item];
+  const int64_t n = cursors[item] - base;
+  float bc1, bc2_sqrt;
+  if (!fused_item_live(A, vlevel / L, bc1, bc2_sqrt)) return;
+  if (dtables != nullptr) dtable = dtables[vlevel / L];
+  const unsigned gbits = gmax_bits[vlevel];
+  float* out = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
+  const int64_t off = out - A.g_base;
+  const float *pp = A.p_base + off, *mm = A.m_base + off, *vv = A.v_base + off;
+  unsigned e[CH];
+  float v[F][CH], ox[CH];
+  auto load_batch = [&](int64_t i0) {
+#pragma unroll
+    for (int h = 0; h < CH; h += 4) {
+      const int64_t i = base + i0 + h;
+      const u32x4 t = *reinterpret_cast<const u32x4*>(rec_idx + i);  // reads past n stay inside the workspace
+      const f32x4 o = *reinterpret_cast<const f32x4*>(rec_val + (int64_t)F * n_rec_max + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e[h + k] = t[k];
+        ox[h + k] = o[k];
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(rec_val + (int64_t)f * n_rec_max + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[f][h + k] = q[k];
+      }
+    }
+  };
+  if (n == 0) {
+    // A slice without records (half of the items of a production tile at 8192 rays): no accumulators, no barriers -- its update is
+    // g = 0 (weight decay and moment decay still reach every entry, as in torch; a non-finite level: NaN for all of its entries)
+    const float g0 = gbits >= 0x7f800000u ? __builtin_nanf("") : 0.0f;
+    float *ppw = A.p_base + off, *mmw = A.m_base + off, *vvw = A.v_base + off;
+    f32x4 P[kVec], M[kVec], V[kVec];
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+      const int i = (threadIdx.x + k * 1024) * 4;
+      P[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pp + i));
+      M[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mm + i));
+      V[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vv + i));
+    }
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+      const int i = (threadIdx.x + k * 1024) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pk = P[k][j], mk = M[k][j], vk = V[k][j];
+        ps::adam_update(pk, g0, mk, vk, A.h, bc1, bc2_sqrt);
+        P[k][j] = pk;
+        M[k][j] = mk;
+        V[k][j] = vk;
+      }
+      __builtin_nontemporal_store(P[k], reinterpret_cast<f32x4*>(ppw + i));
+      __builtin_nontemporal_store(M[k], reinterpret_cast<f32x4*>(mmw + i));
+      __builtin_nontemporal_store(V[k], reinterpret_cast<f32x4*>(vvw + i));
+    }
+    return;
+  }
+  // 1. the first record batch (a lane without records re-reads the stream's first ones: an address select, not a conditional load)
+  const int64_t first_i0 = (int64_t)threadIdx.x * CH;
+  load_batch(first_i0 < n ? first_i0 : 0);
+  // 2. parameters and moments of the slice, behind the records in the (in-order) return queue
+  f32x4 P[kVec], M[kVec], V[kVec];
+#pragma unroll
+  for (int k = 0; k < kVec; ++k) {
+    const int i = (threadIdx.x + k * 1024) * 4;
+    P[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pp + i));
+    M[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mm + i));
+    if (!kLateV) V[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vv + i));
+  }
+  // 3. accumulators
+  typedef long long ll2 __attribute__((ext_vector_type(2)));
+  for (int i = threadIdx.x * 2; i < entries * F; i += 2048) *reinterpret_cast<ll2*>(&acc[i]) = (ll2){0, 0};
+  __syncthreads();
+  const bool nan_level = gbits >= 0x7f800000u;
+  const float scale = fixed_scale(gbits, headroom_log2);
+  const unsigned low = (unsigned)entries - 1u;
+  if (!nan_level) {
+    acc_consume_batch<F, CH>(acc, e, v, ox, first_i0, n, low, scale);  // (first_i0 >= n: no record passes the i0 + k < n test)
+    for (int64_t i0 = first_i0 + 1024 * CH; i0 < n; i0 += 1024 * CH) {
+      load_batch(i0);
+      acc_consume_batch<F, CH>(acc, e, v, ox, i0, n, low, scale);
+    }
+  }
+  __syncthreads();
+  if (kLateV) {
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) V[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vv + (threadIdx.x + k * 1024) * 4));
+  }
+  // 4. the slice's Adam step (the gradient itself is never written)
+  const float inv = 1.0f / scale;
+  float *ppw = A.p_base + off, *mmw = A.m_base + off, *vvw = A.v_base + off;
+#pragma unroll
+  for (int k = 0; k < kVec; ++k) {
+    const int i = (threadIdx.x + k * 1024) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float val = nan_level ? __builtin_nanf("") : (float)((double)acc[i + j] * (double)inv * (double)1.0f);
+      float pk = P[k][j], mk = M[k][j], vk = V[k][j];
+      ps::adam_update(pk, val, mk, vk, A.h, bc1, bc2_sqrt);
+      P[k][j] = pk;
+      M[k][j] = mk;
+      V[k][j] = vk;
+    }
+    __builtin_nontemporal_store(P[k], reinterpret_cast<f32x4*>(ppw + i));
+    __builtin_nontemporal_store(M[k], reinterpret_cast<f32x4*>(mmw + i));
+    __builtin_nontemporal_store(V[k], reinterpret_cast<f32x4*>(vvw + i));
+  }
+}
+
 // records the streams can hold: 8 per (point, level) worst case + every stream start rounded up to 4 records + the
 // vector-load overshoot of the last chunk; a multiple of 4 so that all planes stay 16-byte aligned
 int64_t binned_rec_capacity(int64_t N, int L, int n_slices, int D = 3) {
@@ -1044,6 +1251,13 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
     if (bits > 26) headroom = 62 - bits;
   }
   const size_t lds = (size_t)(1 << ls) * F * 8;
+  // Fused update on many slices with few records each -> the load-everything-up-front kernel (see accumulate_adam_kernel).  Average
+  // records per item decide: a cfg-2 table (1024 items of 262 k records) stays on accumulate_kernel, whose record loop then is the
+  // whole pass.  PS_ACC_STREAM=0 / 1 forces the choice (A/B runs).
+  static const char* acc_stream_env = getenv("PS_ACC_STREAM");
+  const double rec_per_item = (double)N * L * (D == 4 ? 8 : 4) / (double)(n_items > 0 ? n_items : 1);
+  bool stream_fused = fuse.g_base != nullptr && lds == (size_t)kAccBytes && rec_per_item < 16.0 * 1024 * 8;
+  if (acc_stream_env != nullptr && fuse.g_base != nullptr && lds == (size_t)kAccBytes) stream_fused = acc_stream_env[0] != '0';
 #define PS_LAUNCH_BINNED(FF) PS_LAUNCH_BINNED_D(FF, 3)
 #define PS_LAUNCH_BINNED_D(FF, DD)                                                                                            \
   {                                                                                                                       \
@@ -1065,9 +1279,20 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
                                                                              plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
                                                                              absmax_ready ? nullptr : gmax_bits, period, dfeat_b); \
     }                                                                                                                     \
-    if ((phase & 2) && item_end > item_begin)                                                                             \
-      accumulate_kernel<FF><<<(unsigned)(item_end - item_begin), 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
-                                                                                 n_rec_max, headroom, accumulate, dtable, dtables, out_scale, item_begin, fuse); \
+    if ((phase & 2) && item_end > item_begin) {                                                                           \
+      if (stream_fused) {                                                                                                 \
+        static bool attr2_set = false;                                                                                    \
+        if (!attr2_set) {                                                                                                 \
+          hipFuncSetAttribute((const void*)accumulate_adam_kernel<FF>, hipFuncAttributeMaxDynamicSharedMemorySize, kAccBytes); \
+          attr2_set = true;                                                                                               \
+        }                                                                                                                 \
+        accumulate_adam_kernel<FF><<<(unsigned)(item_end - item_begin), 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
+                                                                                        n_rec_max, headroom, dtable, dtables, item_begin, fuse); \
+      } else {                                                                                                            \
+        accumulate_kernel<FF><<<(unsigned)(item_end - item_begin), 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
+                                                                                   n_rec_max, headroom, accumulate, dtable, dtables, out_scale, item_begin, fuse); \
+      }                                                                                                                   \
+    }                                                                                                                     \
   }
   if (D == 3) {
     if (F == 1) PS_LAUNCH_BINNED(1)

@@ -540,8 +540,22 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
     float e0[C::FACT ? PB : 1], e1[C::FACT ? PB : 1];   // FACT: the sample's bin edges (subtracted after `consume`: a fetch only issues loads)
     float ga[PB], gb[PB];                               // gated inference forward: the two other densities of the point
     int op[PB];  // the point's index in the caller's arrays, -1: no such point
+    int opn[MS ? PB : 1];  // MS: raw perm entries of the tile AFTER this one (requested with this tile's loads, see fetch)
   };
-  auto fetch = [&](int64_t first, In& v) {
+  // Multi-sub-field launches reach the caller's arrays (gates, directions, appearance codes, outputs) through perm[slot]: a load whose
+  // address is a loaded value.  Issued inside one fetch, the dependent pair made the wave wait for perm -- and, loads returning in
+  // order, for everything requested before it -- right there: one exposed memory latency per tile (PMC, prior extraction of a routed
+  // tile: 8 M points per launch, 0.75 us of matrix work per tile, the gated forward at 0.34 matrix-pipe busy).  perm therefore runs
+  // one tile further ahead than everything else: fetch(t) takes tile t's perm entries from registers (they arrived with tile t - 1's
+  // inputs, `opn`) and requests those of tile t + 1.
+  auto fetch = [&](int64_t first, int64_t next_first, const int (&op_in)[MS ? PB : 1], In& v) {
+    if constexpr (MS) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t q = next_first + pb * 16 + j;
+        v.opn[pb] = a.perm[q < a.N ? q : a.N - 1];  // (unconditional; entries past the end are masked when they are taken over)
+      }
+    }
     if constexpr (C::FACT) {
       // whole tiles only (N % (16 PB) == 0) and every feature column exists (L*F % 4 == 0): the loads are UNCONDITIONAL, with the
       // point index clamped for the tiles requested past the end (never consumed).  A conditional load is a branch plus a merge of
@@ -579,14 +593,27 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
       const int64_t p = first + pb * 16 + j;
-      const int64_t op = orig_index<MS>(a.perm, p, a.N);
+      int64_t op;
+      if constexpr (MS)
+        op = p < a.N ? (int64_t)op_in[pb] : (int64_t)-1;
+      else
+        op = orig_index<MS>(a.perm, p, a.N);
       v.op[pb] = (int)op;
       if constexpr (MS)
         v.sel[pb] = a.sel[p < a.N ? p : a.N - 1];  // (padded slots carry selector 0)
       else
         v.sel[pb] = (a.sigma != nullptr && p < a.N) ? a.sel[p] : 0.0f;
-      v.ga[pb] = (a.gate_a != nullptr && op >= 0) ? a.gate_a[op] : 0.0f;  // (the gates live in the caller's order)
-      v.gb[pb] = (a.gate_a != nullptr && op >= 0) ? a.gate_b[op] : 0.0f;
+      if constexpr (MS) {
+        if (a.gate_a != nullptr) {  // (uniform; the loads themselves are unconditional, a slot without a point reads entry 0 and is masked later)
+          v.ga[pb] = a.gate_a[op >= 0 ? op : 0];
+          v.gb[pb] = a.gate_b[op >= 0 ? op : 0];
+        } else {
+          v.ga[pb] = v.gb[pb] = 0.0f;
+        }
+      } else {
+        v.ga[pb] = (a.gate_a != nullptr && op >= 0) ? a.gate_a[op] : 0.0f;  // (the gates live in the caller's order)
+        v.gb[pb] = (a.gate_a != nullptr && op >= 0) ? a.gate_b[op] : 0.0f;
+      }
       int64_t r;
       if constexpr (MS)
         r = ray_index(op >= 0 ? op : 0, a.S);
@@ -617,6 +644,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(cur.appv[pb][t]));
         asm volatile("" : "+v"(cur.sel[pb]), "+v"(cur.dirv[pb][0]), "+v"(cur.dirv[pb][1]), "+v"(cur.dirv[pb][2]), "+v"(cur.op[pb]));
         asm volatile("" : "+v"(cur.ga[pb]), "+v"(cur.gb[pb]));
+        if constexpr (MS) asm volatile("" : "+v"(cur.opn[pb]));
       }
     }
   };
@@ -641,9 +669,19 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
   };
   TileIt it0{tr.first_pt + ((int64_t)tr.j * NW + wave) * tpu * (16 * PB), 0};
   TileIt it1 = advance(it0), it2 = advance(it1);
-  fetch(it0.first, nxt);
+  {
+    int op0[MS ? PB : 1] = {0};
+    if constexpr (MS) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const int64_t q = it0.first + pb * 16 + j;
+        op0[pb] = a.perm[q < a.N ? q : a.N - 1];
+      }
+    }
+    fetch(it0.first, it1.first, op0, nxt);
+  }
   consume();
-  fetch(it1.first, nxt);
+  fetch(it1.first, it2.first, cur.opn, nxt);
   float carry = 0.0f;                    // FACT: optical depth of the ray up to this tile
   float racc[C::FACT ? 16 : 1] = {0.f};  // FACT: this lane's part of sum_n w_n s_n (neurons 16nb + 4g + r, samples j, j + 16, ...)
   unsigned n_tiles = 0, n_sem_tiles = 0;  // gated inference: tiles visited / tiles whose semantic head ran (uniform per wave)
@@ -849,7 +887,7 @@ __global__ __launch_bounds__(NW * 64) void main_fwd_kernel(MainArgs a) {
         }
       }
     }
-    fetch(it2.first, nxt);
+    fetch(it2.first, advance(it2).first, cur.opn, nxt);  // (`cur` holds the NEXT tile's inputs by now: its opn = perm of tile it2)
     PS_STAMP(tm, 8)
   }
 #if defined(PS_TIMING)
@@ -1759,12 +1797,19 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
     PS_REQUIRE(a.acts == nullptr || a.rgb != nullptr, "ps_main_field (merged network): activations are kept for full evaluations only");
     PS_REQUIRE(a.A <= 16 && a.S > 0, "ps_main_field (merged network): appearance dim must be <= 16");
     PS_REQUIRE(a.N < (int64_t(1) << 31), "ps_main_field (merged network): at most 2^31 - 1 points per call");
+    // Gated routed launches are dealt 8 x more (shorter) workgroups than the chip holds.  The workgroups of a sub-field share its tiles
+    // round-robin, but the SUB-FIELDS are dealt workgroups by point count while the semantic head (3.4 x the base MLP's matrix work)
+    // runs only where the dense points are: on a lattice slab where 0.4 % of the tiles pass the gate, all in one small sub-field, the
+    // launch took 2.05 ms against 0.73 ms with the gate shut (tools/dbg/gate_probe.py) -- its few workgroups ran alone at the end.
+    // With short workgroups the hardware dispatcher fills the compute units the light sub-fields leave early.
+    static const char* gate_env = getenv("PS_GATE_BLOCKS");
+    const int gate_blocks = a.gate_a != nullptr ? (gate_env != nullptr ? atoi(gate_env) : 8) : 1;
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>;                                                    \
     if (a.perm != nullptr) {                                                                                          \
       a.packed_stride = C::PACKED;                                                                                    \
-      main_fwd_kernel<C, MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, true><<<ms_grid(a.N, 16 * MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, MainFwdShape<C>::kBlocks, a.K), MainFwdShape<C>::kWaves * 64, 0, s>>>(a); \
+      main_fwd_kernel<C, MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, true><<<ms_grid(a.N, 16 * MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, gate_blocks * MainFwdShape<C>::kBlocks, a.K), MainFwdShape<C>::kWaves * 64, 0, s>>>(a); \
     } else {                                                                                                          \
       main_fwd_kernel<C, MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, false><<<grid_for_tiles_nw(a.N, 16 * MainFwdShape<C>::kPB, MainFwdShape<C>::kWaves, MainFwdShape<C>::kBlocks), MainFwdShape<C>::kWaves * 64, 0, s>>>(a); \
     }                                                                                                                 \

@@ -1,0 +1,18 @@
+#!/bin/bash
+# A/B of runtime switches (environment variables read by the library) on ONE box, alternating:
+#   gpurun -- 'bash tools/ab_env.sh "<bench args>" <rounds> "NAME=VAL ..." "NAME=VAL ..." ...'   ("" = the defaults)
+cd $GRAFT_REPO_ROOT
+args=$1; rounds=$2; shift; shift
+cat > /tmp/ab_fmt.py <<'PY'
+import json, sys
+sys.stdin.read()
+d = json.load(open("bench_detail.json"))
+k = d["kernels_ms"]
+keep = {a: round(b, 3) for a, b in k.items() if any(t in a for t in ("scatter", "adam", "prop", "encode", "main_field"))}
+print(sys.argv[1], round(d["ms_per_step"], 2), keep, flush=True)
+PY
+for r in $(seq $rounds); do
+  for v in "$@"; do
+    env $v PRESIGHT_NO_DRY_OVERLAP=1 timeout 400 python bench.py $args --no-cpu-baseline --psnr-steps 0 --no-secondary 2>/dev/null | tail -1 | python /tmp/ab_fmt.py "[$v]"
+  done
+done
