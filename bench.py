@@ -669,6 +669,23 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=(), fused_tables=None):
     return rows
 
 
+def binding_ceiling(cfg, rays, n_params, fused_tables=True):
+    """-> dict: the end-to-end ceilings of one training step in rays/s.  SURVEY.md 8d prices MLP flops against the fp32 matrix peak
+    and hash-table bytes against HBM, per RAY; a step also streams the optimizer state once whatever the ray count -- p, m, v read and
+    written (24 bytes per parameter; + the gradient's write, read and zero fill = 36 when the tables' update is not fused into their
+    backward).  On the production tile (940 M parameters) that is 22.6 GB per step, more than the per-ray hash traffic of 65 536 rays:
+    the HBM ceiling INCLUDING the optimizer stream is the binding one there, and the line says so instead of quoting the MFMA ceiling."""
+    flop_ray, byte_ray = end_to_end_ceilings(cfg)
+    opt_bytes = (24.0 if fused_tables else 36.0) * n_params
+    ceil_mfma = FP32_MFMA_PEAK_TFLOPS * 1e12 / flop_ray
+    ceil_hbm = HBM_PEAK_GBS * 1e9 / byte_ray
+    ceil_hbm_opt = HBM_PEAK_GBS * 1e9 / (byte_ray + opt_bytes / max(rays, 1))
+    binding = "mfma" if ceil_mfma <= ceil_hbm_opt else "hbm (hash traffic + optimizer stream)"
+    return {"flop_per_ray": flop_ray, "hash_bytes_per_ray": byte_ray, "optimizer_bytes_per_step": opt_bytes, "ceiling_mfma_rays_per_s": ceil_mfma,
+            "ceiling_hbm_rays_per_s": ceil_hbm, "ceiling_hbm_incl_optimizer_rays_per_s": ceil_hbm_opt, "binding": binding,
+            "ceiling_binding_rays_per_s": min(ceil_mfma, ceil_hbm_opt)}
+
+
 def end_to_end_ceilings(cfg):
     """(flop_per_ray, hash_bytes_per_ray) of one training ray, SURVEY.md 8d: MLP flops (fwd + 2x bwd) and hash-table bytes (gather
     fwd, read + write bwd); proposal nets counted every step"""
@@ -699,8 +716,6 @@ def secondary_training_lines(config, shapes, dev):
     cfg = CONFIGS[config]
     model, scene = build_model(dev, seed=42, config=config)
     trainer = Trainer(model, scene, 1, exchange="allreduce")
-    flop_ray, byte_ray = end_to_end_ceilings(cfg)
-    ceil = min(FP32_MFMA_PEAK_TFLOPS * 1e12 / flop_ray, HBM_PEAK_GBS * 1e9 / byte_ray)
     n_params = sum(p.numel() for p in trainer.grads.params)
     lines = {}
     for rays, steps, warmup in shapes:
@@ -727,9 +742,12 @@ def secondary_training_lines(config, shapes, dev):
         # ("main_field_bwd" is the sum of the three stage regions when those are timed)
         per_step = {k: n * ms / 2 for k, (n, ms) in kern.items() if k != "main_field_bwd" or "main_bwd_sem_kernel" not in kern}
         top = sorted(per_step.items(), key=lambda kv: -kv[1])[:3]
+        bc = binding_ceiling(cfg, rays, n_params, bool(getattr(trainer, "fused_table_adam", False)))
         lines[rays] = {"workload": cfg["workload"], "rays_per_step": rays, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3,
                        "value": rays / dt, "unit": "rays/s", "parameters": n_params,
-                       "top3_regions_ms_per_step": {k: round(v, 3) for k, v in top}, "frac_of_binding": rays / dt / ceil}
+                       "top3_regions_ms_per_step": {k: round(v, 3) for k, v in top}, "binding": bc["binding"],
+                       "frac_of_binding": rays / dt / bc["ceiling_binding_rays_per_s"], "frac_of_mfma": rays / dt / bc["ceiling_mfma_rays_per_s"],
+                       "frac_of_hbm_incl_optimizer": rays / dt / bc["ceiling_hbm_incl_optimizer_rays_per_s"]}
         del batches
     if config == "cfg3" and os.environ.get("PRESIGHT_NO_DRY_OVERLAP") != "1":
         # strong scaling of the production tile: the exchange schedule by construction from a dry run of the bucketed, sharded exchange
@@ -1192,8 +1210,8 @@ def main():
                                 else (None, "not collected for this shape"))
         # end-to-end ceilings per training ray: MLP flops (fwd + 2x bwd) against the fp32 matrix peak, hash bytes
         # (gather fwd, read + write bwd) against HBM; the binding (lower) ceiling is the fp32 MFMA one
-        flop_ray, byte_ray = end_to_end_ceilings(cfg)
-        ceil_mfma, ceil_hbm = FP32_MFMA_PEAK_TFLOPS * 1e12 / flop_ray, HBM_PEAK_GBS * 1e9 / byte_ray
+        bc = binding_ceiling(cfg, rays, sum(p.numel() for p in trainer.grads.params), bool(getattr(trainer, "fused_table_adam", False)))
+        flop_ray, byte_ray, ceil_mfma, ceil_hbm = bc["flop_per_ray"], bc["hash_bytes_per_ray"], bc["ceiling_mfma_rays_per_s"], bc["ceiling_hbm_rays_per_s"]
         per_gpu = value / world
         line = {
             "metric": "training rays/sec (whole node)", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -1213,10 +1231,8 @@ def main():
                 "executed_flops": dom.get("executed"), "algorithmic_flops": dom["algorithmic"], "frac_algorithmic": dom.get("frac_algorithmic"),
                 "duration_ms_incl_moved_work": dom.get("duration_ms_incl_moved_work"), "moved_work_ms": dom.get("moved_work_ms")},
             "roofline_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows],
-            "end_to_end": {"flop_per_ray": flop_ray, "hash_bytes_per_ray": byte_ray, "ceiling_mfma_rays_per_s": ceil_mfma,
-                           "ceiling_hbm_rays_per_s": ceil_hbm, "binding": "mfma" if ceil_mfma < ceil_hbm else "hbm",
-                           "frac_of_binding": per_gpu / min(ceil_mfma, ceil_hbm), "frac_of_mfma": per_gpu / ceil_mfma,
-                           "frac_of_hbm": per_gpu / ceil_hbm},
+            "end_to_end": {**bc, "frac_of_binding": per_gpu / bc["ceiling_binding_rays_per_s"], "frac_of_mfma": per_gpu / ceil_mfma,
+                           "frac_of_hbm": per_gpu / ceil_hbm, "frac_of_hbm_incl_optimizer": per_gpu / bc["ceiling_hbm_incl_optimizer_rays_per_s"]},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
             "kernels_ms_note": "per-kernel pass without the proposal side stream (each kernel alone on the chip); the timed steps overlap "
                                "the proposal networks' backward with the main field's" if side_was else "single stream",

@@ -985,7 +985,11 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
 //                            record writer + this pass): production tile at 65 536 rays 6.61 - 6.90 -> 6.26 - 6.58 ms, at 8192 rays
 //                            3.93 - 3.97 -> 3.36 - 3.50 ms (16.1 GB of p / m / v: 2.5 ms at the 6.4 TB/s streaming ceiling).  Handing
 //                            the empty slices to a separate streaming launch (256-thread workgroups, the microbenchmark's shape) was
-//                            built and measured too: 3.69 - 3.76 ms with it, 3.65 - 3.66 without -- dropped.
+//                            built and measured too: 3.69 - 3.76 ms with it, 3.65 - 3.66 without -- dropped.  So was a variant with
+//                            TWO 512-thread workgroups per item, each owning half of the slice's rows in 64 KiB of LDS (two
+//                            workgroups per CU cover each other's waits; both read all records, the second read from L2): 6.59 vs
+//                            6.53 ms at 65 536 rays, 3.29 - 3.42 vs 3.25 - 3.30 at 8192 -- no gain, dropped.  The pass streams its
+//                            20 GB (65 536 rays: 16.1 GB of p / m / v + 4 GB of records) at 4.8 TB/s, 16.2 GB at 5.3 TB/s at 8192 rays.
 // Same element update (ps::adam_update) on the same fp32 gradient (integer sums are order-independent): bit-equal to the kernel above.
 #ifndef PS_ACC_LATE_V
 #define PS_ACC_LATE_V 1
