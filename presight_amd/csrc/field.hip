@@ -1567,6 +1567,24 @@ __global__ __launch_bounds__(NW * 64) void main_bwd_base_kernel(MainArgs a) {
   reduce_store<Base, NW>(lds, acc, a.gpart + (size_t)lb * C::GPACKED + C::G_BASE);
 }
 
+// Workgroups of the main field's backward kernels (and partial gradient blocks their callers reduce).  256 = one persistent workgroup
+// per compute unit; PS_MAIN_BWD_BLOCKS (a multiple of 8) deals more, shorter ones: a kernel of exactly 256 workgroups that finds k
+// compute units taken -- by the proposal chain on its side stream -- runs its last k workgroups in a second round, i.e. twice as long.
+// Measured (tools/ab_env.sh, one box, alternating): cfg 2 13.30 / 13.47 ms at 256, 13.78 / 13.77 at 512, 13.75 / 13.73 at 1024; cfg 3
+// 23.8 / 24.2 / 24.5 ms -- the shorter workgroups keep asking for compute units and starve the side chain instead; 256 stays.
+#ifndef PS_MAIN_BWD_BLOCKS_DEFAULT
+#define PS_MAIN_BWD_BLOCKS_DEFAULT 256
+#endif
+int main_bwd_blocks() {
+  static const int n = [] {
+    const char* e = getenv("PS_MAIN_BWD_BLOCKS");
+    int v = e != nullptr ? atoi(e) : PS_MAIN_BWD_BLOCKS_DEFAULT;
+    if (v < 8) v = 8;
+    return v / 8 * 8;
+  }();
+  return n;
+}
+
 int grid_for_tiles_nw(int64_t N, int pts_per_tile, int waves, int max_blocks) {
   const int64_t tiles = (N + pts_per_tile - 1) / pts_per_tile;
   int64_t g = (tiles + waves - 1) / waves;
@@ -1711,7 +1729,7 @@ extern "C" int ps_prop_field_bwd(const float* feat, int64_t plane_stride, int LF
 // ---- multi-sub-field launches (ms_core.hpp): n_slots = slots of the sorted layout, packed = K packed blocks back to back,
 // sigma / dsigma in the CALLER's point order (reached through perm), gpart = ps_*_field_parts_ms partial blocks
 extern "C" int ps_prop_field_parts_ms(int64_t n_slots, int K) { return 4 * ms_grid(n_slots, 16 * kPropBwdPB, 4, kPropBwdBlocks, K); }
-extern "C" int ps_main_field_parts_ms(int64_t n_slots, int K) { return ms_grid(n_slots, 16 * kMainBwdPB, kMainBwdWaves, 256, K); }
+extern "C" int ps_main_field_parts_ms(int64_t n_slots, int K) { return ms_grid(n_slots, 16 * kMainBwdPB, kMainBwdWaves, main_bwd_blocks(), K); }
 
 extern "C" int ps_prop_field_fwd_ms(const float* feat, int64_t plane_stride, int LF, int F, int hidden, const float* sel,
                                     const float* packed, int64_t n_slots, float* sigma, const int32_t* perm,
@@ -1735,7 +1753,7 @@ extern "C" int ps_main_field_sizes(int LF, int hidden, int hidden_color, int64_t
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;              \
     *packed_floats = C::PACKED;                                    \
     *grad_floats = C::GPACKED;                                     \
-    *n_parts = grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256); \
+    *n_parts = grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, main_bwd_blocks()); \
     if (offsets) {                                                 \
       offsets[0] = C::P_BASE;                                      \
       offsets[1] = C::P_SEM;                                       \
@@ -1769,7 +1787,7 @@ extern "C" int ps_main_field_f_sizes(int LF, int hidden, int hidden_color, int64
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;        \
     *packed_floats = C::PACKED;                                    \
     *grad_floats = C::GPACKED;                                     \
-    *n_parts = grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, 256); \
+    *n_parts = grid_for_tiles_nw(N, 16 * kMainBwdPB, kMainBwdWaves, main_bwd_blocks()); \
     if (offsets) {                                                 \
       offsets[0] = C::P_BASE;                                      \
       offsets[1] = C::P_SEM;                                       \
@@ -1867,12 +1885,12 @@ int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStrea
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>;                                                    \
     if (a.perm != nullptr) {                                                                                          \
       a.packed_stride = C::PACKED;                                                                                    \
-      const int grid = ms_grid(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256, a.K);                                        \
+      const int grid = ms_grid(a.N, 16 * kMainBwdPB, kMainBwdWaves, main_bwd_blocks(), a.K);                                        \
       if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);    \
       if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);    \
       if (st & 4) main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);   \
     } else {                                                                                                          \
-      const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256);                                   \
+      const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, main_bwd_blocks());                                   \
       if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);   \
       if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);   \
       if (st & 4) main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
@@ -1890,7 +1908,7 @@ int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStrea
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, true>;                                                           \
-    const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256);                                     \
+    const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, main_bwd_blocks());                                     \
     if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);      \
     if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);      \
     if (st & 4) main_bwd_base_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);     \
@@ -1909,7 +1927,7 @@ int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStrea
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16>;                                                                 \
     if (a.perm != nullptr) {                                                                                          \
       a.packed_stride = C::PACKED;                                                                                    \
-      const int grid = ms_grid(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256, a.K);                                        \
+      const int grid = ms_grid(a.N, 16 * kMainBwdPB, kMainBwdWaves, main_bwd_blocks(), a.K);                                        \
       if (a.acts != nullptr && a.dzb != nullptr) {                                                                    \
         if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
         if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
@@ -1919,7 +1937,7 @@ int main_bwd_impl(MainArgs a, int hidden, int hidden_color, int stages, hipStrea
       else                                                                                                            \
         main_bwd_kernel<C, kMainBwdPB, kMainBwdWaves, false, true><<<grid, kMainBwdWaves * 64, 0, s>>>(a);            \
     } else {                                                                                                          \
-      const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, 256);                                   \
+      const int grid = grid_for_tiles_nw(a.N, 16 * kMainBwdPB, kMainBwdWaves, main_bwd_blocks());                                   \
       if (a.acts != nullptr && a.dzb != nullptr) {                                                                    \
         if (st & 1) main_bwd_sem_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \
         if (st & 2) main_bwd_rgb_kernel<C, kMainBwdPB, kMainBwdWaves, false><<<grid, kMainBwdWaves * 64, 0, s>>>(a);  \

@@ -1,5 +1,8 @@
-"""Per-level cost of the binned table backward on the real sample distribution of a cfg-2 training step:
-captures (u, d(features)) of the main field's scatter, then runs ps_grid_scatter_binned level by level (L=1)."""
+"""Per-level cost of the hash encode and of the binned table backward on the real sample distribution of a cfg-2 training step, for
+the main table AND the two proposal tables: captures (u, d(features), table) of every field's scatter, then runs ps_grid_encode and
+ps_grid_scatter_binned level by level (L = 1; the scatter writes a plain gradient, without the fused Adam step), and prints the
+records per level (4 x-pair records per point and level; the share that the accumulate pass could merge because consecutive records of
+a lane hit the same row pair is what the coarse levels' times show).     gpurun -- python tools/scatter_levels.py [steps_before]"""
 import os
 import sys
 import time
@@ -24,7 +27,7 @@ def main():
     orig = FO._scatter
 
     def spy(u, dfeat, scalings, g, tshape, sink=None, counts=None, ws_with_absmax=None, sink_owner=None):
-        caps.append(dict(u=u.clone(), dfeat=dfeat.clone(), scalings=scalings.clone(), g=g,
+        caps.append(dict(u=u.clone(), dfeat=dfeat.clone(), scalings=scalings.clone(), g=g, table=sink_owner.detach().clone(),
                          counts=None if counts is None else counts.clone(), absmax=ws_with_absmax is not None))
         return orig(u, dfeat, scalings, g, tshape, sink, counts, ws_with_absmax, sink_owner)
 
@@ -60,7 +63,15 @@ def main():
         t_all = timed(lambda: run(u, dfeat, sc, L, 3, c=cnt))
         t_prep = timed(lambda: run(u, dfeat, sc, L, 1, c=cnt))
         t_acc = timed(lambda: run(u, dfeat, sc, L, 2))
-        print(f"after {steps_before} steps: L{L} F{F} T2^{l2t} N={N} counts_from_fwd={cnt is not None}: all {t_all:.3f} ms = prepare {t_prep:.3f} + accumulate {t_acc:.3f}")
+        table = cap["table"].reshape(L, 1 << l2t, F)
+        feat = torch.empty(L, N, F, device=dev)
+
+        def enc(tb, scl, LL, f):
+            check(lib().ps_grid_encode(u.data_ptr(), tb.data_ptr(), scl.data_ptr(), LL, F, l2t, N, N * F, f.data_ptr(), 0, s), "encode")
+
+        t_enc = timed(lambda: enc(table, sc, L, feat))
+        print(f"after {steps_before} steps: L{L} F{F} T2^{l2t} N={N} counts_from_fwd={cnt is not None}: encode (inference form, all levels) {t_enc:.3f} ms; "
+              f"table backward all {t_all:.3f} ms = prepare {t_prep:.3f} + accumulate {t_acc:.3f}")
         per = items // L
         tot = 0.0
         for l in range(L):
@@ -70,7 +81,10 @@ def main():
             ta = timed(lambda: run(u, plane, sl, 1, 2))
             t1 = timed(lambda: run(u, plane, sl, 1, 2, 0, 1))  # slice 0 of the level alone (dense levels: all of it)
             tot += tp + ta
-            print(f"  level {l:2d} res {int(sl[0]):5d}: prepare (count+write) {tp:.3f}  accumulate {ta:.3f} ms (slice 0 alone {t1:.3f}; {per} slices)")
+            te = timed(lambda: enc(table[l].contiguous(), sl, 1, feat[:1]))
+            rows = min((int(sl[0]) + 2) ** 3, 1 << l2t)
+            print(f"  level {l:2d} res {int(sl[0]):5d} (<= {rows:8d} live rows): encode {te:.3f}  prepare (count+write) {tp:.3f}  accumulate {ta:.3f} ms "
+                  f"(slice 0 alone {t1:.3f}; {per} slices; {4 * N / 1e6:.1f} M records)")
         print(f"  sum of single-level runs {tot:.3f} ms")
 
 
