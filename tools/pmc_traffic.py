@@ -31,5 +31,10 @@ for key, pat in (("main_fwd_kernel", "main_fwd_kernel"), ("main_bwd_sem_kernel",
             break
 if sha is None:  # summaries of earlier rounds carry no stamp: the figure cannot be tied to a source state
     sha = "unstamped"
-json.dump(dict(src_sha16=sha, kernels=out), open(dst, "w"), indent=1)
+note = ("hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB.  The x2 on FETCH_SIZE is MI355X_MICROARCH.md's gfx950 correction for "
+        "16-byte-per-lane STREAMING reads; it is calibrated for exactly that access shape.  The four kernels listed here (the main field's "
+        "forward and its three backward kernels) read their operands -- feature planes, kept activations -- as 16-byte / lane streams, so the "
+        "rule applies.  Gather kernels (grid_encode_*, bin_kernel, accumulate_*) are deliberately NOT listed: for 4..16-byte rows fetched as "
+        "64-byte lines the factor is uncalibrated; their rooflines in bench.py use algorithmic bytes and measured line rates instead.")
+json.dump(dict(src_sha16=sha, note=note, kernels=out), open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))

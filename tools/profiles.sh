@@ -3,7 +3,7 @@
 #   un-profiled default bench line (with its secondary block, psnr_after_k_steps and the dry run of the overlapped exchange), rocprofv3
 #   kernel traces of cfg 2 / cfg 3 (65 536 and 8192 rays) / cfg 4, the cfg-5 lines (production tile and cfg-2 fields), PMC passes of
 #   cfg 2 (all counter groups) and of cfg 3 / cfg 4 (HBM bytes, matrix-pipe busy, L2 hit rate)
-T=${1:-r04}
+T=${1:-r05}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export PRESIGHT_NO_DRY_OVERLAP=1   # (the traced / counted runs measure the plain step; the default line below carries the dry run)
 PRESIGHT_NO_DRY_OVERLAP=0 python3 bench.py > gpurun_out/bench_${T}.json 2> gpurun_out/bench_${T}.err
