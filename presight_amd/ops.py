@@ -13,7 +13,9 @@ from ._lib import check, lib
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of torch's current stream on the current device (every library launch goes there).  The raw-handle query is 10 x
+    cheaper than building a torch.cuda.Stream object per call (~900 calls per step: 0.5 ms of host time on a routed tile)"""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 # ---- side stream of the proposal networks (samplers.ProposalNetworkSampler.generate_ray_samples) ----------------------------

@@ -351,7 +351,8 @@ class Trainer:
             raise RuntimeError("presight_amd Trainer: an earlier iteration raised AFTER hash tables had taken their fused Adam step "
                                f"({self._inconsistent}); tables and the other parameters are one step apart.  Restore a checkpoint "
                                "(load_state_dict + the model's state_dict) and call clear_failure() to continue")
-        m.train()
+        if not m.training:  # (nn.Module.train() walks every sub-module: ~1000 of them on a K = 16 tile, 2 ms of host time per step --
+            m.train()       #  at 8192 rays per rank the production tile's step is bound by the host's enqueue time, tools/dbg/host_bound.py)
         self._run_callbacks(TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
         pipe = self._begin_step()
         o, d, pa, dn = ops.generate_rays(batch["ray_indices"], s["c2w"], s["fx"], s["fy"], s["cx"], s["cy"])
