@@ -162,7 +162,8 @@ def test_production_shape_k16_training_step_matches_oracle(dev):
     g64 = {n: (g if g is not None else torch.zeros_like(p.detach())) for (n, p), g in zip(P64.items(), g64)}
     # per-tensor bound = max(5e-5, 4 x |oracle fp32 - oracle fp64|): a few gradients of sub-fields that see a handful of
     # near-saturated rays are ill-conditioned in fp32 on the reference side too (4e-3..7e-3 at this seed), the bulk is ~1e-5
-    errs, names, bounds = assert_grads_within_oracle_noise({n: p.grad for n, p in model.named_parameters()}, g_ref, g64, what="K=16 step")
+    errs, names, bounds = assert_grads_within_oracle_noise({n: p.grad for n, p in model.named_parameters()}, g_ref, g64, what="K=16 step",
+                                                           cap=5e-2)  # (production shape: see test_k8_training_step_matches_reference_fixture)
     n_zero = len(g_ref) - len(errs)
     q = lambda f: errs[min(len(errs) - 1, int(f * len(errs)))]  # noqa: E731
     print(f"K=16 step: {len(errs)} parameter gradients compared, {n_zero} exactly zero on both sides (sub-fields without samples); "
@@ -202,7 +203,12 @@ def test_k8_training_step_matches_reference_fixture(dev, gold_model_k8):
     g64 = torch.autograd.grad(sum(L64.values()), list(P64.values()), allow_unused=True)
     g64 = {n: (g if g is not None else torch.zeros_like(p.detach())) for (n, p), g in zip(P64.items(), g64)}
     g_ref = {n: (t(G["TG_" + n]) if "TG_" + n in G else torch.zeros_like(v)) for n, v in P.items()}
-    errs, names, bounds = assert_grads_within_oracle_noise({n: p.grad for n, p in model.named_parameters()}, g_ref, g64, what="K=8 reference step")
+    # cap 5e-2 instead of the default 1e-2, on purpose and printed by the helper: at the production shape (levels up to resolution
+    # 16384, 64 rays) the REFERENCE's own fp32 gradients of these tables sit 0.2 - 0.7 of their largest entry away from the fp64
+    # gradient in the max-norm (single hash rows behind flipped ReLU units); the per-tensor 2-norm guard -- as close to the exact
+    # gradient as the reference's own fp32 run -- is the tight check for those networks
+    errs, names, bounds = assert_grads_within_oracle_noise({n: p.grad for n, p in model.named_parameters()}, g_ref, g64, what="K=8 reference step",
+                                                           cap=5e-2)
     print(f"K=8 step vs the reference fixture: {len(errs)} gradients, median {errs[len(errs) // 2]:.1e}, max {errs[-1]:.1e} ({names[-1]}, bound {bounds[-1]:.1e})")
     assert len(errs) == int(G["n_grads"]) and errs[len(errs) // 2] < 5e-5
 
