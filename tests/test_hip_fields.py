@@ -403,7 +403,11 @@ def test_table_gradient_non_finite_input_gives_nan_not_garbage(F, dev):
         assert bool(torch.isfinite(per_level[[0, 1, 3]]).all())
 
 
-@pytest.mark.parametrize("L,nf,l2t,mx,N", [(16, 2, 19, 2048, 60001), (8, 1, 20, 4096, 30001), (10, 4, 14, 16384, 5000), (2, 2, 9, 64, 700)])
+# (which accumulate kernel a shape runs -- csrc/encode.hip scatter_binned_impl: full 128-KiB slices with < 128 k records per item on
+#  average take accumulate_adam_kernel (every load of an item up front, slices without records skip the accumulators): the first
+#  three; many records per item, (2, 2, 13, ...), or slices smaller than 128 KiB, (2, 2, 9, ...), stay on accumulate_kernel)
+@pytest.mark.parametrize("L,nf,l2t,mx,N", [(16, 2, 19, 2048, 60001), (8, 1, 20, 4096, 30001), (10, 4, 14, 16384, 5000), (2, 2, 13, 64, 80000),
+                                           (2, 2, 9, 64, 700)])
 def test_table_backward_with_the_adam_step_inside_equals_scatter_then_adam(F, dev, L, nf, l2t, mx, N):
     """ps_grid_scatter_binned_adam (the table backward that applies the optimizer's element update to every slice it finishes: what
     a single-process trainer runs) against the two-call sequence it replaces -- ps_grid_scatter_binned into a zeroed gradient, then
