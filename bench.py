@@ -117,7 +117,8 @@ def compact_line(full: dict, detail_path=None) -> dict:
     roof = full.get("roofline")
     if roof is not None:
         r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_algorithmic", "avg_launch_ms", "launches",
-                         "bytes_per_launch", "flops_per_launch", "traffic_source", "semantic_head_tiles_executed"))
+                         "bytes_per_launch", "flops_per_launch", "traffic_source", "semantic_head_tiles_executed", "traffic_over_algorithmic_io",
+                         "kept_activation_bytes", "traffic_TBps"))
         r["kernel"] = _clip(r.get("kernel"), 120)
         r["traffic_source"] = _clip(r.get("traffic_source"), 100)
         if isinstance(roof.get("gather"), dict):
@@ -686,6 +687,28 @@ def binding_ceiling(cfg, rays, n_params, fused_tables=True):
             "ceiling_binding_rays_per_s": min(ceil_mfma, ceil_hbm_opt)}
 
 
+def main_fwd_io(cfg, rays, traffic, launch_ms):
+    """algorithmic I/O and kept-activation bytes of one main-forward launch (64 samples per ray), next to the measured HBM traffic"""
+    from presight_amd import field_ops
+
+    m = cfg["model"]
+    n = rays * 64
+    lf = m["num_levels"] * m["features_per_level"]
+    fact = field_ops.FACTORED and "dynamic" not in cfg and cfg["K"] == 1
+    io = n * (lf * 4 + 4) + (n * (4 + 12 + 4) + rays * 64 * 4 if fact else n * (4 + 12 + 256))
+    try:
+        act_w = field_ops._main_spec_f(lf, m["hidden_dim"], m["hidden_dim_color"], 16).act_width if fact else None
+    except Exception:
+        act_w = None
+    kept = None if act_w is None else n * act_w * 4
+    out = {"io_bytes_algorithmic": io, "kept_activation_bytes": kept}
+    if traffic:
+        out["traffic_over_algorithmic_io"] = traffic / io
+        if launch_ms:
+            out["traffic_TBps"] = traffic / (launch_ms * 1e-3) / 1e12
+    return out
+
+
 def end_to_end_ceilings(cfg):
     """(flop_per_ray, hash_bytes_per_ray) of one training ray, SURVEY.md 8d: MLP flops (fwd + 2x bwd) and hash-table bytes (gather
     fwd, read + write bwd); proposal nets counted every step"""
@@ -1229,7 +1252,11 @@ def main():
                 # small per-ray launches that took over part of its work) / peak.  `frac_algorithmic` prices the flops of the reference's
                 # unfactored network (26 752 MAC per sample) against the same duration
                 "executed_flops": dom.get("executed"), "algorithmic_flops": dom["algorithmic"], "frac_algorithmic": dom.get("frac_algorithmic"),
-                "duration_ms_incl_moved_work": dom.get("duration_ms_incl_moved_work"), "moved_work_ms": dom.get("moved_work_ms")},
+                "duration_ms_incl_moved_work": dom.get("duration_ms_incl_moved_work"), "moved_work_ms": dom.get("moved_work_ms"),
+                # what the traffic is: the kernel's algorithmic I/O (feature planes in; density, colour, weights per sample and the composited
+                # semantic activations per ray out) against the hidden activations it KEEPS for the three backward kernels (register order,
+                # fp32: the price of an exact-fp32 backward without recompute) -- the MFMA-bound forward also streams this
+                **main_fwd_io(cfg, rays, traffic, dom.get("avg_launch_ms"))},
             "roofline_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows],
             "end_to_end": {**bc, "frac_of_binding": per_gpu / bc["ceiling_binding_rays_per_s"], "frac_of_mfma": per_gpu / ceil_mfma,
                            "frac_of_hbm": per_gpu / ceil_hbm, "frac_of_hbm_incl_optimizer": per_gpu / bc["ceiling_hbm_incl_optimizer_rays_per_s"]},
