@@ -71,6 +71,38 @@ def load_pipeline(model, pipeline: Dict[str, torch.Tensor], step: int) -> None:
     model.load_state_dict(model_state(pipeline), strict=True)
 
 
+def model_kwargs_from_pipeline(pipeline: Dict[str, torch.Tensor]) -> Dict:
+    """the constructor arguments the reference's pipeline takes from its DATA MANAGER (ns/pipelines/PreSight/my_pipeline.py:104-117:
+    centroids and per-sub-field AABBs from the dataparser's k-means, the numbers of training cameras / videos), recovered from a
+    checkpoint instead: they are all there as buffers and embedding shapes.  With them a model can be rebuilt from its config and a
+    checkpoint alone -- what prior extraction needs when the dataset the tile was trained on is not at hand."""
+    sd = model_state(pipeline)
+    K = int(sd["field.centroids"].shape[0])
+    out = {"centroids": sd["field.centroids"].clone(), "aabbs": torch.stack([sd[f"field.fields.{k}.aabb"] for k in range(K)]).clone(),
+           "dino_to_rgb": None}
+    if "appearance_embedding.embedding.weight" in sd:
+        out["num_train_cameras"] = int(sd["appearance_embedding.embedding.weight"].shape[0])
+    if "video_embedding.embedding.weight" in sd:
+        out["num_train_videos"] = int(sd["video_embedding.embedding.weight"].shape[0])
+    return out
+
+
+def build_model_from_checkpoint(model_config, path_or_ckpt, device=None, load_step: Optional[int] = None, **overrides):
+    """`model_config.setup(...)` with the data-manager arguments taken from the checkpoint (model_kwargs_from_pipeline; `overrides`, e.g.
+    dino_to_rgb, win), then load_checkpoint on the evaluation path.  -> (model in eval mode, step)"""
+    ckpt = path_or_ckpt if isinstance(path_or_ckpt, dict) else read_checkpoint(path_or_ckpt, load_step)
+    kw = model_kwargs_from_pipeline(ckpt["pipeline"])
+    kw.update(overrides)
+    kw.setdefault("num_train_cameras", 1)
+    kw.setdefault("num_train_videos", 1)
+    model = model_config.setup(scene_box=None, num_train_data=-1, **kw)
+    if device is not None:
+        model = model.to(device)
+    step = load_checkpoint(ckpt, model)
+    model.eval()
+    return model, step
+
+
 # --------------------------------------------------------------------------------------------------------- optimizer / scheduler layouts
 def _adam_state_dict(opt, params: List[torch.nn.Parameter], index: Dict[int, int], steps: List[int], initial_lr: Optional[float]) -> Dict:
     """torch.optim.Adam.state_dict() of one parameter group: per-parameter state only for parameters that were ever stepped (torch
