@@ -295,7 +295,7 @@ def build_hip_model(cfg, scene, P, dev, **conf_overrides):
     return model.to(dev)
 
 
-def learnable_scene_setup(rays: int = 192, steps: int = 40, test_rays: int = 384):
+def learnable_scene_setup(rays: int = 192, steps: int = 40, test_rays: int = 384, num_cameras: int = 24):
     """The learnable synthetic scene at fixture size, built by the ORACLE (oracle/nerf_oracle.py::teacher_params / teacher_targets;
     presight_amd/synthetic.py is the same construction on the HIP side): tiny K = 1 model, a teacher parameter set, `steps` training
     batches whose targets are the teacher's renders (+ stored jitters), a held-out test batch, and the student's initial parameters.
@@ -303,7 +303,7 @@ def learnable_scene_setup(rays: int = 192, steps: int = 40, test_rays: int = 384
     from oracle import nerf_oracle as O
 
     cfg = O.tiny_config()
-    cfg["num_cameras"] = 24
+    cfg["num_cameras"] = num_cameras
     for p in [cfg["main"]] + cfg["props"]:
         p["log2_hashmap_size"] = 12
     scene = O.make_scene(cfg)

@@ -67,12 +67,13 @@ def code_spread():
     return float((w - w.mean(0)).norm(dim=1).mean()), float(w.mean(0).norm())
 
 
-tr = Trainer(model, scene, 1, max_num_iterations=K)
+WD = float(os.environ.get("SOAK_WEIGHT_DECAY", "1e-5"))  # (the reference's optimizers: Adam(weight_decay=1e-5), method_configs.py:158-168)
+tr = Trainer(model, scene, 1, max_num_iterations=K, weight_decay=WD)
 feed = ChunkFeed(lambda i: chunks[i % NCH], batch_size=65536, device=dev, world=1, rank=0)
 psnr = [eval_psnr(model, scene, tri, tvid, test["rgb"])]
 psnr_in = [eval_psnr(model, scene, tri_in, tvid_in, rgb_in)]
 psnr_tc = [psnr_train_codes()]
-print(f"{NCH} chunk(s) of 4 M pixels in rotation; fused table Adam {tr.fused_table_adam}; env " +
+print(f"{NCH} chunk(s) of 4 M pixels in rotation; weight decay {WD}; fused table Adam {tr.fused_table_adam}; env " +
       str({k: v for k, v in os.environ.items() if k.startswith("PRESIGHT_")}))
 print("iteration 0: held-out PSNR vs teacher %.2f dB, in-chunk %.2f dB" % (psnr[0], psnr_in[0]), flush=True)
 t0 = time.time()
