@@ -20,6 +20,8 @@ strictly in the order they were passed to enable_overlap, whether a bucket is la
 during backward) or from finish_exchange (a sub-field without samples on this rank never completes it)."""
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -96,6 +98,18 @@ def intersect_ranges(xs: Sequence[Tuple[int, int]], ys: Sequence[Tuple[int, int]
         else:
             j += 1
     return out
+
+
+def exchange_in_world_of_one() -> bool:
+    """PRESIGHT_EXCHANGE_WORLD_OF_ONE=1: a process group of ONE rank counts as a distributed run -- every bucket, flag and parameter
+    collective is issued in it (sum over one rank / 1: the identity, bit for bit).  This is how the exchange code runs through RCCL on a
+    one-GPU box (tests/test_hip_dist.py::test_rccl_group_of_one_runs_the_exchange); two ranks cannot share a GPU under RCCL."""
+    return os.environ.get("PRESIGHT_EXCHANGE_WORLD_OF_ONE") == "1"
+
+
+def exchanging(group: Optional["dist.ProcessGroup"] = None) -> bool:
+    """a process group is up and gradients travel through it"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or exchange_in_world_of_one())
 
 
 class FlatGrads:
@@ -254,7 +268,7 @@ class FlatGrads:
 
     def touched(self, group: Optional[dist.ProcessGroup] = None) -> List[bool]:
         flags = [bool(p._ps_touched) for p in self.params]
-        if self.flags_may_differ_across_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if self.flags_may_differ_across_ranks and exchanging(group):
             t = torch.tensor(flags, dtype=torch.int32, device=self.flat.device)  # DDP: a parameter used on ANY rank gets a gradient
             COMM_LOG.issue("all_reduce_max_host_flags", "-", 4 * len(flags), "current", self.step_no)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -334,7 +348,7 @@ class FlatGrads:
             self._comm_stream = torch.cuda.Stream(device=self.flat.device)
 
     def _distributed(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
+        return exchanging(self._group)
 
     def _mark_ready(self, b):
         """the bucket's gradients are complete on the streams as they stand NOW (the proposal networks' backward runs on side
@@ -453,7 +467,7 @@ class FlatGrads:
     def finish_exchange(self):
         """after backward: launch the buckets that are still local (in order), then make the compute stream wait for all of them"""
         self._join_side_streams()
-        if self.n_groups and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
+        if self.n_groups and exchanging(self._group):
             COMM_LOG.issue("all_reduce_max_flags", "-", 4 * self.group_flags.numel(), "current", self.step_no)
             dist.all_reduce(self.group_flags, op=dist.ReduceOp.MAX, group=self._group)  # device tensor, stream-ordered: no host sync
         if not self._buckets:
@@ -577,7 +591,7 @@ class FlatGrads:
     def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
         """Average the flat gradient buffer over the ranks of `group` (no-op without an initialised process group)."""
         self._join_side_streams()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not exchanging(group):
             return None
         world = dist.get_world_size(group)
         self.flat.div_(world)
@@ -591,7 +605,7 @@ def global_depth_clip(group: Optional[dist.ProcessGroup] = None):
     """hook for presight_amd.ops.set_depth_clip_hook: the expected-depth clip bounds become the min / max sample midpoint over
     the batches of ALL ranks (one 2-float all-reduce per render: MAX over {-min, max})"""
     def hook(minmax: Tensor):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not exchanging(group):
             return
         t = torch.stack([-minmax[0], minmax[1]])
         COMM_LOG.issue("all_reduce_max_depth_clip", "-", 8, "current")
@@ -609,7 +623,7 @@ def init_from_env(device_type: str = "cuda") -> tuple:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or exchange_in_world_of_one()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("PRESIGHT_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")

@@ -23,7 +23,7 @@ import torch
 
 from . import ops, prof
 from .callbacks import TrainingCallbackAttributes, TrainingCallbackLocation
-from .dist import FlatGrads, global_depth_clip as _depth_hook
+from .dist import FlatGrads, exchanging, global_depth_clip as _depth_hook
 from .optim import HipAdam, WarmupMultiStepSchedule
 from .rays import RayBundle
 
@@ -128,8 +128,10 @@ class Trainer:
                 add_bucket(groups[k], k)
         assert seen == {id(p) for p in model.parameters() if p.requires_grad and p.numel() > 0}
         self.group_names = kinds  # bucket -> optimizer group name
-        sharded = exchange == "sharded" and world > 1
-        overlap = ((world > 1 or os.environ.get("PRESIGHT_DRY_OVERLAP") == "1") and not model.config.use_same_proposal_network
+        # (a process group of one rank with PRESIGHT_EXCHANGE_WORLD_OF_ONE=1 exchanges like any other: RCCL smoke run on a one-GPU box)
+        self._exchanging = world > 1 or exchanging()
+        sharded = exchange == "sharded" and self._exchanging
+        overlap = ((self._exchanging or os.environ.get("PRESIGHT_DRY_OVERLAP") == "1") and not model.config.use_same_proposal_network
                    and os.environ.get("PRESIGHT_NO_OVERLAP") != "1")
         splits = {table_split: split_pieces} if (overlap and table_split is not None and split_pieces > 1) else None
         self.grads = FlatGrads(uniq, bucket_sizes=sizes, shard_world=world if sharded else 1, splits=splits)
@@ -145,7 +147,7 @@ class Trainer:
                 i += n
             if len(main_tables) > 1 and n_table_buckets > 1:
                 main_tables[0]._ps_ms_parts = n_table_buckets  # field_ops._ms_scatter: one accumulate launch per sub-field group
-            self.grads.enable_overlap(buckets, mode="sharded" if sharded else "allreduce", dry=world == 1)
+            self.grads.enable_overlap(buckets, mode="sharded" if sharded else "allreduce", dry=not self._exchanging)
             if sharded:
                 # (a declared bucket may have become several exchange buckets: the pieces of the split table)
                 gate: Dict[str, list] = {}
@@ -156,7 +158,7 @@ class Trainer:
         self._prop_buckets = [b["index"] for b in self.grads._buckets
                               if kinds[next(j for j, (a0, a1) in enumerate(self.grads.bucket_ranges) if a0 <= b["range"][0] < a1)] == "proposal_networks"]
         self.exchange = "sharded" if sharded else "allreduce"
-        if global_depth_clip and world > 1:
+        if global_depth_clip and self._exchanging:
             ops.set_depth_clip_hook(_depth_hook())
         self.loss_scale = float(loss_scale)
         self.update_grad_scaler = bool(update_grad_scaler)
@@ -174,7 +176,7 @@ class Trainer:
         # tile.  Same bits as the separate step (one shared element update).  Off: PRESIGHT_FUSED_TABLE_ADAM=0, any exchange, the
         # found-inf check of update_grad_scaler (it needs the gradients).  The dual field's static and proposal tables qualify (one
         # evaluation per step); its 4-D table (three position sets, its own scatter entry point) keeps the separate update.
-        can_fuse = world == 1 and not overlap and not self.update_grad_scaler
+        can_fuse = not self._exchanging and not overlap and not self.update_grad_scaler
         if fused_table_adam and not can_fuse:
             raise ValueError("Trainer(fused_table_adam=True) needs world == 1, no exchange overlap and update_grad_scaler=False")
         self.fused_table_adam = can_fuse and (os.environ.get("PRESIGHT_FUSED_TABLE_ADAM", "1") != "0" if fused_table_adam is None else bool(fused_table_adam))
@@ -224,7 +226,7 @@ class Trainer:
             flags[kind].append(~torch.isfinite(fg.flat[a:b]).all())
         found = torch.stack([torch.stack(flags[k]).any() if flags[k] else torch.zeros((), dtype=torch.bool, device=fg.flat.device)
                              for k in kinds]).to(torch.int32)
-        if self.world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+        if self._exchanging and torch.distributed.is_available() and torch.distributed.is_initialized():
             # after a reduce-scatter a rank holds the reduced values of ITS shard only: a rank that neither produced nor owns the
             # inf element would not see it and would step while the others skip -> agree on the flags (GradScaler does the same across
             # its per-device found_inf tensors)
@@ -282,7 +284,7 @@ class Trainer:
 
     def _begin_step(self):
         """clear the gradients of the previous step; -> the pipeline state when this step's optimizer runs pipelined"""
-        pipe = self._pipe_state() if (self.pipeline_adam and self.world == 1 and not self.update_grad_scaler and not self.fused_table_adam
+        pipe = self._pipe_state() if (self.pipeline_adam and not self._exchanging and not self.update_grad_scaler and not self.fused_table_adam
                                       and torch.cuda.is_available()) else None
         if pipe is None:
             self.join()

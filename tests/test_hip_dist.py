@@ -354,6 +354,35 @@ def test_bench_two_ranks_sharded_strong():
     assert line["config"]["rays_per_gpu"] == 2048 and line["config"]["exchange"] == "sharded"
 
 
+@pytest.mark.parametrize("K", [1, 4])
+def test_rccl_group_of_one_runs_the_exchange(K):
+    """The bucketed exchange through RCCL itself on a one-GPU box: a process group of ONE rank (backend nccl = RCCL) with
+    PRESIGHT_EXCHANGE_WORLD_OF_ONE=1, so that every bucket all-reduce / reduce-scatter, the parameter all-gather of the sharded mode and
+    the routed tile's flag all-reduce are issued for real -- on the side stream, during backward, behind the two-stream backward's
+    events -- and the exchanged gradient buffer (sum over one rank / 1) must equal that of a trainer that exchanges nothing (to the 1e-6
+    of the float atomics in a few per-ray gradients; Adam with eps = 1e-15 amplifies that noise, so gradients are compared, not parameters)."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("PRESIGHT_DIST_BACKEND", "PRESIGHT_SINGLE_DEVICE")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PRESIGHT_EXCHANGE_WORLD_OF_ONE="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_group_of_one.py"), str(K)], capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["backend"] == "nccl"
+    for mode in ("allreduce", "sharded"):
+        # 3 steps x (>= 5 gradient buckets [+ the parameter all-gathers of the sharded mode]); all but the tail handed over in backward
+        assert out[mode]["collectives"] >= 3 * out[mode]["buckets"] * (2 if mode == "sharded" else 1), out
+        assert out[mode]["in_backward"] >= 3 * (out[mode]["buckets"] - 1) and out[mode]["gradient_rel_err"] < 1e-4, out
+        assert out[mode]["losses_finite"] and abs(out[mode]["loss_a_b_last"][0] - out[mode]["loss_a_b_last"][1]) < 0.05 * abs(out[mode]["loss_a_b_last"][1]), out
+    want = {"all_reduce", "reduce_scatter", "all_gather_params"} | ({"all_reduce_max_flags"} if K > 1 else set())
+    assert want <= set(out["comm_log_kinds"]), out
+
+
 def test_chunk_feed_yields_the_reference_loader_batches(dev):
     """ChunkFeed over a device-resident chunk == the reference's DataLoader(ImageChunk, DistributedSampler) batch for batch
     (tests/golden/datafeed.npz: ImageChunk.__getitem__ + default collate, generated from the reference), for one rank of one and
