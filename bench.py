@@ -37,6 +37,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: without this RCCL's peer mapping fails (hipIpcGetMemHandle: invalid argument).  Already
+# exported on the GPU boxes; set here too so that a worker started by an external torchrun from a bare environment still has it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 RAYS = 65536
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32 matrix peak
