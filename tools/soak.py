@@ -1,7 +1,7 @@
 """Soak: a 1000-iteration run of the reference loop at cfg-2 size (65 536 rays/step, the reference's proposal update schedule, LR
 schedule with max_num_iterations = 1000, Adam on the 2**10-scaled gradients) on the LEARNABLE teacher-rendered scene
 (presight_amd/synthetic.py): prints losses / held-out PSNR / peak memory every 100 iterations and asserts that the PSNR rises and
-every parameter stays finite.      gpurun -- python tools/soak.py [iterations] [chunks]
+every parameter stays finite.      gpurun -- python tools/soak.py [iterations] [chunks]      (SOAK_CONFIG=cfg3: the same loop on the routed production tile)
 
 chunks (default 8): the training set is `chunks` teacher-rendered chunks of 4 M pixels each, served in rotation -- a new chunk after
 every pass, like the reference's loader (ns/data/PreSight/my_dataset.py:165-330 loads the next `images_per_chunk` images when a chunk is
@@ -26,8 +26,9 @@ from presight_amd.trainer import Trainer  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 NCH = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+CFG = os.environ.get("SOAK_CONFIG", "cfg2")  # cfg3: the routed production tile (K = 16 sub-fields, 940 M parameters), same loop
 dev = torch.device("cuda:0")
-tmodel, scene = bench.build_model(dev, seed=7, config="cfg2", far_plane=TEACHER_FAR)
+tmodel, scene = bench.build_model(dev, seed=7, config=CFG, far_plane=TEACHER_FAR)
 shape_teacher_(tmodel)
 teacher = TeacherScene(tmodel, scene)
 chunks = [teacher.chunk(i, pixels=1 << 22) for i in range(NCH)]
@@ -41,7 +42,7 @@ W_ = scene["W"]
 c0 = chunks[0]
 tri_in = torch.stack([c0["image_indices"][:65536], c0["pixel_indices"][:65536] // W_, c0["pixel_indices"][:65536] % W_], -1)
 tvid_in, rgb_in = c0["video_ids"][:65536], c0["rgbs"][:65536]
-model, scene = bench.build_model(dev, seed=42, config="cfg2", proposal_weights_anneal_max_num_iters=K // 10, proposal_warmup=K // 10)
+model, scene = bench.build_model(dev, seed=42, config=CFG, proposal_weights_anneal_max_num_iters=K // 10, proposal_warmup=K // 10)
 
 
 def psnr_train_codes():
@@ -73,7 +74,7 @@ feed = ChunkFeed(lambda i: chunks[i % NCH], batch_size=65536, device=dev, world=
 psnr = [eval_psnr(model, scene, tri, tvid, test["rgb"])]
 psnr_in = [eval_psnr(model, scene, tri_in, tvid_in, rgb_in)]
 psnr_tc = [psnr_train_codes()]
-print(f"{NCH} chunk(s) of 4 M pixels in rotation; weight decay {WD}; fused table Adam {tr.fused_table_adam}; env " +
+print(f"{CFG}: {NCH} chunk(s) of 4 M pixels in rotation; weight decay {WD}; fused table Adam {tr.fused_table_adam}; env " +
       str({k: v for k, v in os.environ.items() if k.startswith("PRESIGHT_")}))
 print("iteration 0: held-out PSNR vs teacher %.2f dB, in-chunk %.2f dB" % (psnr[0], psnr_in[0]), flush=True)
 t0 = time.time()
