@@ -411,17 +411,27 @@ namespace {
 //   cfg 2 14.16 -> 13.90 ms per step (main table backward 2.67 -> 2.58 with 1024 points, proposal 1.08 -> 1.04 with 512),
 //   cfg 3 24.5 -> 24.2 ms, cfg 4 (4-D table, 512 instead of 256 points) 50.6 -> 49.0 ms.
 // History of the points: F = 4 tables have 256 slices per level, 512 points gave runs of 8 records = 32 bytes per plane (PMC,
-// production tile: 6.6 GB written for 4.0 GB of records), 1024 points double them (4.97 -> 4.34 ms).  1024 points x 1024 threads does
-// not fit F = 2 (staging area > 64 KiB static LDS).
+// production tile: 6.6 GB written for 4.0 GB of records), 1024 points double them (4.97 -> 4.34 ms).
+// Round 5, F = 2 (cfg 2 / cfg 4 main tables): 1024 threads x ONE point instead of 512 x 2 -- the same 1024 points and 71 KiB of staging
+// per workgroup, two workgroups per CU, but 8 waves per SIMD instead of 4 (PMC: the 512-thread kernel's waves WAIT 63 % of their
+// cycles and issue 16 %) -- four alternating triples on one box: cfg 2 13.58 - 13.72 (512 x 2) -> 13.33 - 13.40 ms per step, cfg 4
+// 49.3 -> 48.9 ms.  The same shape for F = 1 (proposal tables: 1024 instead of 512 points) measured neutral on cfg 2 and 0.3 ms
+// WORSE on the routed production tile (proposal table backward 1.64 -> 1.78 ms), 1024 x 2 points worse everywhere: F = 1 stays.
 #ifndef PS_BIN_THREADS
 #define PS_BIN_THREADS 512
 #endif
 #ifndef PS_BIN_THREADS_F4
 #define PS_BIN_THREADS_F4 PS_BIN_THREADS
 #endif
-constexpr int bin_threads(int D, int F) { return (D == 3 && F == 4) ? PS_BIN_THREADS_F4 : PS_BIN_THREADS; }
+#ifndef PS_BIN_THREADS_4D
+#define PS_BIN_THREADS_4D 512
+#endif
+#ifndef PS_BIN_THREADS_F2
+#define PS_BIN_THREADS_F2 1024
+#endif
+constexpr int bin_threads(int D, int F) { return D == 4 ? PS_BIN_THREADS_4D : (F == 4 ? PS_BIN_THREADS_F4 : (F == 2 ? PS_BIN_THREADS_F2 : PS_BIN_THREADS)); }
 #ifndef PS_BIN_PPT
-#define PS_BIN_PPT 2  // F = 2
+#define PS_BIN_PPT 1  // F = 2
 #endif
 #ifndef PS_BIN_PPT_F1
 #define PS_BIN_PPT_F1 1
