@@ -51,8 +51,6 @@ def main():
                 # comparison is made on the gradients of the first step, not on the parameters after it.)
                 fa, fb = tr_a.grads, tr_b.grads
                 assert [tuple(p.shape) for p in fa.params] == [tuple(p.shape) for p in fb.params]
-                for j, (n, _) in enumerate(model_a.named_parameters()):
-                    pass
                 for j in range(len(fa.params)):
                     ga = fa.flat[fa.offsets[j]:fa.offsets[j] + fa.params[j].numel()]
                     gb = fb.flat[fb.offsets[j]:fb.offsets[j] + fb.params[j].numel()]
