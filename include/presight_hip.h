@@ -402,6 +402,10 @@ int ps_voxel_index(const float* pts, int64_t n, double voxel, const double* min_
 int ps_lattice_points(const float* aabb /*host[6]*/, int res, int64_t start, int64_t count, float* pts, void* stream);
 /* (a + b + c) / 3: mean of proposal-net and main-field densities, extract_priors.py:133-137 */
 int ps_mean_density(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
+/* out[i, :] = fp16(clamp(src[idx[i], :], lo, hi)): the features of the points above the density threshold, clipped to [0, 1] and
+ * stored as fp16 (feat.clip(0, 1).astype(np.float16) of the selected rows, extract_priors.py:136-138); src [n,C] fp32, C <= 64,
+ * idx [m] int64 row numbers, out [m,C] fp16 */
+int ps_gather_clip_f16(const float* src, const int64_t* idx, int64_t m, int C, float lo, float hi, void* out_f16, void* stream);
 
 /* voxel down-sampling of the extracted points (extract_priors.py:151-191, 216-245; Open3D voxel_down_sample_and_trace):
  * keys[i] = (ix * ny + iy) * nz + iz of the ps_voxel_index triple; after a stable sort of the keys (order [n] = point of

@@ -3,6 +3,7 @@
 //                      idx = floor((p - (min_bound - voxel/2)) / voxel) per axis, evaluated in fp64 -> int64 (bit exact)
 //   ps_lattice_points: the dense res^3 query lattice over a tile AABB (z fastest), cell centres
 //   ps_mean_density  : mean of the proposal-net and main-field densities (extract_priors.py:133-137)
+//   ps_gather_clip_f16: the kept points' features, clipped to [0, 1] and stored as fp16 (extract_priors.py:136-138), in one pass
 #include <hip/hip_fp16.h>
 #include "common.hpp"
 
@@ -54,6 +55,43 @@ extern "C" int ps_lattice_points(const float* aabb /*host[6]: min xyz, max xyz*/
   if (count == 0) return 0;
   lattice_points_kernel<<<(unsigned)((count + 255) / 256), 256, 0, (hipStream_t)stream>>>(aabb[0], aabb[1], aabb[2], aabb[3],
                                                                                          aabb[4], aabb[5], res, start, count, pts);
+  PS_CHECK_LAUNCH();
+}
+
+namespace {
+// rows idx[i] of src [n, C] (fp32) -> clamp to [lo, hi] -> fp16.  C = 64 (the feature width of the prior extraction): 16 lanes per row,
+// 16 bytes in / 8 bytes out per lane, four rows per wavefront instruction; other widths: one lane per channel
+__device__ __forceinline__ float clampf_nan(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }  // torch.clamp: a NaN stays a NaN
+__global__ __launch_bounds__(256) void gather_clip_f16_c64_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int64_t m, float lo,
+                                                                  float hi, __half* __restrict__ out) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t i = t >> 4;
+  if (i >= m) return;
+  const int q = (int)(t & 15);
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + idx[i] * 64 + 4 * q));
+  const __half2 a = __floats2half2_rn(clampf_nan(v.x, lo, hi), clampf_nan(v.y, lo, hi));
+  const __half2 b = __floats2half2_rn(clampf_nan(v.z, lo, hi), clampf_nan(v.w, lo, hi));
+  uint2 o;
+  o.x = *reinterpret_cast<const unsigned*>(&a);
+  o.y = *reinterpret_cast<const unsigned*>(&b);
+  *reinterpret_cast<uint2*>(out + i * 64 + 4 * q) = o;
+}
+__global__ __launch_bounds__(256) void gather_clip_f16_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int64_t m, int C,
+                                                              float lo, float hi, __half* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= m || lane >= C) return;
+  out[i * C + lane] = __float2half_rn(clampf_nan(src[idx[i] * C + lane], lo, hi));
+}
+}  // namespace
+
+extern "C" int ps_gather_clip_f16(const float* src, const int64_t* idx, int64_t m, int C, float lo, float hi, void* out_f16, void* stream) {
+  if (m == 0) return 0;
+  PS_REQUIRE(C >= 1 && C <= 64, "ps_gather_clip_f16: 1..64 channels");
+  if (C == 64)
+    gather_clip_f16_c64_kernel<<<(unsigned)((m * 16 + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, idx, m, lo, hi, (__half*)out_f16);
+  else
+    gather_clip_f16_kernel<<<(unsigned)((m + 3) / 4), 256, 0, (hipStream_t)stream>>>(src, idx, m, C, lo, hi, (__half*)out_f16);
   PS_CHECK_LAUNCH();
 }
 
@@ -133,6 +171,55 @@ __global__ __launch_bounds__(256) void voxel_reduce_kernel(const int64_t* __rest
   }
 }
 
+// C even: HALF a wavefront per voxel, a lane carries two channels (one 4-byte load per member row instead of 2 bytes); same sums in the
+// same (member) order per channel
+__global__ __launch_bounds__(256) void voxel_reduce_h2_kernel(const int64_t* __restrict__ order, const int64_t* __restrict__ starts,
+                                                              const int64_t* __restrict__ counts, int64_t V, const float* __restrict__ pts,
+                                                              const __half* __restrict__ feats, const float* __restrict__ colors, int C,
+                                                              float* __restrict__ o_pts, __half* __restrict__ o_feat,
+                                                              float* __restrict__ o_col, double* __restrict__ sums) {
+  const int64_t v = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 5;
+  if (v >= V) return;
+  const int lane = threadIdx.x & 31, C2 = C / 2;
+  const int64_t s = starts[v], c = counts[v];
+  double f0 = 0.0, f1 = 0.0, psum = 0.0;
+  for (int64_t m0 = 0; m0 < c; m0 += 32) {
+    const int64_t nm = (c - m0) < 32 ? (c - m0) : 32;
+    const int64_t mine = lane < nm ? order[s + m0 + lane] : 0;
+    for (int64_t m = 0; m < nm; m += 4) {
+      int64_t p[4];
+      __half2 f[4];
+      float q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) p[k] = __shfl(mine, (int)((m + k) < nm ? (m + k) : m), 32);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f[k] = lane < C2 ? *reinterpret_cast<const __half2*>(feats + p[k] * C + 2 * lane) : __half2();
+        q[k] = lane < 3 ? pts[p[k] * 3 + lane] : ((lane < 6 && colors != nullptr) ? colors[p[k] * 3 + (lane - 3)] : 0.0f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (m + k < nm) {
+          f0 += (double)__low2float(f[k]);
+          f1 += (double)__high2float(f[k]);
+          psum += (double)q[k];
+        }
+    }
+  }
+  const double inv = 1.0 / (double)c;
+  if (lane < C2) *reinterpret_cast<__half2*>(o_feat + v * C + 2 * lane) = __halves2half2(__float2half_rn((float)(f0 * inv)), __float2half_rn((float)(f1 * inv)));
+  if (lane < 3) o_pts[v * 3 + lane] = (float)(psum * inv);
+  else if (lane < 6 && colors != nullptr) o_col[v * 3 + (lane - 3)] = (float)(psum * inv);
+  if (sums != nullptr) {
+    double* o = sums + v * (6 + C);
+    if (lane < 6) o[lane] = (lane < 3 || colors != nullptr) ? psum : 0.0;
+    if (lane < C2) {
+      o[6 + 2 * lane] = f0;
+      o[6 + 2 * lane + 1] = f1;
+    }
+  }
+}
+
 }  // namespace
 
 // keys[i] = (ix * ny + iy) * nz + iz with (ix, iy, iz) = ps_voxel_index(p_i); ny, nz = voxel counts along y / z (any bound >=
@@ -151,7 +238,11 @@ extern "C" int ps_voxel_reduce(const int64_t* order, const int64_t* starts, cons
                                double* sums, void* stream) {
   if (V == 0) return 0;
   PS_REQUIRE(C >= 1 && C <= 64, "ps_voxel_reduce: 1..64 feature channels (one lane each)");
-  voxel_reduce_kernel<<<(unsigned)((V + 3) / 4), 256, 0, (hipStream_t)stream>>>(order, starts, counts, V, pts, (const __half*)feats_f16, colors,
-                                                                                C, o_pts, (__half*)o_feat_f16, o_col, sums);
+  if (C % 2 == 0)
+    voxel_reduce_h2_kernel<<<(unsigned)((V + 7) / 8), 256, 0, (hipStream_t)stream>>>(order, starts, counts, V, pts, (const __half*)feats_f16,
+                                                                                     colors, C, o_pts, (__half*)o_feat_f16, o_col, sums);
+  else
+    voxel_reduce_kernel<<<(unsigned)((V + 3) / 4), 256, 0, (hipStream_t)stream>>>(order, starts, counts, V, pts, (const __half*)feats_f16, colors,
+                                                                                  C, o_pts, (__half*)o_feat_f16, o_col, sums);
   PS_CHECK_LAUNCH();
 }

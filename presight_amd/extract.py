@@ -12,11 +12,13 @@
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
 
+from . import field_ops as F
 from ._lib import check, lib
 from .ops import _f32, _p, _stream
 
@@ -39,16 +41,46 @@ def lattice_points(aabb: Tensor, res: int, start: int, count: int, device) -> Te
     return pts
 
 
+SHARE_ROUTING = os.environ.get("PRESIGHT_SHARED_ROUTING", "1") != "0"
+
+
+def shared_routing(model) -> bool:
+    """The three routed modules of a tile (two proposal fields, main field) are queried at the SAME points by the prior extraction
+    (ns/scripts/extract_priors.py:133-138) and are built from the same centroids and sub-field boxes: the nearest-centroid routing, the
+    sorted layout and the per-sub-field normalised points are then computed ONCE per chunk instead of once per module (the reference
+    routes three times: ns/fields/PreSight/ingp_field_ms.py:97-126, prop_density_field_ms.py:90-102).  Checked by VALUE, once per model."""
+    ok = getattr(model, "_shared_routing_ok", None)
+    if ok is None:
+        mods = list(model.proposal_networks) + [model.field]
+        ok = (SHARE_ROUTING and all(hasattr(m, "_ms") and len(getattr(m, "fields", ())) > 1 for m in mods)
+              and F.MERGED_MS and F.merged_supported(*[model.field._ms()[n][0] for n in ("base", "sem", "rgb")]))
+        if ok:
+            ref = model.field._ms()
+            for m in model.proposal_networks:
+                mm = m._ms()
+                ok = ok and torch.equal(m.centroids, model.field.centroids) and torch.equal(mm["aabbs"], ref["aabbs"]) and mm["contract"] == ref["contract"]
+        model._shared_routing_ok = bool(ok)
+    return model._shared_routing_ok
+
+
 @torch.no_grad()
 def _query_raw(model, pts: Tensor, density_threshold: Optional[float] = None) -> Tuple[Tensor, Tensor]:
     """-> (mean density [n], semantics fp32 [n,64] as the field returns them).  With a threshold (and two proposal fields) the main
     field skips its semantic head for the 32-point tiles that cannot contain a kept point: those rows are uninitialised."""
-    dens = [p.density_fn(pts).reshape(-1) for p in model.proposal_networks]
+    routed = None
+    if density_threshold is not None and len(model.proposal_networks) == 2 and shared_routing(model):
+        m = model.field._ms()
+        lay = F.MsLayout(model.field.centroids, pos=pts.reshape(-1, 3))
+        routed = (lay,) + tuple(lay.points(m["aabbs"], m["contract"]))
+        dens = [p._ms_density(lay, points=routed[1:]).reshape(-1) for p in model.proposal_networks]
+    else:
+        dens = [p.density_fn(pts).reshape(-1) for p in model.proposal_networks]
     gate = None
     if density_threshold is not None and len(dens) == 2:
         thr = float(density_threshold)
         gate = (dens[0], dens[1], thr - 1e-5 * abs(thr) - 1e-30)  # a few ulp below the caller's own comparison
-    d_main, sem = model.field.density_and_semantics(pts, gate)  # one pass of the main field for both (the reference makes three)
+    # one pass of the main field for both (the reference makes three)
+    d_main, sem = model.field.density_and_semantics(pts, gate, routed=routed) if routed is not None else model.field.density_and_semantics(pts, gate)
     dens.append(d_main.reshape(-1))
     if len(dens) == 3:
         out = torch.empty_like(dens[0])
@@ -67,7 +99,24 @@ def query_priors(model, pts: Tensor, density_threshold: Optional[float] = None):
     if density_threshold is None:
         return out, sem.clip(0.0, 1.0).to(torch.float16)
     keep = out > density_threshold
-    return out, keep, sem[keep].clip(0.0, 1.0).to(torch.float16)
+    return out, keep, _kept_features(sem, torch.nonzero(keep).squeeze(1))
+
+
+def _kept_features(sem: Tensor, idx: Tensor) -> Tensor:
+    """sem[idx].clip(0, 1).to(float16) in one pass over the kept rows (ps_gather_clip_f16) instead of gather + clamp + convert"""
+    sem = _f32(sem)
+    out = torch.empty(idx.shape[0], sem.shape[1], device=sem.device, dtype=torch.float16)
+    check(lib().ps_gather_clip_f16(_p(sem), _p(idx), idx.shape[0], sem.shape[1], 0.0, 1.0, _p(out), _stream()), "ps_gather_clip_f16")
+    return out
+
+
+def query_priors_indexed(model, pts: Tensor, density_threshold: float):
+    """-> (mean density [n], row numbers of the points above the threshold [kept] (ascending), their features fp16 [kept,64]): the same
+    values as query_priors with a threshold, with ONE nonzero() -- callers that also select points / densities reuse the row numbers
+    (a boolean mask costs every tensor it indexes its own nonzero() and host sync)."""
+    out, sem = _query_raw(model, pts, density_threshold)
+    idx = torch.nonzero(out > density_threshold).squeeze(1)
+    return out, idx, _kept_features(sem, idx)
 
 
 # ------------------------------------------------------------------------------------------------ voxel down-sampling
@@ -309,11 +358,11 @@ def dense_tile_query(model, aabb: Tensor, res: int = 512, chunk: int = 1 << 22, 
     for s in range(start, start + total, chunk):
         n = min(chunk, start + total - s)
         pts = lattice_points(aabb, res, s, n, dev)
-        dens, m, feats = query_priors(model, pts, density_threshold)
-        P = pts[m] / pose_scale_factor
+        dens, m, feats = query_priors_indexed(model, pts, density_threshold)
+        P = pts.index_select(0, m) / pose_scale_factor
         keep_pts.append(P)
         keep_feat.append(feats)
-        keep_dens.append(dens[m])
+        keep_dens.append(dens.index_select(0, m))
         keep_idx.append(voxel_index(P, voxel, min_bound))
     cat = lambda xs, empty: torch.cat(xs) if xs else empty  # noqa: E731
     return {"points": cat(keep_pts, torch.zeros(0, 3, device=dev)), "features": cat(keep_feat, torch.zeros(0, 64, device=dev, dtype=torch.float16)),

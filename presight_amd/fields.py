@@ -312,7 +312,8 @@ class iNGPFieldMS(nn.Module):
             d = self._ms_points(positions, want_sem=False)[0]
         return d.view(*positions.shape[:-1], 1)
 
-    def density_and_semantics(self, positions: Tensor, gate: Optional[Tuple[Tensor, Tensor, float]] = None) -> Tuple[Tensor, Tensor]:
+    def density_and_semantics(self, positions: Tensor, gate: Optional[Tuple[Tensor, Tensor, float]] = None,
+                              routed: Optional[Tuple["F.MsLayout", Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor]:
         """(density [*bs,1], semantics [*bs,64]) from ONE evaluation of the field.  The reference's prior extraction calls
         density_fn and semantic_fn separately (ns/scripts/extract_priors.py:133-138) and semantic_fn re-runs density_fn
         (ingp_field.py:256): the hash encode and the base MLP run three times per point there, once here.
@@ -333,8 +334,11 @@ class iNGPFieldMS(nn.Module):
             d, s = run(self.fields[0], positions.reshape(-1, 3))
         elif gate is not None and not torch.is_grad_enabled() and F.MERGED_MS and F.merged_supported(*[self._ms()[n][0] for n in ("base", "sem", "rgb")]):
             m = self._ms()
-            lay = F.MsLayout(self.centroids, pos=positions.reshape(-1, 3))
-            u, sel = lay.points(m["aabbs"], m["contract"])
+            if routed is not None:  # (routing + normalised points of THESE positions, shared with the proposal fields: extract.shared_routing)
+                lay, u, sel = routed
+            else:
+                lay = F.MsLayout(self.centroids, pos=positions.reshape(-1, 3))
+                u, sel = lay.points(m["aabbs"], m["contract"])
             d, s = F.ms_main_field_gated(lay, u, sel, m["tables"], m["scalings"], m["g"], m["base"], m["sem"], m["rgb"], gate[0], gate[1], gate[2])
         else:
             d, _, s = self._ms_points(positions)
@@ -419,10 +423,10 @@ class PropNetDensityFieldMS(nn.Module):
         return dict(aabbs=aabbs, contract=self.fields[0].spatial_distortion is not None, tables=[f.encoding.hash_table for f in self.fields],
                     scalings=e0.scalings_on(dev), g=_grid_cfg(e0), layers=[f.mlp_base[1].layer_params() for f in self.fields])
 
-    def _ms_density(self, lay: "F.MsLayout") -> Tensor:
-        """all K sub-fields in one launch per kernel (field_ops "MS" path)"""
+    def _ms_density(self, lay: "F.MsLayout", points: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
+        """all K sub-fields in one launch per kernel (field_ops "MS" path); points = (u, sel) of this layout when the caller already has them"""
         m = self._ms()
-        u, sel = lay.points(m["aabbs"], m["contract"])
+        u, sel = points if points is not None else lay.points(m["aabbs"], m["contract"])
         return F.ms_prop_field(lay, u, sel, m["tables"], m["scalings"], m["g"], m["layers"])
 
     def density_fn(self, positions: Tensor) -> Tensor:
