@@ -443,6 +443,51 @@ def test_sharded_exchange_gloo_world2(tmp_path):
     assert "bucket=0 bytes=96" in logs[0][0] and "step=1" in logs[0][0]
 
 
+_WORKER_ONE = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from presight_amd.dist import FlatGrads, init_from_env, exchanging, COMM_LOG
+    from presight_amd.ops import mark_touched
+    rank, local, world = init_from_env("cpu")
+    assert world == 1 and dist.is_initialized() and dist.get_world_size() == 1 and exchanging()
+    for mode in ("allreduce", "sharded"):
+        torch.manual_seed(0)
+        a, b = torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(32, 2))
+        fg = FlatGrads([a, b], bucket_sizes=[1, 1], shard_world=1, splits={{1: 4}})
+        fg.enable_overlap([[a], [b]], mode=mode)
+        assert not fg.dry and fg._distributed()
+        fg.zero_()
+        ga, gb = torch.randn(3, 4), torch.randn(32, 2)
+        a.grad.add_(ga); mark_touched([a])
+        b.grad.add_(gb)
+        for g in range(4):
+            b._ps_part_done(b, g)
+        n0 = COMM_LOG.seq
+        assert n0 >= 5 and all(x["launched"] and x["phase"] == "backward" for x in fg._buckets)
+        fg.finish_exchange()
+        assert torch.equal(a.grad, ga) and torch.equal(b.grad, gb)  # sum over one rank / 1
+        assert fg.owned_ranges() == [(0, fg.total)] or mode == "sharded"
+        os.environ["PRESIGHT_EXCHANGE_WORLD_OF_ONE"] = "0"
+        assert not exchanging() and not fg._distributed()
+        os.environ["PRESIGHT_EXCHANGE_WORLD_OF_ONE"] = "1"
+    kinds = {{ln.split()[1] for ln in COMM_LOG.tail(64)}}
+    assert {{"all_reduce", "reduce_scatter"}} <= kinds, kinds
+    dist.destroy_process_group()
+    print("ok")
+""")
+
+
+def test_process_group_of_one_exchanges_when_asked(tmp_path):
+    """PRESIGHT_EXCHANGE_WORLD_OF_ONE=1: a ONE-rank process group (here gloo; on the GPU box RCCL: test_hip_dist.py) counts as a
+    distributed run -- every bucket collective is issued, the result is the identity; without the switch nothing is issued."""
+    script = tmp_path / "worker_one.py"
+    script.write_text(_WORKER_ONE.format(root=ROOT))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29747",
+               PRESIGHT_EXCHANGE_WORLD_OF_ONE="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_bench_launcher_and_arguments():
     """bench.py --gpus N outside torchrun starts N ranks itself (before touching the GPU) and refuses a node with fewer GPUs;
     a worker whose WORLD_SIZE disagrees with --gpus fails instead of silently measuring one GPU"""
