@@ -151,6 +151,8 @@ def reference_checkpoint(trainer, step: Optional[int] = None, ddp: bool = False)
     trainer.join()
     model, opt = trainer.model, trainer.opt
     step = trainer.step_idx - 1 if step is None else int(step)
+    if step < 0:
+        raise ValueError(f"reference_checkpoint: step {step} < 0 (no iteration has completed; the reference names files step-%09d.ckpt)")
     index = {id(p): i for i, p in enumerate(opt.params)}
     steps = opt.param_steps()
     if getattr(opt, "flat", None) is not None:  # sharded exchange: every rank's moments are valid on its shard only -> gather (collective)
@@ -177,18 +179,45 @@ def reference_checkpoint(trainer, step: Optional[int] = None, ddp: bool = False)
     return ckpt
 
 
-def save_checkpoint(trainer, checkpoint_dir: str, step: Optional[int] = None, save_only_latest_checkpoint: bool = True, ddp: bool = False) -> str:
+def _rank() -> int:
+    return torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+
+
+def save_checkpoint(trainer, checkpoint_dir: str, step: Optional[int] = None, save_only_latest_checkpoint: bool = True, ddp: bool = False,
+                    write: Optional[bool] = None) -> str:
     """Trainer.save_checkpoint (ns/engine/trainer.py:432-460): step-%09d.ckpt in `checkpoint_dir`, older files removed when
-    `save_only_latest_checkpoint` (the reference's default).  Under data parallelism call it on EVERY rank when the exchange is sharded
-    (the moments are gathered); only rank 0 should keep the file."""
+    `save_only_latest_checkpoint` (the reference's default).  Under data parallelism call it on EVERY rank: with the sharded exchange
+    the moment gather inside `reference_checkpoint` is a collective.  Only ONE rank touches the file system -- `write` (default: rank 0
+    of the default process group, as the reference's `@check_main_thread` saves on the main process only); the other ranks return
+    the path without building host copies.  The file is written under a temporary name and moved into place (`os.replace`) BEFORE the
+    older checkpoints are removed, so a crash mid-save never leaves a truncated latest checkpoint next to nothing."""
+    if step is not None and int(step) < 0:
+        raise ValueError(f"save_checkpoint: step {step} < 0")
+    if trainer.step_idx < 1 and step is None:
+        raise ValueError("save_checkpoint: no iteration has completed yet (the reference saves after an iteration: step >= 0); pass step=")
+    write = (_rank() == 0) if write is None else bool(write)
+    if not write:
+        # the collective part only (sharded exchange: every rank's moments are valid on its shard) -- no host copies, no file
+        trainer.join()
+        opt = trainer.opt
+        if getattr(opt, "flat", None) is not None:
+            opt.flat_grads.gather_flat(opt.flat[2])
+            opt.flat_grads.gather_flat(opt.flat[3])
+        return checkpoint_path(checkpoint_dir, trainer.step_idx - 1 if step is None else int(step))
     ckpt = reference_checkpoint(trainer, step, ddp=ddp)
     os.makedirs(str(checkpoint_dir), exist_ok=True)
     path = checkpoint_path(checkpoint_dir, ckpt["step"])
-    torch.save(ckpt, path)
+    tmp = f"{path}.tmp.{os.getpid()}"
+    try:
+        torch.save(ckpt, tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
     if save_only_latest_checkpoint:
         for f in os.listdir(str(checkpoint_dir)):
             full = os.path.join(str(checkpoint_dir), f)
-            if full != path and os.path.isfile(full):
+            if full != path and os.path.isfile(full) and f.endswith(".ckpt"):
                 os.unlink(full)
     return path
 
@@ -211,6 +240,8 @@ def load_checkpoint(path_or_dir, model, trainer=None, load_step: Optional[int] =
     next iteration is `step + 1`.  `path_or_dir` may also be an already loaded checkpoint dict.  -> the checkpoint's step."""
     ckpt = path_or_dir if isinstance(path_or_dir, dict) else read_checkpoint(path_or_dir, load_step)
     step = int(ckpt["step"])
+    if step < 0:
+        raise ValueError(f"load_checkpoint: step {step} < 0 (a checkpoint is written after a completed iteration)")
     with torch.no_grad():
         load_pipeline(model, ckpt["pipeline"], step)
     if trainer is None:
@@ -228,7 +259,7 @@ def load_checkpoint(path_or_dir, model, trainer=None, load_step: Optional[int] =
     dev = opt.params[0].device
     exp_avg = [torch.zeros_like(p) for p in opt.params]
     exp_avg_sq = [torch.zeros_like(p) for p in opt.params]
-    lr = None
+    lr, lr_group, first = None, None, None
     for name, params in groups.items():
         osd = ckpt["optimizers"][name]
         seen, uniq = set(), []
@@ -250,14 +281,24 @@ def load_checkpoint(path_or_dir, model, trainer=None, load_step: Optional[int] =
             steps[i] = int(float(st["step"]))
             exp_avg[i] = st["exp_avg"].to(dev, torch.float32)
             exp_avg_sq[i] = st["exp_avg_sq"].to(dev, torch.float32)
-        lr = float(pg["lr"]) if lr is None else lr
+        this = (float(pg["lr"]), None if pg.get("initial_lr") is None else float(pg["initial_lr"]))
+        if lr is None:
+            lr, lr_group, first = this[0], name, this
+        elif this != first:
+            # HipAdam steps every group with ONE learning rate and ONE schedule (the PreSight method configs give "proposal_networks" and
+            # "fields" identical optimizers, method_configs.py:158-168): a checkpoint whose groups disagree cannot be resumed faithfully
+            raise ValueError(f"load_checkpoint: optimizer groups {lr_group!r} and {name!r} disagree on (lr, initial_lr): {first} vs {this}; "
+                             "this trainer steps all groups with one learning rate")
     extra = ckpt.get("presight_amd", {})
     opt.load_state_dict({"step": int(extra.get("optimizer_step_count", step + 1)), "steps": steps, "exp_avg": exp_avg, "exp_avg_sq": exp_avg_sq})
     if lr is not None:
         opt.lr = lr
     if trainer.scheduler is not None and load_scheduler and ckpt.get("schedulers"):
-        sd = next(iter(ckpt["schedulers"].values()))
-        trainer.scheduler.load_state_dict({"t": _scheduler_position(sd)})
+        positions = {n: _scheduler_position(sd) for n, sd in ckpt["schedulers"].items()}
+        if len(set(positions.values())) != 1:
+            raise ValueError(f"load_checkpoint: the schedulers of the optimizer groups are at different positions {positions}; "
+                             "this trainer steps one schedule for all groups")
+        trainer.scheduler.load_state_dict({"t": next(iter(positions.values()))})
     sc = ckpt.get("scalers") or {}
     if "scale" in sc:  # ({} when the reference ran without CUDA: torch's GradScaler is disabled there)
         trainer.loss_scale = float(sc["scale"])

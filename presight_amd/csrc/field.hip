@@ -77,6 +77,16 @@ __device__ __forceinline__ void publish_absmax(const float (&mx)[KS0], int LF, i
   }
 }
 
+// Ablation build only (tools/build_variant.sh l2acts -DPS_ABL_L2ACTS; the product library never defines it): every kept-activation
+// (and dzb workspace) access of a wave goes to ONE 16-point block per wave of the first 256 workgroups -- 1024 blocks, 2.9 MB per XCD,
+// resident in its L2 -- instead of the block's own rows: wrong numbers, right instruction stream.  The difference to the product
+// is what the HBM round trip of the kept activations costs each of the four main-MLP kernels (EXPERIMENTS.md, round 6).
+#if defined(PS_ABL_L2ACTS)
+#define PS_ACT_BLK(blk) ((int64_t)((blockIdx.x & 255) * 4 + ((threadIdx.x >> 6) & 3)))
+#else
+#define PS_ACT_BLK(blk) (blk)
+#endif
+
 // Kept activations, in REGISTER order: for every 16-point block the buffer holds ACT_W/16 "neuron blocks" of [64 lanes][4]
 // floats (1 KiB each) -- exactly the D registers of the block -- so that the forward's stores and the backward's loads are
 // fully coalesced 16-byte-per-lane accesses (a torch-order [N, width] layout made the forward write 64-byte pieces at a
@@ -89,7 +99,7 @@ __device__ __forceinline__ void store_act(float* __restrict__ acts, int stride, 
   for (int pb = 0; pb < PB; ++pb) {
     const int64_t blk = first / 16 + pb;  // 16-point block index
     if (blk * 16 < N) {
-      float* base = acts + blk * (int64_t)stride * 16 + (int64_t)col0 * 16 + lane * 4;
+      float* base = acts + PS_ACT_BLK(blk) * (int64_t)stride * 16 + (int64_t)col0 * 16 + lane * 4;
 #pragma unroll
       for (int nb = 0; nb < NBLK; ++nb)
         *reinterpret_cast<f32x4*>(base + nb * 256) = (f32x4){v[pb][4 * nb], v[pb][4 * nb + 1], v[pb][4 * nb + 2], v[pb][4 * nb + 3]};
@@ -107,7 +117,7 @@ __device__ __forceinline__ void load_act(const float* __restrict__ acts, int str
   for (int pb = 0; pb < PB; ++pb) {
     int64_t blk = first / 16 + pb;
     if constexpr (CLAMP) blk = blk * 16 < N ? blk : (N - 1) / 16;
-    const float* base = acts + blk * (int64_t)stride * 16 + (int64_t)col0 * 16 + lane * 4;
+    const float* base = acts + PS_ACT_BLK(blk) * (int64_t)stride * 16 + (int64_t)col0 * 16 + lane * 4;
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb) {
       f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1821,7 +1831,7 @@ int main_fwd_impl(MainArgs a, int hidden, int hidden_color, hipStream_t s, bool 
     // launch took 2.05 ms against 0.73 ms with the gate shut (tools/dbg/gate_probe.py) -- its few workgroups ran alone at the end.
     // With short workgroups the hardware dispatcher fills the compute units the light sub-fields leave early.
     static const char* gate_env = getenv("PS_GATE_BLOCKS");
-    const int gate_blocks = a.gate_a != nullptr ? (gate_env != nullptr ? atoi(gate_env) : 8) : 1;
+    const int gate_blocks = a.gate_a != nullptr ? (gate_env != nullptr ? std::max(1, atoi(gate_env)) : 8) : 1;  // (clamped: 0 / negative would void the block cap)
 #define X(lf, h, hc)                                                                                                  \
   if (a.LF == lf && hidden == h && hidden_color == hc) {                                                              \
     using C = MainCfg<(lf + 3) / 4, h / 16, hc / 16, false, true>;                                                    \
