@@ -537,6 +537,44 @@ int ps_blend_bwd(const float* sigma_s, const float* rgb_s, const float* sem_s, c
                  const float* extra_dsigma_d, float* dsigma_s, float* drgb_s, float* dsem_s, float* dsigma_d, float* drgb_d,
                  float* dsem_d, void* stream);
 
+/* ---- round 6: fused per-ray tail of the training step (csrc/raytail.hip, csrc/losses.hip) --------------------------
+ * The same operators as above, fewer launches.  Replaces, for the factored training render node (one sub-field, S <= 64):
+ *   ps_ray_out_fwd        ps_composite_fwd's rgb / accumulation (ns/model_components/renderers.py:70-117,286-314) + ps_sem_out_fwd (the
+ *                         semantic head's output layer per ray, ns/fields/PreSight/ingp_field.py:143-151), same arithmetic and order;
+ *                         weights [R,S], rgb_s [R,S,3], sem_hidden_ray [R,64], W [64,64], b [64] -> rgb [R,3], acc [R] (unclamped), sem [R,64]
+ *   ps_ray_dsigma_bwd     d(weights) = <rgb_s, d_rgb> + d_acc + d_acc2 + add0 + add1 (ps_composite_bwd without the depth terms) handed
+ *                         straight to RaySamples.get_weights' backward (ns/cameras/rays.py:128-150 = ps_weights_bwd): dsigma [R,S]
+ *   ps_blend_losses       rgb += (1 - clamp(acc)) sky_rgb etc. (ns/models/PreSight/nerfacto_nusc_ms.py:512-533) + MSELoss(rgb)
+ *                         (nerfacto_nusc_ms.py:568) + sky_loss + semantic_loss (ns/model_components/PreSight/losses.py:106-125) in one
+ *                         launch: blended outputs, per-workgroup partial sums of the three terms (partial [3][ps_blend_losses_partials(R)],
+ *                         finished by ps_finish_losses), AND the gradients of the k-weighted sum of the terms w.r.t. every input of
+ *                         the blend (k_t = loss_mult_t * seed of the backward pass * d(mean)/d(sum)); targets nullable (term absent)
+ *   ps_*_loss_scaled      ps_distortion_loss / ps_interlevel_loss with the gradient scaling of ps_scale_grad folded in:
+ *                         dw = grad_scale * d(per_ray) (grad_scale = loss_mult / count * seed; the fp32 product ps_scale_grad formed)
+ *   ps_finish_losses      ALL scalar loss values of a step and their sum in one launch: descriptor d = (terms[d] device pointer, n[d],
+ *                         denom[d], scale[d], out_of[d]) -- HOST arrays of n_desc <= 16 entries, out_of non-decreasing;
+ *                         *out[o] = sum over the descriptors of output o, in order, of scale * (sum(terms) / denom) -- each term with
+ *                         the bits of ps_loss_finish, several descriptors per output = term_0 + term_1 as the reference's python sum
+ *                         of the interlevel levels forms it; *total (nullable) = ((*out[0] + *out[1]) + *out[2]) + ... =
+ *                         functools.reduce(torch.add, loss_dict.values()) of ns/engine/trainer.py:478.  out: HOST array of n_out device
+ *                         pointers; ticket: one zeroed uint32 in device memory that the launch leaves zeroed */
+int ps_ray_out_fwd(const float* weights, const float* rgb_s, const float* sem_hidden_ray, const float* W, const float* b, int64_t R,
+                   int S, int C, float* rgb, float* acc, float* sem, void* stream);
+int ps_ray_dsigma_bwd(const float* ebins, const float* sigma, const float* rgb_s, const float* d_rgb, const float* d_acc /*nullable*/,
+                      const float* d_acc2 /*nullable*/, const float* d_weights_add0 /*nullable*/, const float* d_weights_add1 /*nullable*/,
+                      int64_t R, int S, float* dsigma, void* stream);
+int ps_blend_losses_partials(int64_t R);
+int ps_blend_losses(const float* rgb_f, const float* acc_raw, const float* sem_f, const float* sky_rgb, const float* sky_sem,
+                    const float* rgb_t, const float* sky_t, const float* sem_t, int64_t R, int C, int clip_sem_target,
+                    float bce_eps, float k_rgb, float k_sky, float k_sem, float* rgb, float* acc, float* sem, float* d_rgb,
+                    float* d_sem, float* d_acc_raw, float* d_sky_rgb, float* d_sky_sem, float* partial, void* stream);
+int ps_distortion_loss_scaled(const float* sbins, const float* w, int64_t R, int S, float* per_ray, float* dw, float grad_scale,
+                              void* stream);
+int ps_interlevel_loss_scaled(const float* c, const float* w, const float* cp, const float* wp, int64_t R, int S, int Sp,
+                              float pulse_width, float* per_ray, float* dwp, float grad_scale, void* stream);
+int ps_finish_losses(const float* const* terms, const int64_t* n, const float* denom, const float* scale, const int* out_of,
+                     int n_desc, float* const* out, int n_out, float* total, uint32_t* ticket, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

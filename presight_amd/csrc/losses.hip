@@ -28,32 +28,36 @@ __device__ __forceinline__ void wave_scan_lds(float* a, int len) {
   __builtin_amdgcn_wave_barrier();
 }
 
+// gscale: factor on the stored gradient (1 = the plain derivative of the per-ray value; ps_*_loss_scaled passes
+// loss_mult / R * the backward seed, so that the loss node's backward has nothing left to launch)
 __global__ __launch_bounds__(256) void distortion_kernel(const float* __restrict__ sbins, const float* __restrict__ w,
                                                          int64_t R, int S, float* __restrict__ per_ray,
-                                                         float* __restrict__ dw) {
+                                                         float* __restrict__ dw, float gscale) {
   __shared__ float lds[4][2][kMaxSp];
   const int wv = threadIdx.x >> 6, lane = ps_lane();
   const int64_t ray = blockIdx.x * 4 + wv;
-  if (ray >= R) return;
-  float* sw = lds[wv][0];
-  float* su = lds[wv][1];
-  const float* b = sbins + ray * (S + 1);
-  for (int s = lane; s < S; s += 64) {
-    sw[s] = w[ray * S + s];
-    su[s] = (b[s + 1] + b[s]) / 2.0f;
+  if (ray < R) {
+    float* sw = lds[wv][0];
+    float* su = lds[wv][1];
+    const float* b = sbins + ray * (S + 1);
+    for (int s = lane; s < S; s += 64) {
+      sw[s] = w[ray * S + s];
+      su[s] = (b[s + 1] + b[s]) / 2.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float total = 0.f;
+    for (int k = lane; k < S; k += 64) {
+      const float wk = sw[k], uk = su[k];
+      float acc = 0.f;
+      for (int j = 0; j < S; ++j) acc += sw[j] * fabsf(uk - su[j]);
+      const float delta = b[k + 1] - b[k];
+      total += wk * acc + wk * wk * delta / 3.0f;
+      const float g = 2.0f * acc + 2.0f * wk * delta / 3.0f;
+      dw[ray * S + k] = g * gscale;
+    }
+    total = ps_wave_sum(total);
+    if (lane == 0) per_ray[ray] = total;
   }
-  __builtin_amdgcn_wave_barrier();
-  float total = 0.f;
-  for (int k = lane; k < S; k += 64) {
-    const float wk = sw[k], uk = su[k];
-    float acc = 0.f;
-    for (int j = 0; j < S; ++j) acc += sw[j] * fabsf(uk - su[j]);
-    const float delta = b[k + 1] - b[k];
-    total += wk * acc + wk * wk * delta / 3.0f;
-    dw[ray * S + k] = 2.0f * acc + 2.0f * wk * delta / 3.0f;
-  }
-  total = ps_wave_sum(total);
-  if (lane == 0) per_ray[ray] = total;
 }
 
 __device__ __forceinline__ float nan_to_num0(float v) {
@@ -67,14 +71,14 @@ __host__ __device__ constexpr int interlevel_floats_per_ray(int S, int Sp) { ret
 __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict__ c_, const float* __restrict__ w_,
                                                          const float* __restrict__ cp_, const float* __restrict__ wp_,
                                                          int64_t R, int S, int Sp, float r, float* __restrict__ per_ray,
-                                                         float* __restrict__ dwp) {
+                                                         float* __restrict__ dwp, float gscale) {
   // per wave: A,B [n] | xr [m] | v2 [m] | yr [m] | cdf [m] | ret [Sp+1] -- sized for THIS call's S / Sp (dynamic LDS): the kernel is
   // a chain of dependent LDS look-ups (binary searches, scans), so what it needs is resident waves, and at the maximal sizes
   // (S 128, Sp 256: 6.2 KB per ray) a CU held 24 instead of 32
   extern __shared__ float lds_dyn[];
   const int wv = threadIdx.x >> 6, lane = ps_lane();
   const int64_t ray = blockIdx.x * 4 + wv;
-  if (ray >= R) return;
+  if (ray < R) {
   const int n = S + 1, m = 2 * n;
   float* A = lds_dyn + (size_t)wv * interlevel_floats_per_ray(S, Sp);
   float* B = A + n;
@@ -175,10 +179,12 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
     const float e = fmaxf(ws - wp, 0.0f);
     const float den = wp + 1e-5f;
     total += e * e / den;
-    dwp[ray * Sp + k] = -2.0f * e / den - e * e / (den * den);
+    const float g = -2.0f * e / den - e * e / (den * den);
+    dwp[ray * Sp + k] = g * gscale;
   }
   total = ps_wave_sum(total);
   if (lane == 0) per_ray[ray] = total;
+  }
 }
 
 // ---- depth supervision (lidar / monodepth configs): ns/model_components/PreSight/losses.py:28-103 -----------------
@@ -253,7 +259,7 @@ extern "C" int ps_distortion_loss(const float* sbins, const float* w, int64_t R,
                                   void* stream) {
   PS_REQUIRE(S <= kMaxSp, "ps_distortion_loss: samples per ray must be <= 256");
   if (R == 0) return 0;
-  distortion_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(sbins, w, R, S, per_ray, dw);
+  distortion_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(sbins, w, R, S, per_ray, dw, 1.0f);
   PS_CHECK_LAUNCH();
 }
 
@@ -262,7 +268,26 @@ extern "C" int ps_interlevel_loss(const float* c, const float* w, const float* c
   PS_REQUIRE(S <= kMaxS && Sp <= kMaxSp, "ps_interlevel_loss: S must be <= 128 and Sp <= 256");
   if (R == 0) return 0;
   interlevel_kernel<<<(unsigned)((R + 3) / 4), 256, 4 * interlevel_floats_per_ray(S, Sp) * sizeof(float), (hipStream_t)stream>>>(
-      c, w, cp, wp, R, S, Sp, pulse_width, per_ray, dwp);
+      c, w, cp, wp, R, S, Sp, pulse_width, per_ray, dwp, 1.0f);
+  PS_CHECK_LAUNCH();
+}
+
+// The same two losses with the chain rule folded in (round 6): the stored gradient is grad_scale * d(per-ray value); the caller passes
+// loss_mult / count * <the seed of the backward pass>, so the loss node's backward launches nothing (ps_scale_grad's product, same bits).
+extern "C" int ps_distortion_loss_scaled(const float* sbins, const float* w, int64_t R, int S, float* per_ray, float* dw, float grad_scale,
+                                         void* stream) {
+  PS_REQUIRE(S <= kMaxSp, "ps_distortion_loss_scaled: samples per ray must be <= 256");
+  if (R == 0) return 0;
+  distortion_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(sbins, w, R, S, per_ray, dw, grad_scale);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_interlevel_loss_scaled(const float* c, const float* w, const float* cp, const float* wp, int64_t R, int S, int Sp,
+                                         float pulse_width, float* per_ray, float* dwp, float grad_scale, void* stream) {
+  PS_REQUIRE(S <= kMaxS && Sp <= kMaxSp, "ps_interlevel_loss_scaled: S must be <= 128 and Sp <= 256");
+  if (R == 0) return 0;
+  interlevel_kernel<<<(unsigned)((R + 3) / 4), 256, 4 * interlevel_floats_per_ray(S, Sp) * sizeof(float), (hipStream_t)stream>>>(
+      c, w, cp, wp, R, S, Sp, pulse_width, per_ray, dwp, grad_scale);
   PS_CHECK_LAUNCH();
 }
 

@@ -48,19 +48,25 @@ def shared_routing(model) -> bool:
     """The three routed modules of a tile (two proposal fields, main field) are queried at the SAME points by the prior extraction
     (ns/scripts/extract_priors.py:133-138) and are built from the same centroids and sub-field boxes: the nearest-centroid routing, the
     sorted layout and the per-sub-field normalised points are then computed ONCE per chunk instead of once per module (the reference
-    routes three times: ns/fields/PreSight/ingp_field_ms.py:97-126, prop_density_field_ms.py:90-102).  Checked by VALUE, once per model."""
-    ok = getattr(model, "_shared_routing_ok", None)
-    if ok is None:
-        mods = list(model.proposal_networks) + [model.field]
-        ok = (SHARE_ROUTING and all(hasattr(m, "_ms") and len(getattr(m, "fields", ())) > 1 for m in mods)
-              and F.MERGED_MS and F.merged_supported(*[model.field._ms()[n][0] for n in ("base", "sem", "rgb")]))
-        if ok:
-            ref = model.field._ms()
-            for m in model.proposal_networks:
-                mm = m._ms()
-                ok = ok and torch.equal(m.centroids, model.field.centroids) and torch.equal(mm["aabbs"], ref["aabbs"]) and mm["contract"] == ref["contract"]
-        model._shared_routing_ok = bool(ok)
-    return model._shared_routing_ok
+    routes three times: ns/fields/PreSight/ingp_field_ms.py:97-126, prop_density_field_ms.py:90-102).  Checked by VALUE, once per state of the routing buffers."""
+    mods = list(model.proposal_networks) + [model.field]
+    # the verdict is cached per STATE of the buffers it was formed from (address + version of every centroid / box buffer): a later
+    # load_state_dict / load_checkpoint on the same model object re-checks instead of reusing a stale "equal"
+    from .fields import buffers_key
+
+    key = buffers_key([m.centroids for m in mods if hasattr(m, "centroids")] + [f.aabb for m in mods for f in getattr(m, "fields", ())])
+    cached = getattr(model, "_shared_routing_ok", None)
+    if isinstance(cached, tuple) and cached[0] == key:
+        return cached[1]
+    ok = (SHARE_ROUTING and all(hasattr(m, "_ms") and len(getattr(m, "fields", ())) > 1 for m in mods)
+          and F.MERGED_MS and F.merged_supported(*[model.field._ms()[n][0] for n in ("base", "sem", "rgb")]))
+    if ok:
+        ref = model.field._ms()
+        for m in model.proposal_networks:
+            mm = m._ms()
+            ok = ok and torch.equal(m.centroids, model.field.centroids) and torch.equal(mm["aabbs"], ref["aabbs"]) and mm["contract"] == ref["contract"]
+    model._shared_routing_ok = (key, bool(ok))
+    return bool(ok)
 
 
 @torch.no_grad()

@@ -575,9 +575,10 @@ class _MainFieldRenderF(torch.autograd.Function):
     """_MainFieldRender on the factored semantic path (one sub-field, training, S <= 64)"""
 
     @staticmethod
-    def forward(ctx, u, sel, dirs, app, S, ebins, threshold, table, scalings, g: GridCfg, *wb):
+    def forward(ctx, u, sel, dirs, app, S, ebins, threshold, want_depth, table, scalings, g: GridCfg, *wb):
         from . import ops
 
+        ctx.set_materialize_grads(False)  # an output nobody differentiates arrives as None, not as a freshly filled zero tensor
         (Wb0, bb0), (Wb1, bb1), (Ws0, bs0), (Ws1, bs1), (Ws2, bs2), r0, r1, r2 = _layers(wb)
         hidden, hidden_color = Wb0.shape[0], r0[0].shape[0]
         A = r0[0].shape[1] - 16 - GEO_DIM
@@ -588,7 +589,7 @@ class _MainFieldRenderF(torch.autograd.Function):
         N, dev = u.shape[0], u.device
         R = ebins.shape[0]
         table = _f32(table, "hash table")
-        train = _training(ctx.needs_input_grad[7])
+        train = _training(ctx.needs_input_grad[8])
         feat, counts = _encode(u, table, scalings, g, count=train)
         # merged first semantic layer: W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0
         Wb1, bb1, Ws0, bs0 = _f32(Wb1), _f32(bb1), _f32(Ws0), _f32(bs0)
@@ -615,31 +616,43 @@ class _MainFieldRenderF(torch.autograd.Function):
             check(lib().ps_main_field_f_fwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, hidden_color, _p(sel),
                                             _p(ray_colour), _p(ebins), S, _p(packed), N, _p(sigma), _p(rgb_s), _p(w), _p(hid), _p(acts),
                                             _stream()), "ps_main_field_f_fwd")
-        rgb = torch.empty(R, 3, device=dev)
-        acc, depth, expd = torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev)
-        minmax = ops._minmax_init(dev).clone()
-        check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), None, R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth), _p(expd),
-                                     None, _p(minmax), _stream()), "ps_composite_fwd")
-        sem = torch.empty(R, SEM_DIM, device=dev)
+        rgb, acc, sem = torch.empty(R, 3, device=dev), torch.empty(R, 1, device=dev), torch.empty(R, SEM_DIM, device=dev)
         Ws2, bs2 = _f32(Ws2), _f32(bs2)
-        with prof.region("sem_out_fwd"):
-            check(lib().ps_sem_out_fwd(_p(hid), _p(acc), _p(Ws2), _p(bs2), R, SEM_DIM, _p(sem), _stream()), "ps_sem_out_fwd")
-        ops._apply_minmax_hook(minmax)
-        raw = torch.empty_like(expd)  # 1 where the batch-global clip left the value alone (its derivative)
-        check(lib().ps_clip(_p(expd), R, _p(minmax), _p(raw), _stream()), "ps_clip")
+        if want_depth:
+            depth, expd = torch.empty(R, 1, device=dev), torch.empty(R, 1, device=dev)
+            minmax = ops._minmax_init(dev).clone()
+            check(lib().ps_composite_fwd(_p(w), _p(ebins), _p(rgb_s), None, R, S, SEM_DIM, threshold, _p(rgb), _p(acc), _p(depth), _p(expd),
+                                         None, _p(minmax), _stream()), "ps_composite_fwd")
+            with prof.region("sem_out_fwd"):
+                check(lib().ps_sem_out_fwd(_p(hid), _p(acc), _p(Ws2), _p(bs2), R, SEM_DIM, _p(sem), _stream()), "ps_sem_out_fwd")
+            ops._apply_minmax_hook(minmax)
+            raw = torch.empty_like(expd)  # 1 where the batch-global clip left the value alone (its derivative)
+            check(lib().ps_clip(_p(expd), R, _p(minmax), _p(raw), _stream()), "ps_clip")
+        else:
+            # the training step's call: nobody reads the depths in a step (the model hands them out as lazily evaluated entries that
+            # go through ops.composite on the returned weights), so compositing is colour + accumulation and shares its launch with the
+            # per-ray output layer of the semantic head -- no batch-wide min / max, no clip, no depth rows
+            depth = expd = raw = torch.empty(0, device=dev)
+            with prof.region("sem_out_fwd"):
+                check(lib().ps_ray_out_fwd(_p(w), _p(rgb_s), _p(hid), _p(Ws2), _p(bs2), R, S, SEM_DIM, _p(rgb), _p(acc), _p(sem), _stream()),
+                      "ps_ray_out_fwd")
         ctx.save_for_backward(u, sel, dirs, app_c, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, raw, expd, hid, acc, Wm, bm)
-        ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), spec)
+        ctx.meta = (g, hidden, hidden_color, A, S, tuple(table.shape), spec, bool(want_depth))
         ctx.params = wb
         ctx.table_sink = grad_sink(table)
         ctx.table_ref = table
         ctx.direct = direct_params(table, *wb)
         ctx.mark_non_differentiable(depth)
+        if not want_depth:
+            ctx.mark_non_differentiable(expd)
         return rgb, acc, depth, expd, sem, w
 
     @staticmethod
     def backward(ctx, d_rgb, d_acc, _d_depth, d_exp, d_sem, d_w_ext):
         (u, sel, dirs, app, scalings, feat, packed, counts, acts, ebins, sigma, w, rgb_s, raw, expd, hid, acc, Wm, bm) = ctx.saved_tensors
-        g, hidden, hidden_color, A, S, tshape, spec = ctx.meta
+        g, hidden, hidden_color, A, S, tshape, spec, want_depth = ctx.meta
+        if not want_depth:
+            d_exp = None
         wb = ctx.params
         (Wb0, bb0), (Wb1, bb1), (Ws0, bs0), (Ws1, bs1), (Ws2, bs2), r0, r1, r2 = _layers(wb)
         R, dev, N = w.shape[0], w.device, u.shape[0]
@@ -662,8 +675,9 @@ class _MainFieldRenderF(torch.autograd.Function):
         with prof.region("sem_out_bwd"):
             check(lib().ps_sem_out_bwd(_p(d_sem), _p(hid), _p(acc), _p(_f32(Ws2)), _p(_f32(bs2)), R, SEM_DIM, _p(v), _p(cray), _p(dWs2), _p(dbs2),
                                        _stream()), "ps_sem_out_bwd")
-        d_acc = cray if d_acc is None else _f32(d_acc) + cray
-        if d_exp is not None:
+        fused_tail = d_exp is None  # (always in a training step) d(weights) is formed inside the weights' backward launch
+        if not fused_tail:
+            d_acc = cray if d_acc is None else _f32(d_acc) + cray
             d_exp = _f32(d_exp * raw)  # gradient of the batch-global clip
         pf, gf, npart = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
         check(lib().ps_main_field_f_sizes(g.out_dim, hidden, hidden_color, N, ctypes.byref(pf), ctypes.byref(gf), ctypes.byref(npart), None,
@@ -685,13 +699,17 @@ class _MainFieldRenderF(torch.autograd.Function):
         with prof.region("main_field_bwd"):
             with prof.region("main_bwd_sem_kernel") if timed else contextlib.nullcontext():
                 field_bwd(1, None)
-        dw = torch.empty_like(w)
         # (+ the semantic branch's part and the losses that act on the weights directly -- distortion, line of sight -- added in the kernel)
         ext = _f32(d_w_ext).contiguous() if d_w_ext is not None else None
-        check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s), None, _p(d_rgb), _p(d_acc), None, _p(d_exp), R, S, SEM_DIM, _p(dw), None,
-                                     None, _p(dw_sem), _p(ext), _stream()), "ps_composite_bwd")
         dsig = torch.empty_like(sigma)
-        check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
+        if fused_tail:
+            check(lib().ps_ray_dsigma_bwd(_p(ebins), _p(sigma), _p(rgb_s), _p(d_rgb), _p(None if d_acc is None else _f32(d_acc)), _p(cray),
+                                          _p(dw_sem), _p(ext), R, S, _p(dsig), _stream()), "ps_ray_dsigma_bwd")
+        else:
+            dw = torch.empty_like(w)
+            check(lib().ps_composite_bwd(_p(w), _p(ebins), _p(rgb_s), None, _p(d_rgb), _p(d_acc), None, _p(d_exp), R, S, SEM_DIM, _p(dw), None,
+                                         None, _p(dw_sem), _p(ext), _stream()), "ps_composite_bwd")
+            check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(dw), R, S, _p(dsig), _stream()), "ps_weights_bwd")
         with prof.region("main_field_bwd", extend=True):
             if timed:
                 for mask, name in ((2, "main_bwd_rgb_kernel"), (4, "main_bwd_base_kernel")):
@@ -705,7 +723,8 @@ class _MainFieldRenderF(torch.autograd.Function):
                   "ps_ray_colour_bwd")
         # weight gradients: partial blocks -> torch layout.  Base layer 1: rows 0..15 (sigma_raw | geo15) directly, rows 16..79
         # through the merged layer (chain rule of W' = W_sem0 W_base1[16:], b' = W_sem0 b_base1[16:] + b_sem0)
-        dWm, dbm = torch.zeros_like(Wm), torch.zeros_like(bm)
+        dWmb = torch.zeros(Wm.numel() + bm.numel(), device=dev)  # (one fill for both)
+        dWm, dbm = dWmb[:Wm.numel()].view_as(Wm), dWmb[Wm.numel():]
         descs = spec.base.unpack_descs(gpart, spec.g_off[0], [tuple(Wb0.shape), (16, hidden)])
         descs += spec.sem.unpack_descs(gpart, spec.g_off[1], [(64, hidden), (64, 64)])
         descs += spec.rgb.unpack_descs(gpart, spec.g_off[2], [tuple(r0[0].shape), tuple(r1[0].shape), tuple(r2[0].shape)])
@@ -720,13 +739,15 @@ class _MainFieldRenderF(torch.autograd.Function):
         mark_touched([t for t in ctx.direct if t is not ctx.table_ref])
         dtable = _scatter(u, dfeat, scalings, g, tshape, ctx.table_sink, counts, sink_owner=ctx.table_ref)
         mark_touched([t for t in ctx.direct if t is ctx.table_ref])
-        return (None, None, None, dapp, None, None, None, dtable, None, None, *ret)
+        return (None, None, None, dapp, None, None, None, None, dtable, None, None, *ret)
 
 
 def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor], ebins: Tensor, table: Tensor, scalings: Tensor,
-                      g: GridCfg, base, sem, rgb, threshold: float = 0.5):
+                      g: GridCfg, base, sem, rgb, threshold: float = 0.5, want_depth: bool = True):
     """-> (rgb [R,3], accumulation [R,1] (unclamped), threshold depth [R,1], expected depth [R,1], semantics [R,64],
-    weights [R,S]) of a ray batch whose S = ebins.shape[1]-1 <= 64 samples per ray are the points u (point n = ray n // S)."""
+    weights [R,S]) of a ray batch whose S = ebins.shape[1]-1 <= 64 samples per ray are the points u (point n = ray n // S).
+    want_depth=False (factored training node only; elsewhere ignored): the two depths come back as None -- render them from the
+    returned weights with ops.composite when somebody asks (differentiable through the weights)."""
     S = ebins.shape[1] - 1
     if S > 64:
         raise NotImplementedError("main_field_render: at most 64 samples per ray (use main_field + ops.composite)")
@@ -734,7 +755,9 @@ def main_field_render(u: Tensor, sel: Tensor, dirs: Tensor, app: Optional[Tensor
     for W, b in list(base) + list(sem) + list(rgb):
         flat += [W, b]
     if factored_supported(base, sem, rgb, S) and torch.is_grad_enabled():
-        return _apply(_MainFieldRenderF, u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, *flat)
+        rgb_, acc, depth, expd, sem_, w = _apply(_MainFieldRenderF, u, sel, dirs, app, S, ebins, float(threshold), bool(want_depth), table,
+                                                 scalings, g, *flat)
+        return (rgb_, acc, depth, expd, sem_, w) if want_depth else (rgb_, acc, None, None, sem_, w)
     return _apply(_MainFieldRender, u, sel, dirs, app, S, ebins, float(threshold), table, scalings, g, len(base), len(sem), *flat)
 
 

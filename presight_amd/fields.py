@@ -111,10 +111,11 @@ class iNGPField(nn.Module):
                             self.mlp_base_mlp.layer_params(), self.semantic_head.layer_params(), self.rgb_head.layer_params(),
                             want_rgb=want_rgb, want_sem=want_sem)
 
-    def render(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor], threshold: float = 0.5):
+    def render(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor], threshold: float = 0.5, want_depth: bool = True):
         """forward() + RaySamples.get_weights + the RGB / accumulation / depth / semantics renderers as one autograd node
         (field_ops.main_field_render): -> (rgb, accumulation (unclamped), threshold depth, expected depth, semantics, weights
-        [R,S,1])."""
+        [R,S,1]).  want_depth=False: the node may skip the two depth renderers (they come back as None; render them from the weights
+        when needed, renderers.render_all) -- a training step never reads them."""
         self._require_fused()
         rb = ray_samples.ray_bundle
         R = ray_samples.ebins.shape[0]
@@ -123,7 +124,7 @@ class iNGPField(nn.Module):
         g = self.mlp_base_grid
         rgb, acc, depth, expd, sem, w = F.main_field_render(
             u, sel, rb.directions, app, ray_samples.ebins, g.hash_table, g.scalings_on(u.device), _grid_cfg(g),
-            self.mlp_base_mlp.layer_params(), self.semantic_head.layer_params(), self.rgb_head.layer_params(), threshold)
+            self.mlp_base_mlp.layer_params(), self.semantic_head.layer_params(), self.rgb_head.layer_params(), threshold, want_depth)
         return rgb, acc, depth, expd, sem, w[..., None]
 
     def can_render(self, ray_samples: RaySamples) -> bool:
@@ -180,6 +181,21 @@ def _per_ray(appearance_embedding: Tensor, R: int) -> Tensor:
     view when the middle dimension is 1 -- `x[:, 0]` would cost a zero-fill + copy (select_backward) in every backward."""
     a = appearance_embedding.reshape(R, -1, appearance_embedding.shape[-1])
     return a.reshape(R, a.shape[-1]) if a.shape[1] == 1 else a[:, 0]
+
+
+def buffers_key(tensors: Sequence[Tensor]) -> tuple:
+    """identity AND content version of a set of buffers: load_state_dict / load_checkpoint copy into the same storage (the address stays,
+    `_version` advances), .to(device) replaces the tensors -- either way a cache keyed on this is refreshed"""
+    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+
+
+def _stacked_aabbs(module, dev) -> Tensor:
+    """[K, 2, 3] sub-field boxes of a routed module on `dev`, rebuilt whenever a sub-field's `aabb` buffer was written or moved"""
+    key = (str(dev), buffers_key([f.aabb for f in module.fields]))
+    if getattr(module, "_aabbs_key", None) != key:
+        module._aabbs_cache = torch.stack([f.aabb.float() for f in module.fields]).to(dev).contiguous()
+        module._aabbs_key = key
+    return module._aabbs_cache
 
 
 def _route_groups(points: Tensor, centroids: Tensor) -> List[Tuple[int, Tensor]]:
@@ -248,10 +264,7 @@ class iNGPFieldMS(nn.Module):
                     raise NotImplementedError("presight_amd iNGPFieldMS: the sub-fields of a tile must share one configuration")
             self._ms_checked = True
         dev = g0.hash_table.device
-        aabbs = getattr(self, "_aabbs_cache", None)
-        if aabbs is None or aabbs.device != dev:
-            aabbs = torch.stack([f.aabb.float() for f in self.fields]).to(dev).contiguous()
-            self._aabbs_cache = aabbs
+        aabbs = _stacked_aabbs(self, dev)
         return dict(aabbs=aabbs, contract=f0.spatial_distortion is not None, tables=[f.mlp_base_grid.hash_table for f in self.fields],
                     scalings=g0.scalings_on(dev), g=_grid_cfg(g0), base=[f.mlp_base_mlp.layer_params() for f in self.fields],
                     sem=[f.semantic_head.layer_params() for f in self.fields], rgb=[f.rgb_head.layer_params() for f in self.fields])
@@ -266,10 +279,11 @@ class iNGPFieldMS(nn.Module):
     def can_render(self, ray_samples: RaySamples) -> bool:
         return all(f._fusable for f in self.fields) and ray_samples.num_samples <= 64
 
-    def render(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor], threshold: float = 0.5):
-        """iNGPField.render for the routed tile: (rgb, accumulation, threshold depth, expected depth, semantics, weights [R,S,1])"""
+    def render(self, ray_samples: RaySamples, appearance_embedding: Optional[Tensor], threshold: float = 0.5, want_depth: bool = True):
+        """iNGPField.render for the routed tile: (rgb, accumulation, threshold depth, expected depth, semantics, weights [R,S,1]);
+        want_depth=False only concerns the one-sub-field node (iNGPField.render), the routed node always renders the depths"""
         if len(self.fields) == 1:
-            return self.fields[0].render(ray_samples, appearance_embedding, threshold)
+            return self.fields[0].render(ray_samples, appearance_embedding, threshold, want_depth)
         rb = ray_samples.ray_bundle
         R = ray_samples.ebins.shape[0]
         app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
@@ -416,10 +430,7 @@ class PropNetDensityFieldMS(nn.Module):
                     raise NotImplementedError("presight_amd PropNetDensityFieldMS: the sub-fields of a tile must share one configuration")
             self._ms_checked = True
         dev = e0.hash_table.device
-        aabbs = getattr(self, "_aabbs_cache", None)
-        if aabbs is None or aabbs.device != dev:
-            aabbs = torch.stack([f.aabb.float() for f in self.fields]).to(dev).contiguous()
-            self._aabbs_cache = aabbs
+        aabbs = _stacked_aabbs(self, dev)
         return dict(aabbs=aabbs, contract=self.fields[0].spatial_distortion is not None, tables=[f.encoding.hash_table for f in self.fields],
                     scalings=e0.scalings_on(dev), g=_grid_cfg(e0), layers=[f.mlp_base[1].layer_params() for f in self.fields])
 

@@ -21,7 +21,7 @@ from .callbacks import TrainingCallback, TrainingCallbackAttributes, TrainingCal
 from .components import Embedding, SceneContraction
 from .fields import (FieldHeadNames, PropNetDensityField, PropNetDensityFieldMS, SkyField, SkyFieldMS, iNGPField,
                      iNGPFieldMS)
-from .losses import (MSELoss, distortion_loss, expected_depth_loss, expected_monodepth_loss, line_of_sight_loss, semantic_loss, sky_loss,
+from .losses import (LossDict, MSELoss, blend_losses, deferred_finish, distortion_loss, expected_depth_loss, expected_monodepth_loss, line_of_sight_loss, semantic_loss, sky_loss,
                      z_anti_aliasing_interlevel_loss)
 from .rays import RayBundle, RaySamples
 from .renderers import AccumulationRenderer, DepthRenderer, NearFarCollider, RGBRenderer, render_all
@@ -118,9 +118,29 @@ class LazyOutputs(MutableMapping):
         self._lazy[key] = fn
         self._data[key] = None  # (keeps the key's position and membership)
 
+    def lazy_group(self, keys, fn: Callable):
+        """several entries produced by ONE evaluation: fn() -> {key: value} for all `keys`, run when the first of them is read"""
+        keys = tuple(keys)
+
+        def run():
+            vals = fn()
+            for k in keys:
+                self._lazy.pop(k, None)
+                self._data[k] = vals[k]
+
+        for k in keys:
+            self._lazy[k] = (run,)  # (a 1-tuple marks a group member: evaluation fills the entries itself)
+            self._data[k] = None
+
+    def is_lazy(self, key: str) -> bool:
+        """registered and not evaluated yet"""
+        return key in self._lazy
+
     def _force(self, key):
         fn = self._lazy.pop(key, None)
-        if fn is not None:
+        if isinstance(fn, tuple):
+            fn[0]()
+        elif fn is not None:
             self._data[key] = fn()
 
     def __getitem__(self, key):
@@ -254,6 +274,9 @@ class NerfactoNuscMSModel(nn.Module):
             self.semantic_loss = semantic_loss
         self.step = 0
         self.fused_render = True  # training, one sub-field, <= 64 samples: field + weights + renderers as one autograd node
+        # training: sky blend + rgb / sky / semantic losses (+ gradients) as one launch, depths rendered on demand (PRESIGHT_FUSED_TAIL=0:
+        # the separate operators of rounds 1-5)
+        self.fused_tail = __import__("os").environ.get("PRESIGHT_FUSED_TAIL", "1") != "0"
         # data-parallel trainers with a sharded optimizer leave the all-gather of the updated parameters in flight and gate
         # the first use of each optimizer group here: param_gate("proposal_networks" | "fields") (a device-side stream wait)
         self.param_gate = None
@@ -333,8 +356,11 @@ class NerfactoNuscMSModel(nn.Module):
         app = self._appearance(ray_bundle)
         app3 = None if app is None else app[:, None, :]
         if self.training and self.fused_render and c.use_semantics and self.field.can_render(ray_samples):
-            # field + get_weights + renderers in one autograd node (never materialises the per-sample output gradients)
-            rgb, acc_raw, depth, expected_depth, semantics, weights = self.field.render(ray_samples, app3)
+            # field + get_weights + renderers in one autograd node (never materialises the per-sample output gradients).  Without a
+            # depth loss nothing in a training step reads the two depth renderers: the node may skip them (depth is None then) and
+            # the entries below render them from the weights when somebody asks
+            rgb, acc_raw, depth, expected_depth, semantics, weights = self.field.render(
+                ray_samples, app3, want_depth=not self.fused_tail or c.use_monodepth_loss or c.use_lidar_loss)
             weights_list.append(weights)
             ray_samples_list.append(ray_samples)
         else:
@@ -353,13 +379,39 @@ class NerfactoNuscMSModel(nn.Module):
         if c.use_sky_model:
             sky_outputs = self.sky_model(ray_samples, appearance_embedding=None if app is None else app[:, None, :])
         # accumulation = clamp(acc, 0, 1); rgb/semantics += (1 - accumulation) * sky   (nerfacto_nusc_ms.py:512-533)
-        rgb, accumulation, semantics = ops.sky_blend(rgb, acc_raw, semantics if c.use_semantics else None,
-                                                     sky_outputs.get(FieldHeadNames.RGB), sky_outputs.get(FieldHeadNames.SEMANTICS))
-        outputs = LazyOutputs({"rgb": rgb, "accumulation": accumulation, "depth": depth.detach(), "expected_depth": expected_depth})
+        blend_in = (rgb, acc_raw, semantics if c.use_semantics else None, sky_outputs.get(FieldHeadNames.RGB),
+                    sky_outputs.get(FieldHeadNames.SEMANTICS))
+        outputs = LazyOutputs({"rgb": None, "accumulation": None, "depth": None, "expected_depth": None})
         if c.use_semantics:
-            outputs["semantics"] = semantics
-            if not self.training and self.dino_to_rgb is not None:
-                outputs["dino_rgb"] = apply_feature_colormap(semantics, self.dino_to_rgb)
+            outputs["semantics"] = None
+        if self.training and self.fused_tail:
+            # Training: the blend is an entry group evaluated on first access (ops.sky_blend, as before) -- unless get_loss_dict gets
+            # there first, which is what a training iteration does: it then runs the blend TOGETHER with the three per-ray losses and
+            # their gradients in one launch (losses.blend_losses) and fills these entries from it
+            keys = ("rgb", "accumulation") + (("semantics",) if c.use_semantics else ())
+
+            def blend():
+                vals = ops.sky_blend(*blend_in)
+                outputs.pending_blend = None
+                return dict(zip(keys, vals))
+
+            outputs.lazy_group(keys, blend)
+            outputs.pending_blend = blend_in
+        else:
+            rgb, accumulation, semantics = ops.sky_blend(*blend_in)
+            outputs["rgb"], outputs["accumulation"] = rgb, accumulation
+            if c.use_semantics:
+                outputs["semantics"] = semantics
+        if depth is None:  # (the fused node skipped the depth renderers)
+            def depths():
+                _, _, d, e, _ = render_all(weights, ray_samples, None, None)  # differentiable through the node's weights
+                return {"depth": d.detach(), "expected_depth": e}
+
+            outputs.lazy_group(("depth", "expected_depth"), depths)
+        else:
+            outputs["depth"], outputs["expected_depth"] = depth.detach(), expected_depth
+        if c.use_semantics and not self.training and self.dino_to_rgb is not None:
+            outputs["dino_rgb"] = apply_feature_colormap(outputs["semantics"], self.dino_to_rgb)
         if self.training:
             outputs["weights_list"] = weights_list
             outputs["ray_samples_list"] = ray_samples_list
@@ -397,12 +449,37 @@ class NerfactoNuscMSModel(nn.Module):
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
         """nerfacto_nusc_ms.py:558-645 (camera-only); every term is scaled by its *_loss_mult INSIDE the loss launch
         (losses.py: `scale`), the values equal the reference's mult * loss"""
+        with deferred_finish() as fin:  # every term's scalar value AND their sum: one launch at the end of the block (losses.py)
+            loss_dict = self._loss_terms(outputs, batch)
+            if loss_dict and all(torch.is_tensor(v) and v.is_cuda and v.numel() == 1 for v in loss_dict.values()):
+                loss_dict.total = fin.flush(list(loss_dict.values()))
+                loss_dict._total_of = fin.order_ptrs
+        return loss_dict
+
+    def _loss_terms(self, outputs, batch) -> LossDict:
         c = self.config
-        loss_dict = {}
-        if RGB in batch:
-            loss_dict["rgb_loss"] = self.rgb_loss(batch[RGB][..., :3], outputs["rgb"])
-        if c.use_sky_model and SKY in batch:
-            loss_dict["sky_loss"] = self.sky_loss(outputs["accumulation"].view(-1, 1), batch[SKY].view(-1, 1), scale=c.sky_loss_mult)
+        loss_dict = LossDict()
+        pend = getattr(outputs, "pending_blend", None)
+        fused = pend is not None and RGB in batch and outputs.is_lazy("rgb")
+        sem_loss = None
+        if fused:
+            # sky blend + MSELoss(rgb) + sky_loss + semantic_loss, values and gradients, in one launch (losses.blend_losses)
+            (l_rgb, l_sky, sem_loss), (rgb, acc, sem) = blend_losses(
+                *pend, rgb_target=batch[RGB][..., :3], sky_mask=batch[SKY] if (c.use_sky_model and SKY in batch) else None,
+                sem_target=batch[FEATURES] if (c.use_semantics and FEATURES in batch) else None, rgb_mult=1.0, sky_mult=c.sky_loss_mult,
+                sem_mult=c.semantic_loss_mult)
+            outputs["rgb"], outputs["accumulation"] = rgb, acc
+            if c.use_semantics:
+                outputs["semantics"] = sem
+            outputs.pending_blend = None
+            loss_dict["rgb_loss"] = l_rgb
+            if l_sky is not None:
+                loss_dict["sky_loss"] = l_sky
+        else:
+            if RGB in batch:
+                loss_dict["rgb_loss"] = self.rgb_loss(batch[RGB][..., :3], outputs["rgb"])
+            if c.use_sky_model and SKY in batch:
+                loss_dict["sky_loss"] = self.sky_loss(outputs["accumulation"].view(-1, 1), batch[SKY].view(-1, 1), scale=c.sky_loss_mult)
         if (c.use_monodepth_loss or c.use_lidar_loss) and DEPTH in batch:  # nerfacto_nusc_ms.py:576-629
             rs = outputs["ray_samples_list"][-1]
             scale = self._pose_scale_factor(rs)
@@ -419,7 +496,10 @@ class NerfactoNuscMSModel(nn.Module):
             loss_dict["line_of_sight_loss"] = line_of_sight_loss(
                 outputs["weights_list"][-1], batch[DEPTH], rs, sigma=self.get_line_of_sight_sigma(self.step), sky_mask=sky_mask,
                 upper_bound=ub, pose_scale_factor=scale, scale=self.get_line_of_sight_mult(self.step))
-        if c.use_semantics and FEATURES in batch:
+        if fused:
+            if sem_loss is not None:
+                loss_dict["semantic_loss"] = sem_loss
+        elif c.use_semantics and FEATURES in batch:
             loss_dict["semantic_loss"] = self.semantic_loss(pred=outputs["semantics"], target=batch[FEATURES], clip=True, scale=c.semantic_loss_mult)
         if self.training:
             loss_dict["interlevel_loss"] = self.interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"], scale=c.interlevel_loss_mult)

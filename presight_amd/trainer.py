@@ -21,11 +21,20 @@ from typing import Dict, Optional
 
 import torch
 
-from . import ops, prof
+from . import losses, ops, prof
 from .callbacks import TrainingCallbackAttributes, TrainingCallbackLocation
 from .dist import FlatGrads, exchanging, global_depth_clip as _depth_hook
 from .optim import HipAdam, WarmupMultiStepSchedule
 from .rays import RayBundle
+
+
+def _some_module_in_eval_mode(model, depth: int = 3) -> bool:
+    """whether `model` or any module up to `depth` levels below it is in eval mode (~100 flag reads on a K = 16 tile)"""
+    if not model.training:
+        return True
+    if depth == 0:
+        return False
+    return any(_some_module_in_eval_mode(c, depth - 1) for c in model.children())
 
 
 def routed_groups(model) -> list:
@@ -304,15 +313,20 @@ class Trainer:
         from .dist import intersect_ranges
 
         self.opt.step(subset=pipe["others"])  # proposal networks: the next iteration needs them first
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(pipe["stream"]):
-            pipe["stream"].wait_event(ev)
-            self.opt.step(subset=pipe["fields"])
-            for a, b in intersect_ranges(self.grads._dirty or [], pipe["ranges"]):
-                self.grads.flat[a:b].zero_()
-            done = torch.cuda.Event()
-            done.record(pipe["stream"])
+        try:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(pipe["stream"]):
+                pipe["stream"].wait_event(ev)
+                self.opt.step(subset=pipe["fields"])
+                for a, b in intersect_ranges(self.grads._dirty or [], pipe["ranges"]):
+                    self.grads.flat[a:b].zero_()
+                done = torch.cuda.Event()
+                done.record(pipe["stream"])
+        except BaseException:
+            # the proposal networks have taken their step, the fields have not (or only partly): one optimizer step apart
+            self._inconsistent = f"iteration {self.step_idx}, between the two pieces of the pipelined optimizer step"
+            raise
         pipe["event"], pipe["zeroed"] = done, self.grads._dirty is not None
         return True
 
@@ -350,11 +364,17 @@ class Trainer:
     def step(self, batch: Dict[str, torch.Tensor]):
         m, s = self.model, self.scene
         if self._inconsistent:
-            raise RuntimeError("presight_amd Trainer: an earlier iteration raised AFTER hash tables had taken their fused Adam step "
-                               f"({self._inconsistent}); tables and the other parameters are one step apart.  Restore a checkpoint "
+            raise RuntimeError("presight_amd Trainer: an earlier iteration raised AFTER part of the parameters had taken their Adam step "
+                               f"({self._inconsistent}); they and the other parameters are one step apart.  Restore a checkpoint "
                                "(load_state_dict + the model's state_dict) and call clear_failure() to continue")
-        if not m.training:  # (nn.Module.train() walks every sub-module: ~1000 of them on a K = 16 tile, 2 ms of host time per step --
-            m.train()       #  at 8192 rays per rank the production tile's step is bound by the host's enqueue time, tools/dbg/host_bound.py)
+        # nn.Module.train() walks every sub-module (~1000 of them on a K = 16 tile: 2 ms of host time per step, and at 8192 rays per rank
+        # the production tile's step is bound by the host's enqueue time, tools/dbg/host_bound.py), so the full walk only runs when the
+        # model is not in training mode -- where "the model" includes the modules whose mode the step actually reads (samplers, collider,
+        # fields and their sub-fields: three levels), so that a `model.field.eval()` or a callback's `.eval()` on a sub-module does not
+        # silently survive into training as it would behind a check of the top-level flag alone (the reference calls pipeline.train()
+        # every iteration, ns/engine/trainer.py:473)
+        if _some_module_in_eval_mode(m):
+            m.train()
         self._run_callbacks(TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
         pipe = self._begin_step()
         o, d, pa, dn = ops.generate_rays(batch["ray_indices"], s["c2w"], s["fx"], s["fy"], s["cx"], s["cy"])
@@ -375,13 +395,16 @@ class Trainer:
         self.opt.fused_armed = self.fused_table_adam  # table backward nodes of THIS backward pass apply their tables' Adam step
         completed = False
         try:
+            # the loss scale enters as the SEED of the backward pass (grad_scaler.scale(loss).backward(), ns/engine/trainer.py:481); it is
+            # registered before the forward so that the fused loss kernels store their gradients already multiplied with it and the
+            # loss nodes' backward launches nothing (losses.set_seed_hint)
+            if self._seed is None or float(self._seed_value) != self.loss_scale:
+                self._seed = torch.full((), self.loss_scale, device=batch["ray_indices"].device)
+                self._seed_value = self.loss_scale
+            losses.set_seed_hint(self._seed, self.loss_scale)
             out = m(rb, jitters=list(batch["jitter"])) if "jitter" in batch else m(rb)  # stored draws: parity runs only
             loss_dict = m.get_loss_dict(out, batch)
-            # one concat + one reduction instead of a chain of scalar adds; the loss scale enters as the seed of the backward pass
-            loss = torch.stack(list(loss_dict.values())).sum()
-            if self._seed is None or float(self._seed_value) != self.loss_scale:
-                self._seed = torch.full((), self.loss_scale, device=loss.device)
-                self._seed_value = self.loss_scale
+            loss = losses.loss_sum(loss_dict)  # functools.reduce(torch.add, ...): formed by the launch that finished the terms
             loss.backward(gradient=self._seed)
             ops.join_side_streams()  # the proposal networks' backward ran on their side stream: the exchange / optimizer wait for it
             with prof.region("exchange_exposed"):
@@ -390,6 +413,7 @@ class Trainer:
                 scale_kept = self._optimizer_step(pipe)
             completed = True
         finally:
+            losses.set_seed_hint(None)
             self.opt.fused_armed = False  # (also when the iteration raised: a later backward pass must not update anything)
             if not completed and self.fused_table_adam and any(getattr(p, "_ps_fused_done", False) for p in self.opt.params):
                 # the fused update is applied DURING backward: tables that had their turn before the exception are one optimizer step

@@ -202,3 +202,176 @@ def test_loss_finish_and_scale_grad(n):
     fac = torch.tensor([0.125], device=dev)
     torch.testing.assert_close(_chain(buf[:n].contiguous(), up, 2.0), buf[:n] * 3.0, rtol=1e-6, atol=0)
     torch.testing.assert_close(_chain(buf[1:].contiguous(), up, 2.0, fac), buf[1:] * 0.375, rtol=1e-6, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------- round 6: fused tail
+def _tail_inputs(R, dev, seed=11, C=64):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    acc_raw = r(R) * 1.3 - 0.1  # (outside [0, 1] on both sides: the clamp's derivative)
+    acc_raw[:3] = torch.tensor([0.0, 1.0, 0.5])[:min(R, 3)]
+    return dict(rgb_f=r(R, 3).to(dev), acc_raw=acc_raw.view(R, 1).to(dev), sem_f=(r(R, C) * 1.4 - 0.2).to(dev), sky_rgb=r(R, 3).to(dev),
+                sky_sem=r(R, C).to(dev), rgb_t=r(R, 3).to(dev), sky_t=(r(R) < 0.3).float().to(dev), sem_t=(r(R, C) * 1.5 - 0.25).to(dev))
+
+
+@pytest.mark.parametrize("R", [1, 5, 4099])
+@pytest.mark.parametrize("hinted", [True, False])
+def test_blend_losses_equals_the_separate_operators(R, hinted):
+    """ps_blend_losses = ops.sky_blend + MSELoss + sky_loss + semantic_loss: blended outputs bit for bit, values to summation order,
+    and the gradients w.r.t. all five inputs of the blend -- on the seeded fast path (no backward launch) and on the general path"""
+    from presight_amd import losses as L
+    from presight_amd import ops
+
+    dev = torch.device("cuda:0")
+    I = _tail_inputs(R, dev)
+    names = ("rgb_f", "acc_raw", "sem_f", "sky_rgb", "sky_sem")
+    seed_t = torch.full((), 1024.0, device=dev)
+
+    def leaves():
+        return [I[n].clone().requires_grad_(True) for n in names]
+
+    la = leaves()
+    rgb, acc, sem = ops.sky_blend(*la)
+    ref_terms = [L.mse_loss(I["rgb_t"], rgb), L.sky_loss(acc.view(-1, 1), I["sky_t"].view(-1, 1), scale=0.01),
+                 L.semantic_loss(sem, I["sem_t"], clip=True, scale=0.5)]
+    (ref_terms[0] + ref_terms[1] + ref_terms[2]).backward(gradient=seed_t)
+    lb = leaves()
+    if hinted:
+        L.set_seed_hint(seed_t, 1024.0)
+    try:
+        terms, (rgb2, acc2, sem2) = L.blend_losses(*lb, I["rgb_t"], I["sky_t"], I["sem_t"], 1.0, 0.01, 0.5)
+        total = L.loss_sum(list(terms))
+        total.backward(gradient=seed_t)
+    finally:
+        L.set_seed_hint(None)
+    assert torch.equal(rgb2, rgb) and torch.equal(acc2, acc) and torch.equal(sem2, sem)
+    for got, ref in zip(terms, ref_terms):
+        torch.testing.assert_close(got, ref, rtol=2e-6, atol=1e-9)
+    torch.testing.assert_close(total, ref_terms[0] + ref_terms[1] + ref_terms[2], rtol=2e-6, atol=1e-9)
+    for a, b, n in zip(la, lb, names):
+        scale = float(a.grad.abs().max()) + 1e-30
+        assert float((a.grad - b.grad).abs().max()) <= 2e-6 * scale, (n, float((a.grad - b.grad).abs().max()), scale)
+
+
+def test_blend_losses_without_some_terms_and_with_output_gradients():
+    """absent targets (no sky mask / no features) form no term; a gradient that reaches a BLENDED OUTPUT (a user's own loss on
+    outputs["rgb"]) takes the general path and is added to the loss terms' gradients"""
+    from presight_amd import losses as L
+    from presight_amd import ops
+
+    dev = torch.device("cuda:0")
+    I = _tail_inputs(257, dev)
+    names = ("rgb_f", "acc_raw", "sem_f", "sky_rgb", "sky_sem")
+    la = [I[n].clone().requires_grad_(True) for n in names]
+    lb = [I[n].clone().requires_grad_(True) for n in names]
+    rgb, acc, sem = ops.sky_blend(*la)
+    (L.mse_loss(I["rgb_t"], rgb) * 3.0 + (rgb * rgb).sum() + acc.sum() * 0.5).backward()
+    terms, (rgb2, acc2, sem2) = L.blend_losses(*lb, I["rgb_t"], None, None)
+    assert terms[1] is None and terms[2] is None
+    (terms[0] * 3.0 + (rgb2 * rgb2).sum() + acc2.sum() * 0.5).backward()
+    for a, b, n in zip(la, lb, names):
+        if a.grad is None:
+            assert b.grad is None or float(b.grad.abs().max()) == 0.0, n
+            continue
+        torch.testing.assert_close(b.grad, a.grad, rtol=1e-5, atol=1e-8, msg=n)
+    # no semantics at all
+    terms, (rgb3, acc3, sem3) = L.blend_losses(I["rgb_f"], I["acc_raw"], None, I["sky_rgb"], None, I["rgb_t"], I["sky_t"], None, 1.0, 0.01, 1.0)
+    r, a, s = ops.sky_blend(I["rgb_f"], I["acc_raw"], None, I["sky_rgb"], None)
+    assert sem3 is None and s is None and torch.equal(rgb3, r) and torch.equal(acc3, a) and terms[2] is None
+    torch.testing.assert_close(terms[1], L.sky_loss(a.view(-1, 1), I["sky_t"].view(-1, 1), scale=0.01), rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("R", [3, 1000])
+def test_fused_finish_keeps_the_bits_of_the_two_launch_losses(R):
+    """ps_distortion_loss_scaled / ps_interlevel_loss_scaled + ps_finish_losses: the value is the one ps_*_loss + ps_loss_finish formed (same summation order),
+    the stored gradient is the one ps_scale_grad formed from the seed"""
+    from presight_amd import losses as L
+    from presight_amd._lib import check, lib
+    from presight_amd.ops import _p, _stream
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+
+    def bins(S):
+        b = (torch.arange(S + 1)[None, :] + (torch.rand(R, S + 1, generator=g) - 0.5) * 0.6) / S
+        b[:, 0], b[:, -1] = 0.0, 1.0
+        return b.to(dev)
+
+    bl = [bins(128), bins(64), bins(64)]
+    wl = [torch.rand(R, b.shape[1] - 1, generator=g).to(dev) for b in bl]
+    wl = [(w / w.sum(-1, keepdim=True) * 0.9).requires_grad_(True) for w in wl]
+    rs = [_RS(b) for b in bl]
+    seed_t = torch.full((), 1024.0, device=dev)
+    # the two-launch formulation of rounds 1-5, by hand
+    S = 64
+    per_ray, dw = torch.empty(R, device=dev), torch.empty(R, S, device=dev)
+    check(lib().ps_distortion_loss(_p(bl[2]), _p(wl[2].detach()), R, S, _p(per_ray), _p(dw), _stream()), "ps_distortion_loss")
+    ref_val = L._finish(per_ray, R, 0.002)[0]
+    ref_grad = L._chain(dw, seed_t, 0.002 / R)
+    L.set_seed_hint(seed_t, 1024.0)
+    try:
+        d = L.distortion_loss(wl, rs, scale=0.002)
+        il = L.z_anti_aliasing_interlevel_loss(wl, rs, (0.03, 0.003), scale=1.0)
+        L.loss_sum([d, il]).backward(gradient=seed_t)
+    finally:
+        L.set_seed_hint(None)
+    assert torch.equal(d, ref_val)
+    # interlevel: both levels by hand
+    ref_il, ref_g = None, []
+    for i in range(2):
+        Sp = wl[i].shape[1]
+        pr, dwp = torch.empty(R, device=dev), torch.empty(R, Sp, device=dev)
+        check(lib().ps_interlevel_loss(_p(bl[2]), _p(wl[2].detach()), _p(bl[i]), _p(wl[i].detach()), R, S, Sp, (0.03, 0.003)[i], _p(pr), _p(dwp),
+                                       _stream()), "ps_interlevel_loss")
+        term = L._finish(pr, R * Sp, 1.0)[0]
+        ref_il = term if ref_il is None else ref_il + term
+        ref_g.append(L._chain(dwp, seed_t, 1.0 / (R * Sp)))
+    assert torch.equal(il, ref_il)
+    assert torch.equal(wl[0].grad, ref_g[0]) and torch.equal(wl[1].grad, ref_g[1])
+    assert torch.equal(wl[2].grad, ref_grad)  # (the main weights enter the interlevel loss detached)
+    # general path (no hint): same gradients up to one rounding of the scale
+    wl2 = [w.detach().clone().requires_grad_(True) for w in wl]
+    d2 = L.distortion_loss(wl2, rs, scale=0.002)
+    il2 = L.z_anti_aliasing_interlevel_loss(wl2, rs, (0.03, 0.003), scale=1.0)
+    (d2 + il2).backward(gradient=seed_t)
+    assert torch.equal(d2, d) and torch.equal(il2, il)
+    for a, b in zip(wl, wl2):
+        torch.testing.assert_close(b.grad, a.grad, rtol=1e-6, atol=0.0)
+
+
+def test_fused_ray_kernels_keep_the_bits_of_the_separate_launches():
+    """ps_ray_out_fwd = ps_composite_fwd (rgb, accumulation) + ps_sem_out_fwd; ps_ray_dsigma_bwd = ps_composite_bwd (d(weights)) +
+    ps_weights_bwd: same arithmetic in the same order -> torch.equal"""
+    from presight_amd._lib import check, lib
+    from presight_amd.ops import _p, _stream
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    for R, S in ((7, 64), (1001, 64), (130, 32)):
+        eb = torch.cumsum(torch.rand(R, S + 1, generator=g) * 0.3 + 0.01, -1).to(dev)
+        sigma = (torch.rand(R, S, generator=g) * 4.0).to(dev)
+        sigma[0, :] = 0.0
+        sigma[1, 5] = 1e30  # (a non-finite-free but saturated ray)
+        rgb_s, hid = torch.rand(R, S, 3, generator=g).to(dev), torch.randn(R, 64, generator=g).to(dev)
+        W, b = (torch.randn(64, 64, generator=g) * 0.2).to(dev), torch.randn(64, generator=g).to(dev)
+        w = torch.empty(R, S, device=dev)
+        check(lib().ps_weights_fwd(_p(eb), _p(sigma), R, S, _p(w), _stream()), "ps_weights_fwd")
+        rgb_a, acc_a, sem_a = torch.empty(R, 3, device=dev), torch.empty(R, 1, device=dev), torch.empty(R, 64, device=dev)
+        check(lib().ps_composite_fwd(_p(w), _p(eb), _p(rgb_s), None, R, S, 64, 0.5, _p(rgb_a), _p(acc_a), None, None, None, None, _stream()),
+              "ps_composite_fwd")
+        check(lib().ps_sem_out_fwd(_p(hid), _p(acc_a), _p(W), _p(b), R, 64, _p(sem_a), _stream()), "ps_sem_out_fwd")
+        rgb_b, acc_b, sem_b = torch.empty_like(rgb_a), torch.empty_like(acc_a), torch.empty_like(sem_a)
+        check(lib().ps_ray_out_fwd(_p(w), _p(rgb_s), _p(hid), _p(W), _p(b), R, S, 64, _p(rgb_b), _p(acc_b), _p(sem_b), _stream()), "ps_ray_out_fwd")
+        assert torch.equal(rgb_a, rgb_b) and torch.equal(acc_a, acc_b) and torch.equal(sem_a, sem_b), (R, S)
+        d_rgb, d_acc, cray = torch.randn(R, 3, generator=g).to(dev), torch.randn(R, 1, generator=g).to(dev), torch.randn(R, 1, generator=g).to(dev)
+        add0, add1 = torch.randn(R, S, generator=g).to(dev), torch.randn(R, S, generator=g).to(dev)
+        for use_acc, use_add1 in ((True, True), (False, False)):
+            da = (d_acc + cray) if use_acc else cray
+            dw, ds_a = torch.empty(R, S, device=dev), torch.empty(R, S, device=dev)
+            check(lib().ps_composite_bwd(_p(w), _p(eb), _p(rgb_s), None, _p(d_rgb), _p(da), None, None, R, S, 64, _p(dw), None, None, _p(add0),
+                                         _p(add1) if use_add1 else None, _stream()), "ps_composite_bwd")
+            check(lib().ps_weights_bwd(_p(eb), _p(sigma), _p(dw), R, S, _p(ds_a), _stream()), "ps_weights_bwd")
+            ds_b = torch.empty(R, S, device=dev)
+            check(lib().ps_ray_dsigma_bwd(_p(eb), _p(sigma), _p(rgb_s), _p(d_rgb), _p(d_acc) if use_acc else None, _p(cray), _p(add0),
+                                          _p(add1) if use_add1 else None, R, S, _p(ds_b), _stream()), "ps_ray_dsigma_bwd")
+            assert torch.equal(ds_a, ds_b), (R, S, use_acc, float((ds_a - ds_b).abs().max()))

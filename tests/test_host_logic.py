@@ -674,3 +674,32 @@ def test_bench_line_is_compact():
             assert json.load(open(bench.DETAIL_FILE))["roofline_kernels"] == worst["roofline_kernels"]
         finally:
             bench.DETAIL_FILE = old
+
+
+def test_trainer_notices_a_sub_module_left_in_eval_mode():
+    """the per-step fast path (skip nn.Module.train()'s walk over ~1000 modules) must not let a sub-module that somebody put
+    into eval mode on its own stay there: the check reads the flags three levels deep (model -> field / samplers -> sub-fields)"""
+    from presight_amd.trainer import _some_module_in_eval_mode
+
+    class Leaf(torch.nn.Module):
+        pass
+
+    class Mid(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fields = torch.nn.ModuleList([Leaf(), Leaf()])
+
+    class Top(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.field, self.sampler = Mid(), Leaf()
+
+    m = Top().train()
+    assert not _some_module_in_eval_mode(m)
+    m.sampler.eval()
+    assert m.training and _some_module_in_eval_mode(m)
+    m.train()
+    m.field.fields[1].eval()  # depth 3: top -> field -> fields (ModuleList) -> sub-field
+    assert _some_module_in_eval_mode(m)
+    m.train()
+    assert not _some_module_in_eval_mode(m)
