@@ -139,6 +139,14 @@ int ps_embedding_fwd(const int64_t* idx, const float* table, int64_t R, int D, i
                      void* stream);
 int ps_embedding_bwd(const int64_t* idx, const float* dout, int64_t R, int D, int rows, int out_stride, int col0,
                      float* dtable /* += */, void* stream);
+/* two nn.Embedding lookups concatenated (ns/field_components/embedding.py:27-55; the model's appearance + video codes,
+ * nerfacto_nusc_ms.py:472-485) in ONE launch per direction: out [R, D0+D1] = [table0[idx0[r*stride0]] | table1[idx1[r*stride1]]],
+ * indices int64 read through an element stride (the camera index is column 0 of ray_indices [R,3]); bwd: dtable_k += scatter of
+ * dout's columns (small tables pre-reduced in LDS per workgroup, as ps_embedding_bwd) */
+int ps_embedding_pair_fwd(const int64_t* idx0, int64_t stride0, const float* table0, int D0, const int64_t* idx1, int64_t stride1,
+                          const float* table1, int D1, int64_t R, float* out, void* stream);
+int ps_embedding_pair_bwd(const int64_t* idx0, int64_t stride0, int rows0, int D0, float* dtable0, const int64_t* idx1, int64_t stride1,
+                          int rows1, int D1, float* dtable1, const float* dout, int64_t R, void* stream);
 /* sky blending, ns/models/PreSight/nerfacto_nusc_ms.py:512-533: acc = clamp(acc_raw, 0, 1),
  * rgb = rgb_f + (1-acc) sky_rgb, sem = sem_f + (1-acc) sky_sem (sky_* / sem may be NULL).  Backward: d(rgb_f) = d(rgb)
  * and d(sem_f) = d(sem) are identities (not written); d_acc_raw [R], d_sky_rgb [R,3], d_sky_sem [R,C] are. */
@@ -436,6 +444,9 @@ int ps_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
  * count lives in group_steps[group[i]] (device int32) and is advanced after the update (the groups this call references: one
  * optimizer step may be issued as several calls over disjoint ranges, on different streams).  A range whose flag is 0 is left
  * untouched: parameters, both moments and the step count keep their bits.  n_groups <= 256. */
+/* optimizer.zero_grad (ns/engine/trainer.py:470) for the ranges of the flat gradient buffer the previous step wrote: up to 16
+ * (start, count) ranges of floats, HOST arrays, one launch */
+int ps_zero_ranges(float* p, int n_ranges, const int64_t* start /*host*/, const int64_t* count /*host*/, void* stream);
 int ps_adam_step_ranges(float* p, const float* g, float* m, float* v, int n_ranges, const int64_t* start /*host*/,
                         const int64_t* count /*host*/, const int* step /*host*/, const int* group /*host, nullable*/,
                         const int32_t* group_flags /*device, nullable*/, int32_t* group_steps /*device, nullable*/, int n_groups,
@@ -558,6 +569,17 @@ int ps_blend_bwd(const float* sigma_s, const float* rgb_s, const float* sem_s, c
  *                         of the interlevel levels forms it; *total (nullable) = ((*out[0] + *out[1]) + *out[2]) + ... =
  *                         functools.reduce(torch.add, loss_dict.values()) of ns/engine/trainer.py:478.  out: HOST array of n_out device
  *                         pointers; ticket: one zeroed uint32 in device memory that the launch leaves zeroed */
+/*   ps_spaced_bins_points ps_spaced_bins + ps_field_points (the first proposal field's points from these edges), one launch
+ *   ps_weights_resample   RaySamples.get_weights (ps_weights_fwd) + PDFSampler (ps_pdf_resample) of the NEXT level's edges + (u != NULL)
+ *                         ps_field_points on those edges for the next field: one launch per proposal level instead of three, same
+ *                         arithmetic in the same order (ns/cameras/rays.py:128-150, ns/model_components/ray_samplers.py:305-372,
+ *                         ns/cameras/rays.py:49-58 + ns/fields/PreSight/ingp_field.py:169-177); weights [R,S] is written */
+int ps_spaced_bins_points(const float* jitter, int64_t R, int S, float near, float far, float thr, float* sbins, float* ebins,
+                          const float* origins, const float* dirs, const float* aabb, int contract, float* u, float* sel, void* stream);
+int ps_weights_resample(const float* ebins, const float* sigma, const float* sbins, const float* jitter /*nullable*/, int64_t R, int S,
+                        int n_new, float anneal, float pad, float eps, float near, float far, float thr, float* weights,
+                        float* new_sbins, float* new_ebins, const float* origins /*nullable*/, const float* dirs /*nullable*/,
+                        const float* aabb /*nullable*/, int contract, float* u /*nullable*/, float* sel /*nullable*/, void* stream);
 int ps_ray_out_fwd(const float* weights, const float* rgb_s, const float* sem_hidden_ray, const float* W, const float* b, int64_t R,
                    int S, int C, float* rgb, float* acc, float* sem, void* stream);
 int ps_ray_dsigma_bwd(const float* ebins, const float* sigma, const float* rgb_s, const float* d_rgb, const float* d_acc /*nullable*/,

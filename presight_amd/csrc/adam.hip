@@ -189,6 +189,35 @@ __global__ void ms_mark_groups_kernel(const int* __restrict__ field_start, int K
   if (k < K && field_start[k + 1] > field_start[k] && group_of_field[k] >= 0) flags[group_of_field[k]] = 1;
 }
 }  // namespace
+// zero up to 16 ranges of one buffer in ONE launch: the start-of-step clear of the gradient ranges the previous step wrote
+// (optimizer.zero_grad, ns/engine/trainer.py:470) -- a handful of small, non-adjacent MLP ranges between the hash tables
+namespace {
+struct ZeroRanges {
+  int64_t start[16], count[16];
+};
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ p, ZeroRanges z) {
+  float* q = p + z.start[blockIdx.y];
+  const int64_t n = z.count[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) q[i] = 0.0f;
+}
+}  // namespace
+
+extern "C" int ps_zero_ranges(float* p, int n_ranges, const int64_t* start, const int64_t* count, void* stream) {
+  PS_REQUIRE(p != nullptr && start != nullptr && count != nullptr && n_ranges >= 1 && n_ranges <= 16, "ps_zero_ranges: 1..16 ranges");
+  ZeroRanges z;
+  int64_t longest = 0;
+  for (int i = 0; i < 16; ++i) {
+    z.start[i] = i < n_ranges ? start[i] : 0;
+    z.count[i] = i < n_ranges ? count[i] : 0;
+    PS_REQUIRE(z.start[i] >= 0 && z.count[i] >= 0, "ps_zero_ranges: negative range");
+    longest = z.count[i] > longest ? z.count[i] : longest;
+  }
+  if (longest == 0) return 0;
+  const int64_t bx = (longest + 256 * 8 - 1) / (256 * 8);
+  zero_ranges_kernel<<<dim3((unsigned)(bx < 1 ? 1 : (bx > 1024 ? 1024 : bx)), (unsigned)n_ranges), 256, 0, (hipStream_t)stream>>>(p, z);
+  PS_CHECK_LAUNCH();
+}
+
 extern "C" int ps_ms_mark_groups(const int32_t* field_start, int K, const int32_t* group_of_field, int32_t* flags, void* stream) {
   PS_REQUIRE(field_start != nullptr && group_of_field != nullptr && flags != nullptr && K >= 1, "ps_ms_mark_groups: null argument");
   ms_mark_groups_kernel<<<(unsigned)((K + 63) / 64), 64, 0, (hipStream_t)stream>>>(field_start, K, group_of_field, flags);

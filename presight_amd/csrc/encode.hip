@@ -744,17 +744,22 @@ __global__ __launch_bounds__(bin_threads(D, F)) void bin_kernel(const float* __r
 // One workgroup walks the n items in tiles of 4096 (four consecutive items per thread: coalesced loads / stores), wave scans + a
 // 16-entry table per tile, the running total carried in a register.  (The first version gave every thread one contiguous run of n / 1024
 // items: strided, uncoalesced accesses, twice -- 240 us for the 41 k items of a routed production tile, per table backward.)
+// src: where the record counts come from -- the cursors themselves (counted by bin_kernel<COUNT_ONLY>) or the slice counts of the
+// forward encode (read directly: the device-to-device copy into the cursors was a launch of its own); zero_bits / n_zero: the
+// per-level absmax words to clear for the record-writing pass that follows (another memset launch otherwise).
 __global__ __launch_bounds__(1024) void stream_offsets_kernel(unsigned* __restrict__ cursors, unsigned* __restrict__ counts,
-                                                              unsigned* __restrict__ starts, int n) {
+                                                              unsigned* __restrict__ starts, int n, const unsigned* __restrict__ src,
+                                                              unsigned* __restrict__ zero_bits, int n_zero) {
   __shared__ unsigned wsum[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < n_zero; i += 1024) zero_bits[i] = 0u;
   unsigned carry = 0;
   for (int base = 0; base < n; base += 4096) {
     const int i = base + (int)threadIdx.x * 4;
     unsigned c[4], r[4], s = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      c[k] = (i + k < n) ? cursors[i + k] : 0u;
+      c[k] = (i + k < n) ? src[i + k] : 0u;
       r[k] = (c[k] + 3u) & ~3u;  // every stream starts on a multiple of 4 records (vector loads)
       s += r[k];
     }
@@ -1269,13 +1274,12 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
   if (item_end < 0 || item_end > n_items) item_end = n_items;
   PS_REQUIRE(item_begin >= 0 && item_begin <= item_end, "ps_grid_scatter_binned: bad item range");
   hipError_t e = hipSuccess;
-  if (phase & 1) {
+  // record counts (upper bounds) from the forward pass (ps_grid_encode): the prefix kernel reads them in place and clears the absmax
+  // words itself -- no memset, no copy.  Without them the counting pass needs zeroed cursors (and absmax words) first.
+  const bool counted = slice_counts != nullptr && N > 0;
+  if ((phase & 1) && !counted) {
     e = absmax_ready ? hipMemsetAsync(ws + 4096, 0, (int64_t)n_items * 4, s) : hipMemsetAsync(ws, 0, 4096 + (int64_t)n_items * 4, s);
     if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
-    if (slice_counts != nullptr && N > 0) {  // record counts (upper bounds) from the forward pass: ps_grid_encode
-      e = hipMemcpyAsync(cursors, slice_counts, (size_t)n_items * 4, hipMemcpyDeviceToDevice, s);
-      if (e != hipSuccess) { ps_set_error(hipGetErrorString(e)); return (int)e; }
-    }
   }
   int headroom = 62 - 26;  // 8N <= 2^26 contributions per row
   {
@@ -1306,7 +1310,8 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
           bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), bin_threads(DD, FF), 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,    \
                                                                               plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period, dfeat_b); \
       }                                                                                                                   \
-      stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items);                                         \
+      stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items, counted ? slice_counts : cursors,        \
+                                               (counted && !absmax_ready) ? gmax_bits : nullptr, (counted && !absmax_ready) ? K * L : 0); \
       if (N > 0)                                                                                                          \
         bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), bin_threads(DD, FF), 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,     \
                                                                              plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \

@@ -65,8 +65,29 @@ __global__ void generate_rays_kernel(const int64_t* __restrict__ ray_indices, co
 }
 
 // ------------------------------------------------------------------------------------------ spaced sampler
+// The next field's points from the bin edges a sampling kernel has just formed (round 6): point (ray, s) = o + d * (e_s + e_{s+1}) / 2,
+// normalised / contracted into the field's box -- field_points_kernel's arithmetic (encode.hip: mul, then add, separately rounded),
+// without its launch and without re-reading the edges.
+struct RayPoints {
+  const float *origins, *dirs, *aabb;  // [R,3] [R,3] [6]; u == nullptr: no points wanted
+  int contract;
+  float *u, *sel;                       // [R*S,3], [R*S]
+};
+__device__ __forceinline__ void ray_point_store(const RayPoints& P, int64_t ray, int64_t n, float e0, float e1) {
+#pragma clang fp contract(off)
+  const float mid = (e0 + e1) / 2.0f;
+  float p[3], q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = P.origins[ray * 3 + k] + P.dirs[ray * 3 + k] * mid;
+  const bool s_ = ps::normalize_contract(p[0], p[1], p[2], P.aabb, P.contract != 0, q);
+  P.u[n * 3] = q[0];
+  P.u[n * 3 + 1] = q[1];
+  P.u[n * 3 + 2] = q[2];
+  P.sel[n] = s_ ? 1.0f : 0.0f;
+}
+
 __global__ void spaced_bins_kernel(const float* __restrict__ jitter, int64_t R, int S, float near, float far, float thr,
-                                   float* __restrict__ sbins, float* __restrict__ ebins) {
+                                   float* __restrict__ sbins, float* __restrict__ ebins, RayPoints P) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int nb = S + 1;
   if (i >= R * nb) return;
@@ -75,14 +96,21 @@ __global__ void spaced_bins_kernel(const float* __restrict__ jitter, int64_t R, 
   // torch.linspace(0,1,S+1): symmetric evaluation around the midpoint
   const float step = 1.0f / (float)S;
   auto lin = [&](int idx) { return idx < nb / 2 ? step * (float)idx : 1.0f - step * (float)(nb - idx - 1); };
-  float b = lin(k);
-  if (jitter != nullptr) {
-    const float lo = (k == 0) ? lin(0) : (lin(k) + lin(k - 1)) / 2.0f;
-    const float hi = (k == S) ? lin(S) : (lin(k + 1) + lin(k)) / 2.0f;
-    b = lo + (hi - lo) * jitter[r];
-  }
+  const float s_near = spacing_fn(near, thr), s_far = spacing_fn(far, thr);
+  auto edge = [&](int kk) {
+    float b = lin(kk);
+    if (jitter != nullptr) {
+      const float lo = (kk == 0) ? lin(0) : (lin(kk) + lin(kk - 1)) / 2.0f;
+      const float hi = (kk == S) ? lin(S) : (lin(kk + 1) + lin(kk)) / 2.0f;
+      b = lo + (hi - lo) * jitter[r];
+    }
+    return b;
+  };
+  const float b = edge(k);
+  const float e = s_to_euclid(b, s_near, s_far, thr);
   sbins[i] = b;
-  ebins[i] = s_to_euclid(b, spacing_fn(near, thr), spacing_fn(far, thr), thr);
+  ebins[i] = e;
+  if (P.u != nullptr && k < S) ray_point_store(P, r, r * S + k, e, s_to_euclid(edge(k + 1), s_near, s_far, thr));  // (the neighbour's edge: same function, same bits)
 }
 
 // ------------------------------------------------------------------------------------------ weights scan
@@ -228,6 +256,110 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(const float* __restri
     new_sbins[ray * nb + i] = b;
     new_ebins[ray * nb + i] = s_to_euclid(b, s_near, s_far, thr);
   }
+}
+
+// ------------------------------------------------------------------------------------------ weights + resampling (+ next points)
+// One launch per proposal level instead of three (round 6): RaySamples.get_weights (weights_fwd_kernel), the PDF resampling of
+// the next level's bin edges (pdf_resample_kernel) and the next field's points (field_points_kernel) all walk one ray per
+// wavefront with a lane owning CH consecutive samples -- the weights stay in registers between the first two, the new edges in LDS
+// between the last two.  Same arithmetic in the same order as the three kernels (the weights are written out: the interlevel
+// loss and the backward read them).
+template <int CH>
+__global__ __launch_bounds__(256) void weights_resample_kernel(const float* __restrict__ ebins, const float* __restrict__ sigma,
+                                                               const float* __restrict__ sbins, const float* __restrict__ jitter,
+                                                               int64_t R, int S, int n_new, float anneal, float pad, float eps,
+                                                               float near, float far, float thr, float* __restrict__ weights,
+                                                               float* __restrict__ new_sbins, float* __restrict__ new_ebins, RayPoints P) {
+  __shared__ float lds[4][3][kMaxCh * 64 + 1];
+  const int wv = threadIdx.x >> 6;
+  const int64_t ray = blockIdx.x * 4 + wv;
+  if (ray >= R) return;
+  const int lane = ps_lane();
+  float* cdf = lds[wv][0];
+  float* eb = lds[wv][1];
+  float* ne = lds[wv][2];
+  const float* e = ebins + ray * (S + 1);
+  // weights (weights_fwd_kernel<CH>)
+  float dd[CH], wl[CH], local = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int s = lane * CH + c;
+    dd[c] = (s < S) ? (e[s + 1] - e[s]) * sigma[ray * S + s] : 0.0f;
+    local += dd[c];
+  }
+  float excl = ps_wave_incl_scan(local) - local;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int s = lane * CH + c;
+    wl[c] = nan_to_num((1.0f - expf(-dd[c])) * expf(-excl));
+    if (s < S) weights[ray * S + s] = wl[c];
+    excl += dd[c];
+  }
+  // resampling (pdf_resample_kernel with its weights in registers)
+  float wloc[CH];
+  local = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int s = lane * CH + c;
+    float w = 0.f;
+    if (s < S) {
+      w = wl[c];
+      if (anneal != 1.0f) w = powf(w, anneal);
+      w += pad;
+    }
+    wloc[c] = w;
+    local += w;
+  }
+  float wsum = ps_wave_sum(local);
+  const float padding = fmaxf(eps - wsum, 0.0f);
+  const float padw = padding / (float)S;
+  wsum += padding;
+  local = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int s = lane * CH + c;
+    wloc[c] = (s < S) ? (wloc[c] + padw) / wsum : 0.0f;
+    local += wloc[c];
+  }
+  float run = ps_wave_incl_scan(local) - local;
+  if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int s = lane * CH + c;
+    run += wloc[c];
+    if (s < S) cdf[s + 1] = fminf(1.0f, run);
+  }
+  for (int s = lane; s <= S; s += 64) eb[s] = sbins[ray * (S + 1) + s];
+  __builtin_amdgcn_wave_barrier();
+  const int nb = n_new + 1;
+  const float end = (float)(1.0 - 1.0 / (double)nb);
+  const float step = end / (float)(nb - 1);
+  const float s_near = spacing_fn(near, thr), s_far = spacing_fn(far, thr);
+  for (int i = lane; i < nb; i += 64) {
+    float u = (i < nb / 2) ? step * (float)i : end - step * (float)(nb - i - 1);
+    if (jitter != nullptr)
+      u = u + jitter[ray] / (float)nb;
+    else
+      u = u + (float)(1.0 / (2.0 * (double)nb));
+    int lo = 0, hi = S + 1;  // searchsorted(cdf, u, right): number of entries <= u
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int below = min(max(lo - 1, 0), S), above = min(max(lo, 0), S);
+    const float c0 = cdf[below], c1 = cdf[above], b0 = eb[below], b1 = eb[above];
+    float t = (u - c0) / (c1 - c0);
+    if (isnan(t)) t = 0.0f;
+    t = fminf(fmaxf(nan_to_num(t), 0.0f), 1.0f);
+    const float b = b0 + t * (b1 - b0);
+    const float en = s_to_euclid(b, s_near, s_far, thr);
+    new_sbins[ray * nb + i] = b;
+    new_ebins[ray * nb + i] = en;
+    ne[i] = en;
+  }
+  if (P.u == nullptr) return;
+  __builtin_amdgcn_wave_barrier();
+  for (int s2 = lane; s2 < n_new; s2 += 64) ray_point_store(P, ray, ray * n_new + s2, ne[s2], ne[s2 + 1]);
 }
 
 // ------------------------------------------------------------------------------------------ composite
@@ -614,7 +746,40 @@ extern "C" int ps_spaced_bins(const float* jitter, int64_t R, int S, float near,
                               float* ebins, void* stream) {
   if (R == 0) return 0;
   const int64_t n = R * (S + 1);
-  spaced_bins_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(jitter, R, S, near, far, thr, sbins, ebins);
+  spaced_bins_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(jitter, R, S, near, far, thr, sbins, ebins, RayPoints{});
+  PS_CHECK_LAUNCH();
+}
+
+// ps_spaced_bins + ps_field_points (rays + these bin edges) in one launch
+extern "C" int ps_spaced_bins_points(const float* jitter, int64_t R, int S, float near, float far, float thr, float* sbins, float* ebins,
+                                     const float* origins, const float* dirs, const float* aabb, int contract, float* u, float* sel,
+                                     void* stream) {
+  PS_REQUIRE(origins && dirs && aabb && u && sel, "ps_spaced_bins_points: null argument");
+  if (R == 0) return 0;
+  const int64_t n = R * (S + 1);
+  spaced_bins_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(jitter, R, S, near, far, thr, sbins, ebins,
+                                                                                   RayPoints{origins, dirs, aabb, contract, u, sel});
+  PS_CHECK_LAUNCH();
+}
+
+// ps_weights_fwd + ps_pdf_resample (+ ps_field_points on the new edges when u != NULL) in one launch
+extern "C" int ps_weights_resample(const float* ebins, const float* sigma, const float* sbins, const float* jitter, int64_t R, int S,
+                                   int n_new, float anneal, float pad, float eps, float near, float far, float thr, float* weights,
+                                   float* new_sbins, float* new_ebins, const float* origins, const float* dirs, const float* aabb,
+                                   int contract, float* u, float* sel, void* stream) {
+  PS_REQUIRE(S <= kMaxCh * 64 && n_new <= kMaxCh * 64 - 1, "ps_weights_resample: samples per ray must be <= 256 (255 new ones)");
+  PS_REQUIRE(ebins && sigma && sbins && weights && new_sbins && new_ebins, "ps_weights_resample: null argument");
+  PS_REQUIRE(u == nullptr || (origins && dirs && aabb && sel), "ps_weights_resample: points without rays / box");
+  if (R == 0) return 0;
+  const unsigned grid = (unsigned)((R + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const RayPoints P{origins, dirs, aabb, contract, u, sel};
+  int rc = by_chunk(S, [&](auto ch) {
+    weights_resample_kernel<decltype(ch)::value><<<grid, 256, 0, s>>>(ebins, sigma, sbins, jitter, R, S, n_new, anneal, pad, eps, near, far,
+                                                                      thr, weights, new_sbins, new_ebins, P);
+    return 0;
+  });
+  if (rc) return rc;
   PS_CHECK_LAUNCH();
 }
 

@@ -50,6 +50,54 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
   }
 }
 
+// Two tables in one launch each way (the model's per-camera appearance code + per-video code, nerfacto_nusc_ms.py:472-485), indices
+// read through an element stride (camera index = column 0 of ray_indices [R,3]: no contiguous copy): blockIdx.y = table.
+struct EmbedPair {
+  const int64_t* idx[2];
+  int64_t stride[2];
+  const float* table[2];
+  float* dtable[2];
+  int D[2], rows[2], col0[2];
+};
+__global__ void embedding_pair_fwd_kernel(EmbedPair e, int64_t R, int out_stride, float* __restrict__ out) {
+  const int t = blockIdx.y, D = e.D[t];
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= R * D) return;
+  const int64_t r = i / D;
+  const int d = (int)(i - r * D);
+  out[r * out_stride + e.col0[t] + d] = e.table[t][e.idx[t][r * e.stride[t]] * D + d];
+}
+__global__ __launch_bounds__(256) void embedding_pair_bwd_kernel(EmbedPair e, const float* __restrict__ dout, int64_t R, int out_stride) {
+  __shared__ float acc[kEmbLds];
+  const int t = blockIdx.y, D = e.D[t], rows = e.rows[t], col0 = e.col0[t];
+  const int64_t* __restrict__ idx = e.idx[t];
+  const int64_t st = e.stride[t];
+  float* __restrict__ dtable = e.dtable[t];
+  const bool use_lds = (int64_t)rows * D <= kEmbLds;
+  const int n_tab = rows * D;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < n_tab; i += 256) acc[i] = 0.0f;
+    __syncthreads();
+  }
+  const int64_t per = (R * D + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = blockIdx.x * per, hi = min(R * D, lo + per);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const int64_t r = i / D;
+    const int d = (int)(i - r * D);
+    const float g = dout[r * out_stride + col0 + d];
+    const int64_t row = idx[r * st];
+    if (use_lds)
+      atomicAdd(&acc[row * D + d], g);
+    else
+      unsafeAtomicAdd(dtable + row * D + d, g);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_tab; i += 256)
+      if (acc[i] != 0.0f) unsafeAtomicAdd(dtable + i, acc[i]);
+  }
+}
+
 // One wavefront per ray, lane = channel.  sky_* may be null (no sky model): plain clamp of the accumulation.
 __global__ __launch_bounds__(256) void sky_blend_fwd_kernel(const float* __restrict__ rgb_f, const float* __restrict__ acc_raw,
                                                             const float* __restrict__ sem_f, const float* __restrict__ sky_rgb,
@@ -181,6 +229,28 @@ extern "C" int ps_embedding_bwd(const int64_t* idx, const float* dout, int64_t R
   const int64_t want = (R * D + 256 * 32 - 1) / (256 * 32);
   const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 128 ? 128 : want));
   embedding_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(idx, dout, R, D, rows, out_stride, col0, dtable);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_embedding_pair_fwd(const int64_t* idx0, int64_t stride0, const float* table0, int D0, const int64_t* idx1, int64_t stride1,
+                                     const float* table1, int D1, int64_t R, float* out, void* stream) {
+  PS_REQUIRE(idx0 && table0 && idx1 && table1 && out && D0 > 0 && D1 > 0 && stride0 >= 1 && stride1 >= 1, "ps_embedding_pair_fwd: null argument");
+  if (R == 0) return 0;
+  EmbedPair e{{idx0, idx1}, {stride0, stride1}, {table0, table1}, {nullptr, nullptr}, {D0, D1}, {0, 0}, {0, D0}};
+  const int Dm = D0 > D1 ? D0 : D1;
+  embedding_pair_fwd_kernel<<<dim3((unsigned)((R * Dm + 255) / 256), 2), 256, 0, (hipStream_t)stream>>>(e, R, D0 + D1, out);
+  PS_CHECK_LAUNCH();
+}
+
+extern "C" int ps_embedding_pair_bwd(const int64_t* idx0, int64_t stride0, int rows0, int D0, float* dtable0, const int64_t* idx1,
+                                     int64_t stride1, int rows1, int D1, float* dtable1, const float* dout, int64_t R, void* stream) {
+  PS_REQUIRE(idx0 && dtable0 && idx1 && dtable1 && dout && D0 > 0 && D1 > 0 && stride0 >= 1 && stride1 >= 1, "ps_embedding_pair_bwd: null argument");
+  if (R == 0) return 0;
+  EmbedPair e{{idx0, idx1}, {stride0, stride1}, {nullptr, nullptr}, {dtable0, dtable1}, {D0, D1}, {rows0, rows1}, {0, D0}};
+  const int Dm = D0 > D1 ? D0 : D1;
+  const int64_t want = (R * Dm + 256 * 32 - 1) / (256 * 32);
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 128 ? 128 : want));
+  embedding_pair_bwd_kernel<<<dim3(grid, 2), 256, 0, (hipStream_t)stream>>>(e, dout, R, D0 + D1);
   PS_CHECK_LAUNCH();
 }
 

@@ -112,6 +112,28 @@ def exchanging(group: Optional["dist.ProcessGroup"] = None) -> bool:
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or exchange_in_world_of_one())
 
 
+def _zero_ranges(flat: torch.Tensor, ranges) -> None:
+    """flat[a:b] = 0 for every (a, b): several small ranges on the GPU (the MLP gradients between the hash tables of a single-process
+    step) in one launch (ps_zero_ranges); long ranges (a table's gradient under an exchange) keep torch's fill, one each"""
+    small = [(a, b) for a, b in ranges if b > a and (b - a) <= (1 << 22)]
+    for a, b in ranges:
+        if b > a and (b - a) > (1 << 22):
+            flat[a:b].zero_()
+    if len(small) == 1 or (small and not flat.is_cuda):
+        for a, b in small:
+            flat[a:b].zero_()
+    elif small:
+        import ctypes
+
+        from ._lib import check, lib
+
+        for i in range(0, len(small), 16):
+            part = small[i:i + 16]
+            check(lib().ps_zero_ranges(flat.data_ptr(), len(part), (ctypes.c_int64 * len(part))(*[a for a, _ in part]),
+                                       (ctypes.c_int64 * len(part))(*[b - a for a, b in part]),
+                                       torch._C._cuda_getCurrentRawStream(flat.device.index)), "ps_zero_ranges")
+
+
 class FlatGrads:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_sizes: Optional[Sequence[int]] = None, shard_world: int = 1,
                  splits: Optional[Dict[int, int]] = None):
@@ -251,8 +273,7 @@ class FlatGrads:
                     if x < b:
                         keep.append((x, b))
                 todo = keep
-            for a, b in todo:
-                self.flat[a:b].zero_()
+            _zero_ranges(self.flat, todo)
         self._dirty = None
         self.step_no += 1
         if self.n_groups:

@@ -365,10 +365,9 @@ class NerfactoNuscDualModel(NerfactoNuscMSModel):
         sky_outputs = {}
         if c.use_sky_model:
             sky_outputs = self.sky_model(ray_samples, appearance_embedding=app3)
-        rgb, accumulation, semantics = ops.sky_blend(rgb, acc_raw, semantics, sky_outputs.get(FieldHeadNames.RGB),
-                                                     sky_outputs.get(FieldHeadNames.SEMANTICS))
-        outputs = {"rgb": rgb, "accumulation": accumulation, "depth": depth.detach(), "expected_depth": expected_depth,
-                   "semantics": semantics, "dynamic_density": fo["dynamic_density"]}
+        # (sky blend, or -- training -- the entries get_loss_dict fills from its fused blend + losses launch: the static model's helper)
+        outputs = self._blend_outputs(rgb, acc_raw, semantics, sky_outputs, depth, expected_depth, weights, ray_samples)
+        outputs["dynamic_density"] = fo["dynamic_density"]
         if self.training:
             outputs["weights_list"] = weights_list
             outputs["ray_samples_list"] = ray_samples_list

@@ -56,6 +56,25 @@ def _grid_cfg(enc: HashEncoding) -> F.GridCfg:
     return F.GridCfg(enc.num_levels, enc.features_per_level, enc.log2_hashmap_size)
 
 
+def points_key(field) -> tuple:
+    """identity of a field's point normalisation (its box buffer's storage + version, contraction on / off)"""
+    return (field.aabb.data_ptr(), field.aabb._version, field.spatial_distortion is not None)
+
+
+def points_of(field, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
+    """(u, sel) of `field` on the samples: the ones the sampling kernel produced for this very field on the way, else computed here"""
+    pts = getattr(ray_samples, "points", None)
+    if pts is not None and pts[0] == points_key(field):
+        return pts[1], pts[2]
+    rb = ray_samples.ray_bundle
+    return field.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+
+
+def points_spec(field) -> tuple:
+    """what a sampling kernel needs to form this field's points: (aabb, contract, key)"""
+    return (field.aabb, field.spatial_distortion is not None, points_key(field))
+
+
 # ------------------------------------------------------------------------------------------------------------ main
 class iNGPField(nn.Module):
     def __init__(self, aabb: Tensor, num_layers: int = 2, hidden_dim: int = 64, geo_feat_dim: int = 15, num_levels: int = 16,
@@ -119,7 +138,7 @@ class iNGPField(nn.Module):
         self._require_fused()
         rb = ray_samples.ray_bundle
         R = ray_samples.ebins.shape[0]
-        u, sel = self.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        u, sel = points_of(self, ray_samples)
         app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         g = self.mlp_base_grid
         rgb, acc, depth, expd, sem, w = F.main_field_render(
@@ -163,7 +182,7 @@ class iNGPField(nn.Module):
     def forward(self, ray_samples: RaySamples, appearance_embedding=None) -> Dict[FieldHeadNames, Tensor]:
         rb = ray_samples.ray_bundle
         R, S = ray_samples.ebins.shape[0], ray_samples.num_samples
-        u, sel = self.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        u, sel = points_of(self, ray_samples)
         app = None if appearance_embedding is None else _per_ray(appearance_embedding, R)
         sigma, rgb, sem = self.evaluate(u, sel, rb.directions, app, S)
         return {FieldHeadNames.DENSITY: sigma.view(R, S, 1), FieldHeadNames.RGB: rgb.view(R, S, 3),
@@ -405,8 +424,7 @@ class PropNetDensityField(nn.Module):
         return self.evaluate(u, sel).view(*positions.shape[:-1], 1)
 
     def density_of_samples(self, ray_samples: RaySamples) -> Tensor:
-        rb = ray_samples.ray_bundle
-        u, sel = self.points(origins=rb.origins, dirs=rb.directions, ebins=ray_samples.ebins)
+        u, sel = points_of(self, ray_samples)
         return self.evaluate(u, sel).view(ray_samples.ebins.shape[0], ray_samples.num_samples, 1)
 
     def get_density(self, ray_samples: RaySamples):

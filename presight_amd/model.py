@@ -20,7 +20,7 @@ from . import ops
 from .callbacks import TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation  # noqa: F401
 from .components import Embedding, SceneContraction
 from .fields import (FieldHeadNames, PropNetDensityField, PropNetDensityFieldMS, SkyField, SkyFieldMS, iNGPField,
-                     iNGPFieldMS)
+                     iNGPFieldMS, points_spec)
 from .losses import (LossDict, MSELoss, blend_losses, deferred_finish, distortion_loss, expected_depth_loss, expected_monodepth_loss, line_of_sight_loss, semantic_loss, sky_loss,
                      z_anti_aliasing_interlevel_loss)
 from .rays import RayBundle, RaySamples
@@ -182,6 +182,11 @@ class _PropDensityFn:
         if isinstance(x, RaySamples):
             return self.net.density_of_samples(x)
         return self.net.density_fn(x)
+
+    def points_spec(self):
+        """(aabb, contract, key) of the ONE sub-field this network evaluates its samples with (the sampling kernels then form its
+        points on the way, fields.points_of), None for a routed K > 1 module (the router forms the points)"""
+        return points_spec(self.net.fields[0]) if len(self.net.fields) == 1 else None
 
 
 class NerfactoNuscMSModel(nn.Module):
@@ -350,7 +355,9 @@ class NerfactoNuscMSModel(nn.Module):
         c = self.config
         if self.param_gate is not None:
             self.param_gate("proposal_networks")
-        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns, jitters=jitters)
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(
+            ray_bundle, density_fns=self.density_fns, jitters=jitters,
+            final_points_spec=points_spec(self.field.fields[0]) if len(self.field.fields) == 1 else None)
         if self.param_gate is not None:
             self.param_gate("fields")
         app = self._appearance(ray_bundle)
@@ -378,6 +385,25 @@ class NerfactoNuscMSModel(nn.Module):
         sky_outputs = {}
         if c.use_sky_model:
             sky_outputs = self.sky_model(ray_samples, appearance_embedding=None if app is None else app[:, None, :])
+        outputs = self._blend_outputs(rgb, acc_raw, semantics, sky_outputs, depth, expected_depth, weights, ray_samples)
+        if self.training:
+            outputs["weights_list"] = weights_list
+            outputs["ray_samples_list"] = ray_samples_list
+
+        def prop_depth(i):
+            with torch.no_grad():
+                return self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
+
+        for i in range(c.num_proposal_iterations):
+            if self.training:  # evaluated when somebody reads it (nothing in a training step does)
+                outputs.lazy(f"prop_depth_{i}", functools.partial(prop_depth, i))
+            else:
+                outputs[f"prop_depth_{i}"] = prop_depth(i)
+        return outputs
+
+    def _blend_outputs(self, rgb, acc_raw, semantics, sky_outputs, depth, expected_depth, weights, ray_samples) -> "LazyOutputs":
+        """the rendered outputs of get_outputs from the field's composited values and the sky model's (shared with the dual model)"""
+        c = self.config
         # accumulation = clamp(acc, 0, 1); rgb/semantics += (1 - accumulation) * sky   (nerfacto_nusc_ms.py:512-533)
         blend_in = (rgb, acc_raw, semantics if c.use_semantics else None, sky_outputs.get(FieldHeadNames.RGB),
                     sky_outputs.get(FieldHeadNames.SEMANTICS))
@@ -412,19 +438,6 @@ class NerfactoNuscMSModel(nn.Module):
             outputs["depth"], outputs["expected_depth"] = depth.detach(), expected_depth
         if c.use_semantics and not self.training and self.dino_to_rgb is not None:
             outputs["dino_rgb"] = apply_feature_colormap(outputs["semantics"], self.dino_to_rgb)
-        if self.training:
-            outputs["weights_list"] = weights_list
-            outputs["ray_samples_list"] = ray_samples_list
-
-        def prop_depth(i):
-            with torch.no_grad():
-                return self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
-
-        for i in range(c.num_proposal_iterations):
-            if self.training:  # evaluated when somebody reads it (nothing in a training step does)
-                outputs.lazy(f"prop_depth_{i}", functools.partial(prop_depth, i))
-            else:
-                outputs[f"prop_depth_{i}"] = prop_depth(i)
         return outputs
 
     def get_metrics_dict(self, outputs, batch):

@@ -397,12 +397,20 @@ def generate_rays(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx: 
     return o, d, pa, dn
 
 
-def spaced_bins(num_rays: int, S: int, near: float, far: float, thr: float, jitter: Optional[Tensor], device):
+def spaced_bins(num_rays: int, S: int, near: float, far: float, thr: float, jitter: Optional[Tensor], device, points=None):
+    """-> (sbins, ebins) [R, S+1]; points = (origins, dirs, aabb, contract): -> (sbins, ebins, u [R*S,3], sel [R*S]) -- the points of
+    the field that will be evaluated on these bins (field_ops.field_points) from the same launch"""
     sb = torch.empty(num_rays, S + 1, device=device)
     eb = torch.empty(num_rays, S + 1, device=device)
     j = None if jitter is None else _f32(jitter).view(-1)
-    check(lib().ps_spaced_bins(_p(j), num_rays, S, near, far, thr, _p(sb), _p(eb), _stream()), "ps_spaced_bins")
-    return sb, eb
+    if points is None:
+        check(lib().ps_spaced_bins(_p(j), num_rays, S, near, far, thr, _p(sb), _p(eb), _stream()), "ps_spaced_bins")
+        return sb, eb
+    origins, dirs, aabb, contract = points
+    u, sel = torch.empty(num_rays * S, 3, device=device), torch.empty(num_rays * S, device=device)
+    check(lib().ps_spaced_bins_points(_p(j), num_rays, S, near, far, thr, _p(sb), _p(eb), _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(aabb)),
+                                      int(contract), _p(u), _p(sel), _stream()), "ps_spaced_bins_points")
+    return sb, eb, u, sel
 
 
 class _Weights(torch.autograd.Function):
@@ -422,6 +430,56 @@ class _Weights(torch.autograd.Function):
         ds = torch.empty_like(sigma)
         check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(_f32(dw)), R, S, _p(ds), _stream()), "ps_weights_bwd")
         return None, ds
+
+
+class _WeightsResample(torch.autograd.Function):
+    """RaySamples.get_weights + PDFSampler of the next level (+ the next field's points) in one launch (ps_weights_resample); only
+    the weights are differentiable (w.r.t. the densities), the new bin edges are detached like the reference's
+    (ns/model_components/ray_samplers.py:360)"""
+
+    @staticmethod
+    def forward(ctx, ebins, sigma, sbins, jitter, n_new, anneal, pad, eps, near, far, thr, points):
+        ebins, sigma, sbins = _f32(ebins), _f32(sigma), _f32(sbins)
+        R, S = sigma.shape
+        dev = sigma.device
+        ctx.set_materialize_grads(False)
+        w = torch.empty_like(sigma)
+        nsb, neb = torch.empty(R, n_new + 1, device=dev), torch.empty(R, n_new + 1, device=dev)
+        j = None if jitter is None else _f32(jitter).view(-1)
+        if points is not None:
+            origins, dirs, aabb, contract = points
+            origins, dirs, aabb = _f32(origins), _f32(dirs), _f32(aabb)
+            u, sel = torch.empty(R * n_new, 3, device=dev), torch.empty(R * n_new, device=dev)
+        else:
+            origins = dirs = aabb = u = sel = None
+            contract = 0
+        check(lib().ps_weights_resample(_p(ebins), _p(sigma), _p(sbins), _p(j), R, S, n_new, float(anneal), float(pad), float(eps), float(near),
+                                        float(far), float(thr), _p(w), _p(nsb), _p(neb), _p(origins), _p(dirs), _p(aabb), int(contract), _p(u),
+                                        _p(sel), _stream()), "ps_weights_resample")
+        ctx.save_for_backward(ebins, sigma)
+        empty = torch.empty(0, device=dev)
+        outs = (w, nsb, neb, u if u is not None else empty, sel if sel is not None else empty)
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, dw, *_):
+        if dw is None:
+            return (None,) * 12
+        ebins, sigma = ctx.saved_tensors
+        R, S = sigma.shape
+        ds = torch.empty_like(sigma)
+        check(lib().ps_weights_bwd(_p(ebins), _p(sigma), _p(_f32(dw)), R, S, _p(ds), _stream()), "ps_weights_bwd")
+        return (None, ds) + (None,) * 10
+
+
+def weights_resample(ebins: Tensor, sigma: Tensor, sbins: Tensor, n_new: int, jitter: Optional[Tensor], anneal: float, near: float, far: float,
+                     thr: float, pad: float = 0.01, eps: float = float(torch.finfo(torch.float32).eps), points=None):
+    """-> (weights [R,S] (differentiable w.r.t. sigma), new sbins, new ebins [R, n_new+1], u | None, sel | None): weights_from_density +
+    pdf_resample (+ field_ops.field_points of the field that will be evaluated on the new bins; points = (origins, dirs, aabb,
+    contract)) from one launch"""
+    w, nsb, neb, u, sel = _WeightsResample.apply(ebins, sigma, sbins, jitter, int(n_new), anneal, pad, eps, near, far, thr, points)
+    return (w, nsb, neb, u, sel) if points is not None else (w, nsb, neb, None, None)
 
 
 def weights_from_density(ebins: Tensor, sigma: Tensor) -> Tensor:
@@ -549,11 +607,24 @@ class _EmbedCat(torch.autograd.Function):
         dev = tables[0].device
         widths = [t.shape[1] for t in tables]
         out = torch.empty(R, sum(widths), device=dev)
-        idxs = [i.reshape(-1).to(torch.int64).contiguous() for i in idxs]
-        col = 0
-        for i, t in zip(idxs, tables):
-            check(lib().ps_embedding_fwd(_p(i), _p(_f32(t)), R, t.shape[1], out.shape[1], col, _p(out), _stream()), "ps_embedding_fwd")
-            col += t.shape[1]
+        # two tables (the model's case): one launch, indices read in place through their stride (camera index = ray_indices[:, 0])
+        pair = n_tab == 2 and all(i.dtype == torch.int64 and i.is_cuda and i.dim() >= 1 for i in idxs)
+        if pair:
+            idxs = [i.reshape(-1) for i in idxs]
+            pair = all(i.numel() == R and (R <= 1 or i.stride(0) >= 1) for i in idxs)
+        if pair:
+            tabs = [_f32(t) for t in tables]
+            strides = [1 if R <= 1 else i.stride(0) for i in idxs]
+            check(lib().ps_embedding_pair_fwd(_p(idxs[0]), strides[0], _p(tabs[0]), widths[0], _p(idxs[1]), strides[1], _p(tabs[1]), widths[1], R,
+                                              _p(out), _stream()), "ps_embedding_pair_fwd")
+            ctx.strides = strides
+        else:
+            idxs = [i.reshape(-1).to(torch.int64).contiguous() for i in idxs]
+            col = 0
+            for i, t in zip(idxs, tables):
+                check(lib().ps_embedding_fwd(_p(i), _p(_f32(t)), R, t.shape[1], out.shape[1], col, _p(out), _stream()), "ps_embedding_fwd")
+                col += t.shape[1]
+            ctx.strides = None
         ctx.save_for_backward(*idxs)
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.sinks = [grad_sink(t) for t in tables]
@@ -566,11 +637,16 @@ class _EmbedCat(torch.autograd.Function):
         dout = _f32(dout)
         R = dout.shape[0]
         grads, col = [], 0
-        for i, (rows, D), sink in zip(idxs, ctx.shapes, ctx.sinks):
-            dst = sink if sink is not None else torch.zeros(rows, D, device=dout.device)
-            check(lib().ps_embedding_bwd(_p(i), _p(dout), R, D, rows, dout.shape[1], col, _p(dst), _stream()), "ps_embedding_bwd")
-            grads.append(None if sink is not None else dst)
-            col += D
+        dsts = [sink if sink is not None else torch.zeros(rows, D, device=dout.device) for (rows, D), sink in zip(ctx.shapes, ctx.sinks)]
+        if ctx.strides is not None:
+            (r0, D0), (r1, D1) = ctx.shapes
+            check(lib().ps_embedding_pair_bwd(_p(idxs[0]), ctx.strides[0], r0, D0, _p(dsts[0]), _p(idxs[1]), ctx.strides[1], r1, D1, _p(dsts[1]),
+                                              _p(dout), R, _stream()), "ps_embedding_pair_bwd")
+        else:
+            for i, (rows, D), dst in zip(idxs, ctx.shapes, dsts):
+                check(lib().ps_embedding_bwd(_p(i), _p(dout), R, D, rows, dout.shape[1], col, _p(dst), _stream()), "ps_embedding_bwd")
+                col += D
+        grads = [None if sink is not None else dst for sink, dst in zip(ctx.sinks, dsts)]
         mark_touched(ctx.direct)
         return (None, *([None] * len(idxs)), *grads)
 

@@ -12,16 +12,46 @@ from torch import Tensor
 from . import ops
 
 
-@dataclass
 class RayBundle:
-    origins: Tensor  # [R,3]
-    directions: Tensor  # [R,3]
-    pixel_area: Tensor  # [R,1]
-    camera_indices: Optional[Tensor] = None  # [R,1]
-    nears: Optional[Tensor] = None
-    fars: Optional[Tensor] = None
-    metadata: Dict[str, Tensor] = field(default_factory=dict)
-    times: Optional[Tensor] = None
+    """ns/cameras/rays.py:153-249 for the fields the PreSight path touches.  `nears` / `fars` [R,1]: the collider of the PreSight model
+    sets ONE near / far plane for the whole batch (scene_colliders.py:182-187) and the kernels take them as scalars
+    (metadata["_near_far"]); the two tensors the reference fills are materialised when somebody reads them (a training step never
+    does: three element-wise launches per step otherwise)."""
+
+    def __init__(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, camera_indices: Optional[Tensor] = None,
+                 nears: Optional[Tensor] = None, fars: Optional[Tensor] = None, metadata: Optional[Dict[str, Tensor]] = None,
+                 times: Optional[Tensor] = None):
+        self.origins, self.directions, self.pixel_area = origins, directions, pixel_area  # [R,3] [R,3] [R,1]
+        self.camera_indices = camera_indices  # [R,1]
+        self._nears, self._fars = nears, fars
+        self.metadata = {} if metadata is None else metadata
+        self.times = times
+
+    def _plane(self, which: int) -> Optional[Tensor]:
+        nf = self.metadata.get("_near_far")
+        if nf is None:
+            return None
+        return torch.full_like(self.origins[..., 0:1], float(nf[which]))
+
+    @property
+    def nears(self) -> Optional[Tensor]:
+        if self._nears is None:
+            self._nears = self._plane(0)
+        return self._nears
+
+    @nears.setter
+    def nears(self, v):
+        self._nears = v
+
+    @property
+    def fars(self) -> Optional[Tensor]:
+        if self._fars is None:
+            self._fars = self._plane(1)
+        return self._fars
+
+    @fars.setter
+    def fars(self, v):
+        self._fars = v
 
     def __len__(self) -> int:
         return self.origins.shape[0]
@@ -30,8 +60,8 @@ class RayBundle:
         sl = slice(start_idx, end_idx)
         return RayBundle(self.origins[sl], self.directions[sl], self.pixel_area[sl],
                          None if self.camera_indices is None else self.camera_indices[sl],
-                         None if self.nears is None else self.nears[sl], None if self.fars is None else self.fars[sl],
-                         {k: v[sl] for k, v in self.metadata.items()}, None if self.times is None else self.times[sl])
+                         None if self._nears is None else self._nears[sl], None if self._fars is None else self._fars[sl],
+                         {k: (v[sl] if torch.is_tensor(v) else v) for k, v in self.metadata.items()}, None if self.times is None else self.times[sl])
 
 
 @dataclass
@@ -56,6 +86,9 @@ class RaySamples:
     ebins: Tensor
     sbins: Tensor
     spacing_to_euclidean_fn: Optional[Callable] = None
+    # (key, u [R*S,3], sel [R*S]): the normalised sample points of the field identified by `key` (its box + contraction), when the
+    # kernel that formed these bins produced them on the way (fields.points_of); None: the field computes them itself
+    points: Optional[tuple] = None
 
     @property
     def num_samples(self) -> int:

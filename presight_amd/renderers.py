@@ -18,15 +18,15 @@ class NearFarCollider(nn.Module):
         self.far_plane = far_plane
 
     def set_nears_and_fars(self, ray_bundle: RayBundle) -> RayBundle:
-        ones = torch.ones_like(ray_bundle.origins[..., 0:1])
+        """scene_colliders.py:182-187: nears = near_plane (training) / 0 (evaluation), fars = far_plane for every ray.  The planes are
+        recorded as scalars; `ray_bundle.nears` / `.fars` [R,1] are filled when read (rays.RayBundle)"""
         near_plane = self.near_plane if self.training else 0
-        ray_bundle.nears = ones * near_plane
-        ray_bundle.fars = ones * self.far_plane
+        ray_bundle.nears = ray_bundle.fars = None
         ray_bundle.metadata["_near_far"] = (float(near_plane), float(self.far_plane))
         return ray_bundle
 
     def forward(self, ray_bundle: RayBundle) -> RayBundle:
-        if ray_bundle.nears is not None and ray_bundle.fars is not None and "_near_far" in ray_bundle.metadata:
+        if "_near_far" in ray_bundle.metadata:
             return ray_bundle
         return self.set_nears_and_fars(ray_bundle)
 

@@ -85,7 +85,9 @@ class SpacedSampler(Sampler):
         self.spacing_fn, self.spacing_fn_inv = spacing_fn, spacing_fn_inv
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, num_samples: Optional[int] = None,
-                             jitter: Optional[Tensor] = None) -> RaySamples:
+                             jitter: Optional[Tensor] = None, points_spec: Optional[tuple] = None) -> RaySamples:
+        """points_spec = (aabb, contract, key) of the field that will be evaluated on these samples (fields.points_spec): its
+        normalised points are formed by the same launch and travel with the RaySamples"""
         assert ray_bundle is not None
         num_samples = num_samples or self.num_samples
         assert num_samples is not None
@@ -96,8 +98,12 @@ class SpacedSampler(Sampler):
                 jitter = torch.rand((R, 1), device=dev)
         else:
             jitter = None
-        sb, eb = ops.spaced_bins(R, num_samples, near, far, self.thr, jitter, dev)
-        return RaySamples(ray_bundle, eb, sb, spacing_to_euclidean_fn=(near, far, self.thr))
+        if points_spec is None:
+            sb, eb = ops.spaced_bins(R, num_samples, near, far, self.thr, jitter, dev)
+            return RaySamples(ray_bundle, eb, sb, spacing_to_euclidean_fn=(near, far, self.thr))
+        aabb, contract, key = points_spec
+        sb, eb, u, sel = ops.spaced_bins(R, num_samples, near, far, self.thr, jitter, dev, points=(ray_bundle.origins, ray_bundle.directions, aabb, contract))
+        return RaySamples(ray_bundle, eb, sb, spacing_to_euclidean_fn=(near, far, self.thr), points=(key, u, sel))
 
 
 class PDFSampler(Sampler):
@@ -136,8 +142,56 @@ class PDFSampler(Sampler):
 prop_stream = ops.side_stream  # the proposal networks' side stream (ops.side_stream: registry + join)
 
 
+class JitterPool:
+    """The stratified-sampling jitters of MANY steps from one torch.rand call.  The reference draws one U[0, 1) number per ray and
+    sampling level in every iteration (ns/model_components/ray_samplers.py:105,322: three generator launches per step, each with
+    its own fill / philox set-up); the draws are i.i.d., so a block of `steps` x `levels` x R numbers drawn at once and handed out
+    slice by slice is the same distribution with one launch per `steps` iterations (<= 16 MB per block)."""
+
+    def __init__(self, budget_bytes: int = 16 << 20):
+        self.budget = budget_bytes
+        self.buf: Optional[Tensor] = None
+        self.next = 0
+        self.rng_state = None
+
+    @staticmethod
+    def _rng_state(device):
+        """(seed, philox offset) of the device's default generator -- host-side reads, no sync.  A block is only handed out while
+        this is what the block's own draw left behind: torch.manual_seed(...) (or anybody else drawing from the generator) starts a
+        new block, so that re-seeding reproduces a run's jitters exactly as it did with one torch.rand per step."""
+        try:
+            g = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+            return (g.initial_seed(), g.get_offset())
+        except Exception:  # (an exotic generator without offset bookkeeping: never reuse across calls)
+            return None
+
+    def draw(self, levels: int, R: int, device) -> List[Tensor]:
+        b = self.buf
+        state = self._rng_state(device)
+        if (b is None or b.shape[1] != levels or b.shape[2] != R or b.device != device or self.next >= b.shape[0] or state is None
+                or state != self.rng_state):
+            steps = max(1, min(256, self.budget // max(1, 4 * levels * R)))
+            self.buf = b = torch.rand((steps, levels, R), device=device)
+            self.next = 0
+            self.rng_state = self._rng_state(device)
+        i, self.next = self.next, self.next + 1
+        return [b[i, l].view(R, 1) for l in range(levels)]
+
+
 def arg_device(arg):
     return arg.device if torch.is_tensor(arg) else arg.ebins.device
+
+
+def _tensors_of(obj):
+    """the device tensors an object holds directly or inside a tuple attribute (RaySamples.points)"""
+    for v in vars(obj).values():
+        for t in (v if isinstance(v, tuple) else (v,)):
+            if torch.is_tensor(t) and t.is_cuda:
+                yield t
+
+
+# weights + PDF resampling (+ next points) of a proposal level as one launch (PRESIGHT_FUSED_RESAMPLE=0: the three launches of rounds 1-5)
+FUSED_RESAMPLE = os.environ.get("PRESIGHT_FUSED_RESAMPLE", "1") != "0"
 
 
 class ProposalNetworkSampler(Sampler):
@@ -158,6 +212,7 @@ class ProposalNetworkSampler(Sampler):
         self._anneal = 1.0
         self._steps_since_update = 0
         self._step = 0
+        self._jitters = JitterPool()
 
     def set_anneal(self, anneal: float) -> None:
         self._anneal = anneal
@@ -167,28 +222,59 @@ class ProposalNetworkSampler(Sampler):
         self._steps_since_update += 1
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, density_fns: Optional[List[Callable]] = None,
-                             jitters: Optional[List[Tensor]] = None) -> Tuple[RaySamples, List, List]:
+                             jitters: Optional[List[Tensor]] = None, final_points_spec: Optional[tuple] = None) -> Tuple[RaySamples, List, List]:
         """ns/model_components/ray_samplers.py:572-614.  `density_fns[i]` receives a RaySamples when it has the
-        attribute `takes_ray_samples` (fused path: positions are generated inside the field kernel), else positions."""
+        attribute `takes_ray_samples` (fused path: positions are generated inside the field kernel), else positions.
+        One launch per level (round 6): get_weights of level i, the PDF resampling of level i + 1's bins and the points of the field
+        that will be evaluated on them (density_fns[i + 1].points_spec() / final_points_spec: fields.points_spec) run as ONE kernel
+        (ops.weights_resample) -- same arithmetic, the PDFSampler module keeps serving direct calls."""
         assert ray_bundle is not None and density_fns is not None
         weights_list, ray_samples_list = [], []
         n = self.num_proposal_network_iterations
         weights, ray_samples = None, None
         updated = self._steps_since_update > self.update_sched(self._step) or self._step < 10
         eps = float(torch.finfo(torch.float32).eps)
+        if jitters is None and self.training and getattr(self.initial_sampler, "train_stratified", True) and self.pdf_sampler.train_stratified:
+            jitters = self._jitters.draw(n + 1, ray_bundle.origins.shape[0], ray_bundle.origins.device)  # one draw for many steps
+        specs = [getattr(fn, "points_spec", lambda: None)() if getattr(fn, "takes_ray_samples", False) else None for fn in density_fns[:n]]
+        specs.append(final_points_spec)
+        pdf = self.pdf_sampler
+        fuse_pdf = type(pdf) is PDFSampler and FUSED_RESAMPLE
+        near, far, thr = None, None, None
+        nxt = None  # (new sbins, new ebins, points | None) of the next level, formed together with this level's weights
         for i_level in range(n + 1):
             is_prop = i_level < n
             num_samples = self.num_proposal_samples_per_ray[i_level] if is_prop else self.num_nerf_samples_per_ray
             jit = None if jitters is None else jitters[i_level]
             if i_level == 0:
-                ray_samples = self.initial_sampler(ray_bundle, num_samples=num_samples, jitter=jit)
+                ray_samples = self.initial_sampler(ray_bundle, num_samples=num_samples, jitter=jit, points_spec=specs[0])
+            elif nxt is not None:
+                ray_samples = RaySamples(ray_bundle, nxt[1], nxt[0], spacing_to_euclidean_fn=ray_samples.spacing_to_euclidean_fn, points=nxt[2])
             else:
                 assert weights is not None
                 ray_samples = self.pdf_sampler(ray_bundle, ray_samples, weights, num_samples=num_samples, eps=eps,
                                                anneal=self._anneal, jitter=jit)
+            nxt = None
             if is_prop:
                 fn = density_fns[i_level]
                 arg = ray_samples if getattr(fn, "takes_ray_samples", False) else ray_samples.frustums.get_positions()
+                n_next = self.num_proposal_samples_per_ray[i_level + 1] if i_level + 1 < n else self.num_nerf_samples_per_ray
+                next_jit = None
+                if fuse_pdf and pdf.train_stratified and pdf.training:
+                    next_jit = jitters[i_level + 1] if jitters is not None else torch.rand((ray_samples.ebins.shape[0], 1), device=ray_samples.ebins.device)
+
+                def weights_and_next(density):
+                    """get_weights (+ the next level's bins and points from the same launch)"""
+                    if not fuse_pdf:
+                        return ray_samples.get_weights(density), None
+                    near_, far_, thr_ = ray_samples.spacing_to_euclidean_fn
+                    sp = specs[i_level + 1]
+                    pts = None if sp is None else (ray_bundle.origins, ray_bundle.directions, sp[0], sp[1])
+                    w, nsb, neb, u, sel = ops.weights_resample(ray_samples.ebins, density.reshape(density.shape[0], density.shape[1]), ray_samples.sbins,
+                                                               n_next, next_jit, self._anneal, near_, far_, thr_, pad=pdf.histogram_padding, eps=eps,
+                                                               points=pts)
+                    return w[..., None], (nsb, neb, None if sp is None else (sp[2], u, sel))
+
                 if updated and torch.is_grad_enabled():
                     # positions handed to a plain density_fn are allocated on the caller's stream and owned by nobody after this call
                     # (the caching allocator could hand their block out again while the side stream's backward still reads it):
@@ -197,7 +283,7 @@ class ProposalNetworkSampler(Sampler):
                     side = prop_stream(arg_device(arg)) if getattr(fn, "takes_ray_samples", False) else None
                     if side is None:
                         density = fn(arg)
-                        weights = ray_samples.get_weights(density)
+                        weights, nxt = weights_and_next(density)
                     else:
                         # The proposal network runs on a SIDE stream.  Its forward is ordered between the two waits (the sampling
                         # chain is sequential anyway); autograd runs a node's backward on the stream of its forward, so the
@@ -210,18 +296,19 @@ class ProposalNetworkSampler(Sampler):
                         side.wait_stream(cur)
                         with torch.cuda.stream(side):
                             for obj in (ray_samples, ray_samples.ray_bundle):  # allocated on the compute stream, read on the side stream
-                                for tns in vars(obj).values():
-                                    if torch.is_tensor(tns) and tns.is_cuda:
-                                        tns.record_stream(side)
+                                for tns in _tensors_of(obj):
+                                    tns.record_stream(side)
+                            if next_jit is not None:
+                                next_jit.record_stream(side)
                             density = fn(arg)
-                            weights = ray_samples.get_weights(density)
+                            weights, nxt = weights_and_next(density)
                         cur.wait_stream(side)
-                        for tns in (density, weights):
+                        for tns in (density, weights) + (() if nxt is None else (nxt[0], nxt[1]) + (() if nxt[2] is None else nxt[2][1:])):
                             tns.record_stream(cur)
                 else:
                     with torch.no_grad():
                         density = fn(arg)
-                    weights = ray_samples.get_weights(density)
+                    weights, nxt = weights_and_next(density)
                 weights_list.append(weights)
                 ray_samples_list.append(ray_samples)
         if updated:
