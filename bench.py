@@ -127,6 +127,10 @@ def compact_line(full: dict, detail_path=None) -> dict:
         if isinstance(roof.get("gather"), dict):
             r["gather_frac_of_l2_resident_ceiling"] = roof["gather"].get("frac_of_l2_resident_ceiling")
         out["roofline"] = r
+    rm = full.get("roofline_mfma")
+    if isinstance(rm, dict):  # the matrix-bound kernel next to the dominant one (the dominant kernel may be an HBM-bound one)
+        out["roofline_mfma"] = _pick(rm, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "avg_launch_ms", "traffic",
+                                          "traffic_over_algorithmic_io", "kept_activation_bytes"))
     if isinstance(full.get("end_to_end"), dict):
         out["end_to_end"] = _pick(full["end_to_end"], ("binding", "frac_of_binding", "frac_of_mfma", "frac_of_hbm", "frac_of_hbm_incl_optimizer"))
     cb = full.get("cpu_baseline")
@@ -668,6 +672,13 @@ def roofline_entries(kern, cfg, rays, n_params=0, live=(), fused_tables=None):
     tag = " + Adam of the table" if fused_tables else ""
     add(f"table backward main (absmax+bin+accumulate{tag}, L{L} F{F})", f"grid_scatter_L{L}F{F}", "hbm",
         2 * n_main * L * 8 * F * 4 + 24.0 * ft_main, "GB/s")
+    # its two long kernels one by one (single-process training: field_ops._scatter_phases): the record writer reads one d(feature) plane
+    # entry per (point, level) and writes 4 x-pair records of (2 + F) words each; the accumulate pass reads those records and streams
+    # the table's p, m, v in and out (24 bytes per entry) -- the gradient itself never reaches memory.  Algorithmic bytes; the measured
+    # HBM bytes (PMC) are `roofline.traffic` when this kernel is the dominant one.
+    rec = n_main * L * 4 * (2 + F) * 4
+    add(f"bin_kernel<{F}> (main table record writer)", f"bin_kernel_L{L}F{F}", "hbm", n_main * L * F * 4 + rec, "GB/s")
+    add(f"accumulate_kernel<{F}> (main table{tag})", f"accumulate_kernel_L{L}F{F}", "hbm", rec + 24.0 * ft_main, "GB/s")
     add(f"table backward proposal (bin+accumulate{tag}, L8 F1, mean of both)", "grid_scatter_L8F1", "hbm",
         2 * (n_p0 + n_p1) / 2 * 8 * 8 * 4 + 24.0 * ft_prop, "GB/s")
     return rows
@@ -1164,7 +1175,9 @@ def main():
     trainer.grads.stats = {"collectives": 0, "bytes": 0}
     # the longest kernels are timed live inside the timed steps (one HIP-event pair each); every other region -- two dozen
     # event pairs per step and the three-call split of the backward cost the timeline 1 % -- in a separate pass behind it
-    live = ("main_field_fwd",) if trainer.pipeline_adam else ("main_field_fwd", "adam")
+    mcfg_ = cfg["model"]
+    table_regions = (f"bin_kernel_L{mcfg_['num_levels']}F{mcfg_['features_per_level']}", f"accumulate_kernel_L{mcfg_['num_levels']}F{mcfg_['features_per_level']}")
+    live = (("main_field_fwd",) if trainer.pipeline_adam else ("main_field_fwd", "adam")) + (table_regions if (getattr(trainer, "fused_table_adam", False) and os.environ.get("PRESIGHT_BENCH_LIVE_TABLES", "1") != "0") else ())
     prof.enable(True, only=live)
     dt, (loss_dict, out) = timed(args.steps)
     psnr = float(model.get_metrics_dict(out, last_batch[0])["psnr"].detach())
@@ -1229,11 +1242,15 @@ def main():
             prop_t = sum(p.numel() for net in model.proposal_networks for n_, p in net.named_parameters() if n_.endswith("hash_table"))
             fused_tables = (main_t, prop_t / max(1, len(model.proposal_networks)))
         rows = roofline_entries(kern, cfg, rays, n_params=sum(p.numel() for p in trainer.grads.params), live=live, fused_tables=fused_tables)
-        # the dominant kernel: the single kernel with the longest average launch
+        # the dominant kernel: the single KERNEL with the longest average launch INSIDE the timed steps (what rocprofv3's kernel table of
+        # the same command ranks first) -- the main field's forward and the two long kernels of the main table backward are timed live
+        # (`timed_region`), the other rows come from the per-kernel pass; `roofline_mfma` keeps the matrix-bound forward next to it
         single = [r for r in rows if "summed" not in r["kernel"] and "mean of both" not in r["kernel"] and "absmax+bin" not in r["kernel"]]
         dom = max(single, key=lambda r: r["avg_launch_ms"]) if single else None
-        traffic, traffic_src = (pmc_traffic(dom["kernel"]) if (dom is not None and args.config == "cfg2" and rays == RAYS)
+        dom_mfma = next((r for r in rows if r["kernel"] == "main_fwd_kernel"), None)
+        traffic, traffic_src = (pmc_traffic(dom["kernel"].split(" ")[0].split("<")[0]) if (dom is not None and args.config == "cfg2" and rays == RAYS)
                                 else (None, "not collected for this shape"))
+        traffic_mfma = pmc_traffic("main_fwd_kernel")[0] if (dom_mfma is not None and args.config == "cfg2" and rays == RAYS) else None
         # end-to-end ceilings per training ray: MLP flops (fwd + 2x bwd) against the fp32 matrix peak, hash bytes
         # (gather fwd, read + write bwd) against HBM; the binding (lower) ceiling is the fp32 MFMA one
         bc = binding_ceiling(cfg, rays, sum(p.numel() for p in trainer.grads.params), bool(getattr(trainer, "fused_table_adam", False)))
@@ -1254,12 +1271,17 @@ def main():
                 # `achieved` / `frac`: the matrix-core flops the kernel actually ISSUES (padding included) / its HIP-event duration (+ the
                 # small per-ray launches that took over part of its work) / peak.  `frac_algorithmic` prices the flops of the reference's
                 # unfactored network (26 752 MAC per sample) against the same duration
-                "executed_flops": dom.get("executed"), "algorithmic_flops": dom["algorithmic"], "frac_algorithmic": dom.get("frac_algorithmic"),
+                **({"executed_flops": dom.get("executed"), "algorithmic_flops": dom["algorithmic"], "frac_algorithmic": dom.get("frac_algorithmic")}
+                   if dom["bound"] == "mfma" else {"algorithmic_bytes": dom["algorithmic"], "timed_inside_the_timed_steps": dom.get("timed_region")}),
                 "duration_ms_incl_moved_work": dom.get("duration_ms_incl_moved_work"), "moved_work_ms": dom.get("moved_work_ms"),
                 # what the traffic is: the kernel's algorithmic I/O (feature planes in; density, colour, weights per sample and the composited
                 # semantic activations per ray out) against the hidden activations it KEEPS for the three backward kernels (register order,
                 # fp32: the price of an exact-fp32 backward without recompute) -- the MFMA-bound forward also streams this
-                **main_fwd_io(cfg, rays, traffic, dom.get("avg_launch_ms"))},
+                **(main_fwd_io(cfg, rays, traffic, dom.get("avg_launch_ms")) if dom["kernel"] == "main_fwd_kernel" else {})},
+            "roofline_mfma": None if dom_mfma is None else {
+                "bound": "mfma", "kernel": dom_mfma["kernel"], "achieved": dom_mfma["achieved"], "peak": dom_mfma["peak"], "unit": dom_mfma["unit"],
+                "frac": dom_mfma["frac"], "frac_algorithmic": dom_mfma.get("frac_algorithmic"), "avg_launch_ms": dom_mfma["avg_launch_ms"],
+                "traffic": traffic_mfma, **main_fwd_io(cfg, rays, traffic_mfma, dom_mfma.get("avg_launch_ms"))},
             "roofline_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows],
             "end_to_end": {**bc, "frac_of_binding": per_gpu / bc["ceiling_binding_rays_per_s"], "frac_of_mfma": per_gpu / ceil_mfma,
                            "frac_of_hbm": per_gpu / ceil_hbm, "frac_of_hbm_incl_optimizer": per_gpu / bc["ceiling_hbm_incl_optimizer_rays_per_s"]},

@@ -158,9 +158,11 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
         if fused is not None:
             # single-process training: the accumulate pass applies the table's Adam step itself, the gradient is never written
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
-            check(lib().ps_grid_scatter_binned_adam(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), _p(counts),
-                                                    int(ws_with_absmax is not None), _p(ws), 3, 0, -1, *fused, _stream()),
-                  "ps_grid_scatter_binned_adam")
+            for phase, reg in _scatter_phases(L, F):
+                with (prof.region(reg) if reg else contextlib.nullcontext()):
+                    check(lib().ps_grid_scatter_binned_adam(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), _p(counts),
+                                                            int(ws_with_absmax is not None), _p(ws), phase, 0, -1, *fused, _stream()),
+                          "ps_grid_scatter_binned_adam")
         elif _binned(N, L) and pieces > 1:
             # the gradient is exchanged in `pieces` level groups (presight_amd.dist.FlatGrads splits): one accumulate launch per group,
             # every group handed to the exchange as soon as its launch is enqueued -- its reduce-scatter runs under the next launches
@@ -183,6 +185,16 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
             check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _stream()),
                   "ps_grid_scatter")
     return None if sink is not None else dtable
+
+
+def _scatter_phases(L: int, F: int):
+    """the binned table backward as one call -- or, while bench.py times its two long kernels, as two calls of the same entry point
+    (phase 1: prefix + record writer `bin_kernel`, phase 2: `accumulate_kernel`), each inside its own HIP-event region: same kernels,
+    same order, same stream"""
+    names = (f"bin_kernel_L{L}F{F}", f"accumulate_kernel_L{L}F{F}")
+    if prof.enabled(names[0]) and prof.enabled(names[1]):
+        return ((1, names[0]), (2, names[1]))
+    return ((3, None),)
 
 
 def _layers(flat: Sequence[Tensor]) -> List[Tuple[Tensor, Tensor]]:

@@ -119,17 +119,12 @@ class LazyOutputs(MutableMapping):
         self._data[key] = None  # (keeps the key's position and membership)
 
     def lazy_group(self, keys, fn: Callable):
-        """several entries produced by ONE evaluation: fn() -> {key: value} for all `keys`, run when the first of them is read"""
-        keys = tuple(keys)
-
-        def run():
-            vals = fn()
-            for k in keys:
-                self._lazy.pop(k, None)
-                self._data[k] = vals[k]
-
-        for k in keys:
-            self._lazy[k] = (run,)  # (a 1-tuple marks a group member: evaluation fills the entries itself)
+        """several entries produced by ONE evaluation: fn() -> {key: value} for all `keys`, run when the first of them is read.
+        (Stored as (keys, fn), evaluated by _force: a closure over `self` here would tie the mapping into a reference cycle with its
+        own entries, and the tensors they hold would then live until the cyclic collector runs instead of until the step ends.)"""
+        ent = (tuple(keys), fn)
+        for k in ent[0]:
+            self._lazy[k] = ent
             self._data[k] = None
 
     def is_lazy(self, key: str) -> bool:
@@ -139,7 +134,11 @@ class LazyOutputs(MutableMapping):
     def _force(self, key):
         fn = self._lazy.pop(key, None)
         if isinstance(fn, tuple):
-            fn[0]()
+            keys, f = fn
+            vals = f()
+            for k in keys:
+                self._lazy.pop(k, None)
+                self._data[k] = vals[k]
         elif fn is not None:
             self._data[key] = fn()
 
@@ -416,13 +415,8 @@ class NerfactoNuscMSModel(nn.Module):
             # their gradients in one launch (losses.blend_losses) and fills these entries from it
             keys = ("rgb", "accumulation") + (("semantics",) if c.use_semantics else ())
 
-            def blend():
-                vals = ops.sky_blend(*blend_in)
-                outputs.pending_blend = None
-                return dict(zip(keys, vals))
-
-            outputs.lazy_group(keys, blend)
-            outputs.pending_blend = blend_in
+            outputs.lazy_group(keys, lambda: dict(zip(keys, ops.sky_blend(*blend_in))))  # (no reference to `outputs`: no cycle)
+            outputs.pending_blend = blend_in  # (consumed by get_loss_dict only while the group is still unevaluated)
         else:
             rgb, accumulation, semantics = ops.sky_blend(*blend_in)
             outputs["rgb"], outputs["accumulation"] = rgb, accumulation

@@ -171,8 +171,10 @@ class JitterPool:
         if (b is None or b.shape[1] != levels or b.shape[2] != R or b.device != device or self.next >= b.shape[0] or state is None
                 or state != self.rng_state):
             steps = max(1, min(256, self.budget // max(1, 4 * levels * R)))
-            self.buf = b = torch.rand((steps, levels, R), device=device)
-            self.next = 0
+            if b is None or tuple(b.shape) != (steps, levels, R) or b.device != device:
+                self.buf = b = torch.empty((steps, levels, R), device=device)
+            b.uniform_()  # U[0, 1) like torch.rand, IN PLACE: a fresh 16 MB block per refill cost the caching allocator a device malloc
+            self.next = 0  # (+ its implicit sync: ~30 ms, once, in the middle of a timed region)
             self.rng_state = self._rng_state(device)
         i, self.next = self.next, self.next + 1
         return [b[i, l].view(R, 1) for l in range(levels)]

@@ -163,7 +163,7 @@ def test_production_shape_k16_training_step_matches_oracle(dev):
     # per-tensor bound = max(5e-5, 4 x |oracle fp32 - oracle fp64|): a few gradients of sub-fields that see a handful of
     # near-saturated rays are ill-conditioned in fp32 on the reference side too (4e-3..7e-3 at this seed), the bulk is ~1e-5
     errs, names, bounds = assert_grads_within_oracle_noise({n: p.grad for n, p in model.named_parameters()}, g_ref, g64, what="K=16 step",
-                                                           cap=5e-2)  # (production shape: see test_k8_training_step_matches_reference_fixture)
+                                                           cap=1.2e-2)  # (2 x the worst error observed on any tensor of a network whose computed bound exceeds it: 5.2e-3, r06)
     n_zero = len(g_ref) - len(errs)
     q = lambda f: errs[min(len(errs) - 1, int(f * len(errs)))]  # noqa: E731
     print(f"K=16 step: {len(errs)} parameter gradients compared, {n_zero} exactly zero on both sides (sub-fields without samples); "
