@@ -846,6 +846,10 @@ def extract_roofline(model_cfg, points_per_s_per_gpu, gated_frac):
             "frac_algorithmic_hbm": w["alg_byte"] / t / 1e9 / HBM_PEAK_GBS}
 
 
+# lattice points per query chunk of the extraction benchmark (8 M: 2 GB of fp32 semantics per chunk in flight)
+EXTRACT_CHUNK = int(os.environ.get("PRESIGHT_EXTRACT_CHUNK", str(1 << 23)))
+
+
 def tile_aabb(scene):
     """the box the dense lattice spans: the sub-field's AABB (K = 1) / the union of the K sub-field boxes (routed tile)"""
     import torch
@@ -871,7 +875,7 @@ def secondary_extract_line(dev, res=512, passes=2, model_cfg="cfg2"):
     del probe
 
     def one_pass():
-        out = dense_tile_query(model, aabb, res=res, chunk=1 << 23, start=0, count=res ** 3, density_threshold=thr)
+        out = dense_tile_query(model, aabb, res=res, chunk=EXTRACT_CHUNK, start=0, count=res ** 3, density_threshold=thr)
         return out, voxelize(out["points"], out["features"], None, voxel=0.4, min_bound=out["min_bound"], points_max=out["points_max"])
 
     one_pass()
@@ -1006,7 +1010,7 @@ def extract_main(args) -> int:
     del probe
 
     def one_pass():
-        out = dense_tile_query(model, aabb, res=res, chunk=1 << 23, start=start, count=count, density_threshold=thr)
+        out = dense_tile_query(model, aabb, res=res, chunk=EXTRACT_CHUNK, start=start, count=count, density_threshold=thr)
         vox = voxelize(out["points"], out["features"], None, voxel=0.4, min_bound=out["min_bound"], points_max=out["points_max"], want_sums=world > 1)
         return out, vox
 

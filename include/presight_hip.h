@@ -410,6 +410,16 @@ int ps_voxel_index(const float* pts, int64_t n, double voxel, const double* min_
 int ps_lattice_points(const float* aabb /*host[6]*/, int res, int64_t start, int64_t count, float* pts, void* stream);
 /* (a + b + c) / 3: mean of proposal-net and main-field densities, extract_priors.py:133-137 */
 int ps_mean_density(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
+/* The kept rows of a lattice chunk without a host round trip (round 6): what ns/scripts/extract_priors.py:133-152 does with
+ * `mask = density > threshold` + masked selects, as three launches that APPEND to tile-wide arrays at a position kept in device memory
+ * -- no nonzero(), no host synchronisation per chunk.  dens [n], pts [n,3], sem [n,64] fp32; cursor: int64[2] device memory, zeroed
+ * before the first chunk of a tile ({rows so far, rows that did not fit `capacity`}); rows appear in ascending lattice order;
+ * out_pts = pts / pose_scale (torch's scalar division: multiplication with the fp32 reciprocal), out_feat = clamp(sem, 0, 1) as fp16,
+ * out_vox = ps_voxel_index(out_pts), out_row (nullable) = row0 + the point's index.  workspace: ps_emit_kept_workspace(n) bytes. */
+int64_t ps_emit_kept_workspace(int64_t n);
+int ps_emit_kept(const float* dens, int64_t n, float threshold, const float* pts, const float* sem, int C, float pose_scale, double voxel,
+                 const double* min_bound /*host[3]*/, int64_t row0, int64_t* cursor, int64_t capacity, void* workspace, float* out_pts,
+                 float* out_dens, void* out_feat_f16, int64_t* out_vox, int64_t* out_row /*nullable*/, void* stream);
 /* out[i, :] = fp16(clamp(src[idx[i], :], lo, hi)): the features of the points above the density threshold, clipped to [0, 1] and
  * stored as fp16 (feat.clip(0, 1).astype(np.float16) of the selected rows, extract_priors.py:136-138); src [n,C] fp32, C <= 64,
  * idx [m] int64 row numbers, out [m,C] fp16 */

@@ -246,3 +246,153 @@ extern "C" int ps_voxel_reduce(const int64_t* order, const int64_t* starts, cons
                                                                                   C, o_pts, (__half*)o_feat_f16, o_col, sums);
   PS_CHECK_LAUNCH();
 }
+
+// ---- kept rows of a lattice chunk without a host round trip (round 6) --------------------------------------------------------------
+// ns/scripts/extract_priors.py:133-152 keeps the points whose mean density exceeds the threshold; as torch code that is
+// nonzero(dens > thr) (a host synchronisation for the output size, once per 8 M-point chunk) followed by index_select / gather /
+// clamp / convert / divide / voxel-index launches on the selected rows.  Here a chunk's selection is three launches and NO host sync:
+//   count   kept points per 256-point workgroup
+//   scan    one workgroup: exclusive prefix over the workgroup counts, shifted by the running total of the EARLIER chunks, which lives
+//           in device memory (cursor[0]; cursor[1] = rows that did not fit the caller's capacity)
+//   emit    every workgroup ranks its kept points (ballot + popcount), and writes their rows -- point / pose_scale, density,
+//           clamp(features, 0, 1) as fp16, integer voxel index, global lattice row -- at their final position of the tile-wide arrays
+// Rows come out in ascending lattice order, exactly as nonzero() lists them; the host reads cursor[] once, after the last chunk.
+namespace {
+constexpr int kKeptBlock = 256;
+
+__global__ __launch_bounds__(kKeptBlock) void kept_count_kernel(const float* __restrict__ dens, int64_t n, float thr, unsigned* __restrict__ counts) {
+  __shared__ unsigned wsum[kKeptBlock / 64];
+  const int64_t i = (int64_t)blockIdx.x * kKeptBlock + threadIdx.x;
+  const bool keep = i < n && dens[i] > thr;
+  const unsigned c = (unsigned)__popcll(__ballot(keep));
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// counts[b] -> first output row of workgroup b (int64, in `offsets`); cursor[0] += the chunk's total.  One workgroup: thread t owns the
+// contiguous run of ceil(nb / 1024) counts starting at t * per (two passes over its own run around ONE block-wide scan; the first
+// version walked the counts in 1024-wide tiles with a block scan per tile: 47 us for the 32 k counts of an 8 M-point chunk).
+__global__ __launch_bounds__(1024) void kept_scan_kernel(const unsigned* __restrict__ counts, int nb, int64_t* __restrict__ offsets,
+                                                         int64_t* __restrict__ cursor, int64_t capacity) {
+  __shared__ unsigned long long wsum[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = cursor[0];
+  const int per = (nb + 1023) / 1024;
+  const int b0 = (int)threadIdx.x * per, b1 = min(nb, b0 + per);
+  unsigned long long mine = 0;
+  for (int b = b0; b < b1; ++b) mine += counts[b];
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned long long before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    before += w < wave ? wsum[w] : 0ull;
+    total += wsum[w];
+  }
+  unsigned long long run = before + (incl - mine);
+  for (int b = b0; b < b1; ++b) {
+    offsets[b] = base + (int64_t)run;
+    run += counts[b];
+  }
+  if (threadIdx.x == 0) {
+    const int64_t end = base + (int64_t)total;
+    cursor[0] = end;
+    if (end > capacity) cursor[1] = end - capacity;  // (rows beyond the capacity are dropped by the emit pass: the caller retries)
+  }
+}
+
+struct KeptOut {
+  float* pts;          // [cap, 3] points / pose_scale
+  float* dens;         // [cap]
+  __half* feat;        // [cap, 64] clamp(sem, 0, 1)
+  int64_t* vox;        // [cap, 3]
+  int64_t* row;        // [cap] global lattice row (row0 + i), nullable
+};
+__global__ __launch_bounds__(kKeptBlock) void kept_emit_kernel(const float* __restrict__ dens, int64_t n, float thr, const float* __restrict__ pts,
+                                                               const float* __restrict__ sem, float inv_scale, double voxel, double mx, double my,
+                                                               double mz, int64_t row0, const int64_t* __restrict__ offsets, int64_t capacity,
+                                                               KeptOut o) {
+  __shared__ unsigned wsum[kKeptBlock / 64];
+  __shared__ int src_of[kKeptBlock];  // local index of the k-th kept point of this workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kKeptBlock + threadIdx.x;
+  const bool keep = i < n && dens[i] > thr;
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) wsum[wave] = (unsigned)__popcll(m);
+  __syncthreads();
+  unsigned before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kKeptBlock / 64; ++w) {
+    before += w < wave ? wsum[w] : 0u;
+    total += wsum[w];
+  }
+  const int rank = (int)(before + (unsigned)__popcll(m & ((1ull << lane) - 1ull)));
+  if (keep) src_of[rank] = threadIdx.x;
+  __syncthreads();
+  const int64_t out0 = offsets[blockIdx.x];
+  // scalar columns: thread k < total takes the k-th kept point
+  if ((unsigned)threadIdx.x < total && out0 + threadIdx.x < capacity) {
+    const int64_t s = (int64_t)blockIdx.x * kKeptBlock + src_of[threadIdx.x], d = out0 + threadIdx.x;
+    // torch divides a float tensor by a python scalar as a multiplication with the fp32 reciprocal (BinaryDivTrueKernel: cpu-scalar path)
+    const float px = pts[s * 3] * inv_scale, py = pts[s * 3 + 1] * inv_scale, pz = pts[s * 3 + 2] * inv_scale;
+    o.pts[d * 3] = px;
+    o.pts[d * 3 + 1] = py;
+    o.pts[d * 3 + 2] = pz;
+    o.dens[d] = dens[s];
+    const double h = voxel * 0.5;
+    o.vox[d * 3] = (int64_t)floor(((double)px - (mx - h)) / voxel);
+    o.vox[d * 3 + 1] = (int64_t)floor(((double)py - (my - h)) / voxel);
+    o.vox[d * 3 + 2] = (int64_t)floor(((double)pz - (mz - h)) / voxel);
+    if (o.row != nullptr) o.row[d] = row0 + s;
+  }
+  // feature rows: 16 lanes per row, 16 bytes in / 8 bytes out per lane (gather_clip_f16_c64_kernel)
+  const int q = threadIdx.x & 15;
+  for (unsigned k = threadIdx.x >> 4; k < total; k += kKeptBlock / 16) {
+    const int64_t d = out0 + k;
+    if (d >= capacity) break;
+    const int64_t s = (int64_t)blockIdx.x * kKeptBlock + src_of[k];
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sem + s * 64 + 4 * q));
+    const __half2 a = __floats2half2_rn(clampf_nan(v.x, 0.0f, 1.0f), clampf_nan(v.y, 0.0f, 1.0f));
+    const __half2 b = __floats2half2_rn(clampf_nan(v.z, 0.0f, 1.0f), clampf_nan(v.w, 0.0f, 1.0f));
+    uint2 w2;
+    w2.x = *reinterpret_cast<const unsigned*>(&a);
+    w2.y = *reinterpret_cast<const unsigned*>(&b);
+    *reinterpret_cast<uint2*>(o.feat + d * 64 + 4 * q) = w2;
+  }
+}
+}  // namespace
+
+// bytes of scratch ps_emit_kept needs for a chunk of n points
+extern "C" int64_t ps_emit_kept_workspace(int64_t n) {
+  const int64_t nb = (n + kKeptBlock - 1) / kKeptBlock;
+  return nb * 4 + 16 + nb * 8;
+}
+
+// Append the rows of this chunk whose density exceeds `threshold` to the tile-wide arrays (see above).  dens [n], pts [n,3], sem [n,64]
+// fp32; cursor: int64[2] in device memory, zeroed by the caller before the FIRST chunk of a tile ({rows so far, rows that did not fit});
+// capacity: rows the output arrays hold; min_bound: HOST array (the voxel grid's origin, metres); row0: lattice row of point 0.
+extern "C" int ps_emit_kept(const float* dens, int64_t n, float threshold, const float* pts, const float* sem, int C, float pose_scale,
+                            double voxel, const double* min_bound, int64_t row0, int64_t* cursor, int64_t capacity, void* workspace,
+                            float* out_pts, float* out_dens, void* out_feat_f16, int64_t* out_vox, int64_t* out_row, void* stream) {
+  PS_REQUIRE(C == 64, "ps_emit_kept: 64 feature channels");
+  PS_REQUIRE(dens && pts && sem && min_bound && cursor && workspace && out_pts && out_dens && out_feat_f16 && out_vox, "ps_emit_kept: null argument");
+  PS_REQUIRE(pose_scale > 0.f && voxel > 0.0 && capacity >= 0, "ps_emit_kept: pose_scale and voxel must be positive");
+  if (n == 0) return 0;
+  const int64_t nb = (n + kKeptBlock - 1) / kKeptBlock;
+  PS_REQUIRE(nb < (int64_t(1) << 31), "ps_emit_kept: chunk too large");
+  unsigned* counts = (unsigned*)workspace;
+  int64_t* offsets = (int64_t*)((char*)workspace + ((nb * 4 + 15) & ~(int64_t)15));
+  hipStream_t s = (hipStream_t)stream;
+  kept_count_kernel<<<(unsigned)nb, kKeptBlock, 0, s>>>(dens, n, threshold, counts);
+  kept_scan_kernel<<<1, 1024, 0, s>>>(counts, (int)nb, offsets, cursor, capacity);
+  kept_emit_kernel<<<(unsigned)nb, kKeptBlock, 0, s>>>(dens, n, threshold, pts, sem, 1.0f / pose_scale, voxel, min_bound[0], min_bound[1], min_bound[2],
+                                                       row0, offsets, capacity, KeptOut{out_pts, out_dens, (__half*)out_feat_f16, out_vox, out_row});
+  PS_CHECK_LAUNCH();
+}
