@@ -1141,7 +1141,8 @@ def main():
     # dp: same init on every rank (DDP broadcast equivalent).  tiles: every rank owns a DIFFERENT tile -- its own parameters, its own
     # rays, no collective in the step (the process group only brackets the timed region)
     model, scene = build_model(dev, seed=42 + (rank if tiles else 0), config=args.config)
-    trainer = Trainer(model, scene, 1 if tiles else world, exchange=exchange, global_depth_clip=args.global_depth_clip and not tiles)
+    trainer = Trainer(model, scene, 1 if tiles else world, exchange=exchange, global_depth_clip=args.global_depth_clip and not tiles,
+                      table_pieces=2 if (world > 1 and not tiles and rays <= 16384) else None)
     # data: the device-resident chunk feed (one gather launch per batch, next chunk prefetched on a side stream; the reference's
     # loader semantics: shuffled pass over the chunk, rank r takes every world-th slot) or 4 recycled pre-made batches
     feed, batches = None, None

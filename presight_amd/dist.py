@@ -453,12 +453,26 @@ class FlatGrads:
         seg = self.flat[a:e]
 
         def issue():
-            seg.div_(world)
+            # The MEAN over the ranks (DDP's semantics).  Dividing the whole bucket before the collective is a read + write of every
+            # gradient byte on every rank (the production tile: 7.5 GB = 1.3 ms per step, most of what the exchange machinery cost a
+            # rank before any byte moved, profiles/r05_rccl_group_of_one_*).  Sharded mode divides the OWNED shard after the
+            # reduce-scatter instead (1 / world of the bytes; sum then scale -- for world a power of two the same bits as scale then
+            # sum); a group of one rank divides by 1: nothing to do.
+            if world > 1 and self.mode != "sharded":
+                seg.div_(world)
             COMM_LOG.issue("reduce_scatter" if self.mode == "sharded" else "all_reduce", b["index"], 4 * (e - a),
                            "side" if self._comm_stream is not None else "current", self.step_no, phase=b["phase"])
             if self.mode == "sharded":
                 n = (e - a) // world
-                b["work"] = dist.reduce_scatter_tensor(seg[rank * n:(rank + 1) * n], seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+                own = seg[rank * n:(rank + 1) * n]
+                b["work"] = dist.reduce_scatter_tensor(own, seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+                if world > 1:
+                    b["work"].wait()  # (stream-ordered for RCCL: the division is enqueued behind the collective, the host does not block)
+                    b["work"] = None  # (waited for: gloo copies a work's result into place in EVERY wait(), a second one would undo the division)
+                    own.div_(world)
+                    if self._comm_stream is not None:
+                        b["post"] = torch.cuda.Event()
+                        b["post"].record()
                 self.stats["bytes"] += 4 * (e - a) * (world - 1) // world
             else:
                 b["work"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self._group, async_op=True)
@@ -511,6 +525,9 @@ class FlatGrads:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
+            post = b.pop("post", None)
+            if post is not None:  # (the owned shard's division on the communication stream)
+                torch.cuda.current_stream(self.flat.device).wait_event(post)
         if end_ev is not None:
             self._timeline.append(dict(end=end_ev, buckets=[(b["index"], b["range"][1] - b["range"][0], b.get("ready"), b.get("phase"), b["seen"])
                                                            for b in self._buckets]))

@@ -63,7 +63,7 @@ class Trainer:
     def __init__(self, model, scene: Dict, world: int = 1, exchange: str = "allreduce", global_depth_clip: bool = False,
                  lr: float = 1e-2, eps: float = 1e-15, weight_decay: float = 1e-5, loss_scale: float = 2.0 ** 10,
                  update_grad_scaler: bool = False, max_num_iterations: Optional[int] = None, schedule: Optional[Dict] = None,
-                 fused_table_adam: Optional[bool] = None):
+                 fused_table_adam: Optional[bool] = None, table_pieces: Optional[int] = None):
         """loss_scale = TrainerConfig.init_grad_scale, update_grad_scaler = TrainerConfig.update_grad_scaler (trainer.py:70-73).
         max_num_iterations: builds the learning-rate schedule of the PreSight method configs (method_configs.py:158-168: warm-up over
         max // 10 steps, x0.33 at max // 4, max // 2, 3 max // 4); `schedule` = explicit WarmupMultiStepSchedule keyword arguments;
@@ -114,7 +114,10 @@ class Trainer:
         # embeddings (their gradient is an OUTPUT of the main field's backward node) and the sky model close the step: tail bucket
         add_bucket([p for p in fields if not is_table(p) and names.get(id(p), "").startswith("field.")], "fields")
         main_tables = [p for p in fields if is_table(p) and id(p) not in seen and names.get(id(p), "").startswith("field.")]
-        split_pieces = int(os.environ.get("PRESIGHT_TABLE_PIECES", "4"))
+        # pieces the main hash tables' gradient is exchanged in (one accumulate launch + one collective each: the collective of piece g
+        # runs under the accumulate launch of piece g + 1).  4 at full batches; a rank of a strong-scaled run (<= 16 k rays) should pass
+        # 2: its accumulate launches are short and every extra piece costs launches, events and a collective on a host-bound step
+        split_pieces = int(table_pieces) if table_pieces is not None else int(os.environ.get("PRESIGHT_TABLE_PIECES", "4"))
         n_table_buckets, table_split = 0, None
         if len(main_tables) == 1:
             add_bucket(main_tables, "fields")

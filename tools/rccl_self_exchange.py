@@ -24,8 +24,10 @@ import torch.distributed as dist  # noqa: E402
 
 dev = torch.device("cuda", 0)
 out = {"config": cfg, "rays": rays, "steps": steps, "backend": dist.get_backend()}
+pieces = {"table_pieces": 2} if rays <= 16384 else {}  # (what bench.py gives a strong-scaled rank)
 for name, flag, kw in (("no_exchange_fused_tables", "0", {}), ("no_exchange_separate_table_update", "0", {"fused_table_adam": False}),
-                       ("rccl_group_of_one_allreduce", "1", {"exchange": "allreduce"}), ("rccl_group_of_one_sharded", "1", {"exchange": "sharded"})):
+                       ("rccl_group_of_one_allreduce", "1", {"exchange": "allreduce", **pieces}),
+                       ("rccl_group_of_one_sharded", "1", {"exchange": "sharded", **pieces})):
     if only is not None and name not in only:
         continue
     os.environ["PRESIGHT_EXCHANGE_WORLD_OF_ONE"] = flag
