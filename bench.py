@@ -164,6 +164,11 @@ def compact_line(full: dict, detail_path=None) -> dict:
                 c["error"] = _clip(e["error"], 120)
             if isinstance(e.get("exchange_overlap_dry_run"), dict) and "ms_per_step_with_split_launches" in e["exchange_overlap_dry_run"]:
                 c["ms_per_step_unfused_tables"] = e["exchange_overlap_dry_run"]["ms_per_step_with_split_launches"]
+            for k, v in e.items():  # (PREDICTED, never measured: one-GPU measurements + link assumptions, predicted_strong_scaling)
+                if k.startswith("predicted_N") and isinstance(v, dict) and isinstance(v.get("all_links_ASSUMED"), dict):
+                    c[k] = {"step_ms_all_links_ASSUMED": v["all_links_ASSUMED"]["predicted_step_ms"],
+                            "speedup_all_links_ASSUMED": v["all_links_ASSUMED"]["predicted_speedup_vs_one_gpu"],
+                            "speedup_ring_one_link": v["ring_one_link"]["predicted_speedup_vs_one_gpu"], "measured": False}
             out["secondary"][name] = c
     other = full.get("other_scaling")
     if isinstance(other, dict):
@@ -171,6 +176,7 @@ def compact_line(full: dict, detail_path=None) -> dict:
     comm = full.get("comm")
     if isinstance(comm, dict):
         c = _pick(comm, ("backend", "ranks", "collectives_per_step", "gradient_buckets_issued_during_backward_per_step",
+                         "record_bytes_on_link_per_rank_per_step", "dense_table_gradient_bytes",
                          "bytes_on_link_per_rank_per_step", "exchange_exposed_ms"))
         if isinstance(comm.get("model"), dict):
             c["predicted_ms_all_links_ASSUMED"] = comm["model"].get("predicted_ms_all_links")
@@ -216,7 +222,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg4prod", "extract"], default="cfg2")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
-    ap.add_argument("--exchange", choices=["allreduce", "sharded"], default=None)
+    ap.add_argument("--exchange", choices=["allreduce", "sharded", "sparse"], default=None,
+                    help="sparse: the sharded exchange with the hash tables' gradients travelling as records of touched rows (SURVEY.md 8e)")
     ap.add_argument("--rays", type=int, default=RAYS, help="rays per step: per GPU (weak) / over all GPUs (strong)")
     ap.add_argument("--global-depth-clip", action="store_true", help="expected-depth clip bounds over ALL ranks' batches")
     ap.add_argument("--fixed-batches", action="store_true", help="recycle 4 pre-made batches instead of the device chunk feed")
@@ -796,6 +803,9 @@ def secondary_training_lines(config, shapes, dev):
                 dry["predicted"] = {f"N{n}": exchange_schedule(dry["buckets"], n, "sharded")} if n > 1 else {
                     f"N{m}_upper_bound_full_batch_compute": exchange_schedule(dry["buckets"], m, "sharded") for m in (2, 4)}
                 lines[rays]["exchange_overlap_dry_run"] = dry
+                if n > 1 and 65536 in lines:
+                    tables = sum(p.numel() for nm, p in model.named_parameters() if nm.endswith("hash_table"))
+                    lines[rays][f"predicted_N{n}_strong"] = predicted_strong_scaling(lines[65536]["ms_per_step"], dry, n, 4.0 * tables)
             except Exception as e:
                 lines[rays]["exchange_overlap_dry_run"] = {"error": f"{type(e).__name__}: {e}"}
     del trainer, model, scene
@@ -961,19 +971,61 @@ def dry_overlap_timeline(model, scene, rays, dev, steps=5, exchange="allreduce")
             os.environ.pop("PRESIGHT_DRY_OVERLAP", None)
         else:
             os.environ["PRESIGHT_DRY_OVERLAP"] = old
+    from presight_amd import prof
+
     batches = make_batches(scene, dev, 2, 0, rays=rays)
     for i in range(3):
         tr.step(batches[i % 2])
     tr.grads.record_timeline = True
+    prof.enable(True, only=("adam",))  # (the DENSE optimizer pass of this un-fused, un-sharded trainer: a sharded rank runs 1 / N of it)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         tr.step(batches[i % 2])
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    adam = prof.summary().get("adam", (0, None))[1]
+    prof.enable(False)
     tl = tr.grads.timeline_summary()
-    return {"ms_per_step_with_split_launches": ms, "buckets": tl,
+    return {"ms_per_step_with_split_launches": ms, "dense_adam_ms": adam, "buckets": tl,
             "handed_over_in_backward": sum(1 for t in tl if t["handed_over_in_backward"] == t["steps_exchanged"] > 0), "n_buckets": len(tl)}
+
+
+def predicted_strong_scaling(one_gpu_ms: float, dry: dict, n: int, param_bytes: float) -> dict:
+    """What a strong-scaled N-rank run of the production tile would take, assembled from what ONE GPU can measure -- no multi-GPU run
+    exists, every figure below is a measurement of one rank's work or a stated assumption about the links:
+      compute        the per-rank step at 65 536 / N rays with the gradients written (un-fused tables), split accumulate launches and
+                     hand-over bookkeeping, dense Adam (dry run of the bucketed exchange, this process)
+      - (N-1)/N of the dense optimizer pass (a sharded rank updates its 1 / N shard)
+      + machinery    exchange code live through RCCL in a process group of one rank minus the same step without it
+                     (tools/rccl_self_exchange.py, committed under profiles/: host calls, events, the owned shard's division)
+      + exposed      link time of the reduce-scatter buckets left after the end of backward (exchange_schedule: bucket hand-over times
+                     of the dry run, xGMI bounds of exchange_model; both the all-links ASSUMPTION and the one-link ring bound)
+      the all-gather of the updated parameters is left in flight under the next step's sampling front (assumed hidden when it fits)"""
+    out = {"n_gpus": n, "one_gpu_ms_full_batch_fused": one_gpu_ms, "rank_compute_ms_unfused_dense_adam": dry.get("ms_per_step_with_split_launches"),
+           "dense_adam_ms": dry.get("dense_adam_ms")}
+    mach, src = None, None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r06_rccl_group_of_one_cfg3_8192rays.json")))
+        mach = rec["rccl_group_of_one_sharded"]["ms_per_step"] - rec["no_exchange_separate_table_update"]["ms_per_step"]
+        src = "profiles/r06_rccl_group_of_one_cfg3_8192rays.json (sharded exchange live in a group of one - separate table update, same box)"
+    except (OSError, KeyError, ValueError):
+        pass
+    out["machinery_ms"], out["machinery_source"] = mach, src
+    sched = exchange_schedule(dry.get("buckets"), n, "sharded")
+    if not sched or out["rank_compute_ms_unfused_dense_adam"] is None:
+        return out
+    adam = dry.get("dense_adam_ms") or 0.0
+    base = out["rank_compute_ms_unfused_dense_adam"] - adam * (n - 1) / n + max(mach or 0.0, 0.0)
+    gather_ms = param_bytes * (n - 1) / n / ((n - 1) * XGMI_LINK_GBS * 1e9) * 1e3
+    out["param_allgather_link_ms_all_links_ASSUMED"] = gather_ms
+    for label in ("all_links_ASSUMED", "ring_one_link"):
+        step = base + sched[label]["exposed_ms"]
+        out[label] = {"exposed_reduce_scatter_ms": sched[label]["exposed_ms"], "hidden_ms": sched[label]["hidden_ms"], "predicted_step_ms": step,
+                      "predicted_speedup_vs_one_gpu": one_gpu_ms / step}
+    out["note"] = ("a prediction from one-GPU measurements and the stated link assumptions; no scaling curve has been measured in any round "
+                   "(SCALE_rNN.json of the driver is the only source of measured N > 1 numbers)")
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------- extraction bench
@@ -1305,6 +1357,10 @@ def main():
                                              "collectives_per_step": comm["collectives"] / args.steps,
                                              "gradient_buckets_issued_during_backward_per_step": comm.get("in_backward", 0) / args.steps,
                                              "bytes_on_link_per_rank_per_step": comm["bytes"] / args.steps,
+                                             # exchange = sparse: the part of it that is table-gradient RECORDS (the dense table gradient
+                                             # the sharded mode would reduce-scatter instead: dense_table_gradient_bytes * (N - 1) / N)
+                                             "record_bytes_on_link_per_rank_per_step": comm.get("sparse_record_bytes", 0) / args.steps,
+                                             "dense_table_gradient_bytes": 4.0 * sum(p.numel() for n_, p in model.named_parameters() if n_.endswith("hash_table")),
                                              "bucket_timeline": timeline,
                                              "schedule_by_construction": exchange_schedule(timeline, world, trainer.exchange),
                                              "exchange_exposed_ms": kern.get("exchange_exposed", (0, None))[1],

@@ -311,6 +311,16 @@ int ps_grid_scatter_binned_ms_part(const float* u, const float* dfeat, const flo
                                    int64_t plane_stride, float* const* dtables, int K, const int32_t* chunk_field,
                                    const uint32_t* slice_counts, int absmax_ready, void* workspace, int dst_is_zero, int phase,
                                    int item_begin, int item_end, void* stream);
+/* Sparse gradient exchange of a data-parallel run (round 6; replaces DDP's dense all-reduce of the table gradients,
+ * ns/pipelines/PreSight/my_pipeline.py:121-124, for the hash tables): after a phase-1 call the binned backward's record streams lie in
+ * the workspace at ps_grid_scatter_layout's offsets; the ranks exchange the streams of every table slice with the slice's owner
+ * (presight_amd/dist.py) and the owner runs ps_grid_accumulate_runs over all ranks' runs: int64 fixed point with a scale from the
+ * MAX-reduced per-level maximum -> exact, independent of the order of the runs.  out[0..8]: see csrc/encode.hip. */
+int ps_grid_scatter_layout(int L, int F, int log2T, int64_t N, int K, int64_t* out /*host [9]*/);
+int ps_grid_accumulate_runs(const uint32_t* run_starts, const uint32_t* run_counts, int n_runs, const uint32_t* rec_idx, const float* rec_val,
+                            int64_t plane_stride, const uint32_t* gmax_bits, int L, int F, int log2T, int K, int64_t n_points_total,
+                            float* dtable /*K = 1*/, float* const* dtables /*device [K] or NULL*/, float out_scale, int item_begin, int item_end,
+                            void* stream);
 /* Table backward + Adam in ONE pass, for training that exchanges no gradients (a single process, or one tile per GPU:
  * docs/building_priors.md:7-44).  The reference runs loss.backward() and then torch.optim.Adam over every table
  * (ns/engine/trainer.py:470-486, ns/engine/optimizers.py:133-140): the table gradient is written, read back by the optimizer and zeroed

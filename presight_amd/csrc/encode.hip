@@ -1347,6 +1347,132 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
 }
 }  // namespace
 
+// ---- sparse gradient exchange (round 6; SURVEY.md 8e: "sparse exchange of touched rows") ------------------------------------------
+// Under data parallelism the dense table gradient of a production tile is 3.76 GB per step and rank, of which a rank's 8192 rays touch
+// a few percent.  The binned backward already holds the touched rows as RECORDS, sorted by the 128 KiB table slice that owns them:
+// the ranks exchange the records of a slice with the slice's OWNER (all-to-all of the record streams, presight_amd/dist.py) and the
+// owner accumulates all ranks' runs of a slice in ONE int64 LDS accumulator -- fixed point with a scale every rank derives from the
+// MAX-reduced per-level |d(feature)| maximum, so the sum is exact and independent of the order of the runs -- converts once, scales by
+// 1 / world and writes its shard of the (mean) gradient.  The kernel below is accumulate_kernel's record loop over n_runs runs per item.
+namespace {
+template <int F>
+__global__ __launch_bounds__(1024) void accumulate_runs_kernel(const unsigned* __restrict__ run_starts, const unsigned* __restrict__ run_counts,
+                                                               int n_runs, int n_local, const unsigned* __restrict__ rec_idx,
+                                                               const float* __restrict__ rec_val, int64_t plane_stride,
+                                                               const unsigned* __restrict__ gmax_bits, int L, int log2T, int log2_slice,
+                                                               int headroom_log2, float* __restrict__ dtable, float* const* __restrict__ dtables,
+                                                               float out_scale, int item0) {
+  extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F]
+  const int entries = 1 << log2_slice;
+  const int n_slices = 1 << (log2T - log2_slice);
+  const int li = blockIdx.x, item = item0 + li;  // item = (sub-field * L + level) * n_slices + slice
+  const int vlevel = item / n_slices, sl = item % n_slices;
+  const int level = vlevel % L;
+  if (dtables != nullptr) dtable = dtables[vlevel / L];
+  float* out = dtable + (((int64_t)level << log2T) + ((int64_t)sl << log2_slice)) * F;
+  const unsigned gbits = gmax_bits[vlevel];
+  for (int i = threadIdx.x; i < entries * F; i += 1024) acc[i] = 0;
+  __syncthreads();
+  if (gbits >= 0x7f800000u) {  // a non-finite d(feature) on this level on SOME rank: the gradient is NaN, as torch's index_add of a NaN
+    for (int i = threadIdx.x; i < entries * F; i += 1024) out[i] = __builtin_nanf("");
+    return;
+  }
+  const float scale = fixed_scale(gbits, headroom_log2);
+  const unsigned low = (unsigned)entries - 1u;
+  for (int r = 0; r < n_runs; ++r) {
+    const int64_t base = run_starts[(int64_t)r * n_local + li];  // multiple of 4 records: 16-byte aligned vector loads
+    const int64_t n = run_counts[(int64_t)r * n_local + li];
+    for (int64_t i0 = (int64_t)threadIdx.x * 4; i0 < n; i0 += 1024 * 4) {
+      const int64_t i = base + i0;
+      const u32x4 t = *reinterpret_cast<const u32x4*>(rec_idx + i);  // (reads past n stay inside the run's 4-record padding)
+      const f32x4 o = *reinterpret_cast<const f32x4*>(rec_val + (int64_t)F * plane_stride + i);
+      f32x4 q[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) q[f] = *reinterpret_cast<const f32x4*>(rec_val + (int64_t)f * plane_stride + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i0 + k >= n) break;
+        const unsigned row = t[k] & 0xffffu, tt = t[k] >> 16;
+        const bool pair = tt < 30u;  // record = {row | t << 16, ox, q[F]}: see accumulate_kernel
+        const unsigned row_c = pair ? ((row ^ ((2u << tt) - 1u)) & low) : row;
+        const float wf = pair ? 1.0f - o[k] : 1.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row * F + f]), (unsigned long long)__float2ll_rn(q[f][k] * wf * scale));
+          if (pair) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[row_c * F + f]), (unsigned long long)__float2ll_rn(q[f][k] * o[k] * scale));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float inv = 1.0f / scale;
+  for (int i = threadIdx.x; i < entries * F; i += 1024) out[i] = (float)((double)acc[i] * (double)inv * (double)out_scale);
+}
+}  // namespace
+
+// layout of the binned backward's workspace after a phase-1 call (ps_grid_scatter_binned_part / _ms_part with phase = 1), for callers
+// that move the record streams themselves (the sparse gradient exchange): out[0..8] = byte offsets of {gmax_bits [K*L] u32, cursors
+// [items] u32 (stream ENDS after phase 1), counts [items] u32 (upper bounds), starts [items] u32, rec_idx [n_rec_max] u32, rec_val
+// [F+1][n_rec_max] f32 (plane F = ox)}, then n_rec_max, n_items, log2 of the rows per slice
+extern "C" int ps_grid_scatter_layout(int L, int F, int log2T, int64_t N, int K, int64_t* out) {
+  PS_REQUIRE(out != nullptr && (F == 1 || F == 2 || F == 4) && K >= 1, "ps_grid_scatter_layout: bad argument");
+  const int ls = binned_log2_slice(F, log2T);
+  const int n_slices = 1 << (log2T - ls);
+  const int64_t n_rec_max = binned_rec_capacity(N, L, K * n_slices, 3);
+  const int64_t n_items = (int64_t)K * L * n_slices;
+  out[0] = 0;
+  out[1] = 4096;
+  out[2] = out[1] + n_items * 4;
+  out[3] = out[2] + n_items * 4;
+  out[4] = out[3] + ((n_items + 3) & ~(int64_t)3) * 4;
+  out[5] = out[4] + n_rec_max * 4;
+  out[6] = n_rec_max;
+  out[7] = n_items;
+  out[8] = ls;
+  return 0;
+}
+
+// The owner's accumulate pass of the sparse exchange: items [item_begin, item_end) of the K-table launch, each with n_runs record runs
+// (run r of local item i: records [run_starts[r * n_local + i], + run_counts[...]) of the planes rec_idx / rec_val [F+1][plane_stride]);
+// gmax_bits [K*L]: the MAX over the ranks; n_points_total: points of ALL ranks (sets the fixed-point headroom, must be the same on every
+// rank); the slices are WRITTEN (not added to): out = sum over all runs * out_scale.
+extern "C" int ps_grid_accumulate_runs(const uint32_t* run_starts, const uint32_t* run_counts, int n_runs, const uint32_t* rec_idx,
+                                       const float* rec_val, int64_t plane_stride, const uint32_t* gmax_bits, int L, int F, int log2T, int K,
+                                       int64_t n_points_total, float* dtable, float* const* dtables, float out_scale, int item_begin,
+                                       int item_end, void* stream) {
+  PS_REQUIRE(F == 1 || F == 2 || F == 4, "ps_grid_accumulate_runs: features_per_level must be 1, 2 or 4");
+  PS_REQUIRE(run_starts && run_counts && rec_idx && rec_val && gmax_bits && n_runs >= 1 && (dtable != nullptr || dtables != nullptr),
+             "ps_grid_accumulate_runs: null argument");
+  const int ls = binned_log2_slice(F, log2T);
+  const int n_items = K * L * (1 << (log2T - ls));
+  PS_REQUIRE(item_begin >= 0 && item_begin <= item_end && item_end <= n_items, "ps_grid_accumulate_runs: bad item range");
+  if (item_end == item_begin) return 0;
+  int headroom = 62 - 26;
+  {
+    int bits = 0;
+    while (((int64_t)1 << bits) < n_points_total * 8) ++bits;
+    if (bits > 26) headroom = 62 - bits;
+  }
+  const size_t lds = (size_t)(1 << ls) * F * 8;
+  const int n_local = item_end - item_begin;
+  hipStream_t s = (hipStream_t)stream;
+#define PS_LAUNCH_RUNS(FF)                                                                                                          \
+  {                                                                                                                                 \
+    static bool attr_set = false;                                                                                                   \
+    if (!attr_set) {                                                                                                                \
+      hipFuncSetAttribute((const void*)accumulate_runs_kernel<FF>, hipFuncAttributeMaxDynamicSharedMemorySize, kAccBytes);           \
+      attr_set = true;                                                                                                              \
+    }                                                                                                                               \
+    accumulate_runs_kernel<FF><<<(unsigned)n_local, 1024, lds, s>>>(run_starts, run_counts, n_runs, n_local, rec_idx, rec_val, plane_stride, \
+                                                                   gmax_bits, L, log2T, ls, headroom, dtable, dtables, out_scale, item_begin); \
+  }
+  if (F == 1) PS_LAUNCH_RUNS(1)
+  if (F == 2) PS_LAUNCH_RUNS(2)
+  if (F == 4) PS_LAUNCH_RUNS(4)
+#undef PS_LAUNCH_RUNS
+  PS_CHECK_LAUNCH();
+}
+
 // bytes of scratch needed by ps_grid_scatter_binned
 extern "C" int64_t ps_grid_scatter_workspace(int L, int F, int log2T, int64_t N) { return binned_workspace(L, F, log2T, N, 1); }
 extern "C" int64_t ps_grid_scatter_workspace_ms(int L, int F, int log2T, int64_t n_slots, int K) { return binned_workspace(L, F, log2T, n_slots, K); }

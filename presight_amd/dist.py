@@ -285,6 +285,7 @@ class FlatGrads:
             p._ps_fused_done = False  # (HipAdam.enable_fused_tables: "updated inside the table backward this step")
         for b in self._buckets:
             b["seen"], b["launched"], b["work"], b["ready"], b["ready_t"], b["phase"], b["skipped"] = 0, False, None, None, None, None, False
+            b["pending"] = None
         self._next_launch = 0
 
     def touched(self, group: Optional[dist.ProcessGroup] = None) -> List[bool]:
@@ -302,8 +303,18 @@ class FlatGrads:
         flags = self.touched(group)
         idx = [i for i, t in enumerate(flags) if t]
         # (a table whose Adam update ran inside its backward never had its gradient written: its range still holds zeros)
-        self._dirty = _merge([(self.offsets[i], self.offsets[i] + self._pad(self.params[i].numel())) for i in idx
-                              if not getattr(self.params[i], "_ps_fused_done", False)])
+        rngs = [(self.offsets[i], self.offsets[i] + self._pad(self.params[i].numel())) for i in idx
+                if not getattr(self.params[i], "_ps_fused_done", False)]
+        if any(b.get("sparse") for b in self._buckets) and self._distributed():
+            # a record-exchanged table's gradient exists on its owner only (the owned shard of the bucket); the rest of its range was never written
+            rank, world = self._rank_world()
+            own = []
+            for b in self._buckets:
+                a, e = b["range"]
+                n = (e - a) // world
+                own.append((a + rank * n, a + (rank + 1) * n) if b.get("sparse") else (a, e))
+            rngs = intersect_ranges(_merge(rngs), _merge(own))
+        self._dirty = _merge(rngs)
         return idx
 
     def touched_ranges(self, group: Optional[dist.ProcessGroup] = None) -> List[tuple]:
@@ -314,7 +325,7 @@ class FlatGrads:
 
     # ------------------------------------------------------------------ overlapped, bucketed exchange
     def enable_overlap(self, buckets: List[List[torch.nn.Parameter]], group: Optional[dist.ProcessGroup] = None,
-                       mode: str = "allreduce", dry: bool = False):
+                       mode: str = "allreduce", dry: bool = False, sparse: Sequence[int] = ()):
         """Exchange the gradient buffer in buckets, each as soon as it is complete, on a side stream, while the backward of the
         remaining parameters is still running (the reference's DDP overlaps its bucketed all-reduce with backward the same
         way).  A bucket = parameters that are contiguous in the flat buffer (e.g. one optimizer group), or one of the G pieces
@@ -328,9 +339,12 @@ class FlatGrads:
         measures when every bucket becomes ready relative to the end of backward, the input of the scaling model)."""
         if mode not in ("allreduce", "sharded"):
             raise ValueError(mode)
+        if sparse and mode != "sharded":
+            raise ValueError("FlatGrads: record (sparse) buckets belong to the sharded exchange (their owner updates its shard)")
         index = {id(p): i for i, p in enumerate(self.params)}
         self._buckets = []
-        for plist in buckets:
+        sparse = set(sparse)  # positions in `buckets` of the hash-table buckets exchanged as RECORDS (sparse_records / _sparse_exchange)
+        for pos, plist in enumerate(buckets):
             ids = sorted({index[id(p)] for p in plist if id(p) in index})
             if not ids:
                 continue
@@ -355,10 +369,15 @@ class FlatGrads:
                 p._ps_bucket = p._ps_part_buckets[0]
                 p._ps_on_touch = self._on_touch
                 continue
-            self._buckets.append(dict(range=(a, b), n=len(ids), seen=0, launched=False, work=None, index=len(self._buckets), part=None))
+            self._buckets.append(dict(range=(a, b), n=len(ids), seen=0, launched=False, work=None, index=len(self._buckets), part=None,
+                                      sparse=pos in sparse, pending=None))
+            if pos in sparse and parts:
+                raise ValueError("FlatGrads: a record (sparse) bucket is exchanged in one piece")
             for i in ids:
                 self.params[i]._ps_bucket = len(self._buckets) - 1
                 self.params[i]._ps_on_touch = self._on_touch
+                if pos in sparse:
+                    self.params[i]._ps_sparse = (self, len(self._buckets) - 1)  # field_ops: keep the records, hand them to sparse_records
         self._group = group
         self.mode = mode
         self.dry = bool(dry)
@@ -451,6 +470,30 @@ class FlatGrads:
         rank, world = self._rank_world()
         a, e = b["range"]
         seg = self.flat[a:e]
+        if b.get("sparse"):
+            rec = b["pending"]
+            if rec is None:
+                raise RuntimeError(f"FlatGrads: record bucket {b['index']} is due for its exchange but this rank's table backward produced no "
+                                   "records this step (every rank must run the bucket's table backward in every step it is exchanged)")
+
+            def run():
+                self._sparse_exchange(b, rec, rank, world)
+                b["pending"] = None
+                self.stats["in_backward"] = self.stats.get("in_backward", 0) + (b["phase"] == "backward")
+
+            if self._comm_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ev)
+                    for rev in b.get("ready") or ():
+                        self._comm_stream.wait_event(rev)
+                    run()
+                    b["post"] = torch.cuda.Event()
+                    b["post"].record()
+            else:
+                run()
+            return
 
         def issue():
             # The MEAN over the ranks (DDP's semantics).  Dividing the whole bucket before the collective is a read + write of every
@@ -490,6 +533,88 @@ class FlatGrads:
                 issue()
         else:
             issue()
+
+    # ------------------------------------------------------------------ record (sparse) exchange of hash-table gradients
+    def sparse_records(self, bucket: int, rec: dict):
+        """field_ops hands over the record streams of this step's table backward for a record bucket (the binned backward's phase 1 is
+        done; phase 2 -- the accumulate pass -- is replaced by the exchange).  rec: ws (the backward's workspace, uint8, not reused before
+        the exchange ran), layout (ps_grid_scatter_layout), L, F, log2T, K, n_points, accumulate(run_starts, run_counts, n_runs, rec_idx,
+        rec_val, plane_stride, gmax_bits, n_points_total, out_scale, item_begin, item_end).  The exchange itself runs when the bucket's turn
+        in the launch order comes (mark_touched of its tables)."""
+        b = self._buckets[bucket]
+        if b["pending"] is not None or b["launched"]:
+            raise RuntimeError(f"FlatGrads: record bucket {bucket} received a second set of records in one step")
+        b["pending"] = rec
+
+    def _a2a(self, out: Tensor, inp: Tensor, out_splits=None, in_splits=None, what: str = "all_to_all"):
+        """all_to_all_single in the bucket's process group; gloo has no device transport for it: staged through the host there"""
+        # (the log is compared line by line across ranks: the record segments' sizes are data-dependent and are logged as -1)
+        COMM_LOG.issue(what, "-", 4 * inp.numel() if in_splits is None else -1, "side" if self._comm_stream is not None else "current", self.step_no)
+        self.stats["collectives"] += 1
+        if inp.is_cuda and dist.get_backend(self._group) == "gloo":
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self._group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self._group)
+
+    def _sparse_exchange(self, b: dict, rec: dict, rank: int, world: int):
+        """SURVEY.md 8e "sparse exchange of touched rows": instead of reduce-scattering the bucket's dense gradient (the production
+        tile's main tables: 3.3 GB per rank and step), every rank sends the RECORDS of its table backward -- already sorted by the 128 KiB
+        table slice that owns their rows -- to the slice's owner, and the owner accumulates all ranks' runs of a slice in one int64
+        accumulator.  Exact and order-independent: fixed point with a per-level scale from the MAX over the ranks.  Ownership = the
+        sharded exchange's (rank r owns the r-th 1 / world of the bucket's range), so the shard-Adam and the parameter all-gather
+        behind it are unchanged.  One host synchronisation (the segment lengths all_to_all_single needs on the host)."""
+        lay, F, L, K = rec["layout"], rec["F"], rec["L"], rec["K"]
+        n_rec_max, n_items, ls = int(lay[6]), int(lay[7]), int(lay[8])
+        a, e = b["range"]
+        if n_items % world or (e - a) != n_items * (1 << ls) * F:
+            raise ValueError(f"FlatGrads: record bucket {b['index']}: {n_items} slices of {(1 << ls) * F} values do not split into {world} equal "
+                             f"shards of its range [{a}, {e})")
+        per = n_items // world
+        ws = rec["ws"]
+        i32 = lambda off, n: ws[off:off + 4 * n].view(torch.int32)  # noqa: E731
+        gmax, cursors, upper, starts = i32(int(lay[0]), K * L), i32(int(lay[1]), n_items), i32(int(lay[2]), n_items), i32(int(lay[3]), n_items)
+        rec_idx = i32(int(lay[4]), n_rec_max)
+        rec_val = ws[int(lay[5]):int(lay[5]) + 4 * (F + 1) * n_rec_max].view(torch.float32).view(F + 1, n_rec_max)
+        dev = ws.device
+        # (1) one scale per level for everybody: MAX of the per-level |d(feature)| maxima (non-negative float bit patterns order like
+        #     ints, the NaN pattern is the largest and so survives) and of the point counts (the fixed-point headroom)
+        meta = torch.cat([gmax, torch.tensor([int(rec["n_points"])], dtype=torch.int32, device=dev)])
+        COMM_LOG.issue("all_reduce_max_levels", b["index"], 4 * meta.numel(), "side" if self._comm_stream is not None else "current", self.step_no)
+        dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self._group)
+        self.stats["collectives"] += 1
+        gmax_all = meta[:K * L].contiguous()
+        # (2) where every item's run sits inside the segment of its owner, and how many records it really holds
+        seg_start = starts[::per].to(torch.int64)                                        # [world]
+        end_all = (starts[-1:].to(torch.int64) + ((upper[-1:].to(torch.int64) + 3) // 4) * 4)
+        seg_end = torch.cat([seg_start[1:], end_all])
+        send_len = seg_end - seg_start
+        rel = (starts.to(torch.int64) - seg_start.repeat_interleave(per)).to(torch.int32)
+        cnt = cursors - starts
+        item_meta = torch.stack([rel.view(world, per), cnt.view(world, per)], 1).contiguous()   # [world, 2, per]: destination-major
+        recv_meta = torch.empty_like(item_meta)
+        self._a2a(recv_meta, item_meta, what="all_to_all_item_runs")
+        recv_len = torch.empty_like(send_len)
+        self._a2a(recv_len, send_len, what="all_to_all_segment_lengths")
+        host = torch.cat([send_len, recv_len, meta[K * L:].to(torch.int64)]).tolist()          # the ONE host synchronisation
+        send_l, recv_l, n_max = host[:world], host[world:2 * world], host[-1]
+        n_total = n_max * world
+        total = sum(recv_l)
+        # (3) the record planes: row | type words, then the F value planes and the blend weight
+        recv_idx = torch.empty(max(total, 4), dtype=torch.int32, device=dev)
+        recv_val = torch.empty(F + 1, max(total, 4), dtype=torch.float32, device=dev)
+        used = sum(send_l)
+        self._a2a(recv_idx[:total], rec_idx[:used], recv_l, send_l, what="all_to_all_records")
+        for f in range(F + 1):
+            self._a2a(recv_val[f, :total], rec_val[f, :used], recv_l, send_l, what="all_to_all_records")
+        self.stats["bytes"] += 4 * (F + 2) * (used - send_l[rank]) + 8 * per * (world - 1)
+        self.stats["sparse_record_bytes"] = self.stats.get("sparse_record_bytes", 0) + 4 * (F + 2) * (used - send_l[rank])
+        # (4) the owner's accumulate pass over world runs per owned item -> its shard of the MEAN gradient
+        off = torch.tensor([sum(recv_l[:s_]) for s_ in range(world)], dtype=torch.int32, device=dev)
+        run_starts = (recv_meta[:, 0, :] + off[:, None]).contiguous()
+        run_counts = recv_meta[:, 1, :].contiguous()
+        rec["accumulate"](run_starts, run_counts, world, recv_idx, recv_val, max(total, 4), gmax_all, n_total, 1.0 / world, rank * per, (rank + 1) * per)
 
     def _join_side_streams(self):
         """gradients written in place by nodes that ran on the proposal networks' side stream (presight_amd.ops.side_stream) are

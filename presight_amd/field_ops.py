@@ -94,10 +94,12 @@ SCATTER_IMPL = "binned"  # "binned" (records + int64 LDS accumulation) or "owner
 KEEP_ACTIVATIONS = __import__("os").environ.get("PRESIGHT_KEEP_ACTIVATIONS", "1") != "0"
 
 
-def _workspace(nbytes: int, device) -> Tensor:
+def _workspace(nbytes: int, device, owner=None) -> Tensor:
     """Scratch for the binned scatter, grown on demand and reused across steps (stream-ordered reuse is safe: every
-    consumer of the previous contents was enqueued on the same stream before the next producer)."""
-    key = (str(device), _stream())  # per stream: the proposal networks may run beside the main field (samplers.prop_stream)
+    consumer of the previous contents was enqueued on the same stream before the next producer).  owner: a table whose gradient is
+    exchanged as RECORDS (dist.FlatGrads record buckets) keeps a workspace of its own -- its records wait there for the bucket's turn
+    in the exchange order, possibly past the next table backward on the same stream."""
+    key = (str(device), _stream()) if owner is None else (str(device), "records", id(owner))  # per stream: the proposal networks may run beside the main field (samplers.prop_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.05) + 4096, device=device, dtype=torch.uint8)
@@ -111,12 +113,29 @@ def _binned(N: int, L: int = 16) -> bool:
     return SCATTER_IMPL == "binned" and N * L * 8 + 4096 + 4 * L * 256 < (1 << 32)
 
 
-def _scatter_ws(g: GridCfg, N: int, device) -> Optional[Tensor]:
+def _scatter_ws(g: GridCfg, N: int, device, table: Optional[Tensor] = None) -> Optional[Tensor]:
     """workspace of the binned table backward; its first L words receive the per-level max |d(feature)| straight from the
     field backward kernel (level_absmax argument), which saves the scatter its own pass over d(features)"""
     if not _binned(N, g.num_levels):
         return None
-    return _workspace(lib().ps_grid_scatter_workspace(g.num_levels, g.features_per_level, g.log2_hashmap_size, N), device)
+    return _workspace(lib().ps_grid_scatter_workspace(g.num_levels, g.features_per_level, g.log2_hashmap_size, N), device,
+                      owner=table if getattr(table, "_ps_sparse", None) is not None else None)
+
+
+def _hand_over_records(tables: Sequence[Tensor], ws: Tensor, g: GridCfg, N: int, K: int, dtable: Optional[Tensor], dtables: Optional[Tensor]):
+    """record (sparse) exchange: phase 1 of the binned backward has left this step's records in `ws`; the owner of the flat gradient
+    buffer exchanges them when the bucket's turn comes and runs the accumulate pass over all ranks' runs (dist.FlatGrads._sparse_exchange)"""
+    fg, bucket = tables[0]._ps_sparse
+    L, F, l2t = g.num_levels, g.features_per_level, g.log2_hashmap_size
+    lay = (ctypes.c_int64 * 9)()
+    check(lib().ps_grid_scatter_layout(L, F, l2t, N, K, lay), "ps_grid_scatter_layout")
+
+    def accumulate(run_starts, run_counts, n_runs, rec_idx, rec_val, plane_stride, gmax_bits, n_points_total, out_scale, item_begin, item_end):
+        check(lib().ps_grid_accumulate_runs(_p(run_starts), _p(run_counts), n_runs, _p(rec_idx), _p(rec_val), plane_stride, _p(gmax_bits), L, F, l2t, K,
+                                            int(n_points_total), _p(dtable), _p(dtables), float(out_scale), item_begin, item_end, _stream()),
+              "ps_grid_accumulate_runs")
+
+    fg.sparse_records(bucket, dict(ws=ws, layout=list(lay), L=L, F=F, log2T=l2t, K=K, n_points=N, accumulate=accumulate, keep=(dtable, dtables)))
 
 
 def _sink_is_zero(param: Optional[Tensor]) -> bool:
@@ -154,8 +173,16 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
     pieces = getattr(sink_owner, "_ps_parts", 1) if (sink is not None and sink_owner is not None) else 1
     _refuse_second_contribution([sink_owner])
     fused = _fused_adam([sink_owner], routed=False) if (acc == 2 and pieces == 1) else None
+    sparse = sink is not None and getattr(sink_owner, "_ps_sparse", None) is not None and _binned(N, L) and sink_owner._ps_sparse[0]._distributed()
     with prof.region(f"grid_scatter_L{L}F{F}"):
-        if fused is not None:
+        if sparse:
+            # the gradient is exchanged as RECORDS: write them (phase 1) into the table's own workspace and hand them over; the accumulate
+            # pass runs on the slices' owner, over all ranks' records (dist.FlatGrads._sparse_exchange)
+            ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device, sink_owner)
+            check(lib().ps_grid_scatter_binned_part(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
+                                                    int(ws_with_absmax is not None), _p(ws), 1, 0, 0, _stream()), "ps_grid_scatter_binned_part")
+            _hand_over_records([sink_owner], ws, g, N, 1, dtable, None)
+        elif fused is not None:
             # single-process training: the accumulate pass applies the table's Adam step itself, the gradient is never written
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
             for phase, reg in _scatter_phases(L, F):
@@ -245,7 +272,7 @@ class _PropField(torch.autograd.Function):
         assert pf.value == spec.packed and gf.value == spec.g_total
         gpart = torch.empty(npart.value, spec.g_total, device=u.device)
         dfeat = torch.empty_like(feat)
-        ws = _scatter_ws(g, N, u.device)
+        ws = _scatter_ws(g, N, u.device, ctx.table_ref)
         with prof.region("prop_field_bwd"):
             check(lib().ps_prop_field_bwd(_p(feat), N * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
                                           _p(packed), _p(_f32(dsigma)), N, _p(dfeat), _p(gpart), _p(ws), _stream()), "ps_prop_field_bwd")
@@ -1030,9 +1057,10 @@ def _ms_encode(lay: MsLayout, u: Tensor, tables: Sequence[Tensor], scalings: Ten
     return feat, counts
 
 
-def _ms_scatter_ws(lay: MsLayout, g: GridCfg, device) -> Tensor:
+def _ms_scatter_ws(lay: MsLayout, g: GridCfg, device, tables: Optional[Sequence[Tensor]] = None) -> Tensor:
+    own = tables[0] if (tables and getattr(tables[0], "_ps_sparse", None) is not None) else None  # (record exchange: a workspace of the tables' own)
     return _workspace(lib().ps_grid_scatter_workspace_ms(g.num_levels, g.features_per_level, g.log2_hashmap_size, lay.n_slots, lay.K),
-                      device)
+                      device, owner=own)
 
 
 def _ms_scatter(lay: MsLayout, u, dfeat, scalings, g: GridCfg, tables: Sequence[Tensor], counts, ws, absmax_ready: bool, mark: bool = False):
@@ -1049,6 +1077,18 @@ def _ms_scatter(lay: MsLayout, u, dfeat, scalings, g: GridCfg, tables: Sequence[
     groups = getattr(tables[0], "_ps_ms_parts", 1) if mark else 1
     _refuse_second_contribution(tables)
     fused = _fused_adam(list(tables), routed=True) if (zero_dst and groups == 1 and all(s is not None for s in sinks)) else None
+    sp = getattr(tables[0], "_ps_sparse", None)
+    if sp is not None and all(s is not None for s in sinks) and sp[0]._distributed():
+        # record (sparse) exchange of the K tables: write the records (phase 1), hand them over; the slices' owners accumulate
+        with prof.region(f"grid_scatter_L{L}F{F}"):
+            ptrs = _ptr_table(dst)
+            check(lib().ps_grid_scatter_binned_ms_part(_p(u), _p(dfeat), _p(scalings), L, F, l2t, lay.n_slots, lay.n_slots * F, _p(ptrs), K,
+                                                       lay.chunk_field, _p(counts), int(absmax_ready), _p(ws), int(zero_dst), 1, 0, 0, _stream()),
+                  "ps_grid_scatter_binned_ms_part")
+            _hand_over_records(list(tables), ws, g, lay.n_slots, K, None, ptrs)
+        if mark:
+            mark_touched(direct_params(*tables), groups_on_device=True)
+        return fresh
     with prof.region(f"grid_scatter_L{L}F{F}"):
         if fused is not None:
             check(lib().ps_grid_scatter_binned_ms_adam(_p(u), _p(dfeat), _p(scalings), L, F, l2t, lay.n_slots, lay.n_slots * F,
@@ -1122,7 +1162,7 @@ class _PropFieldMS(torch.autograd.Function):
         lay, g, hidden, st, tables, wb = ctx.meta
         K = lay.K
         dfeat = torch.empty_like(feat)
-        ws = _ms_scatter_ws(lay, g, u.device)
+        ws = _ms_scatter_ws(lay, g, u.device, tables)
         nparts = lib().ps_prop_field_parts_ms(lay.n_slots, K)
         with prof.region("prop_field_bwd"):
             check(lib().ps_prop_field_bwd_ms(_p(feat), lay.n_slots * g.features_per_level, g.out_dim, g.features_per_level, hidden, _p(sel),
@@ -1343,7 +1383,7 @@ def _ms_main_backward(ctx, saved, d_sigma, d_rgb, d_sem, weights):
         st.unpack(dsts, lay.field_start, nparts, 1)
     # the MLP gradients are complete: their bucket may leave while the table backward runs; the tables follow (group by group)
     mark_touched(direct_params(*wb), groups_on_device=True)
-    ws = _ms_scatter_ws(lay, g, u.device)
+    ws = _ms_scatter_ws(lay, g, u.device, tables)
     mark_groups(lay, tables)  # (before the table backward: with the tables' Adam step fused into it, it reads the flags)
     dtables = _ms_scatter(lay, u, dfeat, scalings, g, tables, counts, ws, absmax_ready=False, mark=True)
     return dapp, dtables, returned

@@ -17,7 +17,7 @@ The reference's Trainer also owns logging, checkpoint rotation, the viewer and t
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 
@@ -101,13 +101,25 @@ class Trainer:
                 sizes.append(len(uniq) - n0)
                 kinds.append(kind)
 
+        # exchange = "sparse": the sharded exchange with the HASH TABLES' gradients travelling as the binned backward's records instead of
+        # dense buffers (dist.FlatGrads._sparse_exchange): every network's tables form one record bucket of their own
+        self._exchanging = world > 1 or exchanging()
+        sparse_tables = exchange == "sparse" and self._exchanging
+        sparse_pos: List[int] = []
         prop_nets = list(getattr(model, "proposal_networks", []))
         prop_ids = {id(p) for p in groups.get("proposal_networks", [])}
         if model.config.use_same_proposal_network or not prop_nets:
+            if sparse_tables:
+                raise ValueError("Trainer(exchange='sparse'): one record bucket per proposal network (use_same_proposal_network=False)")
             add_bucket(groups.get("proposal_networks", []), "proposal_networks")
         else:
             for i in reversed(range(len(prop_nets))):
-                add_bucket([p for p in prop_nets[i].parameters() if id(p) in prop_ids], "proposal_networks")
+                mine = [p for p in prop_nets[i].parameters() if id(p) in prop_ids]
+                if sparse_tables:
+                    n0 = len(sizes)
+                    add_bucket([p for p in mine if is_table(p)], "proposal_networks")
+                    sparse_pos += list(range(n0, len(sizes)))
+                add_bucket(mine, "proposal_networks")
             add_bucket(groups.get("proposal_networks", []), "proposal_networks")  # (anything the loop did not reach)
         fields = list(groups.get("fields", []))
         # the main field's MLPs are complete after its backward kernels + the gradient unpack, BEFORE its table backward starts; the
@@ -119,7 +131,12 @@ class Trainer:
         # 2: its accumulate launches are short and every extra piece costs launches, events and a collective on a host-bound step
         split_pieces = int(table_pieces) if table_pieces is not None else int(os.environ.get("PRESIGHT_TABLE_PIECES", "4"))
         n_table_buckets, table_split = 0, None
-        if len(main_tables) == 1:
+        if sparse_tables and main_tables:
+            n0 = len(sizes)
+            add_bucket(main_tables, "fields")  # all K tables: ONE record bucket (ownership = contiguous 1 / world of their slices)
+            sparse_pos += list(range(n0, len(sizes)))
+            n_table_buckets = 1
+        elif len(main_tables) == 1:
             add_bucket(main_tables, "fields")
             table_split = len(sizes) - 1
             n_table_buckets = 1
@@ -141,8 +158,7 @@ class Trainer:
         assert seen == {id(p) for p in model.parameters() if p.requires_grad and p.numel() > 0}
         self.group_names = kinds  # bucket -> optimizer group name
         # (a process group of one rank with PRESIGHT_EXCHANGE_WORLD_OF_ONE=1 exchanges like any other: RCCL smoke run on a one-GPU box)
-        self._exchanging = world > 1 or exchanging()
-        sharded = exchange == "sharded" and self._exchanging
+        sharded = exchange in ("sharded", "sparse") and self._exchanging
         overlap = ((self._exchanging or os.environ.get("PRESIGHT_DRY_OVERLAP") == "1") and not model.config.use_same_proposal_network
                    and os.environ.get("PRESIGHT_NO_OVERLAP") != "1")
         splits = {table_split: split_pieces} if (overlap and table_split is not None and split_pieces > 1) else None
@@ -159,7 +175,8 @@ class Trainer:
                 i += n
             if len(main_tables) > 1 and n_table_buckets > 1:
                 main_tables[0]._ps_ms_parts = n_table_buckets  # field_ops._ms_scatter: one accumulate launch per sub-field group
-            self.grads.enable_overlap(buckets, mode="sharded" if sharded else "allreduce", dry=not self._exchanging)
+            self.grads.enable_overlap(buckets, mode="sharded" if sharded else "allreduce", dry=not self._exchanging,
+                                      sparse=sparse_pos if sparse_tables else ())
             if sharded:
                 # (a declared bucket may have become several exchange buckets: the pieces of the split table)
                 gate: Dict[str, list] = {}
@@ -169,7 +186,7 @@ class Trainer:
                 model.param_gate = lambda name: [self.grads.wait_params(j) for j in gate.get(name, ())]
         self._prop_buckets = [b["index"] for b in self.grads._buckets
                               if kinds[next(j for j, (a0, a1) in enumerate(self.grads.bucket_ranges) if a0 <= b["range"][0] < a1)] == "proposal_networks"]
-        self.exchange = "sharded" if sharded else "allreduce"
+        self.exchange = ("sparse" if sparse_tables else "sharded") if sharded else "allreduce"
         if global_depth_clip and self._exchanging:
             ops.set_depth_clip_hook(_depth_hook())
         self.loss_scale = float(loss_scale)

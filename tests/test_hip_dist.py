@@ -354,6 +354,18 @@ def test_bench_two_ranks_sharded_strong():
     assert line["config"]["rays_per_gpu"] == 2048 and line["config"]["exchange"] == "sharded"
 
 
+def test_bench_two_ranks_sparse_record_exchange():
+    """exchange = sparse (SURVEY.md 8e "sparse exchange of touched rows"): the hash tables' gradients travel as the binned backward's
+    records to the owner of their table slice (all-to-all), the owner accumulates both ranks' runs in int64 and updates its shard; MLP
+    gradients are reduce-scattered as in the sharded mode; the parameters return by the same all-gather.  Replicas stay bit-identical
+    and the records on the link are a fraction of the dense table gradient."""
+    line = _run_bench_two_ranks(["--exchange", "sparse", "--scaling", "strong"])
+    assert line["replicas_max_abs_diff"] == 0.0
+    assert line["config"]["exchange"] == "sparse"
+    rec, dense = line["comm"]["record_bytes_on_link_per_rank_per_step"], line["comm"]["dense_table_gradient_bytes"]
+    assert 0 < rec < 0.5 * dense, (rec, dense)  # (2048 rays per rank: ~40 MB of records against 67 MB of the dense gradient's other half)
+
+
 @pytest.mark.parametrize("K", [1, 4])
 def test_rccl_group_of_one_runs_the_exchange(K):
     """The bucketed exchange through RCCL itself on a one-GPU box: a process group of ONE rank (backend nccl = RCCL) with
@@ -374,12 +386,14 @@ def test_rccl_group_of_one_runs_the_exchange(K):
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["backend"] == "nccl"
-    for mode in ("allreduce", "sharded"):
+    for mode in ("allreduce", "sharded", "sparse"):
         # 3 steps x (>= 5 gradient buckets [+ the parameter all-gathers of the sharded mode]); all but the tail handed over in backward
-        assert out[mode]["collectives"] >= 3 * out[mode]["buckets"] * (2 if mode == "sharded" else 1), out
+        assert out[mode]["collectives"] >= 3 * out[mode]["buckets"] * (2 if mode != "allreduce" else 1), out
+        assert out[f"{mode}_tables_bit_equal"], out  # (integer accumulation: the exchanged table gradient equals the plain one exactly)
         assert out[mode]["in_backward"] >= 3 * (out[mode]["buckets"] - 1) and out[mode]["gradient_rel_err"] < 1e-4, out
         assert out[mode]["losses_finite"] and abs(out[mode]["loss_a_b_last"][0] - out[mode]["loss_a_b_last"][1]) < 0.05 * abs(out[mode]["loss_a_b_last"][1]), out
-    want = {"all_reduce", "reduce_scatter", "all_gather_params"} | ({"all_reduce_max_flags"} if K > 1 else set())
+    want = ({"all_reduce", "reduce_scatter", "all_gather_params", "all_to_all_records", "all_to_all_item_runs", "all_reduce_max_levels"}
+            | ({"all_reduce_max_flags"} if K > 1 else set()))
     assert want <= set(out["comm_log_kinds"]), out
 
 

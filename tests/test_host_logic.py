@@ -703,3 +703,126 @@ def test_trainer_notices_a_sub_module_left_in_eval_mode():
     assert _some_module_in_eval_mode(m)
     m.train()
     assert not _some_module_in_eval_mode(m)
+
+
+_WORKER_SPARSE = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from presight_amd.dist import FlatGrads, init_from_env, intersect_ranges, COMM_LOG
+    from presight_amd.ops import mark_touched
+    rank, local, world = init_from_env("cpu")
+    torch.manual_seed(0)
+    K, L, LS, F = 1, 2, 2, 1                      # 2 levels x 4 slices of 4 rows: 8 items, 32 table entries
+    n_slices, rows = 4, 1 << LS
+    n_items = K * L * n_slices
+    small, table = torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(n_items * rows, F))
+
+    def build(sparse):
+        for p in (small, table):
+            for a in ("_ps_sparse", "_ps_bucket", "_ps_on_touch", "_ps_parts", "_ps_part_done", "_ps_part_buckets"):
+                if hasattr(p, a):
+                    delattr(p, a)
+        fg = FlatGrads([small, table], bucket_sizes=[1, 1], shard_world=world)
+        fg.enable_overlap([[small], [table]], mode="sharded", sparse=[1] if sparse else [])
+        return fg
+
+    # this rank's records: item i holds n_i = (i + rank) % 3 + (i == 5) * 6 records, its stream is sized for an UPPER bound of them
+    g = torch.Generator().manual_seed(100 + rank)
+    n = [(i + rank) % 3 + (6 if i == 5 else 0) for i in range(n_items)]
+    upper = [c + (i + 2 * rank) % 3 for i, c in enumerate(n)]
+    starts, off = [], 0
+    for u in upper:
+        starts.append(off)
+        off += (u + 3) // 4 * 4
+    n_rec_max = off + 8
+    rec_idx = torch.full((n_rec_max,), -1, dtype=torch.int32)
+    rec_val = torch.full((F + 1, n_rec_max), float("nan"))
+    dense = torch.zeros(n_items * rows)             # what the plain (dense) table backward of this rank would have written
+    for i in range(n_items):
+        for j in range(n[i]):
+            row, val = int(torch.randint(0, rows, (1,), generator=g)), float(torch.randint(-8, 9, (1,), generator=g))
+            rec_idx[starts[i] + j] = row | (31 << 16)                       # t = 31: a single corner, weight already applied
+            rec_val[0, starts[i] + j], rec_val[F, starts[i] + j] = val, 0.0
+            dense[i * rows + row] += val
+    lay = [0, 4096, 4096 + 4 * n_items, 4096 + 8 * n_items, 4096 + 8 * n_items + 4 * ((n_items + 3) // 4 * 4), 0, n_rec_max, n_items, LS]
+    lay[5] = lay[4] + 4 * n_rec_max
+    ws = torch.zeros(lay[5] + 4 * (F + 1) * n_rec_max, dtype=torch.uint8)
+    put = lambda o, t: ws[o:o + t.numel() * 4].copy_(t.contiguous().view(torch.uint8).reshape(-1))
+    gmax = torch.tensor([1.0 + rank, 4.0 - rank]).view(torch.int32)          # per-level maxima differ between the ranks
+    put(lay[0], gmax)
+    put(lay[1], torch.tensor([s + c for s, c in zip(starts, n)], dtype=torch.int32))   # cursors = stream ends
+    put(lay[2], torch.tensor(upper, dtype=torch.int32))
+    put(lay[3], torch.tensor(starts, dtype=torch.int32))
+    put(lay[4], rec_idx)
+    put(lay[5], rec_val)
+    seen = {{}}
+
+    def make_accumulate(fg):
+        def accumulate(run_starts, run_counts, n_runs, ridx, rval, stride, gmax_bits, n_points_total, out_scale, i0, i1):
+            # the owner's pass: every run of every owned item, summed exactly (small integers), scaled, WRITTEN into its shard
+            seen.update(gmax=gmax_bits.view(torch.float32).tolist(), n_total=n_points_total, n_runs=n_runs)
+            out = fg.flat[fg.offsets[1]:fg.offsets[1] + n_items * rows]
+            for li in range(i1 - i0):
+                acc = torch.zeros(rows, dtype=torch.float64)
+                for r in range(n_runs):
+                    b, c = int(run_starts[r, li]), int(run_counts[r, li])
+                    assert b % 4 == 0
+                    for j in range(c):
+                        assert int(ridx[b + j]) >> 16 == 31 and rval[F, b + j] == 0.0
+                        acc[int(ridx[b + j]) & 0xffff] += float(rval[0, b + j])
+                out[(i0 + li) * rows:(i0 + li + 1) * rows] = (acc * out_scale).float()
+        return accumulate
+
+    flat_p = {{}}
+    for mode in ("dense", "sparse"):
+        fg = build(mode == "sparse")
+        fp = torch.zeros(fg.total)
+        for p, o in zip([small, table], fg.offsets):
+            fp[o:o + p.numel()] = torch.arange(p.numel(), dtype=torch.float32)
+        fg.zero_()
+        small.grad.add_(rank + 1.0)
+        mark_touched([small])
+        if mode == "sparse":
+            fg.sparse_records(1, dict(ws=ws, layout=lay, L=L, F=F, log2T=4, K=K, n_points=1000 + 24 * rank, accumulate=make_accumulate(fg)))
+        else:
+            table.grad.view(-1).add_(dense)
+        mark_touched([table])
+        assert all(b["launched"] and b["phase"] == "backward" for b in fg._buckets)   # both buckets left during "backward"
+        fg.finish_exchange()
+        owned, touched = fg.owned_ranges(), fg.touched_ranges()
+        t0 = fg.offsets[1]
+        half = n_items * rows // world
+        assert (t0 + rank * half, t0 + (rank + 1) * half) in [(max(a, t0), b) for a, b in owned if b > t0]      # the r-th half of the table
+        for a, b in intersect_ranges(touched, owned):
+            fp[a:b] -= 0.25 * fg.flat[a:b]
+        fg.gather_params(fp, touched)
+        fg.wait_params()
+        ref = fp.clone(); dist.broadcast(ref, src=0)
+        assert torch.equal(ref, fp), mode                                                                         # replicas bit-identical
+        flat_p[mode] = fp
+    assert torch.equal(flat_p["dense"], flat_p["sparse"])   # integer-valued gradients: the record exchange IS the dense sharded result
+    both = [torch.zeros_like(dense) for _ in range(world)]
+    dist.all_gather(both, dense)
+    exp = torch.arange(n_items * rows, dtype=torch.float32) - 0.25 * sum(both) / world
+    assert torch.equal(flat_p["sparse"][t0:t0 + n_items * rows], exp)
+    assert seen["gmax"] == [2.0, 4.0] and seen["n_total"] == 1024 * world and seen["n_runs"] == world    # MAX over the ranks of both
+    kinds = [ln.split()[1] for ln in COMM_LOG.tail(64)]
+    assert kinds.count("all_to_all_records") == F + 2 and "all_reduce_max_levels" in kinds and "all_to_all_item_runs" in kinds
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_sparse_record_exchange_gloo_world2(tmp_path):
+    """exchange = sparse: a hash table's gradient travels as the binned backward's RECORD streams to the owners of its
+    slices (all_to_all of the streams + per-item run tables, per-level maxima MAX-reduced first), the owner accumulates every rank's run
+    and writes its shard of the mean; Adam-on-the-shard and the parameter all-gather are the sharded mode's.  Two gloo ranks on the CPU
+    with a stand-in accumulate pass: replicas bit-identical, and -- on integer-valued records, where float sums are exact -- bit-equal
+    to the DENSE sharded exchange of the same gradients; streams sized for upper bounds, empty runs and a hot slice included."""
+    script = tmp_path / "worker_sparse.py"
+    script.write_text(_WORKER_SPARSE.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29747")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29747", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
