@@ -581,7 +581,8 @@ class FlatGrads:
         # (1) one scale per level for everybody: MAX of the per-level |d(feature)| maxima (non-negative float bit patterns order like
         #     ints, the NaN pattern is the largest and so survives) and of the point counts (the fixed-point headroom)
         meta = torch.cat([gmax, torch.tensor([int(rec["n_points"])], dtype=torch.int32, device=dev)])
-        COMM_LOG.issue("all_reduce_max_levels", b["index"], 4 * meta.numel(), "side" if self._comm_stream is not None else "current", self.step_no)
+        COMM_LOG.issue("all_reduce_max_levels", b["index"], 4 * meta.numel(), "side" if self._comm_stream is not None else "current", self.step_no,
+                       phase=b.get("phase"))  # (the first collective of a record bucket's exchange: carries the bucket's hand-over phase)
         dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self._group)
         self.stats["collectives"] += 1
         gmax_all = meta[:K * L].contiguous()
