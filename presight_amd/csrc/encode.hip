@@ -741,20 +741,24 @@ __global__ __launch_bounds__(bin_threads(D, F)) void bin_kernel(const float* __r
 }
 
 // exclusive prefix over the (level, slice) counts: starts[i], and cursors[i] := starts[i] for the second pass.
-// One workgroup walks the n items in tiles of 4096 (four consecutive items per thread: coalesced loads / stores), wave scans + a
+// One workgroup walks the n items in tiles of 4 TPB (four consecutive items per thread: coalesced loads / stores), wave scans + a
 // 16-entry table per tile, the running total carried in a register.  (The first version gave every thread one contiguous run of n / 1024
 // items: strided, uncoalesced accesses, twice -- 240 us for the 41 k items of a routed production tile, per table backward.)
 // src: where the record counts come from -- the cursors themselves (counted by bin_kernel<COUNT_ONLY>) or the slice counts of the
 // forward encode (read directly: the device-to-device copy into the cursors was a launch of its own); zero_bits / n_zero: the
 // per-level absmax words to clear for the record-writing pass that follows (another memset launch otherwise).
-__global__ __launch_bounds__(1024) void stream_offsets_kernel(unsigned* __restrict__ cursors, unsigned* __restrict__ counts,
-                                                              unsigned* __restrict__ starts, int n, const unsigned* __restrict__ src,
-                                                              unsigned* __restrict__ zero_bits, int n_zero) {
+// TPB = 256 for tables of <= 4096 streams: this kernel sits at the head of a table backward that runs BESIDE the main field's matrix
+// kernels (one 350 - 420-register wave per SIMD), and a 1024-thread workgroup (4 waves x 40 registers per SIMD) found no compute unit to
+// start on until one of their workgroups retired -- 0.6 - 1.2 ms of waiting for 5 us of work on the proposal chain (round-6 timeline).
+template <int TPB>
+__global__ __launch_bounds__(TPB) void stream_offsets_kernel(unsigned* __restrict__ cursors, unsigned* __restrict__ counts,
+                                                             unsigned* __restrict__ starts, int n, const unsigned* __restrict__ src,
+                                                             unsigned* __restrict__ zero_bits, int n_zero) {
   __shared__ unsigned wsum[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < n_zero; i += 1024) zero_bits[i] = 0u;
+  for (int i = threadIdx.x; i < n_zero; i += TPB) zero_bits[i] = 0u;
   unsigned carry = 0;
-  for (int base = 0; base < n; base += 4096) {
+  for (int base = 0; base < n; base += TPB * 4) {
     const int i = base + (int)threadIdx.x * 4;
     unsigned c[4], r[4], s = 0;
 #pragma unroll
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(1024) void stream_offsets_kernel(unsigned* __restri
     __syncthreads();
     unsigned before = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < TPB / 64; ++w) {
       const unsigned v = wsum[w];
       before += w < wave ? v : 0u;
       total += v;
@@ -1310,8 +1314,12 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
           bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), bin_threads(DD, FF), 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,    \
                                                                               plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period, dfeat_b); \
       }                                                                                                                   \
-      stream_offsets_kernel<<<1, 1024, 0, s>>>(cursors, counts, starts, n_items, counted ? slice_counts : cursors,        \
-                                               (counted && !absmax_ready) ? gmax_bits : nullptr, (counted && !absmax_ready) ? K * L : 0); \
+      if (n_items <= 4096)                                                                                                \
+        stream_offsets_kernel<256><<<1, 256, 0, s>>>(cursors, counts, starts, n_items, counted ? slice_counts : cursors,  \
+                                                     (counted && !absmax_ready) ? gmax_bits : nullptr, (counted && !absmax_ready) ? K * L : 0); \
+      else                                                                                                                \
+        stream_offsets_kernel<1024><<<1, 1024, 0, s>>>(cursors, counts, starts, n_items, counted ? slice_counts : cursors, \
+                                                       (counted && !absmax_ready) ? gmax_bits : nullptr, (counted && !absmax_ready) ? K * L : 0); \
       if (N > 0)                                                                                                          \
         bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), bin_threads(DD, FF), 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,     \
                                                                              plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
