@@ -34,8 +34,16 @@ def voxel_index(points: Tensor, voxel: float, min_bound: Tensor) -> Tensor:
     return idx
 
 
-def lattice_points(aabb: Tensor, res: int, start: int, count: int, device) -> Tensor:
-    a = (ctypes.c_float * 6)(*[float(v) for v in aabb.reshape(-1).cpu().tolist()])
+def _host_aabb(aabb):
+    """the six floats of an AABB as the host array ps_lattice_points takes (a device tensor costs a copy AND a host synchronisation:
+    loops over chunks convert once)"""
+    if isinstance(aabb, ctypes.Array):
+        return aabb
+    return (ctypes.c_float * 6)(*[float(v) for v in torch.as_tensor(aabb).reshape(-1).cpu().tolist()])
+
+
+def lattice_points(aabb, res: int, start: int, count: int, device) -> Tensor:
+    a = _host_aabb(aabb)
     pts = torch.empty(count, 3, device=device)
     check(lib().ps_lattice_points(a, res, start, count, _p(pts), _stream()), "ps_lattice_points")
     return pts
@@ -375,6 +383,8 @@ def dense_tile_query(model, aabb: Tensor, res: int = 512, chunk: int = 1 << 22, 
     # hold `capacity` rows; a tile that keeps more (cursor[1] > 0) is simply run again with room for all of them.
     capacity = max(1 << 16, int(KEEP_FRACTION_GUESS * total) + 4096)
     mb = _host3(min_bound)
+    aabb_h = _host_aabb(aabb)  # (once per tile: read per chunk from a device tensor it was a host synchronisation per chunk -- the host
+    #                             never ran ahead of the GPU, 4 ms of launch gaps per 512^3 pass)
     while True:
         o_pts, o_dens = torch.empty(capacity, 3, device=dev), torch.empty(capacity, device=dev)
         o_feat = torch.empty(capacity, 64, device=dev, dtype=torch.float16)
@@ -383,7 +393,7 @@ def dense_tile_query(model, aabb: Tensor, res: int = 512, chunk: int = 1 << 22, 
         ws = torch.empty(lib().ps_emit_kept_workspace(min(chunk, total)), device=dev, dtype=torch.uint8)
         for s in range(start, start + total, chunk):
             n = min(chunk, start + total - s)
-            pts = lattice_points(aabb, res, s, n, dev)
+            pts = lattice_points(aabb_h, res, s, n, dev)
             with torch.no_grad():
                 dens, sem = _query_raw(model, pts, density_threshold)
             sem = _f32(sem)
@@ -409,6 +419,7 @@ def _dense_tile_query_synced(model, aabb, res, chunk, start, total, density_thre
     """the loop of rounds 2-5: one nonzero() (host sync) per chunk, then gather / select / voxel-index launches on the kept rows"""
     dev = model.device
     keep_pts, keep_feat, keep_dens, keep_idx = [], [], [], []
+    aabb = _host_aabb(aabb)
     for s in range(start, start + total, chunk):
         n = min(chunk, start + total - s)
         pts = lattice_points(aabb, res, s, n, dev)
