@@ -302,7 +302,11 @@ int ps_grid_scatter_binned_ms(const float* u, const float* dfeat, const float* s
 /* The binned table backward in PIECES, for a gradient that is exchanged bucket by bucket while the backward is still running
  * (the reference's DDP overlaps its bucketed all-reduce with backward: ns/pipelines/PreSight/my_pipeline.py:121-124): phase 1 = prepare
  * (counts, stream offsets, record write pass), phase 2 = accumulate the items [item_begin, item_end) of ps_grid_scatter_items()
- * = K * L * slices, ordered (sub-field, level, slice) like the gradient in memory; the same arguments in every call of one scatter. */
+ * = K * L * slices, ordered (sub-field, level, slice) like the gradient in memory; the same arguments in every call of one scatter.
+ * phase | 8 (in every call of the scatter): the coarsest level of a single table is summed per cell corner into a dense int64 histogram
+ * in the workspace instead of travelling as records (its (ceil(scalings[0]) + 1)^3 cells fit on chip: 1 / L of the record traffic and
+ * the accumulate pass's hot rows gone; same fixed-point terms, bit-identical gradient).  phase | 4 overrides it: EVERY level as records
+ * (a caller that consumes the records themselves -- the sparse exchange below). */
 int ps_grid_scatter_items(int L, int F, int log2T, int K);
 int ps_grid_scatter_binned_part(const float* u, const float* dfeat, const float* scalings, int L, int F, int log2T, int64_t N,
                                 int64_t plane_stride, float* dtable, int accumulate, const uint32_t* slice_counts, int absmax_ready,

@@ -454,6 +454,20 @@ __device__ __forceinline__ float fixed_scale(unsigned gmax_bits, int headroom_lo
   return ldexpf(1.0f, headroom_log2 - (ex + 1));
 }
 
+// __float2ll_rn(x) for |x| < 2^54 in six vector instructions (the library routine is a software sequence of ~20): rint in fp32 is exact,
+// an integer-valued float splits exactly into a multiple of 2^24 and a remainder below it, and both halves fit 32-bit conversions
+__device__ __forceinline__ long long fixed_ll(float x) {
+  const float r = rintf(x);
+  const float hi = floorf(r * (1.0f / 16777216.0f));
+  const float lo = r - hi * 16777216.0f;  // in [0, 2^24): exact
+  return (long long)(int)hi * 16777216ll + (long long)(int)lo;
+}
+
+// level 0 as a dense histogram (level0_hist_kernel below): side of the level's cube of cell corners, and whether it fits the budget
+constexpr int kDense0Bytes = 80 * 1024;  // LDS budget of the histogram = its size in the workspace
+__device__ __forceinline__ int dense0_side(const float* __restrict__ scalings) { return (int)ceilf(scalings[0]) + 1; }
+__device__ __forceinline__ bool dense0_fits(int R, int F) { return (int64_t)R * R * R * F * 8 <= kDense0Bytes; }
+
 // COUNT_ONLY = true : pass 1, per-(level, slice) record counts (cursors[] += bucket sizes)
 // COUNT_ONLY = false: pass 2, cursors[] hold the exclusive prefix (stream start) of every (level, slice) and are
 //                     advanced by the reservations; records are written at their exact final position.
@@ -468,7 +482,8 @@ __global__ __launch_bounds__(bin_threads(D, F)) void bin_kernel(const float* __r
                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
                                                           float* __restrict__ rec_val, const int* __restrict__ chunk_field,
                                                           unsigned* __restrict__ gmax_track /* nullable: per-level max |dfeat| bits */,
-                                                          int64_t period, const float* __restrict__ dfeat_b) {
+                                                          int64_t period, const float* __restrict__ dfeat_b,
+                                                          int dense0 /* level 0 goes through level0_hist_kernel (when its cube fits) */) {
   constexpr int kBinPointsPerThread = bin_points_per_thread(D, F);
   constexpr int kBinThreads = bin_threads(D, F);
   constexpr int kBinPoints = kBinThreads * kBinPointsPerThread;  // points per workgroup
@@ -486,6 +501,9 @@ __global__ __launch_bounds__(bin_threads(D, F)) void bin_kernel(const float* __r
   // on the 2 cache lines of a level's cursors) contend 1/L as much, and the L reads of a chunk's points hit in L2
   const int level = (int)(blockIdx.x % L);
   const int64_t first = (blockIdx.x / L) * kBinPoints;
+  if constexpr (!COUNT_ONLY && D == 3) {
+    if (dense0 && level == 0 && dense0_fits(dense0_side(scalings), F)) return;  // (workgroup-uniform; the count pass still counts level 0)
+  }
   if (chunk_field != nullptr) {  // multi-sub-field launch: (sub-field, level) takes the place of the level in the stream index
     const int kf = chunk_field[first / ps::kMsChunk];
     if (kf < 0) return;
@@ -740,23 +758,214 @@ __global__ __launch_bounds__(bin_threads(D, F)) void bin_kernel(const float* __r
   }
 }
 
+// ---- level 0 as a DENSE histogram (round 6) ------------------------------------------------------------------------------
+// The coarsest level of a grid has (ceil(scale_0) + 1)^3 live cells (17^3 = 4913 at the reference's min_res = 16) however many
+// points there are: as records its contributions are 1/L of the record traffic of both passes and -- consecutive samples of a ray
+// share their cell -- the hot rows of the accumulate pass (2.7 x the time of a fine level, profiles/r05_scatter_levels.txt).
+// Here they never become records: a workgroup sums the fixed-point contributions of its points per CELL CORNER in LDS (int64,
+// the same rint(w g 2^e) terms the accumulate kernel would form, so the result is bit-identical), adds its non-zero cells to a
+// dense int64 histogram in the workspace, and the accumulate workgroup of a level-0 slice adds the cells whose hash lands in
+// its slice to its accumulators before the flush.  Requirements (host: one table, 3-D, no position sets, accumulate_kernel
+// path; device: the cube fits the LDS budget): otherwise level 0 travels as records like every other level.
+// A point with a corner outside the cube (|u| beyond [0, 1]: possible without scene contraction) is written as ordinary
+// records into the level-0 streams (sized for all of them by the count pass), one reservation per record.
+
+// max |d(feature)| of level 0 (the record writer folds this into its pass over the levels it writes; it no longer reads level 0)
+template <int F>
+__global__ __launch_bounds__(1024) void level0_absmax_kernel(const float* __restrict__ dfeat, const float* __restrict__ scalings, int64_t N,
+                                                             unsigned* __restrict__ gmax_bits) {
+  if (!dense0_fits(dense0_side(scalings), F)) return;
+  float m = 0.f;
+  const int64_t n = N * F, n4 = ((uintptr_t)dfeat & 15) == 0 ? n / 4 : 0;  // 16-byte loads over the aligned body, scalars for the rest
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 1024) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(dfeat + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = fabsf(t[k]);
+      m = (a == a) ? fmaxf(m, a) : __builtin_inff();
+    }
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+    const float a = fabsf(dfeat[i]);
+    m = (a == a) ? fmaxf(m, a) : __builtin_inff();
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+  // one atomic per WORKGROUP (same-address atomics serialise in L2: one per wave cost this kernel 0.1 ms for 10 us of reading)
+  __shared__ float wmax[16];
+  if (ps_lane() == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, wmax[w]);  // (a NaN never reaches here: non-finite inputs were turned into +inf above)
+    if (!(m <= 0.f)) atomicMax(gmax_bits, isfinite(m) ? __float_as_uint(m) : 0x7fc00000u);
+  }
+}
+
+// 256-thread workgroups: one wave per SIMD with < 96 registers and <= 80 KiB of LDS starts on a compute unit that holds a 400-register
+// wave of the main field's matrix kernels on every SIMD (the proposal chain runs beside them); at 1024 threads the kernel waited for
+// whole compute units (0.05 ms alone, 0.5 ms on average in the step)
+constexpr int kHistThreads = 256;
+template <int F>
+__global__ __launch_bounds__(kHistThreads) void level0_hist_kernel(const float* __restrict__ u, const float* __restrict__ dfeat,
+                                                           const float* __restrict__ scalings, int log2T, int log2_slice, int64_t N,
+                                                           int64_t n_rec_max, unsigned* __restrict__ cursors, unsigned* __restrict__ rec_idx,
+                                                           float* __restrict__ rec_val, const unsigned* __restrict__ gmax_bits,
+                                                           int headroom_log2, unsigned long long* __restrict__ hist0) {
+  constexpr int kRun = 8;  // consecutive points per thread: samples of one ray, merged in registers while they stay in one cell
+  extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];  // [R^3][F]
+  const int R = dense0_side(scalings);
+  if (!dense0_fits(R, F)) return;
+  const int cells = R * R * R;
+  const unsigned gbits = gmax_bits[0];
+  if (gbits >= 0x7f800000u) return;  // a non-finite gradient on the level: the accumulate pass writes NaN whatever the sums are
+  const float scale = fixed_scale(gbits, headroom_log2);
+  const float s = scalings[0];
+  const uint32_t mask = (1u << log2T) - 1u, low = (1u << log2_slice) - 1u;
+  for (int i = threadIdx.x; i < cells * F; i += kHistThreads) hist[i] = 0ull;
+  __syncthreads();
+  int tgt[8];
+  long long sum[8][F];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    tgt[k] = -1;
+#pragma unroll
+    for (int f = 0; f < F; ++f) sum[k][f] = 0;
+  }
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (tgt[k] >= 0) {
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+          if (sum[k][f] != 0) atomicAdd(&hist[tgt[k] * F + f], (unsigned long long)sum[k][f]);  // ds_add_u64
+      }
+    }
+  };
+  for (int64_t base = (int64_t)blockIdx.x * kHistThreads * kRun; base < N; base += (int64_t)gridDim.x * kHistThreads * kRun) {
+    const int64_t n0 = base + (int64_t)threadIdx.x * kRun;
+    // all inputs of the run requested before the first is used (one memory round trip per run instead of one per point: with two
+    // waves per SIMD nothing else hides them)
+    float ux[kRun][3], gx[kRun][F];
+#pragma unroll
+    for (int q = 0; q < kRun; ++q) {
+      const int64_t n = n0 + q < N ? n0 + q : N - 1;  // (an address select, not a conditional load)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) ux[q][d] = u[n * 3 + d];
+#pragma unroll
+      for (int f = 0; f < F; ++f) gx[q][f] = dfeat[n * F + f];
+    }
+#pragma unroll
+    for (int q = 0; q < kRun; ++q) {
+      const int64_t n = n0 + q;
+      if (n >= N) break;
+      float g[F];
+      bool live = false;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        g[f] = gx[q][f];
+        live |= (g[f] != 0.0f);
+      }
+      if (!live) continue;  // (every product below would be zero: the record writer emits nothing for such a point either)
+      const ps::Cell c = ps::make_cell(ux[q][0], ux[q][1], ux[q][2], s);
+      const float oy = c.oy, oz = c.oz, uy = 1.0f - oy, uz = 1.0f - oz;
+      const float w4[4] = {oy * oz, uy * oz, oy * uz, uy * uz};  // (y, z) corner order of the record writer: (c,c) (f,c) (c,f) (f,f)
+      const int y4[4] = {c.cy, c.fy, c.cy, c.fy}, z4[4] = {c.cz, c.cz, c.fz, c.fz};
+      const bool inside = c.fx >= 0 && c.fy >= 0 && c.fz >= 0 && c.cx < R && c.cy < R && c.cz < R;
+      if (__builtin_expect(!inside, 0)) {
+        // outside the cube: the records bin_kernel would have written for this (point, level 0)
+        const uint32_t fx = (uint32_t)c.fx, cx = (uint32_t)c.cx, xdiff = (cx ^ fx) & mask;
+        const bool together = (xdiff >> log2_slice) == 0u;
+        const uint32_t tcode = xdiff == 0u ? 30u : (uint32_t)(31 - __clz((int)xdiff));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t hyz = ((uint32_t)y4[k] * 2654435761u) ^ ((uint32_t)z4[k] * 805459861u);
+          float qv[F];
+          bool any = false;
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            qv[f] = w4[k] * g[f];
+            any |= (qv[f] != 0.0f);
+          }
+          if (!any) continue;
+          const uint32_t hf = (fx ^ hyz) & mask;
+          unsigned dst = atomicAdd(&cursors[hf >> log2_slice], 1u);
+          rec_idx[dst] = (hf & low) | ((together ? tcode : 31u) << 16);
+#pragma unroll
+          for (int f = 0; f < F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = together ? qv[f] : qv[f] * (1.0f - c.ox);
+          rec_val[(int64_t)F * n_rec_max + dst] = together ? c.ox : 0.0f;
+          if (!together && c.ox != 0.0f) {
+            const uint32_t hc = (cx ^ hyz) & mask;
+            dst = atomicAdd(&cursors[hc >> log2_slice], 1u);
+            rec_idx[dst] = (hc & low) | (31u << 16);
+#pragma unroll
+            for (int f = 0; f < F; ++f) rec_val[(int64_t)f * n_rec_max + dst] = qv[f] * c.ox;
+            rec_val[(int64_t)F * n_rec_max + dst] = 0.0f;
+          }
+        }
+        continue;
+      }
+      // the eight corner cells in the order (floor-x, ceil-x) x (y, z) corner; a ceil-x corner that coincides with the floor one
+      // (exact integer x: ox == 0) receives nothing, as in the accumulate kernel's t == 30 case
+      const bool same_x = c.cx == c.fx;
+      const float wf = same_x ? 1.0f : 1.0f - c.ox;
+      int t8[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t8[k] = c.fx + R * (y4[k] + R * z4[k]);
+        t8[4 + k] = same_x ? -1 : c.cx + R * (y4[k] + R * z4[k]);
+      }
+      bool same = true;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) same &= (t8[k] == tgt[k]);
+      if (!same) {
+        flush();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          tgt[k] = t8[k];
+#pragma unroll
+          for (int f = 0; f < F; ++f) sum[k][f] = 0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const float qv = w4[k] * g[f];
+          sum[k][f] += fixed_ll(qv * wf * scale);
+          if (!same_x) sum[4 + k][f] += fixed_ll(qv * c.ox * scale);
+        }
+      }
+    }
+  }
+  flush();
+  __syncthreads();
+  for (int i = threadIdx.x; i < cells * F; i += kHistThreads) {
+    const unsigned long long v = hist[i];
+    if (v != 0ull) atomicAdd(&hist0[i], v);
+  }
+}
+
 // exclusive prefix over the (level, slice) counts: starts[i], and cursors[i] := starts[i] for the second pass.
 // One workgroup walks the n items in tiles of 4 TPB (four consecutive items per thread: coalesced loads / stores), wave scans + a
 // 16-entry table per tile, the running total carried in a register.  (The first version gave every thread one contiguous run of n / 1024
 // items: strided, uncoalesced accesses, twice -- 240 us for the 41 k items of a routed production tile, per table backward.)
 // src: where the record counts come from -- the cursors themselves (counted by bin_kernel<COUNT_ONLY>) or the slice counts of the
 // forward encode (read directly: the device-to-device copy into the cursors was a launch of its own); zero_bits / n_zero: the
-// per-level absmax words to clear for the record-writing pass that follows (another memset launch otherwise).
+// per-level absmax words to clear for the record-writing pass that follows (another memset launch otherwise); zero_hist / n_zero_hist:
+// the dense level-0 histogram (level0_hist_kernel) to clear.
 // TPB = 256 for tables of <= 4096 streams: this kernel sits at the head of a table backward that runs BESIDE the main field's matrix
 // kernels (one 350 - 420-register wave per SIMD), and a 1024-thread workgroup (4 waves x 40 registers per SIMD) found no compute unit to
 // start on until one of their workgroups retired -- 0.6 - 1.2 ms of waiting for 5 us of work on the proposal chain (round-6 timeline).
 template <int TPB>
 __global__ __launch_bounds__(TPB) void stream_offsets_kernel(unsigned* __restrict__ cursors, unsigned* __restrict__ counts,
                                                              unsigned* __restrict__ starts, int n, const unsigned* __restrict__ src,
-                                                             unsigned* __restrict__ zero_bits, int n_zero) {
+                                                             unsigned* __restrict__ zero_bits, int n_zero,
+                                                             unsigned long long* __restrict__ zero_hist, int n_zero_hist) {
   __shared__ unsigned wsum[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < n_zero; i += TPB) zero_bits[i] = 0u;
+  for (int i = threadIdx.x; i < n_zero_hist; i += TPB) zero_hist[i] = 0ull;  // (the level-0 histogram of the pass that follows)
   unsigned carry = 0;
   for (int base = 0; base < n; base += TPB * 4) {
     const int i = base + (int)threadIdx.x * 4;
@@ -819,7 +1028,8 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
                                                           int accumulate, float* __restrict__ dtable, float* const* __restrict__ dtables,
                                                           float out_scale /* the gradient is multiplied by this (1: exactly the plain result) */,
                                                           int item0 /* first item of this launch (the items may be dealt to several launches) */,
-                                                          AdamFuse A) {
+                                                          AdamFuse A, const float* __restrict__ scalings,
+                                                          const unsigned long long* __restrict__ hist0 /* nullable: dense level-0 sums */) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];  // [entries][F]
   const int entries = 1 << log2_slice;
   const int n_slices = 1 << (log2T - log2_slice);
@@ -829,7 +1039,11 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   const int64_t base = starts[item];  // multiple of 4 records (stream_offsets_kernel) -> 16-byte aligned vector loads
   const int64_t n = cursors[item] - base;  // the write pass advanced the cursor from the stream start to its end
   const bool fused = A.g_base != nullptr;
-  if (n == 0 && accumulate && !fused) return;  // nothing to add (a sub-field without points: most slices of a multi-sub-field launch)
+  // level 0 of a single table may have been summed per cell corner instead of written as records (level0_hist_kernel): its slices
+  // then take those sums, whatever records they hold besides
+  const int R0 = (hist0 != nullptr && vlevel == 0) ? dense0_side(scalings) : 0;
+  const bool from_hist = R0 > 0 && dense0_fits(R0, F);
+  if (n == 0 && accumulate && !fused && !from_hist) return;  // nothing to add (a sub-field without points: most slices of a multi-sub-field launch)
   float bc1 = A.bc1, bc2_sqrt = A.bc2_sqrt;
   if (fused && A.group_of_field != nullptr) {
     const int grp = A.group_of_field[vlevel / L];
@@ -878,7 +1092,7 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   // (production shape: ~4 k records per slice, the kernel is a chain of latencies: 3.2 ms for 41 k workgroups)
   const int64_t first_i0 = (int64_t)threadIdx.x * kChunk;
   if (first_i0 < n) load_batch(first_i0);
-  const bool dense = fused || !(accumulate && n * 4 < entries);  // (fused: every entry of the slice is updated, gradient or not)
+  const bool dense = fused || from_hist || !(accumulate && n * 4 < entries);  // (fused: every entry of the slice is updated, gradient or not)
   constexpr int kOutPerThread = kAccBytes / 8 / 1024;  // 16 values of the slice per thread
   float prev[kOutPerThread];
 #pragma unroll
@@ -895,6 +1109,21 @@ __global__ __launch_bounds__(1024) void accumulate_kernel(const unsigned* __rest
   }
   const float scale = fixed_scale(gbits, headroom_log2);
   const unsigned low = (unsigned)entries - 1u;
+  if (from_hist && !nan_level) {
+    // the cells whose hash lands in this slice (two cells may share a row: LDS atomics); 4913 cells for the workgroup's 1024 threads
+    const uint32_t mask = (1u << log2T) - 1u;
+    for (int c = threadIdx.x; c < R0 * R0 * R0; c += 1024) {
+      const uint32_t x = (uint32_t)(c % R0), y = (uint32_t)((c / R0) % R0), z = (uint32_t)(c / (R0 * R0));
+      const uint32_t h = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & mask;
+      if ((int)(h >> log2_slice) == sl) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const unsigned long long v = hist0[c * F + f];
+          if (v != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(h & low) * F + f]), v);
+        }
+      }
+    }
+  }
   for (int64_t i0 = first_i0; i0 < n && !nan_level; i0 += 1024 * kChunk) {
     if (i0 != first_i0) load_batch(i0);
     unsigned p_row = 0xffffffffu, p_rowc = 0xffffffffu;
@@ -1239,7 +1468,7 @@ int64_t binned_workspace(int L, int F, int log2T, int64_t N, int K, int D = 3) {
   const int ls = binned_log2_slice(F, log2T);
   const int n_slices = 1 << (log2T - ls);
   const int64_t n_rec_max = binned_rec_capacity(N, L, K * n_slices, D);
-  return 4096 + (int64_t)K * L * n_slices * 4 * 3 + 16 + n_rec_max * 4 * (2 + F) + 256;
+  return 4096 + (int64_t)K * L * n_slices * 4 * 3 + 16 + n_rec_max * 4 * (2 + F) + 256 + kDense0Bytes;  // (+ the level-0 histogram, behind the planes)
 }
 
 // K = 1, chunk_field = null: one table.  Otherwise the multi-sub-field launch of ms_core.hpp: "level" of every stream,
@@ -1273,6 +1502,7 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
   unsigned* starts = counts + n_items;            // [n_items]
   unsigned* rec_idx = starts + ((n_items + 3) & ~3);  // [n_rec_max], 16-byte aligned like every plane behind it
   float* rec_val = (float*)(rec_idx + n_rec_max); // [F+1][n_rec_max] (plane F = ox)
+  unsigned long long* hist0 = (unsigned long long*)(((uintptr_t)(rec_val + (int64_t)(F + 1) * n_rec_max) + 255) & ~(uintptr_t)255);  // [kDense0Bytes / 8]
   // absmax_ready: the first K*L words of the workspace already hold the per-level max |d(feature)| bits (written by the
   // field backward kernel that produced dfeat) -> keep them and skip the absmax pass
   if (item_end < 0 || item_end > n_items) item_end = n_items;
@@ -1299,6 +1529,13 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
   const double rec_per_item = (double)N * L * (D == 4 ? 8 : 4) / (double)(n_items > 0 ? n_items : 1);
   bool stream_fused = fuse.g_base != nullptr && lds == (size_t)kAccBytes && rec_per_item < 16.0 * 1024 * 8;
   if (acc_stream_env != nullptr && fuse.g_base != nullptr && lds == (size_t)kAccBytes) stream_fused = acc_stream_env[0] != '0';
+  // level 0 as a dense histogram instead of records (level0_hist_kernel), on request (phase bit 3): one table, 3-D, no position sets,
+  // the generic accumulate kernel, a histogram budget that holds at least the smallest cube.  Both phases of a split call carry the
+  // bit and decide alike; the device side decides (from scalings[0]) whether the level's cube fits.  Measured neutral on cfg 2
+  // (EXPERIMENTS.md A.7): presight_amd.field_ops requests it only under PRESIGHT_DENSE_LEVEL0=1.
+  const bool dense0 = (phase & 8) && !(phase & 4) && D == 3 && K == 1 && chunk_field == nullptr && period == 0 && !stream_fused && N > 0 &&
+                      L > 1 && (int64_t)8 * F * 8 <= kDense0Bytes;
+  const int n_zero_hist = dense0 ? kDense0Bytes / 8 : 0;
 #define PS_LAUNCH_BINNED(FF) PS_LAUNCH_BINNED_D(FF, 3)
 #define PS_LAUNCH_BINNED_D(FF, DD)                                                                                            \
   {                                                                                                                       \
@@ -1312,18 +1549,34 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
       if (N > 0) {                                                                                                        \
         if (slice_counts == nullptr)                                                                                      \
           bin_kernel<FF, true, DD><<<(unsigned)(chunks * L), bin_threads(DD, FF), 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,    \
-                                                                              plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period, dfeat_b); \
+                                                                              plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, nullptr, period, dfeat_b, 0); \
       }                                                                                                                   \
       if (n_items <= 4096)                                                                                                \
         stream_offsets_kernel<256><<<1, 256, 0, s>>>(cursors, counts, starts, n_items, counted ? slice_counts : cursors,  \
-                                                     (counted && !absmax_ready) ? gmax_bits : nullptr, (counted && !absmax_ready) ? K * L : 0); \
+                                                     (counted && !absmax_ready) ? gmax_bits : nullptr, (counted && !absmax_ready) ? K * L : 0, \
+                                                     hist0, n_zero_hist);                                                 \
       else                                                                                                                \
         stream_offsets_kernel<1024><<<1, 1024, 0, s>>>(cursors, counts, starts, n_items, counted ? slice_counts : cursors, \
-                                                       (counted && !absmax_ready) ? gmax_bits : nullptr, (counted && !absmax_ready) ? K * L : 0); \
+                                                       (counted && !absmax_ready) ? gmax_bits : nullptr, (counted && !absmax_ready) ? K * L : 0, \
+                                                       hist0, n_zero_hist);                                               \
       if (N > 0)                                                                                                          \
         bin_kernel<FF, false, DD><<<(unsigned)(chunks * L), bin_threads(DD, FF), 0, s>>>(u, dfeat, scalings, L, log2T, ls, N,     \
                                                                              plane_stride, n_rec_max, cursors, rec_idx, rec_val, chunk_field, \
-                                                                             absmax_ready ? nullptr : gmax_bits, period, dfeat_b); \
+                                                                             absmax_ready ? nullptr : gmax_bits, period, dfeat_b, (int)dense0); \
+      if constexpr (DD == 3) {                                                                                            \
+        if (dense0) {                                                                                                     \
+          static bool attr0_set = false;                                                                                  \
+          if (!attr0_set) {                                                                                               \
+            hipFuncSetAttribute((const void*)level0_hist_kernel<FF>, hipFuncAttributeMaxDynamicSharedMemorySize, kDense0Bytes); \
+            attr0_set = true;                                                                                             \
+          }                                                                                                               \
+          const int64_t per_wg = kHistThreads * 8;                                                                        \
+          const unsigned hist_grid = (unsigned)std::min<int64_t>(1024, (N + per_wg - 1) / per_wg);                        \
+          if (!absmax_ready) level0_absmax_kernel<FF><<<256, 1024, 0, s>>>(dfeat, scalings, N, gmax_bits);               \
+          level0_hist_kernel<FF><<<hist_grid, kHistThreads, kDense0Bytes, s>>>(u, dfeat, scalings, log2T, ls, N, n_rec_max, cursors, rec_idx, \
+                                                                       rec_val, gmax_bits, headroom, hist0);              \
+        }                                                                                                                 \
+      }                                                                                                                   \
     }                                                                                                                     \
     if ((phase & 2) && item_end > item_begin) {                                                                           \
       if (stream_fused) {                                                                                                 \
@@ -1336,7 +1589,8 @@ int scatter_binned_impl(const float* u, const float* dfeat, const float* scaling
                                                                                         n_rec_max, headroom, dtable, dtables, item_begin, fuse); \
       } else {                                                                                                            \
         accumulate_kernel<FF><<<(unsigned)(item_end - item_begin), 1024, lds, s>>>(cursors, starts, rec_idx, rec_val, gmax_bits, L, log2T, ls, \
-                                                                                   n_rec_max, headroom, accumulate, dtable, dtables, out_scale, item_begin, fuse); \
+                                                                                   n_rec_max, headroom, accumulate, dtable, dtables, out_scale, item_begin, fuse, \
+                                                                                   scalings, dense0 ? hist0 : nullptr);           \
       }                                                                                                                   \
     }                                                                                                                     \
   }

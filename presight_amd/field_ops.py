@@ -89,6 +89,9 @@ def _training(needs_grad) -> bool:
 
 _WORKSPACES = {}
 SCATTER_IMPL = "binned"  # "binned" (records + int64 LDS accumulation) or "owner" (LDS slice-owner scan)
+# the coarsest level of a one-table backward as a dense int64 histogram instead of records (csrc/encode.hip level0_hist_kernel; phase bit 3 of
+# the binned entry points): bit-identical, measured neutral on cfg 2 (EXPERIMENTS.md A.7) -> off unless PRESIGHT_DENSE_LEVEL0=1
+DENSE_LEVEL0 = __import__("os").environ.get("PRESIGHT_DENSE_LEVEL0", "0") == "1"
 # training forward of the main field keeps its hidden activations (1.6 KB/point) for the backward; PRESIGHT_KEEP_ACTIVATIONS=0
 # (or this flag) switches to recomputing them there (7 GB less memory at cfg 2, same results)
 KEEP_ACTIVATIONS = __import__("os").environ.get("PRESIGHT_KEEP_ACTIVATIONS", "1") != "0"
@@ -180,15 +183,15 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
             # pass runs on the slices' owner, over all ranks' records (dist.FlatGrads._sparse_exchange)
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device, sink_owner)
             check(lib().ps_grid_scatter_binned_part(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
-                                                    int(ws_with_absmax is not None), _p(ws), 1, 0, 0, _stream()), "ps_grid_scatter_binned_part")
-            _hand_over_records([sink_owner], ws, g, N, 1, dtable, None)
+                                                    int(ws_with_absmax is not None), _p(ws), 1 | 4, 0, 0, _stream()), "ps_grid_scatter_binned_part")
+            _hand_over_records([sink_owner], ws, g, N, 1, dtable, None)  # (phase bit 2: every level as records -- they are what travels)
         elif fused is not None:
             # single-process training: the accumulate pass applies the table's Adam step itself, the gradient is never written
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
             for phase, reg in _scatter_phases(L, F):
                 with (prof.region(reg) if reg else contextlib.nullcontext()):
                     check(lib().ps_grid_scatter_binned_adam(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), _p(counts),
-                                                            int(ws_with_absmax is not None), _p(ws), phase, 0, -1, *fused, _stream()),
+                                                            int(ws_with_absmax is not None), _p(ws), phase | (8 if DENSE_LEVEL0 else 0), 0, -1, *fused, _stream()),
                           "ps_grid_scatter_binned_adam")
         elif _binned(N, L) and pieces > 1:
             # the gradient is exchanged in `pieces` level groups (presight_amd.dist.FlatGrads splits): one accumulate launch per group,
@@ -199,15 +202,20 @@ def _scatter(u: Tensor, dfeat: Tensor, scalings: Tensor, g: GridCfg, table_shape
             if L % pieces:
                 raise RuntimeError(f"presight_amd: a table of {L} levels cannot be exchanged in {pieces} equal level groups")
             args = (_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts), int(ws_with_absmax is not None), _p(ws))
-            check(lib().ps_grid_scatter_binned_part(*args, 1, 0, 0, _stream()), "ps_grid_scatter_binned_part")
+            d0 = 8 if DENSE_LEVEL0 else 0
+            check(lib().ps_grid_scatter_binned_part(*args, 1 | d0, 0, 0, _stream()), "ps_grid_scatter_binned_part")
             for gi in range(pieces):
                 l0, l1 = L * gi // pieces, L * (gi + 1) // pieces
-                check(lib().ps_grid_scatter_binned_part(*args, 2, l0 * per_level, l1 * per_level, _stream()), "ps_grid_scatter_binned_part")
+                check(lib().ps_grid_scatter_binned_part(*args, 2 | d0, l0 * per_level, l1 * per_level, _stream()), "ps_grid_scatter_binned_part")
                 sink_owner._ps_part_done(sink_owner, gi)
         elif _binned(N, L):
             ws = ws_with_absmax if ws_with_absmax is not None else _scatter_ws(g, N, u.device)
-            check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
-                                               int(ws_with_absmax is not None), _p(ws), _stream()), "ps_grid_scatter_binned")
+            if DENSE_LEVEL0:
+                check(lib().ps_grid_scatter_binned_part(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
+                                                        int(ws_with_absmax is not None), _p(ws), 3 | 8, 0, -1, _stream()), "ps_grid_scatter_binned_part")
+            else:
+                check(lib().ps_grid_scatter_binned(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _p(counts),
+                                                   int(ws_with_absmax is not None), _p(ws), _stream()), "ps_grid_scatter_binned")
         else:
             check(lib().ps_grid_scatter(_p(u), _p(dfeat), _p(scalings), L, F, l2t, N, N * F, _p(dtable), acc, _stream()),
                   "ps_grid_scatter")

@@ -403,6 +403,71 @@ def test_table_gradient_non_finite_input_gives_nan_not_garbage(F, dev):
         assert bool(torch.isfinite(per_level[[0, 1, 3]]).all())
 
 
+@pytest.mark.parametrize("L,nf,l2t,mx,N,ready", [(16, 2, 19, 2048, 150001, False), (8, 1, 20, 4096, 120001, True), (8, 1, 20, 4096, 9001, False),
+                                                 (2, 2, 13, 64, 30000, False)])
+def test_table_gradient_level0_histogram_equals_records(F, dev, L, nf, l2t, mx, N, ready):
+    """The coarsest level summed per cell corner into the dense int64 histogram (csrc/encode.hip level0_hist_kernel: what a
+    single-table backward does) against the same backward with EVERY level written as records (phase bit 2, what the sparse exchange
+    asks for): bit-equal -- same fixed-point terms, integer sums.  With ray-coherent runs (consecutive points in one cell: the
+    register merge), points with zero gradient, points on exact cell boundaries, points OUTSIDE the unit cube (no cell of the
+    histogram: they travel as records in the level-0 streams) and -- `ready` -- the per-level absmax handed in by the caller (the
+    proposal fields' backward publishes it), plus accumulate = 1 and the forward's record counts.  Against the oracle as well."""
+    from presight_amd import field_ops
+    from presight_amd._lib import check, lib
+
+    gen = torch.Generator().manual_seed(L * 13 + nf + N)
+    g = F.GridCfg(L, nf, l2t)
+    sc = O.hash_scalings(L, 16, mx)
+    u = torch.rand(N, 3, generator=gen)
+    run = torch.rand(N // 64 + 1, 3, generator=gen).repeat_interleave(64, 0)[:N]  # 64 consecutive points march through a few cells
+    u[: N // 2] = (run + torch.arange(N).view(-1, 1).remainder(64) * torch.tensor([[0.004, 0.001, 0.0005]]))[: N // 2].clamp(0, 1)
+    u[5] = torch.tensor([0.0, 0.0, 0.0])
+    u[6] = torch.tensor([1.0, 1.0, 1.0])
+    u[7] = torch.tensor([0.5, 0.25, 1.0])                 # exact cell boundaries at level 0 (scale 16)
+    u[100:140] = torch.rand(40, 3, generator=gen) * 1.4          # beyond 1 on some axes: no cell of the histogram, record path of its kernel
+    dfeat = (torch.randn(L, N, nf, generator=gen) * torch.logspace(-3, 1, L).view(L, 1, 1))
+    dfeat[:, 200:400] = 0.0                                # no gradient: nothing is emitted
+    table = torch.zeros((1 << l2t) * L, nf, requires_grad=True)
+    enc = O.hash_encode(u, table, sc, l2t)
+    (ref,) = torch.autograd.grad((enc * dfeat.permute(1, 0, 2).reshape(N, L * nf)).sum(), table)
+    ud, dd, scd = u.to(dev), dfeat.to(dev).contiguous(), sc.to(dev)
+    nbytes = lib().ps_grid_scatter_workspace(L, nf, l2t, N)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run_scatter(phases, accumulate=0, counts=None, base=None):
+        ws = torch.zeros(nbytes + 4096, dtype=torch.uint8, device=dev)
+        if ready:  # per-level max |d(feature)| bits in the first words of the workspace, as ps_prop_field_bwd leaves them
+            ws[: 4 * L].view(torch.int32).copy_(dd.abs().amax(dim=(1, 2)).view(torch.int32))
+        out = torch.full(table.shape, float("nan"), device=dev) if base is None else base.clone()
+        for ph in phases:
+            check(lib().ps_grid_scatter_binned_part(ud.data_ptr(), dd.data_ptr(), scd.data_ptr(), L, nf, l2t, N, N * nf, out.data_ptr(), accumulate,
+                                                    None if counts is None else counts.data_ptr(), int(ready), ws.data_ptr(), ph, 0, -1, s), "scatter")
+        # records in the level-0 streams: stream ends (cursors) - stream starts of the level's slices (workspace layout: csrc/encode.hip)
+        n_sl = lib().ps_grid_scatter_slices(nf, l2t)
+        words = ws[4096: 4096 + 12 * L * n_sl].view(torch.int32)
+        level0_records = int((words[:n_sl] - words[2 * L * n_sl: 2 * L * n_sl + n_sl]).sum())
+        return out, level0_records
+
+    def run(*a):
+        return run_scatter(*a)[0]
+
+    hist, n_hist = run_scatter([3 | 8])        # level 0 through the histogram (phase bit 3)
+    recs, n_recs = run_scatter([1 | 4, 2 | 4])  # every level as records
+    assert n_recs > 3 * (N - 250) and n_hist <= 8 * 40, (n_hist, n_recs)  # the histogram path ran: only the points outside the cube left records
+    assert torch.equal(hist, recs)
+    assert torch.equal(run([1 | 8, 2 | 8]), hist)  # the two phases as separate calls (how a gradient exchanged in pieces runs)
+    T = 1 << l2t
+    for l in range(L):
+        a, b = hist[l * T:(l + 1) * T].cpu(), ref[l * T:(l + 1) * T]
+        sl = float(b.abs().max()) + 1e-30
+        torch.testing.assert_close(a / sl, b / sl, rtol=2e-4, atol=2e-6, msg=lambda m: f"level {l}: {m}")
+    # record counts from the forward encode + accumulate = 1 into a pre-filled buffer
+    _, counts = field_ops._encode(ud, torch.zeros(table.shape, device=dev), scd, g, count=True)
+    base = torch.randn(table.shape, generator=gen).to(dev)
+    assert torch.equal(run([3 | 8], 1, counts, base), run([1 | 4, 2 | 4], 1, counts, base))
+    assert torch.equal(run([3], 1, counts, base), run([3 | 8], 1, counts, base))  # (and the default: records, no bit)
+
+
 # (which accumulate kernel a shape runs -- csrc/encode.hip scatter_binned_impl: full 128-KiB slices with < 128 k records per item on
 #  average take accumulate_adam_kernel (every load of an item up front, slices without records skip the accumulators): the first
 #  three; many records per item, (2, 2, 13, ...), or slices smaller than 128 KiB, (2, 2, 9, ...), stay on accumulate_kernel)
