@@ -1,5 +1,6 @@
 #!/bin/bash
 # Same-box A/B of two source TREES (e.g. a git worktree of the previous round under _wt_r05/ against the working tree), alternating:
+#   git worktree add _wt_r05 <commit> && (cd _wt_r05 && python -c 'import __graft_entry__ as g; g.build()')   # (_wt_*/ is git-ignored, travels with gpurun)
 #   gpurun -- 'bash tools/ab_trees.sh "<bench args>" <rounds> <dir A> <dir B> ...'      ("." = the working tree)
 # prints ms_per_step of every run; a failed run prints FAILED
 root=$GRAFT_REPO_ROOT
