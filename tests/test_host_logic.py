@@ -307,6 +307,7 @@ _WORKER_PIECES = textwrap.dedent("""
     from presight_amd.ops import mark_touched
     rank, local, world = init_from_env("cpu")
     mode = {mode!r}
+    M = (world + 1) / 2.0   # mean over the ranks of (rank + 1)
     torch.manual_seed(0)
     small, table = torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(32, 2))
     fg = FlatGrads([small, table], bucket_sizes=[1, 1], shard_world=world if mode == "sharded" else 1, splits={{1: 4}})
@@ -341,9 +342,9 @@ _WORKER_PIECES = textwrap.dedent("""
     assert all(b["phase"] == "backward" for b in fg._buckets)  # EVERY bucket left before finish_exchange
     update()
     exp = before.clone()
-    exp[0:12] -= 0.1 * 1.5
+    exp[0:12] -= 0.1 * M
     for g in range(4):
-        exp[t0 + 16 * g:t0 + 16 * (g + 1)] -= 0.1 * 1.5 * (g + 1)
+        exp[t0 + 16 * g:t0 + 16 * (g + 1)] -= 0.1 * M * (g + 1)
     assert torch.allclose(flat_p, exp, atol=1e-6), (rank, (flat_p - exp).abs().max())
     # step 2: a producer that does not work in pieces reports the whole parameter: all pieces go out at once, in order
     fg.zero_()
@@ -354,8 +355,8 @@ _WORKER_PIECES = textwrap.dedent("""
     mark_touched([small])
     assert [b["launched"] for b in fg._buckets] == [True] * 5
     update()
-    exp[0:12] -= 0.1 * 3.0
-    exp[t0:t0 + 64] -= 0.1 * 1.5
+    exp[0:12] -= 0.1 * 2.0 * M
+    exp[t0:t0 + 64] -= 0.1 * M
     assert torch.allclose(flat_p, exp, atol=1e-6)
     # step 3: the table receives nothing on any rank (off-schedule): its pieces are skipped, only the small bucket is exchanged
     fg.zero_()
@@ -363,7 +364,7 @@ _WORKER_PIECES = textwrap.dedent("""
     mark_touched([small])
     n_before = COMM_LOG.seq
     update()
-    exp[0:12] -= 0.1 * 1.5
+    exp[0:12] -= 0.1 * M
     assert torch.allclose(flat_p, exp, atol=1e-6) and COMM_LOG.seq - n_before == (1 if mode == "sharded" else 0)
     # step 4: the FIRST bucket is known to receive nothing on any rank (schedule-driven, e.g. proposal networks off schedule):
     # skip_buckets takes it out of the launch order, the pieces behind it still leave during backward
@@ -375,7 +376,7 @@ _WORKER_PIECES = textwrap.dedent("""
     assert [b["launched"] for b in fg._buckets] == [True] * 5 and [b["phase"] for b in fg._buckets[1:]] == ["backward"] * 4
     mark_touched([table])
     update()
-    exp[t0:t0 + 64] -= 0.1 * 1.5
+    exp[t0:t0 + 64] -= 0.1 * M
     assert torch.allclose(flat_p, exp, atol=1e-6)
     try:
         fg.zero_()
@@ -403,8 +404,8 @@ _WORKER_PIECES = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
-def test_split_table_buckets_gloo_world2(tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("allreduce", 2), ("sharded", 2), ("sharded", 4)])
+def test_split_table_buckets_gloo_world2(tmp_path, mode, world):
     """A hash table exchanged as level-group PIECES (FlatGrads splits): every piece is its own collective, handed over by the producer
     as soon as the accumulate launch of that level group is enqueued -- before backward ends -- strictly in bucket order on every
     rank; a producer that reports the whole parameter, an off-schedule step and the sharded update work as before."""
@@ -412,12 +413,12 @@ def test_split_table_buckets_gloo_world2(tmp_path, mode):
     script.write_text(_WORKER_PIECES.format(root=ROOT, mode=mode))
     port = "29741" if mode == "allreduce" else "29743"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PRESIGHT_COMM_LOG=str(tmp_path / "comm_{rank}.log"))
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", port, str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("ok") == 2
-    logs = [(tmp_path / f"comm_{r_}.log").read_text().splitlines() for r_ in range(2)]
-    assert logs[0] == logs[1]
+    assert r.stdout.count("ok") == world
+    logs = [(tmp_path / f"comm_{r_}.log").read_text().splitlines() for r_ in range(world)]
+    assert all(lg == logs[0] for lg in logs)
     kind = "reduce_scatter" if mode == "sharded" else "all_reduce"
     step1 = [ln for ln in logs[0] if f" {kind} " in ln and "step=1" in ln]
     assert len(step1) == 5 and all("phase=backward" in ln for ln in step1)  # all 5 buckets of the first step left during backward
@@ -805,7 +806,7 @@ _WORKER_SPARSE = textwrap.dedent("""
     dist.all_gather(both, dense)
     exp = torch.arange(n_items * rows, dtype=torch.float32) - 0.25 * sum(both) / world
     assert torch.equal(flat_p["sparse"][t0:t0 + n_items * rows], exp)
-    assert seen["gmax"] == [2.0, 4.0] and seen["n_total"] == 1024 * world and seen["n_runs"] == world    # MAX over the ranks of both
+    assert seen["gmax"] == [float(world), 4.0] and seen["n_total"] == (1000 + 24 * (world - 1)) * world and seen["n_runs"] == world  # MAX over the ranks of both
     kinds = [ln.split()[1] for ln in COMM_LOG.tail(64)]
     assert kinds.count("all_to_all_records") == F + 2 and "all_reduce_max_levels" in kinds and "all_to_all_item_runs" in kinds
     dist.barrier(); dist.destroy_process_group()
@@ -813,16 +814,17 @@ _WORKER_SPARSE = textwrap.dedent("""
 """)
 
 
-def test_sparse_record_exchange_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sparse_record_exchange_gloo_world2(tmp_path, world):
     """exchange = sparse: a hash table's gradient travels as the binned backward's RECORD streams to the owners of its
     slices (all_to_all of the streams + per-item run tables, per-level maxima MAX-reduced first), the owner accumulates every rank's run
-    and writes its shard of the mean; Adam-on-the-shard and the parameter all-gather are the sharded mode's.  Two gloo ranks on the CPU
+    and writes its shard of the mean; Adam-on-the-shard and the parameter all-gather are the sharded mode's.  Two / four gloo ranks on the CPU
     with a stand-in accumulate pass: replicas bit-identical, and -- on integer-valued records, where float sums are exact -- bit-equal
     to the DENSE sharded exchange of the same gradients; streams sized for upper bounds, empty runs and a hot slice included."""
     script = tmp_path / "worker_sparse.py"
     script.write_text(_WORKER_SPARSE.format(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29747")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", "29747", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
