@@ -381,3 +381,36 @@ def test_proposal_side_stream_changes_nothing_but_the_schedule():
         # hash-table gradients are bit-reproducible (integer accumulation), MLP / embedding gradients use float atomics
         torch.testing.assert_close(gb / s, ga / s, rtol=1e-4, atol=1e-6)
         assert float(ga.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_dense_level0_histogram_in_a_training_step_is_bit_identical():
+    """PRESIGHT_DENSE_LEVEL0 (field_ops.DENSE_LEVEL0: the coarsest level of every one-table backward summed into a dense int64
+    histogram instead of written as records -- off by default, EXPERIMENTS.md A.7): a cfg-2 training step gives the same hash tables
+    bit for bit, with the tables' Adam step inside their backward (the default of a single-process trainer) and with written
+    gradients + the optimizer kernel."""
+    import bench
+    from presight_amd import field_ops
+    from presight_amd.trainer import Trainer
+
+    dev = torch.device("cuda:0")
+
+    def tables_after_one_step(dense0: bool, fused: bool):
+        field_ops.DENSE_LEVEL0 = dense0
+        try:
+            model, scene = bench.build_model(dev, seed=11, config="cfg2")
+            batch = bench.make_batches(scene, dev, 1, 0, rays=4096)[0]
+            torch.manual_seed(4)
+            tr = Trainer(model, scene, 1, exchange="allreduce", fused_table_adam=fused)
+            tr.step(batch)  # (ONE step: the table gradient is integer-accumulated = deterministic; the MLP gradients behind a second one use float atomics)
+            torch.cuda.synchronize()
+            return {k: v.detach().clone() for k, v in model.state_dict().items() if k.endswith("hash_table")}
+        finally:
+            field_ops.DENSE_LEVEL0 = False
+
+    for fused in (True, False):
+        a, b = tables_after_one_step(False, fused), tables_after_one_step(True, fused)
+        assert len(a) >= 3 and a.keys() == b.keys()  # (main + two proposal tables, also under their mlp_base alias keys)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (fused, k)
+        assert any(bool((v != 0).any()) for v in a.values())
