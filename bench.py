@@ -169,6 +169,10 @@ def compact_line(full: dict, detail_path=None) -> dict:
                     c[k] = {"step_ms_all_links_ASSUMED": v["all_links_ASSUMED"]["predicted_step_ms"],
                             "speedup_all_links_ASSUMED": v["all_links_ASSUMED"]["predicted_speedup_vs_one_gpu"],
                             "speedup_ring_one_link": v["ring_one_link"]["predicted_speedup_vs_one_gpu"], "measured": False}
+                    sp = v.get("sparse_records")
+                    if isinstance(sp, dict) and isinstance(sp.get("all_links_ASSUMED"), dict):  # (the same prediction with the tables travelling as records)
+                        c[k]["sparse_speedup_all_links_ASSUMED"] = sp["all_links_ASSUMED"]["predicted_speedup_vs_one_gpu"]
+                        c[k]["sparse_speedup_ring_one_link"] = sp["ring_one_link"]["predicted_speedup_vs_one_gpu"]
             out["secondary"][name] = c
     other = full.get("other_scaling")
     if isinstance(other, dict):
@@ -805,7 +809,8 @@ def secondary_training_lines(config, shapes, dev):
                 lines[rays]["exchange_overlap_dry_run"] = dry
                 if n > 1 and 65536 in lines:
                     tables = sum(p.numel() for nm, p in model.named_parameters() if nm.endswith("hash_table"))
-                    lines[rays][f"predicted_N{n}_strong"] = predicted_strong_scaling(lines[65536]["ms_per_step"], dry, n, 4.0 * tables)
+                    lines[rays][f"predicted_N{n}_strong"] = predicted_strong_scaling(lines[65536]["ms_per_step"], dry, n, 4.0 * tables,
+                                                                                      record_bytes=record_bytes_per_rank(cfg, rays))
             except Exception as e:
                 lines[rays]["exchange_overlap_dry_run"] = {"error": f"{type(e).__name__}: {e}"}
     del trainer, model, scene
@@ -991,7 +996,17 @@ def dry_overlap_timeline(model, scene, rays, dev, steps=5, exchange="allreduce")
             "handed_over_in_backward": sum(1 for t in tl if t["handed_over_in_backward"] == t["steps_exchanged"] > 0), "n_buckets": len(tl)}
 
 
-def predicted_strong_scaling(one_gpu_ms: float, dry: dict, n: int, param_bytes: float) -> dict:
+def record_bytes_per_rank(cfg: dict, rays: int) -> float:
+    """bytes of the binned backward's record streams one rank writes per step (exchange = sparse ships them instead of the dense
+    table gradient): every sample emits 4 x-pair records of 4 * (F + 2) bytes per level, on the main grid and on both proposal grids"""
+    m = cfg["model"]
+    total = rays * 64 * m["num_levels"] * 4 * 4 * (m["features_per_level"] + 2)   # main field: 64 samples per ray
+    for S in (128, 64):                                                              # proposal nets (L = 8, F = 1) on 128 / 64 samples
+        total += rays * S * 8 * 4 * 4 * (1 + 2)
+    return float(total)
+
+
+def predicted_strong_scaling(one_gpu_ms: float, dry: dict, n: int, param_bytes: float, record_bytes: float = None) -> dict:
     """What a strong-scaled N-rank run of the production tile would take, assembled from what ONE GPU can measure -- no multi-GPU run
     exists, every figure below is a measurement of one rank's work or a stated assumption about the links:
       compute        the per-rank step at 65 536 / N rays with the gradients written (un-fused tables), split accumulate launches and
@@ -1023,6 +1038,22 @@ def predicted_strong_scaling(one_gpu_ms: float, dry: dict, n: int, param_bytes: 
         step = base + sched[label]["exposed_ms"]
         out[label] = {"exposed_reduce_scatter_ms": sched[label]["exposed_ms"], "hidden_ms": sched[label]["hidden_ms"], "predicted_step_ms": step,
                       "predicted_speedup_vs_one_gpu": one_gpu_ms / step}
+    if record_bytes:
+        # exchange = sparse: the hash tables' buckets (everything above 64 MB on this tile) travel as RECORDS.  Same hand-over times as
+        # the dense pieces (conservative: the records are complete one accumulate pass earlier), bytes scaled to the record streams; the
+        # owner's accumulate pass over the received runs replaces the rank's own (same record count, 1 / N of the slices to flush).
+        try:
+            tl = dry.get("buckets") or []
+            dense_tables = sum(b_["bytes"] for b_ in tl if b_["bytes"] >= 64e6 and b_["steps_exchanged"])
+            scaled = [dict(b_, bytes=b_["bytes"] * record_bytes / dense_tables) if (b_["bytes"] >= 64e6 and dense_tables) else b_ for b_ in tl]
+            ssched = exchange_schedule(scaled, n, "sharded")
+            out["sparse_records"] = {"record_bytes_per_rank": record_bytes, "dense_table_gradient_bytes": dense_tables}
+            for label in ("all_links_ASSUMED", "ring_one_link"):
+                step = base + ssched[label]["exposed_ms"]
+                out["sparse_records"][label] = {"exposed_ms": ssched[label]["exposed_ms"], "predicted_step_ms": step,
+                                                "predicted_speedup_vs_one_gpu": one_gpu_ms / step}
+        except Exception as e:  # (a prediction must never take the line down)
+            out["sparse_records"] = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("a prediction from one-GPU measurements and the stated link assumptions; no scaling curve has been measured in any round "
                    "(SCALE_rNN.json of the driver is the only source of measured N > 1 numbers)")
     return out
